@@ -1,0 +1,292 @@
+"""ctypes binding of libfplhip.so (include/fplhip.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails,
+`FplHipError` is raised with the library's own message.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
+
+MEM_HOST, MEM_DEVICE = 0, 1
+U8, F32, F64 = 0, 1, 2
+PREC_F32, PREC_BF16 = 0, 1
+ABI_VERSION = 1
+
+
+class FplHipError(RuntimeError):
+    pass
+
+
+class fpl_op(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('src0', C.c_int32), ('src1', C.c_int32),
+                ('dst', C.c_int32), ('k', C.c_int32), ('cin', C.c_int32),
+                ('cout', C.c_int32), ('act', C.c_int32), ('w_off', C.c_int64),
+                ('scale_off', C.c_int64), ('shift_off', C.c_int64),
+                ('p', C.c_int32 * 6)]
+
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+_pi32, _pi64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); every symbol include/fplhip.h declares
+SIGNATURES = {
+    'fpl_abi_version': (C.c_int, []),
+    'fpl_ctx_create': (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    'fpl_ctx_destroy': (C.c_int, [_vp]),
+    'fpl_last_error': (C.c_char_p, [_vp]),
+    'fpl_ctx_set_stream': (C.c_int, [_vp, _vp]),
+    'fpl_ctx_synchronize': (C.c_int, [_vp]),
+    'fpl_device_info': (C.c_int, [_vp, _pi32, _pi64, C.c_char_p, C.c_size_t]),
+    'fpl_malloc': (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    'fpl_free': (C.c_int, [_vp, _vp]),
+    'fpl_memcpy': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_size_t]),
+    'fpl_program_create': (C.c_int, [_vp, C.POINTER(fpl_op), _i32, _i32, _i32,
+                                     _vp, _i64, _pi32, C.POINTER(_vp)]),
+    'fpl_program_destroy': (C.c_int, [_vp]),
+    'fpl_program_set_arena': (C.c_int, [_vp, _vp, _i64]),
+    'fpl_program_forward': (C.c_int, [_vp, _vp, _vp, C.c_int, _i32, _pi32,
+                                      C.c_int, _vp, C.c_int, _pi32]),
+    'fpl_infer_volume': (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32,
+                                   _pi64, _pi32, _pi32, C.c_int, _i32, _i32,
+                                   _vp, C.c_int]),
+    'fpl_v2o_smooth': (C.c_int, [_vp, _vp, C.c_int, _pi64, _i32, _vp, _i32,
+                                 _pi64, _i32, _vp]),
+    'fpl_v2o_nms': (C.c_int, [_vp, _f64, _vp, _i64, _pi64, _pi32]),
+    'fpl_v2o_copy_smoothed': (C.c_int, [_vp, _vp, C.c_int]),
+    'fpl_synth_volume_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _vp,
+                                      C.c_int]),
+    'fpl_timing_enable': (C.c_int, [_vp, C.c_int]),
+    'fpl_timing_reset': (C.c_int, [_vp]),
+    'fpl_timing_get': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _pi32]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libfplhip.so and bind every declared symbol (no GPU needed)"""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise FplHipError(
+            'libfplhip.so not found at %s - build it with '
+            '`python -m flypylib_amd.csrc.build` (there is no CPU fallback)'
+            % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fpl_abi_version() != ABI_VERSION:
+        raise FplHipError('libfplhip.so ABI %d, binding expects %d'
+                          % (lib.fpl_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    """void* of a numpy array, torch tensor (data_ptr) or raw int address"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(_vp)
+    if hasattr(a, 'data_ptr'):
+        return _vp(a.data_ptr())
+    return _vp(int(a))
+
+
+def _mem_of(a):
+    if isinstance(a, np.ndarray):
+        return MEM_HOST
+    if hasattr(a, 'is_cuda'):
+        return MEM_DEVICE if a.is_cuda else MEM_HOST
+    return MEM_DEVICE
+
+
+def _arr(vals, ctype):
+    return (ctype * len(vals))(*[int(v) for v in vals])
+
+
+class Context:
+    """one GPU (fpl_ctx).  Create after fork(); use from one thread at a time."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.fpl_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise FplHipError(self.lib.fpl_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+
+    def check(self, rc):
+        if rc != 0:
+            raise FplHipError(self.lib.fpl_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.fpl_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        self.check(self.lib.fpl_ctx_set_stream(self.h, _vp(hip_stream or 0)))
+
+    def synchronize(self):
+        self.check(self.lib.fpl_ctx_synchronize(self.h))
+
+    def device_info(self):
+        ncu, hbm = C.c_int32(), C.c_int64()
+        name = C.create_string_buffer(256)
+        self.check(self.lib.fpl_device_info(self.h, C.byref(ncu), C.byref(hbm),
+                                            name, 256))
+        return dict(n_cu=ncu.value, hbm_bytes=hbm.value,
+                    name=name.value.decode())
+
+    # ---- timing
+    def timing(self, on=True):
+        self.check(self.lib.fpl_timing_enable(self.h, int(bool(on))))
+
+    def timing_reset(self):
+        self.check(self.lib.fpl_timing_reset(self.h))
+
+    def timing_get(self, cap=256):
+        names = C.create_string_buffer(64 * cap)
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int64 * cap)()
+        n = C.c_int32()
+        self.check(self.lib.fpl_timing_get(self.h, names, ms, cnt, cap,
+                                           C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            nm = names.raw[64 * i:64 * (i + 1)].split(b'\0')[0].decode()
+            out[nm] = dict(ms=ms[i], launches=cnt[i])
+        return out
+
+    # ---- synthetic data
+    def synth_volume_u8(self, seed, dims, origin=(0, 0, 0), out=None):
+        if out is None:
+            out = np.empty(tuple(int(d) for d in dims), np.uint8)
+        self.check(self.lib.fpl_synth_volume_u8(
+            self.h, C.c_uint64(int(seed)), _arr(dims, C.c_int64),
+            _arr(origin, C.c_int64), _ptr(out), _mem_of(out)))
+        return out
+
+    # ---- voxel2obj stages
+    def v2o_smooth(self, pred, dims, r, weights, ranks):
+        weights = np.ascontiguousarray(weights, np.float64)
+        wr = (weights.size - 1) // 2
+        ranks = np.ascontiguousarray(ranks, np.int64)
+        vals = np.zeros(max(ranks.size, 1), np.float32)
+        self.check(self.lib.fpl_v2o_smooth(
+            self.h, _ptr(pred), _mem_of(pred), _arr(dims, C.c_int64), int(r),
+            _ptr(weights), int(wr), ranks.ctypes.data_as(_pi64),
+            int(ranks.size), _ptr(vals)))
+        return vals[:ranks.size]
+
+    def v2o_nms(self, thresh, cap=1 << 20):
+        out = np.zeros((cap, 4), np.float64)
+        n, rounds = C.c_int64(), C.c_int32()
+        self.check(self.lib.fpl_v2o_nms(self.h, float(thresh), _ptr(out),
+                                        int(cap), C.byref(n), C.byref(rounds)))
+        return out[:n.value].copy(), rounds.value
+
+    def v2o_smoothed(self, pdims):
+        out = np.empty(tuple(int(d) for d in pdims), np.float32)
+        self.check(self.lib.fpl_v2o_copy_smoothed(self.h, _ptr(out), MEM_HOST))
+        return out
+
+
+class Program:
+    """lowered layer program resident on one GPU (fpl_program)"""
+
+    def __init__(self, ctx, graph, stride=(1, 1, 1)):
+        self.ctx = ctx
+        ops, arena, out_tensor, n_tensors = graph.lower_inference()
+        self.n_arena = arena.size
+        c_ops = (fpl_op * len(ops))()
+        for i, o in enumerate(ops):
+            c_ops[i] = fpl_op(o['kind'], o['src0'], o['src1'], o['dst'], o['k'],
+                              o['cin'], o['cout'], o['act'], o['w_off'],
+                              o['scale_off'], o['shift_off'],
+                              (C.c_int32 * 6)(*[int(v) for v in o['p']]))
+        h = _vp()
+        arena = np.ascontiguousarray(arena, np.float32)
+        ctx.check(ctx.lib.fpl_program_create(
+            ctx.h, c_ops, len(ops), n_tensors, out_tensor, _ptr(arena),
+            arena.size, _arr(stride, C.c_int32), C.byref(h)))
+        self.h = h
+        self.stride = tuple(int(s) for s in stride)
+
+    def set_weights_from(self, graph):
+        _, arena, _, _ = graph.lower_inference()
+        arena = np.ascontiguousarray(arena, np.float32)
+        self.ctx.check(self.ctx.lib.fpl_program_set_arena(
+            self.h, _ptr(arena), arena.size))
+
+    def close(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.lib.fpl_program_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def out_dims(self, in_dims):
+        od = (C.c_int32 * 3)()
+        dummy = np.zeros(1, np.float32)
+        self.ctx.check(self.ctx.lib.fpl_program_forward(
+            self.ctx.h, self.h, _ptr(dummy), MEM_HOST, 1,
+            _arr(in_dims, C.c_int32), PREC_F32, None, MEM_HOST, od))
+        return tuple(od)
+
+    def forward(self, batch, precision=PREC_F32):
+        """batch (n, D, H, W[, 1]) float32 host array -> (n, d, h, w, 1)"""
+        x = np.ascontiguousarray(batch, np.float32)
+        if x.ndim == 5:
+            x = x[..., 0]
+        n, in_dims = x.shape[0], x.shape[1:]
+        od = self.out_dims(in_dims)
+        out = np.empty((n,) + od, np.float32)
+        odc = (C.c_int32 * 3)()
+        self.ctx.check(self.ctx.lib.fpl_program_forward(
+            self.ctx.h, self.h, _ptr(x), MEM_HOST, n, _arr(in_dims, C.c_int32),
+            precision, _ptr(out), MEM_HOST, odc))
+        return out[..., None]
+
+    def infer_volume(self, src, tile_in, offset, mean=0.0, std=1.0,
+                     precision=PREC_F32, z_range=(0, -1), dst=None, dims=None):
+        """src: numpy (Z,Y,X) uint8/float32, or a device tensor/pointer (then
+        `dims` and dtype via `src.dtype`/uint8 are required)"""
+        if isinstance(src, np.ndarray):
+            if src.dtype != np.uint8:
+                src = np.ascontiguousarray(src, np.float32)
+            src = np.ascontiguousarray(src)
+            dims = src.shape
+            dt = U8 if src.dtype == np.uint8 else F32
+        else:
+            dt = U8 if 'uint8' in str(getattr(src, 'dtype', 'uint8')) else F32
+            if dims is None:
+                dims = tuple(src.shape)
+        if dst is None:
+            dst = np.empty(tuple(int(d) for d in dims), np.float32)
+        self.ctx.check(self.ctx.lib.fpl_infer_volume(
+            self.ctx.h, self.h, _ptr(src), dt, _mem_of(src), float(mean),
+            float(std), _arr(dims, C.c_int64), _arr(tile_in, C.c_int32),
+            _arr(offset, C.c_int32), precision, int(z_range[0]),
+            int(z_range[1]), _ptr(dst), _mem_of(dst)))
+        return dst

@@ -1,0 +1,88 @@
+"""Build libfplhip.so for gfx950 (MI355X) with hipcc, in-tree.
+
+    python -m flypylib_amd.csrc.build [--force] [-j N]
+
+Each .hip translation unit is compiled to build/<name>.o (skipped when newer
+than its sources) and linked into flypylib_amd/lib/libfplhip.so.  hipcc
+cross-compiles without a GPU, so this runs in the CPU-only build container.
+"""
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OBJ_DIR = os.path.join(HERE, 'build')
+LIB_DIR = os.path.join(os.path.dirname(HERE), 'lib')
+LIB = os.path.join(LIB_DIR, 'libfplhip.so')
+ARCH = 'gfx950'
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC',
+            '-ffp-contract=on', '-Wall', '-Wno-unused-function',
+            '-Wno-unused-but-set-variable', '-Wno-unused-variable',
+            '-Wno-unused-value', '-Wno-unused-result']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+
+
+def _headers_mtime():
+    hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
+    hs.append(os.path.join(ROOT, 'include', 'fplhip.h'))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force, hdr_m):
+    obj = os.path.join(OBJ_DIR, src[:-4] + '.o')
+    sp = os.path.join(HERE, src)
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_m)):
+        return obj, None
+    cmd = [HIPCC] + CXXFLAGS + ['-c', sp, '-o', obj]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout))
+    return obj, r.stdout
+
+
+def build(force=False, jobs=4, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdr_m = _headers_mtime()
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, hdr_m), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = [s for s, (_, out) in zip(srcs, results) if out is not None]
+    for s, (_, out) in zip(srcs, results):
+        if out and verbose and out.strip():
+            print('[%s]\n%s' % (s, out.strip()))
+    if (rebuilt or not os.path.exists(LIB)
+            or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):
+        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stdout)
+        if verbose:
+            print('linked %s (%d objects, rebuilt: %s)' % (
+                os.path.relpath(LIB, ROOT), len(objs), ', '.join(rebuilt) or '-'))
+    elif verbose:
+        print('%s is up to date' % os.path.relpath(LIB, ROOT))
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('-j', type=int, default=4)
+    a = ap.parse_args()
+    try:
+        build(a.force, a.j)
+    except RuntimeError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)

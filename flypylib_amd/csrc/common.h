@@ -1,0 +1,118 @@
+// Shared host-side plumbing of libfplhip.so: context, error reporting, device
+// buffer cache, per-kernel HIP-event timing.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fplhip.h"
+
+#define FPL_MAX_ERR 1024
+
+struct KernelStat {
+  double ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct PendingTiming {
+  int name_id;
+  hipEvent_t start, stop;
+};
+
+// padded smoothed volume + NMS scratch kept between fpl_v2o_smooth / fpl_v2o_nms
+struct V2oState {
+  float *smoothed = nullptr;   // padded dims
+  size_t cap_bytes = 0;
+  int64_t pdims[3] = {0, 0, 0};
+  int32_t r = 0;
+  bool valid = false;
+};
+
+struct fpl_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  char err[FPL_MAX_ERR] = {0};
+  int n_cu = 0;
+  // size-bucketed cache of device blocks (hipMalloc is slow and synchronising)
+  std::multimap<size_t, void *> free_blocks;
+  std::unordered_map<void *, size_t> live_blocks;
+  size_t cached_bytes = 0;
+  // timing
+  bool timing = false;
+  std::vector<std::string> stat_names;
+  std::unordered_map<std::string, int> stat_index;
+  std::vector<KernelStat> stats;
+  std::vector<PendingTiming> pending;
+  std::vector<hipEvent_t> event_pool;
+  V2oState v2o;
+};
+
+extern thread_local char g_fpl_err[FPL_MAX_ERR];
+
+int fpl_fail(fpl_ctx *ctx, const char *fmt, ...);
+
+#define FPL_HIP(ctx, expr)                                                     \
+  do {                                                                         \
+    hipError_t e__ = (expr);                                                   \
+    if (e__ != hipSuccess)                                                     \
+      return fpl_fail((ctx), "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,     \
+                      hipGetErrorString(e__));                                 \
+  } while (0)
+
+#define FPL_TRY(expr)                                                          \
+  do {                                                                         \
+    int rc__ = (expr);                                                         \
+    if (rc__ != 0) return rc__;                                                \
+  } while (0)
+
+#define FPL_REQUIRE(ctx, cond, ...)                                            \
+  do {                                                                         \
+    if (!(cond)) return fpl_fail((ctx), __VA_ARGS__);                          \
+  } while (0)
+
+// device block cache
+int fpl_dev_alloc(fpl_ctx *ctx, size_t bytes, void **out);
+void fpl_dev_release(fpl_ctx *ctx, void *p);          // back to the cache
+int fpl_dev_trim(fpl_ctx *ctx);                       // hipFree everything cached
+
+// RAII guard for temporaries inside one API call
+struct DevTemp {
+  fpl_ctx *ctx;
+  std::vector<void *> ptrs;
+  explicit DevTemp(fpl_ctx *c) : ctx(c) {}
+  ~DevTemp() {
+    for (void *p : ptrs) fpl_dev_release(ctx, p);
+  }
+  int alloc(size_t bytes, void **out) {
+    int rc = fpl_dev_alloc(ctx, bytes, out);
+    if (rc == 0) ptrs.push_back(*out);
+    return rc;
+  }
+  void release(void *p) {
+    for (size_t i = 0; i < ptrs.size(); ++i)
+      if (ptrs[i] == p) {
+        ptrs.erase(ptrs.begin() + i);
+        fpl_dev_release(ctx, p);
+        return;
+      }
+  }
+};
+
+// timing scope: records start/stop events around a launch when enabled
+struct TimedLaunch {
+  fpl_ctx *ctx;
+  bool on;
+  PendingTiming pt;
+  TimedLaunch(fpl_ctx *c, const char *name);
+  ~TimedLaunch();
+};
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,16 @@
+// Fused whole-slab MFMA fast paths (pattern-matched on the layer program).
+#pragma once
+#include <vector>
+
+#include "program.h"
+
+// Tries to run the slab [zb, ze) of the tile lattice with fused kernels.  Sets
+// *handled = false (and returns 0) when the program / precision has no fast path.
+// `src` / `dst` point at row 0 of the (Z,Y,X) volume on the device.
+int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
+                          int src_dtype, float mean, float sd,
+                          const int64_t dims[3], const int32_t tile_in[3],
+                          const int32_t offset[3], int precision,
+                          const std::vector<int32_t> origins[3],
+                          const int32_t out_sz[3], int32_t zb, int32_t ze,
+                          float *dst, bool *handled);

@@ -1,0 +1,310 @@
+// fpl_program_forward / fpl_infer_volume: the tile -> predict -> stitch lattice of
+// FplNetwork.infer (flypylib/fplnetwork.py:136-189) on the device.
+//
+// Lattice (fplnetwork.py:146-159): out = tile_in - 2*off; tile origins (output
+// coordinates) off, off+out, ... while < dim - off; input window
+// [origin-off, min(origin+out+off, dim)), zero-padded (in the normalised domain)
+// up to tile_in; valid outputs [origin, window_end - off).
+#include "fast_paths.h"
+#include "program.h"
+
+namespace {
+
+struct TileDesc {
+  int32_t start[3];   // input window origin in the volume
+  int32_t ext[3];     // input window extent (<= tile_in)
+};
+
+template <typename T>
+__global__ void gather_tiles(const T *__restrict__ src, int64_t Y, int64_t X,
+                             const TileDesc *__restrict__ tiles, int I0, int I1,
+                             int I2, float mean, float sd, float *__restrict__ out,
+                             int64_t n_total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  int64_t t = i;
+  const int x = (int)(t % I2); t /= I2;
+  const int y = (int)(t % I1); t /= I1;
+  const int z = (int)(t % I0); t /= I0;
+  const TileDesc td = tiles[t];
+  float v = 0.f;
+  if (z < td.ext[0] && y < td.ext[1] && x < td.ext[2]) {
+    const float raw = (float)src[((int64_t)(td.start[0] + z) * Y + td.start[1] + y) * X +
+                                 td.start[2] + x];
+    v = (raw - mean) / sd;
+  }
+  out[i] = v;
+}
+
+// dst[origin + p] = tile_out[p / stride] for p < ext - 2*off (per axis)
+__global__ void stitch_tiles(const float *__restrict__ tile_out, int o0, int o1,
+                             int o2, const TileDesc *__restrict__ tiles, int off0,
+                             int off1, int off2, int s0, int s1, int s2, int F0,
+                             int F1, int F2, float *__restrict__ dst, int64_t Y,
+                             int64_t X, int64_t z_base, int64_t n_total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  int64_t t = i;
+  const int x = (int)(t % F2); t /= F2;
+  const int y = (int)(t % F1); t /= F1;
+  const int z = (int)(t % F0); t /= F0;
+  const TileDesc td = tiles[t];
+  if (z >= td.ext[0] - 2 * off0 || y >= td.ext[1] - 2 * off1 ||
+      x >= td.ext[2] - 2 * off2)
+    return;
+  const float v =
+      tile_out[((t * o0 + z / s0) * o1 + y / s1) * (int64_t)o2 + x / s2];
+  dst[((int64_t)(td.start[0] + off0 + z - z_base) * Y + td.start[1] + off1 + y) * X +
+      td.start[2] + off2 + x] = v;
+}
+
+__global__ void upsample_out(const float *__restrict__ in, float *__restrict__ out,
+                             int64_t n_total, int d, int h, int w, int c, int s0,
+                             int s1, int s2) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  int64_t t = i;
+  const int cc = (int)(t % c); t /= c;
+  const int x = (int)(t % (w * s2)); t /= (w * s2);
+  const int y = (int)(t % (h * s1)); t /= (h * s1);
+  const int z = (int)(t % (d * s0)); t /= (d * s0);
+  out[i] = in[(((t * d + z / s0) * h + y / s1) * (int64_t)w + x / s2) * c + cc];
+}
+
+}  // namespace
+
+extern "C" {
+
+int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
+                        int in_mem, int32_t n, const int32_t in_dims[3],
+                        int precision, float *out, int out_mem,
+                        int32_t out_dims[3]) {
+  if (!ctx || !prog || !in || !in_dims)
+    return fpl_fail(ctx, "fpl_program_forward: NULL argument");
+  FPL_REQUIRE(ctx, n > 0, "fpl_program_forward: batch %d", n);
+  FPL_REQUIRE(ctx, precision == FPL_PREC_F32,
+              "fpl_program_forward: the per-op executor is fp32 only");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<TensorShape> shp;
+  FPL_TRY(fpl_infer_shapes(ctx, prog, in_dims, &shp));
+  const TensorShape o = shp[prog->out_tensor];
+  const int *s = prog->stride;
+  if (out_dims) {
+    out_dims[0] = o.d * s[0]; out_dims[1] = o.h * s[1]; out_dims[2] = o.w * s[2];
+  }
+  if (!out) return 0;  // shape query
+  DevTemp tmp(ctx);
+  const int64_t in_elems = (int64_t)n * in_dims[0] * in_dims[1] * in_dims[2];
+  const float *in_dev = in;
+  if (in_mem == FPL_MEM_HOST) {
+    void *p;
+    FPL_TRY(tmp.alloc(in_elems * sizeof(float), &p));
+    FPL_HIP(ctx, hipMemcpyAsync(p, in, in_elems * sizeof(float),
+                                hipMemcpyHostToDevice, ctx->stream));
+    in_dev = (const float *)p;
+  }
+  const int64_t net_elems = (int64_t)n * o.elems();
+  const int64_t out_elems = net_elems * s[0] * s[1] * s[2];
+  const bool up = s[0] * s[1] * s[2] != 1;
+  float *out_dev = out;
+  if (out_mem == FPL_MEM_HOST) {
+    void *p;
+    FPL_TRY(tmp.alloc(out_elems * sizeof(float), &p));
+    out_dev = (float *)p;
+  }
+  float *net_out = out_dev;
+  if (up) {
+    void *p;
+    FPL_TRY(tmp.alloc(net_elems * sizeof(float), &p));
+    net_out = (float *)p;
+  }
+  FPL_TRY(fpl_forward_generic(ctx, prog, in_dev, n, in_dims, net_out));
+  if (up) {
+    TimedLaunch tl(ctx, "upsample_out");
+    upsample_out<<<(unsigned)ceil_div64(out_elems, 256), 256, 0, ctx->stream>>>(
+        net_out, out_dev, out_elems, o.d, o.h, o.w, o.c, s[0], s[1], s[2]);
+    FPL_HIP(ctx, hipGetLastError());
+  }
+  if (out_mem == FPL_MEM_HOST)
+    FPL_HIP(ctx, hipMemcpyAsync(out, out_dev, out_elems * sizeof(float),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  FPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
+                     int src_dtype, int src_mem, float mean, float sd,
+                     const int64_t dims[3], const int32_t tile_in[3],
+                     const int32_t offset[3], int precision, int32_t z_begin,
+                     int32_t z_end, float *dst, int dst_mem) {
+  if (!ctx || !prog || !src || !dims || !tile_in || !offset || !dst)
+    return fpl_fail(ctx, "fpl_infer_volume: NULL argument");
+  FPL_REQUIRE(ctx, src_dtype == FPL_U8 || src_dtype == FPL_F32,
+              "fpl_infer_volume: src dtype must be u8 or f32");
+  FPL_REQUIRE(ctx, sd != 0.f, "fpl_infer_volume: std is 0");
+  FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || precision == FPL_PREC_BF16,
+              "fpl_infer_volume: unknown precision %d", precision);
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  int32_t out_sz[3];
+  std::vector<int32_t> origins[3];
+  for (int a = 0; a < 3; ++a) {
+    FPL_REQUIRE(ctx, dims[a] > 0 && dims[a] < (int64_t)1 << 31,
+                "fpl_infer_volume: bad dims[%d]=%lld", a, (long long)dims[a]);
+    out_sz[a] = tile_in[a] - 2 * offset[a];
+    FPL_REQUIRE(ctx, out_sz[a] > 0 && offset[a] >= 0,
+                "fpl_infer_volume: tile %d / offset %d", tile_in[a], offset[a]);
+    for (int64_t o = offset[a]; o < dims[a] - offset[a]; o += out_sz[a])
+      origins[a].push_back((int32_t)o);
+  }
+  // network output for one tile must cover tile_in - 2*off after upsampling
+  std::vector<TensorShape> shp;
+  FPL_TRY(fpl_infer_shapes(ctx, prog, tile_in, &shp));
+  const TensorShape o = shp[prog->out_tensor];
+  const int *s = prog->stride;
+  FPL_REQUIRE(ctx, o.c == 1, "fpl_infer_volume: network output has %d channels",
+              o.c);
+  FPL_REQUIRE(ctx, o.d * s[0] == out_sz[0] && o.h * s[1] == out_sz[1] &&
+                       o.w * s[2] == out_sz[2],
+              "network input shape does not match expected infer_sz: tile "
+              "(%d,%d,%d) offset (%d,%d,%d) gives output (%d,%d,%d)*stride, "
+              "expected (%d,%d,%d)", tile_in[0], tile_in[1], tile_in[2],
+              offset[0], offset[1], offset[2], o.d, o.h, o.w, out_sz[0],
+              out_sz[1], out_sz[2]);
+  const int32_t nz = (int32_t)origins[0].size();
+  const int32_t zb = z_begin < 0 ? 0 : z_begin;
+  const int32_t ze = (z_end < 0 || z_end > nz) ? nz : z_end;
+  const int64_t Z = dims[0], Y = dims[1], X = dims[2];
+  const size_t esz = src_dtype == FPL_U8 ? 1 : 4;
+  hipStream_t st = ctx->stream;
+  DevTemp tmp(ctx);
+
+  // rows of the volume this call reads / writes
+  int64_t rd_lo = 0, rd_hi = 0, wr_lo = 0, wr_hi = 0;
+  if (zb < ze) {
+    rd_lo = origins[0][zb] - offset[0];
+    rd_hi = std::min<int64_t>(origins[0][ze - 1] + out_sz[0] + offset[0], Z);
+    wr_lo = origins[0][zb];
+    wr_hi = rd_hi - offset[0];
+  }
+  // the first / last slab also clears the rf_offset border shell
+  if (zb == 0) wr_lo = 0;
+  if (ze == nz) wr_hi = Z;
+  if (zb >= ze && !(zb == 0 && ze == nz)) { wr_lo = wr_hi = 0; }
+
+  // destination rows on the device
+  float *dst_dev = dst;        // indexed from row wr_lo when staged
+  int64_t dst_base = 0;
+  if (dst_mem == FPL_MEM_HOST) {
+    void *p;
+    FPL_TRY(tmp.alloc((size_t)(wr_hi - wr_lo) * Y * X * sizeof(float), &p));
+    dst_dev = (float *)p;
+    dst_base = wr_lo;
+  }
+  if (wr_hi > wr_lo)
+    FPL_HIP(ctx, hipMemsetAsync(dst_dev + (wr_lo - dst_base) * Y * X, 0,
+                                (size_t)(wr_hi - wr_lo) * Y * X * sizeof(float),
+                                st));
+  if (zb >= ze) {
+    if (dst_mem == FPL_MEM_HOST && wr_hi > wr_lo)
+      FPL_HIP(ctx, hipMemcpyAsync(dst + wr_lo * Y * X, dst_dev,
+                                  (size_t)(wr_hi - wr_lo) * Y * X * sizeof(float),
+                                  hipMemcpyDeviceToHost, st));
+    FPL_HIP(ctx, hipStreamSynchronize(st));
+    return 0;
+  }
+
+  // source rows on the device
+  const uint8_t *src_dev = (const uint8_t *)src;   // byte pointer to row 0
+  int64_t src_base = 0;
+  if (src_mem == FPL_MEM_HOST) {
+    void *p;
+    FPL_TRY(tmp.alloc((size_t)(rd_hi - rd_lo) * Y * X * esz, &p));
+    FPL_HIP(ctx, hipMemcpyAsync(p, (const uint8_t *)src + rd_lo * Y * X * esz,
+                                (size_t)(rd_hi - rd_lo) * Y * X * esz,
+                                hipMemcpyHostToDevice, st));
+    src_dev = (const uint8_t *)p;
+    src_base = rd_lo;
+  }
+
+  // fused whole-slab fast paths (vgg_like): no tile batch, no stitch
+  bool handled = false;
+  FPL_TRY(fpl_fast_infer_volume(ctx, prog, src_dev - src_base * Y * X * esz,
+                                src_dtype, mean, sd, dims, tile_in, offset,
+                                precision, origins, out_sz, zb, ze,
+                                dst_dev - dst_base * Y * X, &handled));
+  if (!handled) {
+    FPL_REQUIRE(ctx, precision == FPL_PREC_F32,
+                "fpl_infer_volume: no bf16 kernels for this architecture yet; "
+                "use precision f32");
+    // tile list in the reference's order (z outer, x inner)
+    std::vector<TileDesc> tiles;
+    for (int32_t iz = zb; iz < ze; ++iz)
+      for (size_t iy = 0; iy < origins[1].size(); ++iy)
+        for (size_t ix = 0; ix < origins[2].size(); ++ix) {
+          TileDesc td;
+          const int32_t org[3] = {origins[0][iz], origins[1][iy], origins[2][ix]};
+          for (int a = 0; a < 3; ++a) {
+            td.start[a] = org[a] - offset[a];
+            const int64_t end =
+                std::min<int64_t>((int64_t)org[a] + out_sz[a] + offset[a], dims[a]);
+            td.ext[a] = (int32_t)(end - td.start[a]);
+          }
+          tiles.push_back(td);
+        }
+    const int64_t n_tiles = (int64_t)tiles.size();
+    void *p;
+    FPL_TRY(tmp.alloc(n_tiles * sizeof(TileDesc), &p));
+    TileDesc *tiles_dev = (TileDesc *)p;
+    FPL_HIP(ctx, hipMemcpyAsync(tiles_dev, tiles.data(), n_tiles * sizeof(TileDesc),
+                                hipMemcpyHostToDevice, st));
+    // batch size from an activation budget (fp32 per-op path keeps every live
+    // tensor of the batch in HBM)
+    int64_t per_tile = 0;
+    for (auto &t : shp) per_tile += t.elems() * (int64_t)sizeof(float);
+    const int64_t budget = (int64_t)24 << 30;
+    int64_t B = std::max<int64_t>(1, std::min<int64_t>(n_tiles, budget / std::max<int64_t>(per_tile, 1)));
+    B = std::min<int64_t>(B, 64);
+    const int64_t tile_elems = (int64_t)tile_in[0] * tile_in[1] * tile_in[2];
+    void *in_batch, *out_batch;
+    FPL_TRY(tmp.alloc(B * tile_elems * sizeof(float), &in_batch));
+    FPL_TRY(tmp.alloc(B * o.elems() * sizeof(float), &out_batch));
+    const int64_t fine = (int64_t)out_sz[0] * out_sz[1] * out_sz[2];
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += B) {
+      const int64_t nb = std::min<int64_t>(B, n_tiles - t0);
+      {
+        TimedLaunch tl(ctx, "gather_tiles");
+        const int64_t tot = nb * tile_elems;
+        const unsigned g = (unsigned)ceil_div64(tot, 256);
+        if (src_dtype == FPL_U8)
+          gather_tiles<uint8_t><<<g, 256, 0, st>>>(
+              src_dev - src_base * Y * X, Y, X, tiles_dev + t0, tile_in[0],
+              tile_in[1], tile_in[2], mean, sd, (float *)in_batch, tot);
+        else
+          gather_tiles<float><<<g, 256, 0, st>>>(
+              (const float *)src_dev - src_base * Y * X, Y, X, tiles_dev + t0,
+              tile_in[0], tile_in[1], tile_in[2], mean, sd, (float *)in_batch,
+              tot);
+        FPL_HIP(ctx, hipGetLastError());
+      }
+      FPL_TRY(fpl_forward_generic(ctx, prog, (const float *)in_batch, (int32_t)nb,
+                                  tile_in, (float *)out_batch));
+      {
+        TimedLaunch tl(ctx, "stitch_tiles");
+        const int64_t tot = nb * fine;
+        stitch_tiles<<<(unsigned)ceil_div64(tot, 256), 256, 0, st>>>(
+            (const float *)out_batch, o.d, o.h, o.w, tiles_dev + t0, offset[0],
+            offset[1], offset[2], s[0], s[1], s[2], out_sz[0], out_sz[1],
+            out_sz[2], dst_dev, Y, X, dst_base, tot);
+        FPL_HIP(ctx, hipGetLastError());
+      }
+    }
+  }
+  if (dst_mem == FPL_MEM_HOST)
+    FPL_HIP(ctx, hipMemcpyAsync(dst + wr_lo * Y * X, dst_dev,
+                                (size_t)(wr_hi - wr_lo) * Y * X * sizeof(float),
+                                hipMemcpyDeviceToHost, st));
+  FPL_HIP(ctx, hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,457 @@
+// voxel2obj device stages (flypylib/fplobjdetect.py:158-231): pad, Gaussian
+// smoothing bit-identical to scipy.ndimage.gaussian_filter on float32, margin
+// zeroing, exact order statistics (radix select) for np.percentile, and a
+// round-based parallel form of the greedy radius NMS.
+//
+// Smoothing arithmetic (scipy ni_filters.c, symmetric branch; restated and
+// checked in oracle/voxel2obj_oracle.py::gaussian_filter_restated): per axis
+// 0,1,2: acc = x[0]*w[0]; for j = R..1: acc += (x[-j] + x[+j]) * w[j], all in
+// fp64 with separate multiply and add (no FMA), rounded to fp32 per axis,
+// 'reflect' boundary.
+//
+// NMS: the reference repeatedly takes the arg-max of the live candidates (ties:
+// lowest flat index) and kills every candidate within distance r.  That set is
+// the lexicographically-first maximal independent set in (value desc, index asc)
+// order, so any candidate that beats every live candidate of a region covering
+// its r-ball can be selected in parallel.  Per round: per-cell (4^3) best live
+// key -> separable 15-cell window max (covers >= the ball for r <= 28; window
+// scales with r) -> cells whose best equals the window max are winners -> their
+// balls are cleared.  The global best always wins, so every round progresses.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CELL = 4;
+
+__device__ __forceinline__ int64_t reflect_idx(int64_t i, int64_t n) {
+  const int64_t p = 2 * n;
+  i %= p;
+  if (i < 0) i += p;
+  return i >= n ? p - 1 - i : i;
+}
+
+// virtual zero-padded view of the unpadded prediction
+struct PadView {
+  const float *pred;
+  int64_t D0, D1, D2;
+  int r;
+  __device__ __forceinline__ float at(int64_t z, int64_t y, int64_t x) const {
+    z -= r; y -= r; x -= r;
+    if (z < 0 || y < 0 || x < 0 || z >= D0 || y >= D1 || x >= D2) return 0.f;
+    return pred[(z * D1 + y) * D2 + x];
+  }
+};
+
+// One separable pass.  AXIS 0 reads the virtual padded input; AXIS 2 also
+// zeroes the outer r shell on store.
+template <int AXIS>
+__global__ __launch_bounds__(256) void gauss_pass(
+    PadView pv, const float *__restrict__ in, float *__restrict__ out, int64_t P0,
+    int64_t P1, int64_t P2, const double *__restrict__ w, int wr, int r) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P0 * P1 * P2) return;
+  const int64_t x = i % P2, y = (i / P2) % P1, z = i / (P2 * P1);
+  auto load = [&](int64_t d) -> double {
+    if (AXIS == 0) return (double)pv.at(reflect_idx(z + d, P0), y, x);
+    if (AXIS == 1) return (double)in[(z * P1 + reflect_idx(y + d, P1)) * P2 + x];
+    return (double)in[(z * P1 + y) * P2 + reflect_idx(x + d, P2)];
+  };
+  double acc = __dmul_rn(load(0), w[0]);
+  for (int j = wr; j >= 1; --j)
+    acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(load(-j), load(j)), w[j]));
+  float v = (float)acc;
+  if (AXIS == 2 && r > 0 &&
+      (z < r || y < r || x < r || z >= P0 - r || y >= P1 - r || x >= P2 - r))
+    v = 0.f;
+  out[i] = v;
+}
+
+__device__ __forceinline__ uint32_t float_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// histogram of `bits` key bits at `shift` over the elements whose key matches
+// (key & mask) == want
+__global__ __launch_bounds__(256) void key_histogram(
+    const float *__restrict__ v, int64_t n, uint32_t mask, uint32_t want,
+    int shift, int bits, unsigned long long *__restrict__ hist) {
+  __shared__ unsigned int lh[2048];
+  const int nb = 1 << bits;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += stride) {
+    const uint32_t k = float_key(v[i]);
+    if ((k & mask) == want) atomicAdd(&lh[(k >> shift) & (nb - 1)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += blockDim.x)
+    if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
+// live-key volume on the cell-aligned grid (dims L0,L1,L2 = multiples of CELL)
+__global__ void build_live(const float *__restrict__ s, int64_t P0, int64_t P1,
+                           int64_t P2, int64_t L1, int64_t L2, double thresh,
+                           uint32_t *__restrict__ live, int64_t n_live) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_live) return;
+  const int64_t x = i % L2, y = (i / L2) % L1, z = i / (L2 * L1);
+  uint32_t k = 0;
+  if (z < P0 && y < P1 && x < P2) {
+    const float v = s[(z * P1 + y) * P2 + x];
+    if ((double)v > thresh && v > 0.f) k = __float_as_uint(v);
+  }
+  live[i] = k;
+}
+
+// best live key per 4x4x4 cell: (value bits << 32) | ~flat_index(padded volume)
+__global__ void cell_best(const uint32_t *__restrict__ live, int64_t L1,
+                          int64_t L2, int64_t P1, int64_t P2, int64_t C0,
+                          int64_t C1, int64_t C2,
+                          unsigned long long *__restrict__ best,
+                          unsigned long long *__restrict__ counters) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C0 * C1 * C2) return;
+  const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
+  unsigned long long b = 0;
+#pragma unroll
+  for (int dz = 0; dz < CELL; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < CELL; ++dy) {
+      const int64_t z = cz * CELL + dz, y = cy * CELL + dy;
+      const uint4 q =
+          *reinterpret_cast<const uint4 *>(live + (z * L1 + y) * L2 + cx * CELL);
+      const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int dx = 0; dx < CELL; ++dx)
+        if (v[dx]) {
+          const uint32_t flat = (uint32_t)((z * P1 + y) * P2 + cx * CELL + dx);
+          const unsigned long long k =
+              ((unsigned long long)v[dx] << 32) | (0xFFFFFFFFu - flat);
+          b = k > b ? k : b;
+        }
+    }
+  best[c] = b;
+  if (b) atomicAdd(&counters[0], 1ull);
+}
+
+template <int AXIS>
+__global__ void window_max(const unsigned long long *__restrict__ in,
+                           unsigned long long *__restrict__ out, int64_t C0,
+                           int64_t C1, int64_t C2, int hw) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C0 * C1 * C2) return;
+  const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
+  const int64_t pos = AXIS == 0 ? cz : (AXIS == 1 ? cy : cx);
+  const int64_t n = AXIS == 0 ? C0 : (AXIS == 1 ? C1 : C2);
+  const int64_t stride = AXIS == 0 ? C1 * C2 : (AXIS == 1 ? C2 : 1);
+  const int64_t lo = pos - hw < 0 ? 0 : pos - hw;
+  const int64_t hi = pos + hw >= n ? n - 1 : pos + hw;
+  unsigned long long m = 0;
+  for (int64_t p = lo; p <= hi; ++p) {
+    const unsigned long long v = in[c + (p - pos) * stride];
+    m = v > m ? v : m;
+  }
+  out[c] = m;
+}
+
+// counters: [0] live cells, [1] winners this round, [2] winners total
+__global__ void pick_winners(const unsigned long long *__restrict__ best,
+                             const unsigned long long *__restrict__ wmax,
+                             int64_t n_cells,
+                             unsigned long long *__restrict__ counters,
+                             unsigned long long *__restrict__ round_list,
+                             unsigned long long *__restrict__ all_list,
+                             int64_t cap) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  const unsigned long long b = best[c];
+  if (b == 0 || b != wmax[c]) return;
+  const unsigned long long slot = atomicAdd(&counters[1], 1ull);
+  round_list[slot] = b;             // one winner per cell at most: fits n_cells
+  const unsigned long long g = atomicAdd(&counters[2], 1ull);
+  if ((int64_t)g < cap) all_list[g] = b;
+}
+
+// one block per winner: clear the r-ball in the live volume
+__global__ __launch_bounds__(256) void clear_balls(
+    const unsigned long long *__restrict__ round_list,
+    const unsigned long long *__restrict__ counters, uint32_t *__restrict__ live,
+    int64_t L1, int64_t L2, int64_t P1, int64_t P2, int r) {
+  const unsigned long long nwin = counters[1];
+  for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
+    const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(round_list[wi] & 0xFFFFFFFFu);
+    const int64_t x = flat % P2, y = (flat / P2) % P1, z = flat / (P2 * P1);
+    const int side = 2 * r + 1;
+    const int rows = side * side;
+    for (int row = threadIdx.x / 8; row < rows; row += blockDim.x / 8) {
+      const int dz = row / side - r, dy = row % side - r;
+      const int rem = r * r - dz * dz - dy * dy;
+      if (rem < 0) continue;
+      int hx = (int)sqrtf((float)rem);
+      while ((hx + 1) * (hx + 1) <= rem) ++hx;
+      while (hx * hx > rem) --hx;
+      uint32_t *rowp = live + ((z + dz) * L1 + (y + dy)) * L2 + x;
+      for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0;
+    }
+  }
+}
+
+struct RankQuery {
+  int64_t rank;       // remaining rank inside the current prefix
+  uint32_t prefix;    // key bits fixed so far
+};
+
+}  // namespace
+
+extern "C" {
+
+int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
+                   const int64_t dims[3], int32_t r, const double *weights,
+                   int32_t wr, const int64_t *ranks, int32_t n_ranks,
+                   float *rank_values) {
+  if (!ctx || !pred || !dims || !weights)
+    return fpl_fail(ctx, "fpl_v2o_smooth: NULL argument");
+  FPL_REQUIRE(ctx, r >= 0 && wr >= 0, "fpl_v2o_smooth: negative radius");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  int64_t P[3];
+  for (int a = 0; a < 3; ++a) {
+    FPL_REQUIRE(ctx, dims[a] > 0, "fpl_v2o_smooth: dims[%d] = %lld", a,
+                (long long)dims[a]);
+    P[a] = dims[a] + 2 * (int64_t)r;
+  }
+  const int64_t n_pad = P[0] * P[1] * P[2];
+  FPL_REQUIRE(ctx, n_pad < ((int64_t)1 << 32) - 1,
+              "fpl_v2o_smooth: padded volume has %lld voxels; the NMS keys hold "
+              "32-bit flat indices - process it as substacks (as "
+              "fplobjdetect.full_roi_inference does)", (long long)n_pad);
+  for (int i = 0; i < n_ranks; ++i)
+    FPL_REQUIRE(ctx, ranks[i] >= 0 && ranks[i] < n_pad,
+                "fpl_v2o_smooth: rank %lld out of range", (long long)ranks[i]);
+  hipStream_t st = ctx->stream;
+  DevTemp tmp(ctx);
+  V2oState &S = ctx->v2o;
+  S.valid = false;
+  const size_t vol_bytes = (size_t)n_pad * sizeof(float);
+  if (S.cap_bytes < vol_bytes) {
+    if (S.smoothed) fpl_dev_release(ctx, S.smoothed);
+    S.smoothed = nullptr;
+    S.cap_bytes = 0;
+    void *p;
+    FPL_TRY(fpl_dev_alloc(ctx, vol_bytes, &p));
+    S.smoothed = (float *)p;
+    S.cap_bytes = vol_bytes;
+  }
+  const float *pred_dev = pred;
+  if (pred_mem == FPL_MEM_HOST) {
+    void *p;
+    const size_t nb = (size_t)(dims[0] * dims[1] * dims[2]) * sizeof(float);
+    FPL_TRY(tmp.alloc(nb, &p));
+    FPL_HIP(ctx, hipMemcpyAsync(p, pred, nb, hipMemcpyHostToDevice, st));
+    pred_dev = (const float *)p;
+  }
+  void *p;
+  FPL_TRY(tmp.alloc(vol_bytes, &p));
+  float *scratch = (float *)p;
+  FPL_TRY(tmp.alloc((size_t)(wr + 1) * sizeof(double), &p));
+  double *w_dev = (double *)p;
+  // weights[0..2wr] symmetric; kernel wants w[j] by distance j
+  FPL_HIP(ctx, hipMemcpyAsync(w_dev, weights + wr, (size_t)(wr + 1) * sizeof(double),
+                              hipMemcpyHostToDevice, st));
+  PadView pv{pred_dev, dims[0], dims[1], dims[2], r};
+  const unsigned grid = (unsigned)ceil_div64(n_pad, 256);
+  {
+    TimedLaunch tl(ctx, "v2o_gauss_z");
+    gauss_pass<0><<<grid, 256, 0, st>>>(pv, nullptr, S.smoothed, P[0], P[1], P[2],
+                                        w_dev, wr, r);
+  }
+  {
+    TimedLaunch tl(ctx, "v2o_gauss_y");
+    gauss_pass<1><<<grid, 256, 0, st>>>(pv, S.smoothed, scratch, P[0], P[1], P[2],
+                                        w_dev, wr, r);
+  }
+  {
+    TimedLaunch tl(ctx, "v2o_gauss_x");
+    gauss_pass<2><<<grid, 256, 0, st>>>(pv, scratch, S.smoothed, P[0], P[1], P[2],
+                                        w_dev, wr, r);
+  }
+  FPL_HIP(ctx, hipGetLastError());
+  for (int a = 0; a < 3; ++a) S.pdims[a] = P[a];
+  S.r = r;
+
+  // exact order statistics: 3-level radix select on the monotone float key
+  if (n_ranks > 0) {
+    FPL_REQUIRE(ctx, rank_values, "fpl_v2o_smooth: rank_values is NULL");
+    FPL_TRY(tmp.alloc(2048 * sizeof(unsigned long long), &p));
+    unsigned long long *hist_dev = (unsigned long long *)p;
+    std::vector<unsigned long long> hist(2048);
+    std::vector<RankQuery> q(n_ranks);
+    for (int i = 0; i < n_ranks; ++i) q[i] = RankQuery{ranks[i], 0u};
+    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    uint32_t mask = 0;
+    const unsigned hgrid = (unsigned)std::min<int64_t>(ceil_div64(n_pad, 256 * 8),
+                                                      (int64_t)ctx->n_cu * 16);
+    for (int lvl = 0; lvl < 3; ++lvl) {
+      std::vector<bool> done(n_ranks, false);
+      for (int i = 0; i < n_ranks; ++i) {
+        if (done[i]) continue;
+        FPL_HIP(ctx, hipMemsetAsync(hist_dev, 0, 2048 * sizeof(unsigned long long), st));
+        {
+          TimedLaunch tl(ctx, "v2o_key_histogram");
+          key_histogram<<<hgrid ? hgrid : 1, 256, 0, st>>>(
+              S.smoothed, n_pad, mask, q[i].prefix, shifts[lvl], nbits[lvl],
+              hist_dev);
+        }
+        FPL_HIP(ctx, hipMemcpyAsync(hist.data(), hist_dev,
+                                    2048 * sizeof(unsigned long long),
+                                    hipMemcpyDeviceToHost, st));
+        FPL_HIP(ctx, hipStreamSynchronize(st));
+        const uint32_t pref = q[i].prefix;
+        for (int j = i; j < n_ranks; ++j) {
+          if (done[j] || q[j].prefix != pref) continue;
+          int64_t k = q[j].rank;
+          int b = 0;
+          const int nb = 1 << nbits[lvl];
+          for (; b < nb; ++b) {
+            if (k < (int64_t)hist[b]) break;
+            k -= (int64_t)hist[b];
+          }
+          FPL_REQUIRE(ctx, b < nb, "fpl_v2o_smooth: radix select ran off the "
+                                   "histogram (NaN in the volume?)");
+          q[j].rank = k;
+          q[j].prefix = pref | ((uint32_t)b << shifts[lvl]);
+          done[j] = true;
+        }
+      }
+      mask |= (uint32_t)((1u << nbits[lvl]) - 1) << shifts[lvl];
+    }
+    for (int i = 0; i < n_ranks; ++i) {
+      const uint32_t k = q[i].prefix;
+      const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+      memcpy(&rank_values[i], &u, 4);
+    }
+  }
+  FPL_HIP(ctx, hipStreamSynchronize(st));
+  S.valid = true;
+  return 0;
+}
+
+int fpl_v2o_copy_smoothed(fpl_ctx *ctx, float *dst, int dst_mem) {
+  if (!ctx || !dst) return fpl_fail(ctx, "fpl_v2o_copy_smoothed: NULL argument");
+  FPL_REQUIRE(ctx, ctx->v2o.valid, "fpl_v2o_copy_smoothed: no smoothed volume");
+  const V2oState &S = ctx->v2o;
+  const size_t nb = (size_t)(S.pdims[0] * S.pdims[1] * S.pdims[2]) * sizeof(float);
+  FPL_HIP(ctx, hipMemcpyAsync(dst, S.smoothed, nb,
+                              dst_mem == FPL_MEM_HOST ? hipMemcpyDeviceToHost
+                                                      : hipMemcpyDeviceToDevice,
+                              ctx->stream));
+  FPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
+                int64_t *n_out, int32_t *n_rounds) {
+  if (!ctx || !out_zyxv || !n_out)
+    return fpl_fail(ctx, "fpl_v2o_nms: NULL argument");
+  FPL_REQUIRE(ctx, ctx->v2o.valid,
+              "fpl_v2o_nms: call fpl_v2o_smooth first");
+  FPL_REQUIRE(ctx, cap > 0, "fpl_v2o_nms: cap must be positive");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  const V2oState &S = ctx->v2o;
+  const int64_t P0 = S.pdims[0], P1 = S.pdims[1], P2 = S.pdims[2];
+  const int r = S.r;
+  hipStream_t st = ctx->stream;
+  DevTemp tmp(ctx);
+  const int64_t C0 = ceil_div64(P0, CELL), C1 = ceil_div64(P1, CELL),
+                C2 = ceil_div64(P2, CELL);
+  const int64_t L0 = C0 * CELL, L1 = C1 * CELL, L2 = C2 * CELL;
+  const int64_t n_live = L0 * L1 * L2, n_cells = C0 * C1 * C2;
+  // window half-width in cells: cells [c-hw, c+hw] cover [4c-4hw, 4c+4hw+3]
+  // which must contain [p-r, p+r] for every p in [4c, 4c+3]
+  const int hw = (r + CELL - 1) / CELL;
+  void *p;
+  FPL_TRY(tmp.alloc((size_t)n_live * sizeof(uint32_t), &p));
+  uint32_t *live = (uint32_t *)p;
+  FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
+  unsigned long long *best = (unsigned long long *)p;
+  FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
+  unsigned long long *wa = (unsigned long long *)p;
+  FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
+  unsigned long long *wb = (unsigned long long *)p;
+  FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
+  unsigned long long *round_list = (unsigned long long *)p;
+  FPL_TRY(tmp.alloc((size_t)cap * 8, &p));
+  unsigned long long *all_list = (unsigned long long *)p;
+  FPL_TRY(tmp.alloc(4 * 8, &p));
+  unsigned long long *counters = (unsigned long long *)p;
+  FPL_HIP(ctx, hipMemsetAsync(counters, 0, 4 * 8, st));
+  {
+    TimedLaunch tl(ctx, "v2o_build_live");
+    build_live<<<(unsigned)ceil_div64(n_live, 256), 256, 0, st>>>(
+        S.smoothed, P0, P1, P2, L1, L2, thresh, live, n_live);
+  }
+  const unsigned cgrid = (unsigned)ceil_div64(n_cells, 256);
+  unsigned long long host_cnt[4];
+  int rounds = 0;
+  for (;;) {
+    FPL_HIP(ctx, hipMemsetAsync(counters, 0, 2 * 8, st));   // live cells, round winners
+    {
+      TimedLaunch tl(ctx, "v2o_cell_best");
+      cell_best<<<cgrid, 256, 0, st>>>(live, L1, L2, P1, P2, C0, C1, C2, best,
+                                       counters);
+    }
+    {
+      TimedLaunch tl(ctx, "v2o_window_max");
+      window_max<2><<<cgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw);
+      window_max<1><<<cgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw);
+      window_max<0><<<cgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw);
+    }
+    {
+      TimedLaunch tl(ctx, "v2o_pick_winners");
+      pick_winners<<<cgrid, 256, 0, st>>>(best, wa, n_cells, counters, round_list,
+                                          all_list, cap);
+    }
+    {
+      TimedLaunch tl(ctx, "v2o_clear_balls");
+      clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, L1, L2, P1, P2,
+                                        r);
+    }
+    FPL_HIP(ctx, hipGetLastError());
+    FPL_HIP(ctx, hipMemcpyAsync(host_cnt, counters, 4 * 8, hipMemcpyDeviceToHost, st));
+    FPL_HIP(ctx, hipStreamSynchronize(st));
+    if (host_cnt[0] == 0) break;
+    ++rounds;
+    FPL_REQUIRE(ctx, host_cnt[1] > 0,
+                "fpl_v2o_nms: round %d made no progress (internal error)", rounds);
+    FPL_REQUIRE(ctx, (int64_t)host_cnt[2] <= cap,
+                "fpl_v2o_nms: more than %lld detections; raise cap",
+                (long long)cap);
+  }
+  const int64_t n = (int64_t)host_cnt[2];
+  std::vector<unsigned long long> keys((size_t)n);
+  if (n)
+    FPL_HIP(ctx, hipMemcpy(keys.data(), all_list, (size_t)n * 8,
+                           hipMemcpyDeviceToHost));
+  // key order descending = (value desc, flat index asc)
+  std::sort(keys.begin(), keys.end(),
+            [](unsigned long long a, unsigned long long b) { return a > b; });
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(keys[i] & 0xFFFFFFFFu);
+    const uint32_t vb = (uint32_t)(keys[i] >> 32);
+    float v;
+    memcpy(&v, &vb, 4);
+    out_zyxv[4 * i + 0] = (double)(flat / (P2 * P1));
+    out_zyxv[4 * i + 1] = (double)((flat / P2) % P1);
+    out_zyxv[4 * i + 2] = (double)(flat % P2);
+    out_zyxv[4 * i + 3] = (double)v;
+  }
+  *n_out = n;
+  if (n_rounds) *n_rounds = rounds;
+  return 0;
+}
+
+}  // extern "C"

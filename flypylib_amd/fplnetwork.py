@@ -1,0 +1,191 @@
+"""`FplNetwork`: the reference's network wrapper (`flypylib/fplnetwork.py:46-220`)
+on the MI355X engine.
+
+Same surface: `FplNetwork(model)`, attributes `rf_size / rf_offset / rf_stride /
+infer_sz / n_gpu / compile_args / train_network / train_single / infer_network`,
+methods `train`, `make_train_parallel`, `make_infer_parallel`, `infer`,
+`save_network`, module function `load_network`.  `model` is a factory from
+`fplmodels` returning `(LayerGraph, rf_info, infer_sz, compile_args)`.
+
+Inference runs entirely in libfplhip.so (`fpl_infer_volume`): tile lattice, edge
+zero-padding, forward, upsample and stitch happen on the device; there is no CPU
+fallback.
+"""
+import pickle
+
+import numpy as np
+
+from . import _capi, fplutils, multi_gpu, runtime
+
+_PRECISIONS = {'f32': _capi.PREC_F32, 'fp32': _capi.PREC_F32,
+               'float32': _capi.PREC_F32, 'bf16': _capi.PREC_BF16}
+
+
+class InferNetwork:
+    """what `FplNetwork.infer_network` holds: the fixed-size inference program
+    (+ UpSampling3D(rf_stride)), resident on one GPU"""
+
+    def __init__(self, graph, stride, device):
+        self.graph = graph
+        self.stride = stride
+        self.device = device
+        self.program = _capi.Program(runtime.get_context(device), graph, stride)
+
+    @property
+    def input_shape(self):
+        return self.graph.input_shape
+
+    def set_weights(self, weights):
+        self.graph.set_weights(weights)
+        self.program.set_weights_from(self.graph)
+
+    def get_weights(self):
+        return self.graph.get_weights()
+
+    def predict(self, data_batch, batch_size=1):
+        """(n, I,I,I, 1) -> (n, O,O,O, 1) float32 (Keras `Model.predict` shape
+        contract, fplnetwork.py:175-176); batch_size is irrelevant here"""
+        return self.program.forward(np.asarray(data_batch, np.float32))
+
+
+def load_network(filepath, device=None):
+    """inverse of `FplNetwork.save_network` (reference fplnetwork.py:32-44)"""
+    with open(filepath, 'rb') as fn:
+        network = pickle.load(fn)
+    network._device = runtime.default_device() if device is None else device
+    network.train_single, _, _, _ = network.model()
+    network.train_single.load(filepath + '.weights.npz')
+    network.train_single.compile(**network.compile_args)
+    network.train_network = network.train_single
+    network._parallel = None
+    network._set_infer()
+    return network
+
+
+class FplNetwork:
+    """3D-CNN voxel classifier: training by generator, full-volume inference"""
+
+    def __init__(self, model, device=None, precision='f32'):
+        self.model = model
+        self.train_network, rf_info, infer_sz, compile_args = self.model()
+        self.train_network.summary()
+        self.train_single = self.train_network
+
+        self.rf_size = tuple(fplutils.to3d(rf_info[0]))
+        self.rf_offset = tuple(fplutils.to3d(rf_info[1]))
+        self.rf_stride = tuple(fplutils.to3d(rf_info[2]))
+
+        self.infer_network = None
+        self.n_gpu = 1
+        self.infer_sz = tuple(fplutils.to3d(infer_sz))
+
+        if compile_args is None:
+            compile_args = {'loss': 'binary_crossentropy',
+                            'optimizer': 'adam',
+                            'metrics': ['accuracy']}
+        self.train_network.compile(**compile_args)
+        self.compile_args = compile_args
+
+        self.precision = precision
+        self._device = runtime.default_device() if device is None else device
+        self._parallel = None
+
+    # ---- persistence (reference :81-97; Keras .h5 replaced by .npz) -----------
+    def save_network(self, filepath):
+        self.train_single.save(filepath + '.weights.npz')
+        keep = (self.train_single, self.train_network, self.infer_network,
+                self._parallel)
+        self.train_single = self.train_network = self.infer_network = None
+        self._parallel = None
+        try:
+            with open(filepath, 'wb') as fn:
+                pickle.dump(self, fn)
+        finally:
+            (self.train_single, self.train_network, self.infer_network,
+             self._parallel) = keep
+
+    # ---- inference network (reference :99-110) --------------------------------
+    def _build_infer(self, device):
+        graph, _, _, _ = self.model(self.infer_sz)
+        graph.set_weights(self.train_single.get_weights())
+        return InferNetwork(graph, self.rf_stride, device)
+
+    def _set_infer(self):
+        self.infer_network = self._build_infer(self._device)
+        if self._parallel is not None:
+            self.make_infer_parallel(self.n_gpu)
+
+    def make_infer_parallel(self, n_gpu):
+        """reference :130-134; tiles are sharded as Z slabs, one per GPU"""
+        if self.infer_network is None:
+            self.infer_network = self._build_infer(self._device)
+        nets = [self.infer_network if d == self._device else
+                self._build_infer(d) for d in range(n_gpu)]
+        self._parallel_nets = nets
+        self._parallel = multi_gpu.make_parallel(
+            lambda d: nets[d].program, n_gpu)
+        self.n_gpu = n_gpu
+
+    def make_train_parallel(self, n_gpu, batch_size, input_shape):
+        """reference :124-128.  Data-parallel training runs one process per GPU
+        (RCCL gradient all-reduce); see flypylib_amd/train.py"""
+        from . import train
+        self.train_network = train.make_parallel(
+            self.train_single, n_gpu, batch_size,
+            list(fplutils.to3d(input_shape)) + [1])
+        self.train_network.compile(**self.compile_args)
+
+    def train(self, generator, steps_per_epoch, epochs, log_file,
+              save_filepath):
+        """reference :112-122: fit from a batch generator, CSV log, per-epoch
+        checkpoint '<save_filepath>_%03d', then rebuild the inference net"""
+        from . import train
+        train.fit_generator(self, generator, steps_per_epoch, epochs, log_file,
+                            save_filepath)
+        self._set_infer()
+
+    # ---- full-volume inference (reference :136-189) -----------------------------
+    def infer(self, image, normalize=None, precision=None):
+        """image: (Z,Y,X) array (already normalised float, as in the reference)
+        or uint8 with `normalize=(mean, std)`; or an h5 path with dataset /main.
+        Returns float32 predictions of the same shape; the rf_offset border
+        shell is zero."""
+        if isinstance(image, str):
+            try:
+                import h5py
+            except ImportError:
+                raise ImportError('reading %r needs h5py, which is not '
+                                  'installed; pass an array' % image)
+            with h5py.File(image, 'r') as f:
+                image = f['/main'][:]
+
+        assert self.infer_network is not None, \
+            'network has not been trained'
+        assert self.infer_network.input_shape[1:-1] == self.infer_sz, \
+            'network input shape does not match expected infer_sz'
+
+        image = np.asarray(image)
+        assert image.ndim == 3, 'image must be (Z,Y,X)'
+        mean, std = (0.0, 1.0) if normalize is None else normalize
+        if image.dtype != np.uint8:
+            image = np.ascontiguousarray(image, dtype=np.float32)
+        prec = _PRECISIONS[precision or self.precision]
+        kw = dict(mean=mean, std=std, precision=prec)
+        if self._parallel is not None and self.n_gpu > 1:
+            return self._parallel.infer_volume(image, self.infer_sz,
+                                               self.rf_offset, **kw)
+        return self.infer_network.program.infer_volume(
+            image, self.infer_sz, self.rf_offset, **kw)
+
+    def voxel_loss(self, image, lm_prefix, l0_thresh=None, l1_thresh=None):
+        raise NotImplementedError(
+            'voxel_loss (reference fplnetwork.py:191-220) is a SURVEY 8f '
+            'follow-on; it needs the h5 label/mask files')
+
+    # pickling: device handles never travel
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        for k in ('train_single', 'train_network', 'infer_network', '_parallel',
+                  '_parallel_nets'):
+            d[k] = None
+        return d

@@ -1,0 +1,163 @@
+/*
+ * fplhip.h - C ABI of libfplhip.so: the MI355X (gfx950) engine behind
+ * flypylib's T-bar detection hot path.
+ *
+ * The reference (janelia-flyem/flypylib) is pure Python on Keras/TensorFlow and
+ * has no FFI of its own; its boundary for this path is the Python API.  Each
+ * entry point below names the reference interface it stands in for
+ * (paths relative to the reference repository).  Host bindings: ctypes, see
+ * flypylib_amd/_capi.py and INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from fpl_last_error(ctx) (ctx may be NULL for create failures).
+ *   - no exceptions / abort across the boundary.
+ *   - host buffers are caller-owned, C-contiguous.  Pointers tagged
+ *     `mem = FPL_MEM_DEVICE` are device pointers of the same HIP device/primary
+ *     context (e.g. a torch tensor's data_ptr()).
+ *   - library-owned device memory is freed by the matching *_destroy.
+ *   - one context per GPU per process; a context is used by one host thread at
+ *     a time; create contexts after fork() (HIP state does not survive fork).
+ *   - volumes are (Z, Y, X) with X fastest, as numpy C-order arrays.
+ */
+#ifndef FPLHIP_H
+#define FPLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPL_ABI_VERSION 1
+
+typedef struct fpl_ctx fpl_ctx;
+typedef struct fpl_program fpl_program;
+
+enum fpl_mem { FPL_MEM_HOST = 0, FPL_MEM_DEVICE = 1 };
+enum fpl_dtype { FPL_U8 = 0, FPL_F32 = 1, FPL_F64 = 2 };
+enum fpl_precision { FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1 };
+
+/* fused layer-program ops, produced by LayerGraph.lower_inference()
+ * (flypylib_amd/program.py); layer semantics = Keras layers instantiated in
+ * flypylib/fplmodels.py:67-526 */
+enum fpl_op_kind {
+  FPL_OP_CONV = 0,   /* y = act(scale * conv3d_valid(x, W) + shift)          */
+  FPL_OP_POOL = 1,   /* MaxPooling3D(p0)                                     */
+  FPL_OP_UP = 2,     /* UpSampling3D((p0,p1,p2)) nearest                     */
+  FPL_OP_CROP = 3,   /* Cropping3D(((p0,p1),(p2,p3),(p4,p5)))                */
+  FPL_OP_CONCAT = 4, /* concatenate([src0, src1]) on channels                */
+  FPL_OP_ADD = 5     /* act(src0 + src1)                                     */
+};
+enum fpl_act { FPL_ACT_NONE = 0, FPL_ACT_RELU = 1, FPL_ACT_SIGMOID = 2 };
+
+typedef struct fpl_op {
+  int32_t kind;      /* fpl_op_kind                                          */
+  int32_t src0, src1;/* tensor ids (0 = network input); src1 = -1 if unused  */
+  int32_t dst;       /* tensor id produced                                   */
+  int32_t k;         /* conv kernel edge (1 or 3)                            */
+  int32_t cin, cout; /* channels in / out                                    */
+  int32_t act;       /* fpl_act                                              */
+  int64_t w_off;     /* offsets (floats) into the weight arena:              */
+  int64_t scale_off; /*   kernel [k^3*cin][cout] (Keras memory order),       */
+  int64_t shift_off; /*   scale[cout], shift[cout]                           */
+  int32_t p[6];      /* pool/up factors or crop pairs                        */
+} fpl_op;
+
+/* ---- context -------------------------------------------------------------- */
+int fpl_abi_version(void);
+/* replaces: the implicit TF session/device placement of multi_gpu.make_parallel
+ * (flypylib/multi_gpu.py:33-35); one context binds one GPU */
+int fpl_ctx_create(int device_id, fpl_ctx **out);
+int fpl_ctx_destroy(fpl_ctx *ctx);
+const char *fpl_last_error(fpl_ctx *ctx);
+/* run all subsequent work of this context on `hip_stream` (hipStream_t; NULL =
+ * the context's own stream) */
+int fpl_ctx_set_stream(fpl_ctx *ctx, void *hip_stream);
+int fpl_ctx_synchronize(fpl_ctx *ctx);
+int fpl_device_info(fpl_ctx *ctx, int32_t *n_cu, int64_t *hbm_bytes,
+                    char *name, size_t name_cap);
+
+/* ---- device buffers (thin; for callers without torch) ---------------------- */
+int fpl_malloc(fpl_ctx *ctx, size_t bytes, void **dev_ptr);
+int fpl_free(fpl_ctx *ctx, void *dev_ptr);
+int fpl_memcpy(fpl_ctx *ctx, void *dst, int dst_mem, const void *src,
+               int src_mem, size_t bytes);
+
+/* ---- layer program --------------------------------------------------------- */
+/* replaces: FplNetwork._set_infer (flypylib/fplnetwork.py:99-110): build the
+ * inference network and load the weights.  `stride[3]` is rf_stride: the final
+ * UpSampling3D(rf_stride) is applied on store when != 1. */
+int fpl_program_create(fpl_ctx *ctx, const fpl_op *ops, int32_t n_ops,
+                       int32_t n_tensors, int32_t out_tensor,
+                       const float *arena, int64_t n_arena,
+                       const int32_t stride[3], fpl_program **out);
+int fpl_program_destroy(fpl_program *prog);
+/* replaces: Model.set_weights (fplnetwork.py:109-110) for a lowered arena */
+int fpl_program_set_arena(fpl_program *prog, const float *arena,
+                          int64_t n_arena);
+
+/* replaces: infer_network.predict(data_batch) (fplnetwork.py:175-176) for a
+ * batch of equally-sized tiles: in (n, D,H,W) f32 -> out (n, d,h,w) f32, where
+ * (d,h,w) is the network output size for input (D,H,W) (times stride).  Generic
+ * per-op kernels, fp32: the parity path for every architecture. */
+int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
+                        int in_mem, int32_t n, const int32_t in_dims[3],
+                        int precision, float *out, int out_mem,
+                        int32_t out_dims[3]);
+
+/* replaces: FplNetwork.infer (fplnetwork.py:136-189): tile lattice, zero-padded
+ * edge tiles, predict, stitch; the rf_offset border shell of `dst` is zero.
+ *   src        (Z,Y,X) volume, dtype u8 or f32; normalised on load as
+ *              (v - mean) / std   (pass mean=0,std=1 for pre-normalised input)
+ *   tile_in    input tile edge per axis (reference: infer_sz, e.g. 102 / 100);
+ *              tiles advance by tile_in - 2*offset exactly as fplnetwork.py:149-159
+ *   z_begin/z_end  restrict the work to tile rows [z_begin, z_end) of the tile
+ *              lattice along Z (slab sharding across GPUs; 0, -1 = all)
+ *   dst        (Z,Y,X) f32, same shape as src */
+int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
+                     int src_dtype, int src_mem, float mean, float std,
+                     const int64_t dims[3], const int32_t tile_in[3],
+                     const int32_t offset[3], int precision,
+                     int32_t z_begin, int32_t z_end, float *dst, int dst_mem);
+
+/* ---- post-process ----------------------------------------------------------- */
+/* replaces: fplobjdetect.voxel2obj device stages (flypylib/fplobjdetect.py:
+ * 158-231): pad by r, Gaussian smooth (weights = scipy's float64 kernel, radius
+ * `wr`, passed by the host), zero the r-shell, exact order statistics for the
+ * percentile, threshold, radius NMS.  Host epilogue (:233-257) stays in Python.
+ *
+ * Step 1: smooth; returns the k-th smallest values (0-based ranks, ascending) of
+ * the padded smoothed volume for `n_ranks` requested ranks. */
+int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
+                   const int64_t dims[3], int32_t r, const double *weights,
+                   int32_t wr, const int64_t *ranks, int32_t n_ranks,
+                   float *rank_values);
+/* Step 2: NMS over voxels with (double)value > thresh (and > 0) of the volume prepared
+ * by step 1.  out_zyxv: rows (z, y, x in padded coordinates, value) as f64,
+ * sorted by (value desc, flat index asc) = the reference's emission order.
+ * Returns the number of detections in *n_out (<= cap, else error). */
+int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
+                int64_t *n_out, int32_t *n_rounds);
+/* smoothed padded volume of the last fpl_v2o_smooth call (tests) */
+int fpl_v2o_copy_smoothed(fpl_ctx *ctx, float *dst, int dst_mem);
+
+/* ---- synthetic data (bench / tests) -------------------- */
+/* EM-like uint8 volume from a counter-based hash; bit-identical to
+ * flypylib_amd.synth.em_volume_u8 on the host */
+int fpl_synth_volume_u8(fpl_ctx *ctx, uint64_t seed, const int64_t dims[3],
+                        const int64_t origin[3], uint8_t *dst, int dst_mem);
+
+/* ---- timing ------------------------------------------------------------------ */
+/* per-kernel accumulated HIP-event time since the last reset.  Names are
+ * NUL-terminated, up to `cap` entries of 64 bytes each. */
+int fpl_timing_enable(fpl_ctx *ctx, int on);
+int fpl_timing_reset(fpl_ctx *ctx);
+int fpl_timing_get(fpl_ctx *ctx, char *names, double *ms, int64_t *launches,
+                   int32_t cap, int32_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPLHIP_H */

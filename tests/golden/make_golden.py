@@ -1,0 +1,157 @@
+"""Regenerate tests/golden/*.npz from the REFERENCE's own code.
+
+Dev-time tool for the build container only (needs /root/reference; the GPU box
+never runs this).  Fixtures hold data only: case parameters, seeds of the
+deterministic input generators in flypylib_amd/synth.py, and the reference's
+outputs (point lists, checksums, small arrays).
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from _ref_import import import_reference  # noqa: E402
+from flypylib_amd import synth  # noqa: E402
+
+fplutils, fplobjdetect, fplnetwork = import_reference()
+
+# (name, generator, seed, shape, r, sigma, thd, buffer, offset)
+V2O_CASES = [
+    ('uniform_small', 'uniform', 11, (40, 44, 48), 7, 2.0, 0, 0, (0, 0, 0)),
+    ('uniform_buf3', 'uniform', 12, (30, 50, 41), 9, 1.5, 0.1, (3, 4, 5), (1, 2, 3)),
+    ('uniform_thd', 'uniform', 13, (64, 64, 64), 5, 5.0, 0.5, 5, (10, 20, 30)),
+    ('reflect_r3_s5', 'uniform', 14, (33, 20, 25), 3, 5.0, 0, 2, (0, 0, 0)),
+    ('blobs_r9', 'blobs', 21, (72, 80, 96), 9, 2.0, 0.1, 5, (100, 200, 300)),
+    ('blobs_r27_s5', 'blobs', 22, (96, 96, 96), 27, 5.0, 0, 0, (0, 0, 0)),
+    ('blobs_noncubic', 'blobs', 23, (50, 120, 70), 12, 3.0, 0.3, (2, 0, 7), (5, 6, 7)),
+    ('plateau_ties', 'plateau', 31, (48, 48, 48), 7, 1.5, 0, 0, (0, 0, 0)),
+    ('all_zero', 'zeros', 0, (20, 22, 24), 5, 2.0, 0, 0, (0, 0, 0)),
+    ('thd_above_all', 'uniform', 15, (24, 24, 24), 4, 2.0, 2.0, 0, (0, 0, 0)),
+]
+
+
+def make_pred(kind, seed, shape):
+    if kind == 'uniform':
+        return synth.hash_uniform_f32(seed, shape)
+    if kind == 'blobs':
+        return synth.blob_prob_volume(seed, shape)
+    if kind == 'zeros':
+        return np.zeros(shape, np.float32)
+    if kind == 'plateau':
+        # exact ties: identical flat-topped cubes on a lattice -> argmax ties
+        v = np.zeros(shape, np.float32)
+        for z in range(8, shape[0] - 8, 16):
+            for y in range(8, shape[1] - 8, 16):
+                for x in range(8, shape[2] - 8, 16):
+                    v[z:z + 4, y:y + 4, x:x + 4] = 0.75
+        return v
+    raise ValueError(kind)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_set_filter():
+    out = {}
+    for r in (1, 3, 7, 27):
+        f = fplutils.set_filter(r)
+        out['r%d_count' % r] = np.int64(f.sum())
+        out['r%d_sha' % r] = np.array(sha(f.astype(np.uint8)))
+        if r <= 3:
+            out['r%d_mask' % r] = f
+    np.savez_compressed(os.path.join(HERE, 'set_filter.npz'), **out)
+
+
+def gen_voxel2obj():
+    from scipy import ndimage
+    out = {'names': np.array([c[0] for c in V2O_CASES])}
+    for name, kind, seed, shape, r, sigma, thd, buf, off in V2O_CASES:
+        pred = make_pred(kind, seed, shape)
+        res = fplobjdetect.voxel2obj(pred.copy(), r, sigma, off, buf, thd)
+        out[name + '_kind'] = np.array(kind)
+        out[name + '_params'] = np.array(
+            [seed, shape[0], shape[1], shape[2], r], np.int64)
+        out[name + '_sigma_thd'] = np.array([sigma, thd], np.float64)
+        out[name + '_buffer'] = np.array(fplutils.to3d(buf), np.int64)
+        out[name + '_offset'] = np.array(off, np.int64)
+        out[name + '_locs'] = res['locs']
+        out[name + '_conf'] = res['conf']
+        out[name + '_pred_sha'] = np.array(sha(pred))
+        # intermediate pins: smoothed padded volume checksum + threshold
+        sm = ndimage.gaussian_filter(np.pad(pred, r, 'constant'), sigma,
+                                     truncate=2.0)
+        sm[:r] = 0; sm[-r:] = 0; sm[:, :r] = 0; sm[:, -r:] = 0
+        sm[:, :, :r] = 0; sm[:, :, -r:] = 0
+        out[name + '_smooth_sha'] = np.array(sha(sm))
+        out[name + '_pct97'] = np.array(np.percentile(sm, 97))
+        print('%-16s %4d detections' % (name, len(res['conf'])))
+    np.savez_compressed(os.path.join(HERE, 'voxel2obj.npz'), **out)
+
+
+class _FakeNet:
+    """crop-identity stand-in for the Keras inference network"""
+
+    def __init__(self, infer_sz, off, fn):
+        self.input_shape = (None,) + tuple(infer_sz) + (1,)
+        self.off, self.fn = off, fn
+
+    def predict(self, x, batch_size=1):
+        return self.fn(x, self.off)
+
+
+def _crop_identity(x, off):
+    # upsampled full-resolution output of the valid region: out = in cropped
+    return x[:, off[0]:x.shape[1] - off[0], off[1]:x.shape[2] - off[1],
+             off[2]:x.shape[3] - off[2], :].astype(np.float32)
+
+
+def _coarse4(x, off):
+    # stride-4 net stand-in: value of the voxel at the coarse cell's origin
+    c = x[:, off[0]:x.shape[1] - off[0], off[1]:x.shape[2] - off[1],
+          off[2]:x.shape[3] - off[2], :]
+    c = c[:, ::4, ::4, ::4, :]
+    for ax in (1, 2, 3):
+        c = np.repeat(c, 4, axis=ax)
+    return c.astype(np.float32)
+
+
+def gen_infer():
+    cases = [
+        ('crop_50_47_41', 41, (50, 47, 41), (30, 30, 30), (7, 7, 7), _crop_identity, 1),
+        ('crop_n_gpu3', 42, (64, 33, 40), (30, 30, 30), (7, 7, 7), _crop_identity, 3),
+        ('coarse4_61', 43, (61, 58, 47), (30, 30, 30), (7, 7, 7), _coarse4, 1),
+        ('unet_lattice', 44, (70, 45, 52), (28, 28, 28), (9, 9, 9), _crop_identity, 2),
+        ('exact_multiple', 45, (46, 46, 46), (30, 30, 30), (7, 7, 7), _crop_identity, 1),
+    ]
+    out = {'names': np.array([c[0] for c in cases])}
+    for name, seed, shape, isz, off, fn, n_gpu in cases:
+        img = synth.hash_uniform_f32(seed, shape)
+        net = fplnetwork.FplNetwork.__new__(fplnetwork.FplNetwork)
+        net.infer_network = _FakeNet(isz, off, fn)
+        net.infer_sz, net.rf_offset, net.n_gpu = isz, off, n_gpu
+        pred = net.infer(img)
+        out[name + '_shape'] = np.array(shape, np.int64)
+        out[name + '_isz'] = np.array(isz, np.int64)
+        out[name + '_off'] = np.array(off, np.int64)
+        out[name + '_n_gpu'] = np.int64(n_gpu)
+        out[name + '_fn'] = np.array(fn.__name__)
+        out[name + '_seed'] = np.int64(seed)
+        out[name + '_pred_sha'] = np.array(sha(pred))
+        out[name + '_pred_sample'] = pred[::7, ::5, ::3].copy()
+        print('%-16s pred sum %.4f' % (name, pred.sum()))
+    np.savez_compressed(os.path.join(HERE, 'infer_lattice.npz'), **out)
+
+
+if __name__ == '__main__':
+    gen_set_filter()
+    gen_voxel2obj()
+    gen_infer()
+    print('golden fixtures written to', HERE)

@@ -1,0 +1,62 @@
+"""shared test helpers: golden-case input generators (same as make_golden.py)"""
+import hashlib
+
+import numpy as np
+
+from flypylib_amd import synth
+
+
+def make_pred(kind, seed, shape):
+    if kind == 'uniform':
+        return synth.hash_uniform_f32(seed, shape)
+    if kind == 'blobs':
+        return synth.blob_prob_volume(seed, shape)
+    if kind == 'zeros':
+        return np.zeros(shape, np.float32)
+    if kind == 'plateau':
+        v = np.zeros(shape, np.float32)
+        for z in range(8, shape[0] - 8, 16):
+            for y in range(8, shape[1] - 8, 16):
+                for x in range(8, shape[2] - 8, 16):
+                    v[z:z + 4, y:y + 4, x:x + 4] = 0.75
+        return v
+    raise ValueError(kind)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def v2o_cases(g):
+    """yield dicts for every case of tests/golden/voxel2obj.npz"""
+    for name in [str(n) for n in g['names']]:
+        p = g[name + '_params']
+        st = g[name + '_sigma_thd']
+        thd = float(st[1])
+        yield dict(name=name, kind=str(g[name + '_kind']), seed=int(p[0]),
+                   shape=tuple(int(v) for v in p[1:4]), r=int(p[4]),
+                   sigma=float(st[0]),
+                   thd=int(thd) if thd == int(thd) else thd,
+                   buffer=tuple(int(v) for v in g[name + '_buffer']),
+                   offset=tuple(int(v) for v in g[name + '_offset']),
+                   locs=g[name + '_locs'], conf=g[name + '_conf'],
+                   pred_sha=str(g[name + '_pred_sha']),
+                   smooth_sha=str(g[name + '_smooth_sha']),
+                   pct97=g[name + '_pct97'])
+
+
+def crop_identity(x, off):
+    return x[:, off[0]:x.shape[1] - off[0], off[1]:x.shape[2] - off[1],
+             off[2]:x.shape[3] - off[2], :].astype(np.float32)
+
+
+def coarse4(x, off):
+    c = x[:, off[0]:x.shape[1] - off[0], off[1]:x.shape[2] - off[1],
+          off[2]:x.shape[3] - off[2], :]
+    c = c[:, ::4, ::4, ::4, :]
+    for ax in (1, 2, 3):
+        c = np.repeat(c, 4, axis=ax)
+    return c.astype(np.float32)
+
+
+FAKE_NETS = {'_crop_identity': crop_identity, '_coarse4': coarse4}

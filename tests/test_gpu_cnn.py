@@ -1,0 +1,206 @@
+"""GPU parity: the HIP inference path (through the C ABI) against the CPU oracle
+on the same seeded inputs.  Tolerance for the fp32 path: 1e-3 on probabilities
+(BASELINE north star); observed errors are ~1e-6."""
+import numpy as np
+import pytest
+
+from flypylib_amd import FplNetwork, _capi, fplmodels, synth
+from flypylib_amd.program import LayerGraph
+from oracle import cnn_oracle, infer_oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _prog(ctx, graph, stride=(1, 1, 1)):
+    return _capi.Program(ctx, graph, stride)
+
+
+def test_device_is_gfx950(ctx):
+    info = ctx.device_info()
+    assert 'gfx950' in info['name'] and info['n_cu'] >= 200
+
+
+def test_synth_volume_device_matches_host(ctx):
+    dims, org = (37, 70, 129), (5, 60, 1000)
+    dev = ctx.synth_volume_u8(99, dims, org)
+    assert np.array_equal(dev, synth.em_volume_u8(99, dims, org))
+
+
+@pytest.mark.parametrize('k,cin,cout,act', [
+    (3, 1, 48, 'relu'), (1, 48, 48, 'relu'), (3, 48, 48, 'relu'),
+    (1, 48, 96, 'relu'), (1, 96, 1, 'sigmoid'), (3, 32, 64, None),
+    (3, 5, 7, 'relu')])
+def test_single_conv_layer(ctx, k, cin, cout, act):
+    rng = np.random.default_rng(k * 100 + cin)
+    g = LayerGraph(10 if k == 3 else 6, seed=cin)
+    x = g.input()
+    if cin != 1:
+        x = g.conv(x, cin, 1)                 # lift to cin channels
+    y = g.conv(x, cout, k, use_bias=(act == 'sigmoid'), activation=act
+               if act == 'sigmoid' else None)
+    if act == 'relu':
+        y = g.bn_relu(y)
+    g.finish(y)
+    g.randomize_bn(cout)
+    sz = g.in_sz[0]
+    inp = rng.standard_normal((3, sz, sz, sz, 1)).astype(np.float32)
+    got = _prog(ctx, g).forward(inp)
+    ref = cnn_oracle.graph_forward(g, inp)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) < 1e-4
+
+
+def test_vgg_like_tile_forward(ctx):
+    g = fplmodels.vgg_like(30)[0]
+    synth.synthetic_weights(g, 5)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 30, 30, 30, 1)).astype(np.float32)
+    got = _prog(ctx, g, (4, 4, 4)).forward(x)
+    ref = cnn_oracle.vgg_like_forward(x, g.weights, upsample_stride=4)
+    assert got.shape == ref.shape == (2, 16, 16, 16, 1)
+    assert np.max(np.abs(got - ref)) < TOL
+    assert ref.std() > 1e-3, 'degenerate test network'
+
+
+def test_unet_like2_tile_forward(ctx):
+    g = fplmodels.unet_like2(28)[0]
+    synth.synthetic_weights(g, 6)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 28, 28, 28, 1)).astype(np.float32)
+    got = _prog(ctx, g).forward(x)
+    ref = cnn_oracle.unet_like2_forward(x, g.weights)
+    assert got.shape == ref.shape == (2, 10, 10, 10, 1)
+    assert np.max(np.abs(got - ref)) < TOL
+    assert ref.std() > 1e-3
+
+
+@pytest.mark.parametrize('factory,size', [
+    (fplmodels.baseline_model, 22), (fplmodels.vgg_like2, 28),
+    (fplmodels.resnet_like, 22), (fplmodels.unet_like, 22),
+    (fplmodels.unet_like3, 36), (fplmodels.unet_like4, 44),
+    (fplmodels.unet_like4b, 44), (fplmodels.unet_like_vol, 62)])
+def test_other_architectures_forward(ctx, factory, size):
+    g, rf, _, _ = factory(size)
+    synth.synthetic_weights(g, 7)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((1, size, size, size, 1)).astype(np.float32)
+    got = _prog(ctx, g).forward(x)
+    ref = cnn_oracle.graph_forward(g, x)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) < TOL
+
+
+def test_unet_incompatible_tile_is_an_error(ctx):
+    g = fplmodels.unet_like2()[0]
+    p = _prog(ctx, g)
+    with pytest.raises(_capi.FplHipError, match='concatenate'):
+        p.forward(np.zeros((1, 26, 26, 26, 1), np.float32))
+
+
+def _crop_identity_program(ctx, off, stride=1):
+    g = LayerGraph(None)
+    y = g.conv(g.crop(g.input(), off), 1, 1)
+    g.finish(y)
+    g.set_weights([np.ones((1, 1, 1, 1, 1), np.float32)])
+    return _prog(ctx, g, (stride,) * 3)
+
+
+def test_infer_lattice_matches_reference_golden(ctx, golden):
+    """a crop-identity program through fpl_infer_volume reproduces the outputs of
+    the reference's own FplNetwork.infer (tests/golden/infer_lattice.npz)"""
+    g = golden('infer_lattice.npz')
+    done = 0
+    for name in [str(n) for n in g['names']]:
+        if str(g[name + '_fn']) != '_crop_identity':
+            continue
+        shape = tuple(int(v) for v in g[name + '_shape'])
+        isz = tuple(int(v) for v in g[name + '_isz'])
+        off = tuple(int(v) for v in g[name + '_off'])
+        img = synth.hash_uniform_f32(int(g[name + '_seed']), shape)
+        pred = _crop_identity_program(ctx, off[0]).infer_volume(img, isz, off)
+        assert helpers.sha(pred) == str(g[name + '_pred_sha']), name
+        done += 1
+    assert done == 4
+
+
+@pytest.mark.parametrize('shape', [(50, 47, 41), (46, 46, 46), (31, 30, 64)])
+def test_infer_volume_vgg_matches_oracle_lattice(ctx, shape):
+    g = fplmodels.vgg_like(30)[0]
+    synth.synthetic_weights(g, 8)
+    prog = _prog(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(3, shape)
+    img = ((u8.astype(np.float32) - np.float32(128)) / np.float32(33))
+
+    def predict(batch):
+        return cnn_oracle.vgg_like_forward(batch.astype(np.float32), g.weights,
+                                           upsample_stride=4)
+    ref = infer_oracle.infer_lattice(img, (30,) * 3, (7,) * 3, predict)
+    got_f = prog.infer_volume(img, (30,) * 3, (7,) * 3)
+    got_u = prog.infer_volume(u8, (30,) * 3, (7,) * 3, mean=128.0, std=33.0)
+    assert got_f.shape == shape and got_f.dtype == np.float32
+    assert np.max(np.abs(got_f - ref)) < TOL
+    assert np.array_equal(got_f, got_u)          # on-device normalisation
+    assert not got_f[:7].any() and not got_f[:, :, -7:].any()
+    assert ref[7:-7, 7:-7, 7:-7].std() > 1e-3
+
+
+def test_infer_volume_slabs_equal_whole(ctx):
+    """Z-slab sharding (the multi-GPU partition) reproduces the whole-volume
+    result row for row"""
+    from flypylib_amd import multi_gpu
+    g = fplmodels.vgg_like(30)[0]
+    synth.synthetic_weights(g, 9)
+    prog = _prog(ctx, g, (4, 4, 4))
+    img = synth.hash_uniform_f32(4, (90, 40, 36)) - np.float32(0.5)
+    whole = prog.infer_volume(img, (30,) * 3, (7,) * 3)
+    n = multi_gpu.n_tile_rows(90, 30, 7)
+    assert n == 5
+    out = np.full_like(whole, np.nan)
+    for zr in multi_gpu.slab_partition(n, 3):
+        lo, hi = multi_gpu.slab_rows(zr, 90, 30, 7)
+        part = prog.infer_volume(img, (30,) * 3, (7,) * 3, z_range=zr)
+        out[lo:hi] = part[lo:hi]
+    assert np.array_equal(out, whole)
+
+
+def test_fplnetwork_infer_api(ctx):
+    net = FplNetwork(fplmodels.vgg_like)
+    assert net.rf_size == (18, 18, 18) and net.rf_offset == (7, 7, 7)
+    assert net.rf_stride == (4, 4, 4) and net.infer_sz == (102, 102, 102)
+    with pytest.raises(AssertionError, match='not been trained'):
+        net.infer(np.zeros((40, 40, 40), np.float32))
+    net.infer_sz = (30, 30, 30)                 # small tiles keep the test fast
+    synth.synthetic_weights(net.train_single, 10)
+    net._set_infer()
+    img = synth.hash_uniform_f32(5, (40, 44, 38)) - np.float32(0.5)
+    pred = net.infer(img)
+
+    def predict(batch):
+        return cnn_oracle.vgg_like_forward(batch.astype(np.float32),
+                                           net.train_single.weights, 4)
+    ref = infer_oracle.infer_lattice(img, (30,) * 3, (7,) * 3, predict)
+    assert pred.dtype == np.float32 and pred.shape == img.shape
+    assert np.max(np.abs(pred - ref)) < TOL
+    # Keras-style predict on the inference network
+    tile = np.zeros((1, 30, 30, 30, 1), np.float32)
+    tile[0, :, :, :, 0] = img[:30, :30, :30]
+    assert np.max(np.abs(net.infer_network.predict(tile) - predict(tile))) < TOL
+
+
+def test_fplnetwork_unet_reference_lattice(ctx):
+    """unet_like2 keeps the reference lattice (tile 28 here, stride 10)"""
+    net = FplNetwork(fplmodels.unet_like2)
+    assert net.rf_offset == (9, 9, 9) and net.infer_sz == (100, 100, 100)
+    net.infer_sz = (28, 28, 28)
+    synth.synthetic_weights(net.train_single, 12)
+    net._set_infer()
+    img = synth.hash_uniform_f32(6, (45, 38, 31)) - np.float32(0.5)
+    pred = net.infer(img)
+
+    def predict(batch):
+        return cnn_oracle.unet_like2_forward(batch.astype(np.float32),
+                                             net.train_single.weights)
+    ref = infer_oracle.infer_lattice(img, (28,) * 3, (9,) * 3, predict)
+    assert np.max(np.abs(pred - ref)) < TOL

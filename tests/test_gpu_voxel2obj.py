@@ -1,0 +1,70 @@
+"""GPU parity for voxel2obj: bit-exact against the reference's golden point lists
+and against the CPU oracle on larger seeded volumes."""
+import numpy as np
+import pytest
+
+from flypylib_amd import fplobjdetect, synth
+from oracle import voxel2obj_oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_cases_bit_exact(ctx, golden):
+    g = golden('voxel2obj.npz')
+    n = 0
+    for c in helpers.v2o_cases(g):
+        pred = helpers.make_pred(c['kind'], c['seed'], c['shape'])
+        res, info = fplobjdetect.voxel2obj(pred, c['r'], c['sigma'], c['offset'],
+                                           c['buffer'], c['thd'],
+                                           return_info=True)
+        pdims = tuple(s + 2 * c['r'] for s in c['shape'])
+        sm = ctx.v2o_smoothed(pdims)
+        assert helpers.sha(sm) == c['smooth_sha'], \
+            '%s: smoothed volume differs from scipy' % c['name']
+        assert np.array_equal(res['locs'], c['locs']), c['name']
+        assert np.array_equal(res['conf'], c['conf']), c['name']
+        assert res['locs'].dtype == np.float64 and res['conf'].dtype == np.float64
+        n += 1
+    assert n == 10
+
+
+@pytest.mark.parametrize('shape,r,sigma,thd,buf', [
+    ((120, 110, 130), 27, 5.0, 0, 0),
+    ((160, 160, 160), 27, 5.0, 0.02, 30),
+    ((90, 140, 75), 9, 2.0, 0.2, (3, 4, 5)),
+    ((64, 64, 200), 15, 3.0, 0, 0)])
+def test_matches_oracle_on_seeded_volumes(ctx, shape, r, sigma, thd, buf):
+    pred = synth.blob_prob_volume(77, shape, period=32, radius=7.0)
+    ref = voxel2obj_oracle.voxel2obj(pred, r, sigma, (3, 2, 1), buf, thd)
+    got, info = fplobjdetect.voxel2obj(pred, r, sigma, (3, 2, 1), buf, thd,
+                                       return_info=True)
+    assert len(ref['conf']) > 3
+    assert np.array_equal(got['locs'], ref['locs'])
+    assert np.array_equal(got['conf'], ref['conf'])
+    assert info['rounds'] >= 1
+
+
+def test_order_statistics_exact(ctx):
+    pred = synth.hash_uniform_f32(5, (50, 60, 70))
+    r, sigma = 6, 2.0
+    pdims = tuple(s + 2 * r for s in pred.shape)
+    n = int(np.prod(pdims))
+    ranks = [0, 1, n // 3, n // 2, int(0.97 * (n - 1)), n - 2, n - 1]
+    vals = ctx.v2o_smooth(pred, pred.shape, r,
+                          fplobjdetect.gaussian_kernel1d(sigma), ranks)
+    sm = voxel2obj_oracle.smooth_and_clear(pred, r, sigma)
+    s = np.sort(sm.reshape(-1))
+    assert np.array_equal(vals, s[ranks])
+
+
+def test_negative_and_empty_inputs(ctx):
+    # all-negative predictions: threshold < 0 but nothing positive -> no points
+    pred = -synth.hash_uniform_f32(6, (30, 30, 30)) - np.float32(0.1)
+    ref = voxel2obj_oracle.voxel2obj(pred, 5, 2.0)
+    got = fplobjdetect.voxel2obj(pred, 5, 2.0)
+    assert got['locs'].shape == ref['locs'].shape == (0, 3)
+    with pytest.raises(NotImplementedError):
+        fplobjdetect.voxel2obj(pred, 5, 2.0, seg=np.zeros((30, 30, 30)))
+    with pytest.raises(TypeError):
+        fplobjdetect.voxel2obj(pred.astype(np.float64), 5, 2.0)

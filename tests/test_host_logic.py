@@ -1,0 +1,177 @@
+"""CPU: product host logic (layer programs, lowering, sharding) and the C-ABI
+library surface.  No compute calls - there is no GPU in the build container."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from flypylib_amd import _capi, fplmodels, multi_gpu, program
+from oracle import cnn_oracle, infer_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'fplhip.h')).read()
+    declared = set(re.findall(r'\b(fpl_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libfplhip.so does not export %s' % name
+    assert declared == set(_capi.SIGNATURES), \
+        'ctypes binding and header disagree: %s' % (
+            declared ^ set(_capi.SIGNATURES))
+    assert _capi.load_library().fpl_abi_version() == _capi.ABI_VERSION
+
+
+def test_fpl_op_struct_layout_matches_header():
+    # int32 x8, int64 x3, int32 x6 -> 80 bytes with natural alignment
+    assert ctypes.sizeof(_capi.fpl_op) == 80
+    assert _capi.fpl_op.w_off.offset == 32 and _capi.fpl_op.p.offset == 56
+
+
+def test_ctx_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_capi.FplHipError):
+        _capi.Context(0)
+
+
+def test_model_contracts_match_reference_table():
+    # (factory, rf_info, infer_sz, trainable params) - SURVEY 7/8a
+    cases = [(fplmodels.vgg_like, (18, 7, 4), 102, 145105),
+             (fplmodels.unet_like2, (24, 9, 1), 100, 623488),
+             (fplmodels.baseline_model, (18, 7, 4), 102, None),
+             (fplmodels.vgg_like2, (24, 10, 4), 100, None),
+             (fplmodels.resnet_like, (18, 7, 4), 102, None),
+             (fplmodels.unet_like, (18, 6, 1), 102, None),
+             (fplmodels.unet_like3, (32, 13, 1), 100, None),
+             (fplmodels.unet_like4, (40, 17, 1), 100, None),
+             (fplmodels.unet_like4b, (40, 17, 1), 100, None),
+             (fplmodels.unet_like_vol, (62, 6, 1), 102, None)]
+    for f, rf, isz, ntrain in cases:
+        g, rf_info, infer_sz, compile_args = f()
+        assert rf_info == rf and infer_sz == isz, f.__name__
+        if ntrain is not None:
+            assert g.count_trainable() == ntrain
+        gi = f(isz)[0]
+        out = gi.output.size
+        # fully-convolutional identity: out*stride == infer_sz - 2*offset
+        assert all(o * rf[2] == isz - 2 * rf[1] for o in out), f.__name__
+        # at the receptive-field size the net yields exactly one coarse output
+        # (vgg family) or rf-2*off voxels (unets)
+        gr = f(rf[0])[0]
+        assert all(o * rf[2] == max(rf[0] - 2 * rf[1], rf[2])
+                   for o in gr.output.size), f.__name__
+    assert fplmodels.vgg_like()[3] is None
+    ca = fplmodels.unet_like2()[3]
+    assert ca['loss'] == fplmodels.masked_focal_loss and ca['optimizer'] == 'adam'
+
+
+def test_vgg_layer_shapes_follow_survey_table():
+    g = fplmodels.vgg_like(102)[0]
+    convs = [n for n in g.nodes if n.kind in ('conv', 'pool')]
+    sizes = [n.size[0] for n in convs]
+    assert sizes == [100, 100, 50, 48, 48, 24, 22, 22, 22, 22]
+    ch = [n.channels for n in convs]
+    assert ch == [48, 48, 48, 48, 48, 48, 48, 96, 96, 1]
+    g = fplmodels.unet_like2(100)[0]
+    sizes = [n.size[0] for n in g.nodes if n.kind == 'conv']
+    assert sizes == [98, 96, 46, 44, 22, 42, 42, 82, 82, 82]
+
+
+def test_unet_rejects_incompatible_input():
+    with pytest.raises(ValueError):
+        fplmodels.unet_like2(26)        # 26 is not 0 mod 4 -> concat mismatch
+
+
+def test_lowering_folds_bn_relu_dropout():
+    g = fplmodels.vgg_like(30)[0]
+    g.randomize_bn(3)
+    ops, arena, out_t, n_t = g.lower_inference()
+    kinds = [o['kind'] for o in ops]
+    assert kinds == [0, 0, 1, 0, 0, 1, 0, 0, 0, 0]
+    assert [o['act'] for o in ops if o['kind'] == 0] == [1] * 7 + [2]
+    assert out_t == ops[-1]['dst'] and n_t == len(ops) + 1
+    # folded scale/shift reproduce BN inference arithmetic
+    o = ops[0]
+    gamma, beta, mean, var = (g.weights[i] for i in (1, 2, 3, 4))
+    sc = arena[o['scale_off']:o['scale_off'] + 48]
+    sh = arena[o['shift_off']:o['shift_off'] + 48]
+    x = np.linspace(-2, 2, 48).astype(np.float32)
+    ref = gamma * (x - mean) / np.sqrt(var + 1e-3) + beta
+    assert np.allclose(sc * x + sh, ref, atol=1e-6)
+    # kernel is stored [k^3*cin][cout] in Keras memory order
+    k = arena[o['w_off']:o['w_off'] + 27 * 48].reshape(3, 3, 3, 1, 48)
+    assert np.array_equal(k, g.weights[0])
+    # final conv keeps its bias as the shift
+    o = ops[-1]
+    assert o['cout'] == 1 and o['k'] == 1 and o['cin'] == 96
+
+
+def test_lowering_unet_and_resnet_graphs():
+    ops, _, _, _ = fplmodels.unet_like2(28)[0].lower_inference()
+    assert [o['kind'] for o in ops].count(program.OP_CONCAT) == 2
+    assert [o['kind'] for o in ops].count(program.OP_CROP) == 1
+    crop = [o for o in ops if o['kind'] == program.OP_CROP][0]
+    assert tuple(crop['p']) == (6,) * 6
+    ops, _, _, _ = fplmodels.resnet_like(30)[0].lower_inference()
+    adds = [o for o in ops if o['kind'] == program.OP_ADD]
+    assert len(adds) == 2 and all(o['act'] == program.ACT_RELU for o in adds)
+
+
+def test_set_get_weights_roundtrip_and_validation():
+    g = fplmodels.vgg_like()[0]
+    w = g.get_weights()
+    assert len(w) == 8 + 1 + 7 * 4      # 8 kernels, 1 bias, 7 BN x 4
+    w2 = [a + 1 for a in w]
+    g.set_weights(w2)
+    assert all(np.array_equal(a, b) for a, b in zip(g.get_weights(), w2))
+    with pytest.raises(ValueError):
+        g.set_weights(w[:-1])
+    bad = list(w)
+    bad[0] = np.zeros((3, 3, 3, 1, 47), np.float32)
+    with pytest.raises(ValueError):
+        g.set_weights(bad)
+
+
+def test_slab_partition_covers_lattice_once():
+    for n_rows in (1, 5, 8, 12, 47):
+        for parts in (1, 2, 3, 4, 8):
+            sl = multi_gpu.slab_partition(n_rows, parts)
+            assert len(sl) == parts and sl[0][0] == 0 and sl[-1][1] == n_rows
+            assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            sizes = [e - b for b, e in sl]
+            assert max(sizes) - min(sizes) <= 1
+    # tile-row count equals the reference lattice's
+    for dim in (50, 102, 103, 190, 520, 1024):
+        locs, _, _ = infer_oracle.tile_lattice((dim, 102, 102), (102,) * 3,
+                                               (7,) * 3)
+        nz = len(np.unique(locs[0]))
+        assert multi_gpu.n_tile_rows(dim, 102, 7) == nz
+    # slab rows tile the volume exactly
+    dim = 520
+    n = multi_gpu.n_tile_rows(dim, 102, 7)
+    rows = [multi_gpu.slab_rows(z, dim, 102, 7)
+            for z in multi_gpu.slab_partition(n, 4)]
+    assert rows[0][0] == 0 and rows[-1][1] == dim
+    assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+
+
+def test_oracle_graph_interpreter_agrees_with_handwritten_forwards():
+    rng = np.random.default_rng(0)
+    g = fplmodels.vgg_like(22)[0]
+    g.randomize_bn(1)
+    x = rng.standard_normal((2, 22, 22, 22, 1)).astype(np.float32)
+    a = cnn_oracle.vgg_like_forward(x, g.weights)
+    b = cnn_oracle.graph_forward(g, x)
+    assert a.shape == (2, 2, 2, 2, 1) and np.allclose(a, b, atol=1e-6)
+    g = fplmodels.unet_like2(28)[0]
+    g.randomize_bn(2)
+    x = rng.standard_normal((1, 28, 28, 28, 1)).astype(np.float32)
+    a = cnn_oracle.unet_like2_forward(x, g.weights)
+    b = cnn_oracle.graph_forward(g, x)
+    assert a.shape == (1, 10, 10, 10, 1) and np.allclose(a, b, atol=1e-6)
