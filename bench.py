@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: vgg_like sliding-window inference Mvoxels/s on a synthetic
+uint8 EM volume (BASELINE.json metric; N=1 workload = configs[1]: 1024^3).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of FplNetwork.infer's hot path (normalise -> tile lattice ->
+3D-CNN -> upsample -> stitch) over the volume, input uint8 and output float32
+both resident in HBM.  With N ranks the volume is N x 1024 rows along Z and every
+rank takes a contiguous slab of tile rows (weak scaling, no collective on the
+data path; RCCL is only used for the barrier / max-over-ranks of the clock).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel from HIP
+events recorded on the library's stream during the timed steps; `cpu_baseline`
+times the CPU oracle (torch-CPU restatement, NOT Keras) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOP per valid output voxel of vgg_like, by layer:
+# conv3 1->48, conv1 48->48 (full res); conv3 48->48, conv1 (1/8); conv3 48->48,
+# conv1 48->96, conv1 96->96, conv1 96->1 (1/64)
+VGG_FLOP = dict(L1=2592.0, L2=4608.0, L3=15552.0, L4=576.0, L5=1944.0, L6=144.0,
+                L7=288.0, L8=3.0)
+VGG_FLOP_TOTAL = sum(VGG_FLOP.values())          # 25 707
+# which layers each kernel name computes (for roofline.achieved)
+KERNEL_LAYERS = {
+    'generic_conv3_f32': ('L1', 'L3', 'L5'),
+    'generic_conv1_f32': ('L2', 'L4', 'L6', 'L7', 'L8'),
+    'vgg_stem_pool_bf16': ('L1', 'L2'), 'vgg_stem_pool_f32': ('L1', 'L2'),
+    'vgg_mid_pool_bf16': ('L3', 'L4'), 'vgg_mid_pool_f32': ('L3', 'L4'),
+    'vgg_head_bf16': ('L5', 'L6', 'L7', 'L8'),
+    'vgg_head_f32': ('L5', 'L6', 'L7', 'L8'),
+}
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """CPU oracle (oracle/cnn_oracle.py, torch-CPU fp32 conv3d) on reference
+    tiles 102^3 -> 88^3, all host cores; bounded to ~seconds_budget"""
+    import torch
+    from flypylib_amd import fplmodels, synth
+    from oracle import cnn_oracle
+    g = fplmodels.vgg_like(102)[0]
+    synth.synthetic_weights(g, 1234)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    u8 = synth.em_volume_u8(1, (102, 102, 102))
+    tile = ((u8.astype(np.float32) - 128.0) / 33.0)[None, ..., None]
+    cnn_oracle.vgg_like_forward(tile, g.weights, 4)          # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cnn_oracle.vgg_like_forward(tile, g.weights, 4)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or n >= 64:
+            break
+    return dict(value=n * 88 ** 3 / dt / 1e6, unit='Mvoxels/s',
+                cores=torch.get_num_threads(), kind='port',
+                sample='%d reference tiles 102^3->88^3 of the same synthetic '
+                       'volume, torch-CPU fp32 restatement of vgg_like '
+                       '(oracle/cnn_oracle.py), %.1f s' % (n, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--size', type=int, default=1024,
+                    help='volume edge per GPU (Z is size*gpus)')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--tile', type=int, default=102,
+                    help='reference infer_sz (tile lattice pitch = tile-14)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from flypylib_amd import _capi, fplmodels, multi_gpu, synth
+    ctx = _capi.Context(local_rank)
+    info = ctx.device_info()
+
+    tile, off = args.tile, 7
+    graph = fplmodels.vgg_like(tile)[0]
+    synth.synthetic_weights(graph, 1234)
+    prog = _capi.Program(ctx, graph, (4, 4, 4))
+    prec = _capi.PREC_BF16 if args.precision == 'bf16' else _capi.PREC_F32
+
+    # global volume (size*N, size, size); rank slab = contiguous tile rows, which
+    # is itself a standalone volume whose lattice coincides with the global one
+    Z, Y, X = args.size * world, args.size, args.size
+    pitch = tile - 2 * off
+    n_rows = multi_gpu.n_tile_rows(Z, tile, off)
+    zb, ze = multi_gpu.slab_partition(n_rows, world)[rank]
+    z_lo = zb * pitch
+    z_hi = min(ze * pitch + 2 * off, Z)
+    dims = (z_hi - z_lo, Y, X)
+    src = torch.empty(dims, dtype=torch.uint8, device='cuda')
+    dst = torch.empty(dims, dtype=torch.float32, device='cuda')
+    ctx.synth_volume_u8(20250101, dims, (z_lo, 0, 0), out=src)
+    valid_global = (Z - 2 * off) * (Y - 2 * off) * (X - 2 * off)
+    # valid outputs this rank produces (rows of the global valid region it owns)
+    own_rows = min(ze * pitch + off, Z - off) - (zb * pitch + off)
+    valid_local = own_rows * (Y - 2 * off) * (X - 2 * off)
+
+    def step():
+        prog.infer_volume(src, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0,
+                          precision=prec, dst=dst, dims=dims)
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.timing(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timings = ctx.timing_get()
+    ctx.timing(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant kernel roofline (this rank; ranks are symmetric)
+    roof = None
+    if timings:
+        name = max(timings, key=lambda k: timings[k]['ms'])
+        tk = timings[name]
+        layers = KERNEL_LAYERS.get(name)
+        flop_per_vox = sum(VGG_FLOP[l] for l in layers) if layers else None
+        avg_ms = tk['ms'] / tk['launches']
+        if flop_per_vox is not None:
+            flops_per_launch = flop_per_vox * valid_local * args.steps / tk['launches']
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.precision if 'generic' not in name else 'f32']
+            roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 3),
+                        peak=peak, unit='TFLOP/s',
+                        frac=round(achieved / peak, 5), traffic=None,
+                        avg_launch_ms=round(avg_ms, 4), launches=tk['launches'],
+                        algorithmic_flop_per_voxel=flop_per_vox,
+                        kernel_ms_total={k: round(v['ms'], 3)
+                                         for k, v in timings.items()})
+
+    if rank == 0:
+        value = valid_global * args.steps / dt / 1e6
+        line = {
+            'metric': 'inference Mvoxels/sec, vgg_like (rf 18, 22^3 coarse -> 88^3 '
+                      'per reference tile), synthetic EM uint8 volume',
+            'value': round(value, 2), 'unit': 'Mvoxels/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: vgg_like inference, %dx%dx%d '
+                                   'synthetic uint8 volume, reference tile '
+                                   'lattice %d^3 (pitch %d), u8 in / f32 out '
+                                   'resident in HBM' % (Z, Y, X, tile, pitch),
+                       'volume': [Z, Y, X], 'tile_in': tile,
+                       'parallelism': 'z-slab tile sharding x%d, no collective'
+                                      % world,
+                       'device': info['name']},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

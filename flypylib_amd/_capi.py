@@ -247,7 +247,7 @@ class Program:
             pass
 
     def out_dims(self, in_dims):
-        od = (C.c_int32 * 3)()
+        od = (C.c_int32 * 4)()
         dummy = np.zeros(1, np.float32)
         self.ctx.check(self.ctx.lib.fpl_program_forward(
             self.ctx.h, self.h, _ptr(dummy), MEM_HOST, 1,
@@ -255,18 +255,18 @@ class Program:
         return tuple(od)
 
     def forward(self, batch, precision=PREC_F32):
-        """batch (n, D, H, W[, 1]) float32 host array -> (n, d, h, w, 1)"""
+        """batch (n, D, H, W[, 1]) float32 host array -> (n, d, h, w, c)"""
         x = np.ascontiguousarray(batch, np.float32)
         if x.ndim == 5:
             x = x[..., 0]
         n, in_dims = x.shape[0], x.shape[1:]
         od = self.out_dims(in_dims)
         out = np.empty((n,) + od, np.float32)
-        odc = (C.c_int32 * 3)()
+        odc = (C.c_int32 * 4)()
         self.ctx.check(self.ctx.lib.fpl_program_forward(
             self.ctx.h, self.h, _ptr(x), MEM_HOST, n, _arr(in_dims, C.c_int32),
             precision, _ptr(out), MEM_HOST, odc))
-        return out[..., None]
+        return out
 
     def infer_volume(self, src, tile_in, offset, mean=0.0, std=1.0,
                      precision=PREC_F32, z_range=(0, -1), dst=None, dims=None):

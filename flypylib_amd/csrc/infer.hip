@@ -78,7 +78,7 @@ extern "C" {
 int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
                         int in_mem, int32_t n, const int32_t in_dims[3],
                         int precision, float *out, int out_mem,
-                        int32_t out_dims[3]) {
+                        int32_t out_dims[4]) {
   if (!ctx || !prog || !in || !in_dims)
     return fpl_fail(ctx, "fpl_program_forward: NULL argument");
   FPL_REQUIRE(ctx, n > 0, "fpl_program_forward: batch %d", n);
@@ -91,6 +91,7 @@ int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
   const int *s = prog->stride;
   if (out_dims) {
     out_dims[0] = o.d * s[0]; out_dims[1] = o.h * s[1]; out_dims[2] = o.w * s[2];
+    out_dims[3] = o.c;
   }
   if (!out) return 0;  // shape query
   DevTemp tmp(ctx);

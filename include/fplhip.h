@@ -99,13 +99,15 @@ int fpl_program_set_arena(fpl_program *prog, const float *arena,
                           int64_t n_arena);
 
 /* replaces: infer_network.predict(data_batch) (fplnetwork.py:175-176) for a
- * batch of equally-sized tiles: in (n, D,H,W) f32 -> out (n, d,h,w) f32, where
- * (d,h,w) is the network output size for input (D,H,W) (times stride).  Generic
- * per-op kernels, fp32: the parity path for every architecture. */
+ * batch of equally-sized tiles: in (n, D,H,W) f32 -> out (n, d,h,w,c) f32, where
+ * (d,h,w) is the network output size for input (D,H,W) (times stride) and c its
+ * channel count (1 for every reference model).  out_dims receives (d,h,w,c);
+ * pass out = NULL to query the shape only.  Generic per-op kernels, fp32: the
+ * parity path for every architecture. */
 int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
                         int in_mem, int32_t n, const int32_t in_dims[3],
                         int precision, float *out, int out_mem,
-                        int32_t out_dims[3]);
+                        int32_t out_dims[4]);
 
 /* replaces: FplNetwork.infer (fplnetwork.py:136-189): tile lattice, zero-padded
  * edge tiles, predict, stitch; the rf_offset border shell of `dst` is zero.
