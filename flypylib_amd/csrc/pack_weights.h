@@ -1,0 +1,51 @@
+// Host-side packing of folded conv weights into MFMA A-fragment order (bf16).
+// One fragment = 64 lanes x 8 bf16 = 1 KiB, stored [kstep][mblock][lane][8] so a
+// wave fetches a fragment with one coalesced 16-B-per-lane load (or one
+// ds_read_b128 per lane from an LDS copy).  Slot maps: see mfma_util.h.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+enum FplSlotMap {
+  SLOT_STEM = 0,     // cin = 1: k-slot f = 32s + 8g + j is tap f
+  SLOT_SPATIAL = 1,  // k-slot f -> (tap = f / cin, memory channel = f % cin)
+  SLOT_CHAIN = 2     // k-slot (s,g,j) -> channel 16(2s + (j>>2)) + 4g + (j&3)
+};
+
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// W: [ntaps * cin][cout] fp32 (Keras memory order), scale[cout] folded in.
+// out: n_ksteps * n_mblocks fragments.
+static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
+                                  int cin, int cout, int n_mblocks, int n_ksteps,
+                                  FplSlotMap map, std::vector<uint16_t> *out) {
+  out->assign((size_t)n_ksteps * n_mblocks * 512, 0);
+  for (int s = 0; s < n_ksteps; ++s)
+    for (int b = 0; b < n_mblocks; ++b)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 15, g = lane >> 4, co = 16 * b + m;
+        if (co >= cout) continue;
+        for (int j = 0; j < 8; ++j) {
+          int kidx = -1;
+          if (map == SLOT_CHAIN) {
+            const int c = 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3);
+            if (c < cin) kidx = c;
+          } else {
+            const int f = 32 * s + 8 * g + j;
+            const int tap = f / cin, ch = f % cin;
+            if (tap < ntaps) kidx = tap * cin + ch;
+          }
+          if (kidx < 0) continue;
+          const float v = W[(size_t)kidx * cout + co] * scale[co];
+          (*out)[(((size_t)s * n_mblocks + b) * 64 + lane) * 8 + j] =
+              f32_to_bf16_rne(v);
+        }
+      }
+}

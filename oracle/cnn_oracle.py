@@ -172,3 +172,42 @@ def conv3d_valid_numpy(x, kernel):
                                     kernel[a, b, c].astype(np.float64),
                                     axes=([3], [0]))
     return out
+
+
+# ---- bf16 emulation of the fused MI355X kernels (csrc/vgg_fused.hip) -----------
+def _bf16_round(t):
+    """round-to-nearest-even to bfloat16, kept in float32"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def vgg_like_forward_bf16emu(x, weights, upsample_stride=None):
+    """vgg_like with the rounding points of the fused bf16 kernels: BN scale is
+    folded into the kernel before rounding it to bf16, BN shift stays fp32,
+    activations are rounded to bf16 after every ReLU, accumulation is fp32.
+    x: (N,D,H,W,1) float32 already normalised."""
+    w = _W(weights, torch.float32)
+    h = _bf16_round(_t(x, torch.float32).permute(0, 4, 1, 2, 3))
+
+    def block(h, pool):
+        kern = w.take()
+        g, b, m, v = w.take(4)
+        s = g / torch.sqrt(v + BN_EPS)
+        kf = _bf16_round(kern * s.view(1, 1, 1, 1, -1))
+        y = conv3d_valid(h, kf) + (b - m * s).view(1, -1, 1, 1, 1)
+        if pool:
+            y = maxpool2(y)
+        return _bf16_round(torch.relu(y))
+
+    h = block(h, False)
+    h = block(h, True)
+    h = block(h, False)
+    h = block(h, True)
+    h = block(h, False)
+    h = block(h, False)
+    h = block(h, False)
+    kern, bias = w.take(2)
+    h = torch.sigmoid(conv3d_valid(h, _bf16_round(kern)) + bias.view(1, -1, 1, 1, 1))
+    w.done()
+    if upsample_stride is not None:
+        h = upsample(h, upsample_stride)
+    return h.permute(0, 2, 3, 4, 1).contiguous().numpy()

@@ -1,0 +1,105 @@
+"""GPU parity for the fused bf16 MFMA vgg_like path (csrc/vgg_fused.hip).
+
+Two references:
+  * the bf16 emulation oracle (same rounding points as the kernels): tight
+    tolerance - proves indexing, fragment maps, pooling, lattice and edges;
+  * the fp32 oracle: the bf16 path's precision cost, asserted at BF16_TOL (the
+    1e-3 north-star gate applies to the fp32 path, tests/test_gpu_cnn.py).
+"""
+import numpy as np
+import pytest
+
+from flypylib_amd import _capi, fplmodels, multi_gpu, synth
+from oracle import cnn_oracle, infer_oracle
+
+pytestmark = pytest.mark.gpu
+EMU_TOL = 4e-3       # bf16 one-ulp flips at rounding points, amplified by the net
+BF16_TOL = 5e-2      # bf16 vs fp32 probabilities, max abs
+
+
+def _net(seed, tile=30):
+    g = fplmodels.vgg_like(tile)[0]
+    synth.synthetic_weights(g, seed)
+    return g
+
+
+def _refs(g, img, tile):
+    def emu(batch):
+        return cnn_oracle.vgg_like_forward_bf16emu(batch.astype(np.float32),
+                                                   g.weights, 4)
+
+    def f32(batch):
+        return cnn_oracle.vgg_like_forward(batch.astype(np.float32), g.weights, 4)
+    a = infer_oracle.infer_lattice(img, (tile,) * 3, (7,) * 3, emu)
+    b = infer_oracle.infer_lattice(img, (tile,) * 3, (7,) * 3, f32)
+    return a, b
+
+
+@pytest.mark.parametrize('shape,tile', [
+    ((50, 47, 41), 30), ((46, 46, 46), 30), ((31, 30, 64), 30),
+    ((75, 33, 90), 30), ((104, 120, 110), 102), ((40, 135, 52), 46)])
+def test_fused_bf16_matches_emulation_and_fp32(ctx, shape, tile):
+    g = _net(21, tile)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(9, shape)
+    img = (u8.astype(np.float32) - np.float32(128)) / np.float32(33)
+    got = prog.infer_volume(u8, (tile,) * 3, (7,) * 3, mean=128.0, std=33.0,
+                            precision=_capi.PREC_BF16)
+    emu, f32 = _refs(g, img, tile)
+    assert got.shape == shape and got.dtype == np.float32
+    assert not got[:7].any() and not got[-7:].any()
+    assert not got[:, :7].any() and not got[:, :, -7:].any()
+    d_emu = np.abs(got - emu)
+    d_f32 = np.abs(got - f32)
+    assert d_emu.max() < EMU_TOL, 'vs bf16 emulation: max %g' % d_emu.max()
+    assert d_emu.mean() < 1e-4
+    assert d_f32.max() < BF16_TOL, 'vs fp32 oracle: max %g' % d_f32.max()
+    assert f32[7:-7, 7:-7, 7:-7].std() > 1e-3
+
+
+def test_fused_bf16_float_input(ctx):
+    g = _net(22)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    img = synth.hash_uniform_f32(3, (44, 52, 39)) * np.float32(4) - np.float32(2)
+    got = prog.infer_volume(img, (30,) * 3, (7,) * 3, precision=_capi.PREC_BF16)
+    emu, _ = _refs(g, img, 30)
+    assert np.abs(got - emu).max() < EMU_TOL
+
+
+def test_fused_bf16_slabs_equal_whole(ctx):
+    g = _net(23)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(4, (120, 40, 52))
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_BF16)
+    whole = prog.infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
+    n = multi_gpu.n_tile_rows(120, 30, 7)
+    out = np.full_like(whole, np.nan)
+    for zr in multi_gpu.slab_partition(n, 3):
+        lo, hi = multi_gpu.slab_rows(zr, 120, 30, 7)
+        part = prog.infer_volume(u8, (30,) * 3, (7,) * 3, z_range=zr, **kw)
+        out[lo:hi] = part[lo:hi]
+    assert np.array_equal(out, whole)
+
+
+def test_fused_bf16_is_tiling_independent(ctx):
+    """the coarse grid is anchored at the volume origin: any infer_sz = 4n+14
+    gives bit-identical output (vgg_like is phase-safe)"""
+    g30, g46 = _net(24, 30), _net(24, 46)
+    u8 = synth.em_volume_u8(5, (60, 66, 58))
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_BF16)
+    a = _capi.Program(ctx, g30, (4, 4, 4)).infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
+    b = _capi.Program(ctx, g46, (4, 4, 4)).infer_volume(u8, (46,) * 3, (7,) * 3, **kw)
+    assert np.array_equal(a, b)
+
+
+def test_set_weights_repacks_fragments(ctx):
+    g = _net(25)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(6, (38, 38, 38))
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_BF16)
+    a = prog.infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
+    synth.synthetic_weights(g, 26)
+    prog.set_weights_from(g)
+    b = prog.infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
+    fresh = _capi.Program(ctx, g, (4, 4, 4)).infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
+    assert not np.array_equal(a, b) and np.array_equal(b, fresh)
