@@ -52,7 +52,12 @@ def cpu_baseline(seconds_budget=20.0):
     from oracle import cnn_oracle
     g = fplmodels.vgg_like(102)[0]
     synth.synthetic_weights(g, 1234)
-    cores = os.cpu_count() or 1
+    # the 1-GPU box's CPU share is 16 cores (os.cpu_count() reports the whole host)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     u8 = synth.em_volume_u8(1, (102, 102, 102))
     tile = ((u8.astype(np.float32) - 128.0) / 33.0)[None, ..., None]

@@ -26,39 +26,53 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// single-instruction ReLU (fmaxf() would add a canonicalising v_max per value)
-__device__ __forceinline__ float relu1(float x) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// two f32 -> packed bf16 pair (one v_cvt_pk_bf16_f32, RNE)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  f32x2 f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
 }
 
-__device__ __forceinline__ float max1(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+// max of packed bf16 pairs AS SIGNED INT16 (one v_pk_max_i16).  Against 0 this
+// is ReLU on both halves (negative bf16 = negative int16, -0.0 included);
+// between non-negative values it is the float max - which is all a max-pool of
+// post-ReLU activations needs.
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
+  return __builtin_bit_cast(
+      unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a),
+                                          __builtin_bit_cast(s16x2, b)));
 }
 
-// two accumulator tiles (M-blocks 2s and 2s+1) -> one B fragment of K-step s,
-// with ReLU; `hi_valid` = false packs zeros for a missing block
+// two accumulator tiles (M-blocks 2s and 2s+1 of the previous layer) -> the B
+// fragment of K-step s of the next layer, ReLU applied: 4 cvt_pk + 4 pk_max
 __device__ __forceinline__ bf16x8 pack_relu(const f32x4 &lo, const f32x4 &hi) {
-  bf16x8 v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    v[r] = (__bf16)relu1(lo[r]);
-    v[4 + r] = (__bf16)relu1(hi[r]);
-  }
-  return v;
+  u32x4 v;
+  v[0] = pk_max_i16(cvt_pk_bf16(lo[0], lo[1]), 0u);
+  v[1] = pk_max_i16(cvt_pk_bf16(lo[2], lo[3]), 0u);
+  v[2] = pk_max_i16(cvt_pk_bf16(hi[0], hi[1]), 0u);
+  v[3] = pk_max_i16(cvt_pk_bf16(hi[2], hi[3]), 0u);
+  return __builtin_bit_cast(bf16x8, v);
 }
 
+// same with the upper block missing (48 channels = 3 blocks): zeros
 __device__ __forceinline__ bf16x8 pack_relu_lo(const f32x4 &lo) {
-  bf16x8 v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    v[r] = (__bf16)relu1(lo[r]);
-    v[4 + r] = (__bf16)0.0f;
-  }
-  return v;
+  u32x4 v;
+  v[0] = pk_max_i16(cvt_pk_bf16(lo[0], lo[1]), 0u);
+  v[1] = pk_max_i16(cvt_pk_bf16(lo[2], lo[3]), 0u);
+  v[2] = 0u;
+  v[3] = 0u;
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// running max-pool of relu(acc) in packed bf16: pooled = max(pooled, bf16(acc))
+// with pooled initialised to 0 (rounding is monotonic, so this equals rounding
+// the fp32 max)
+__device__ __forceinline__ void pool_relu_bf16(u32x2 &pooled, const f32x4 &acc) {
+  pooled[0] = pk_max_i16(pooled[0], cvt_pk_bf16(acc[0], acc[1]));
+  pooled[1] = pk_max_i16(pooled[1], cvt_pk_bf16(acc[2], acc[3]));
 }
 
 __device__ __forceinline__ unsigned short bf16_bits(float f) {

@@ -49,3 +49,44 @@ static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
         }
       }
 }
+
+// ---- stem (conv3 1->48) k-slot layout ------------------------------------------
+// The input tile sits in LDS as bf16; a lane's base x is even, so per tap row
+// (tz,ty) one (tx,tx+1) pair is an aligned 32-bit read.  For sub-step parity
+// e = dx the three taps of a row sit at element offsets e, e+1, e+2:
+//   e = 0: aligned pair (tx0,tx1) at +0, single tx2 at +2
+//   e = 1: single tx0 at +1,            aligned pair (tx1,tx2) at +2
+// Per lane the 8 k-slots are 3 pair registers + 1 register of two singles:
+//   g = 0..2: pairs of rows 3g, 3g+1, 3g+2;  singles of rows 2g, 2g+1
+//   g = 3   : singles of rows 6, 7, 8 read as aligned pairs whose other half
+//             has zero weight; last register unused
+// Returns the tap (0..26) bound to slot j of lane group g, or -1 (zero weight).
+static inline int fpl_stem_slot_tap(int e, int g, int j) {
+  const int i = j >> 1, h = j & 1;
+  if (i < 3) {
+    if (g < 3) return (3 * g + i) * 3 + (e == 0 ? h : 1 + h);
+    const int row = 6 + i;
+    if (e == 0) return h == 0 ? row * 3 + 2 : -1;
+    return h == 1 ? row * 3 + 0 : -1;
+  }
+  if (g == 3) return -1;
+  return (2 * g + h) * 3 + (e == 0 ? 2 : 0);
+}
+
+// 6 fragments [e][b]: W [27][48] fp32, scale[48]
+static inline void fpl_pack_stem(const float *W, const float *scale, int cout,
+                                 std::vector<uint16_t> *out) {
+  out->assign((size_t)2 * 3 * 512, 0);
+  for (int e = 0; e < 2; ++e)
+    for (int b = 0; b < 3; ++b)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 15, g = lane >> 4, co = 16 * b + m;
+        if (co >= cout) continue;
+        for (int j = 0; j < 8; ++j) {
+          const int tap = fpl_stem_slot_tap(e, g, j);
+          if (tap < 0) continue;
+          (*out)[(((size_t)e * 3 + b) * 64 + lane) * 8 + j] =
+              f32_to_bf16_rne(W[(size_t)tap * cout + co] * scale[co]);
+        }
+      }
+}

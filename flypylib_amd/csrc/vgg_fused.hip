@@ -29,16 +29,13 @@ namespace {
 constexpr int CH = 48;                 // channels of P1 / P2
 constexpr int VOX_BYTES = CH * 2;      // 96 B per voxel (bf16)
 constexpr int KSTEPS = 42;             // 27*48 = 1296 -> 41 K-steps of 32, padded
-constexpr int KCHUNK = 6;              // K-steps per weight ring slot
-constexpr int NCHUNK = KSTEPS / KCHUNK;
-constexpr int RING_BYTES = KCHUNK * 3 * 1024;   // 3 M-blocks x 1 KiB per K-step
 
 // -------------------------------------------------------------------------------
-// K1: stem.  WG = 4 waves; pooled block 2 x 4 x 32; wave task = 16 pooled x of one
+// K1: stem.  WG = 4 waves; pooled block 4 x 8 x 32; wave task = 16 pooled x of one
 // (pz,py) row; 8 sub-steps walk the 2x2x2 pooling window so the pool is an
 // element-wise max over accumulators (no cross-lane traffic).
 // -------------------------------------------------------------------------------
-constexpr int S_PZ = 2, S_PY = 4, S_PX = 32;
+constexpr int S_PZ = 4, S_PY = 8, S_PX = 32;
 constexpr int S_TZ = 2 * S_PZ + 2, S_TY = 2 * S_PY + 2, S_TX = 2 * S_PX + 2;
 
 struct StemArgs {
@@ -52,39 +49,72 @@ struct StemArgs {
   int P1Z, P1Y, P1X;       // chunk-local dims
 };
 
+// element offset of tap row `row` = (tz,ty) inside the input tile
+__device__ __forceinline__ int stem_row_off(int row) {
+  return ((row / 3) * S_TY + row % 3) * S_TX;
+}
+
 template <typename SRC>
-__global__ __launch_bounds__(256) void vgg_stem_pool_bf16(StemArgs a) {
-  __shared__ unsigned short tile[S_TZ * S_TY * S_TX];
+__global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[S_TZ * S_TY * S_TX];
+  __shared__ unsigned short lut[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int px0 = blockIdx.x * S_PX, py0 = blockIdx.y * S_PY, pz0 = blockIdx.z * S_PZ;
 
-  // ---- input tile: normalise, round to bf16; zero past the volume end
+  // ---- input tile: normalise, round to bf16; zero past the volume end.  For u8
+  // sources the 256 possible values go through a per-WG lookup table, so the
+  // divide + convert happen once per value, not once per voxel.
   {
     const SRC *src = (const SRC *)a.src;
     const int64_t gz0 = 2 * (a.p1z0 + pz0), gy0 = 2 * (int64_t)py0, gx0 = 2 * (int64_t)px0;
-    for (int i = tid; i < S_TZ * S_TY * S_TX; i += 256) {
+    constexpr int N = S_TZ * S_TY * S_TX;
+    constexpr int PER = (N + 255) / 256;
+    if (sizeof(SRC) == 1) {
+      lut[tid] = bf16_bits(((float)tid - a.mean) / a.sd);
+      __syncthreads();
+    }
+    // issue all loads first (PER independent loads in flight per thread)
+    SRC raw[PER];
+    bool inb[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 256 * k;
       const int tx = i % S_TX, ty = (i / S_TX) % S_TY, tz = i / (S_TX * S_TY);
       const int64_t z = gz0 + tz, y = gy0 + ty, x = gx0 + tx;
-      float v = 0.f;
-      if (z < a.SZ && y < a.SY && x < a.SX)
-        v = ((float)src[(z * a.SY + y) * a.SX + x] - a.mean) / a.sd;
-      tile[i] = bf16_bits(v);
+      inb[k] = i < N && z < a.SZ && y < a.SY && x < a.SX;
+      raw[k] = inb[k] ? src[(z * a.SY + y) * a.SX + x] : (SRC)0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + 256 * k;
+      unsigned short v = 0;
+      if (inb[k])
+        v = sizeof(SRC) == 1 ? lut[(int)raw[k]]
+                             : bf16_bits(((float)raw[k] - a.mean) / a.sd);
+      if (i < N) tile[i] = v;
     }
   }
 
-  // ---- per-lane constants
-  int toff[8];                       // tap offsets (elements) of k-slots 8g..8g+7
+  // ---- per-lane constants: byte offsets of the 3 pair reads and 2 single reads
+  // for sub-step parity e = dx (k-slot layout: pack_weights.h::fpl_stem_slot_tap)
+  int offP[2][3], offS[2][2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int t = 8 * g + j;
-    toff[j] = t < 27 ? ((t / 9) * S_TY + (t / 3) % 3) * S_TX + t % 3 : 0;
+  for (int e = 0; e < 2; ++e) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      offP[e][i] = 2 * (g < 3 ? stem_row_off(3 * g + i) + (e == 0 ? 0 : 2)
+                              : stem_row_off(6 + i) + (e == 0 ? 2 : 0));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      offS[e][h] = g < 3 ? 2 * (stem_row_off(2 * g + h) + (e == 0 ? 2 : 1)) : 0;
   }
-  bf16x8 w1[3], w2[2][3];
+  bf16x8 w1[2][3], w2[2][3];
   f32x4 sh1[3], sh2[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    w1[b] = a.w1[b * 64 + lane];
+    w1[0][b] = a.w1[(0 * 3 + b) * 64 + lane];
+    w1[1][b] = a.w1[(1 * 3 + b) * 64 + lane];
     w2[0][b] = a.w2[(0 * 3 + b) * 64 + lane];
     w2[1][b] = a.w2[(1 * 3 + b) * 64 + lane];
 #pragma unroll
@@ -94,48 +124,42 @@ __global__ __launch_bounds__(256) void vgg_stem_pool_bf16(StemArgs a) {
     }
   }
   __syncthreads();
+  const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile);
 
   for (int task = wave; task < S_PZ * S_PY * 2; task += 4) {
     const int row = task >> 1, xh = task & 1;
     const int pzl = row / S_PY, pyl = row % S_PY;
-    const int base = ((2 * pzl) * S_TY + 2 * pyl) * S_TX + 2 * (16 * xh + c);
-    f32x4 pooled[3];
+    const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TX + 2 * (16 * xh + c));
+    u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
 #pragma unroll
     for (int sub = 0; sub < 8; ++sub) {
-      const int so = (((sub >> 2) & 1) * S_TY + ((sub >> 1) & 1)) * S_TX + (sub & 1);
-      u16x8 raw;
+      const int e = sub & 1;
+      const int so = 2 * ((((sub >> 2) & 1) * S_TY + ((sub >> 1) & 1)) * S_TX);
+      u32x4 raw;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[j] = tile[base + so + toff[j]];
+      for (int i = 0; i < 3; ++i)
+        raw[i] = *reinterpret_cast<const unsigned *>(tb + base + so + offP[e][i]);
+      const unsigned s0 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][0]);
+      const unsigned s1 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][1]);
+      raw[3] = s0 | (s1 << 16);
       const bf16x8 bfrag = __builtin_bit_cast(bf16x8, raw);
       f32x4 a1[3];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[b], bfrag, sh1[b]);
+      for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[e][b], bfrag, sh1[b]);
       const bf16x8 h0 = pack_relu(a1[0], a1[1]);
       const bf16x8 h1 = pack_relu_lo(a1[2]);
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
-        a2 = mfma16(w2[0][b], h0, a2);
+        f32x4 a2 = mfma16(w2[0][b], h0, sh2[b]);
         a2 = mfma16(w2[1][b], h1, a2);
-        if (sub == 0) {
-          pooled[b] = a2;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pooled[b][r] = max1(pooled[b][r], a2[r]);
-        }
+        pool_relu_bf16(pooled[b], a2);
       }
     }
-    // relu(max(conv) + shift) == max over the window of relu(conv + shift)
     const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + 16 * xh + c;
     if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
       __bf16 *dst = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * CH + 4 * g;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (__bf16)relu1(pooled[b][r] + sh2[b][r]);
-        *reinterpret_cast<bf16x4 *>(dst + 16 * b) = o;
-      }
+      for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
     }
   }
 }
@@ -165,14 +189,56 @@ __device__ __forceinline__ unsigned kslot_offset(int s, int g) {
                     ch0 * 2);
 }
 
-// stage one ring slot (KCHUNK K-steps x 3 fragments, contiguous in global)
-__device__ __forceinline__ void stage_weights(const unsigned char *wglobal,
-                                              unsigned char *slot, int chunk,
-                                              int wave, int lane) {
-  const unsigned char *srcp = wglobal + (size_t)chunk * RING_BYTES;
-  for (int i = wave; i < RING_BYTES / 1024; i += 4)
-    glds16(srcp + i * 1024 + lane * 16, slot + i * 1024);
+// k-slot offset table [g][chunk][KQ]: entry q = offset of K-step KC*chunk + q;
+// q = KC looks ahead into the next chunk (clamped at the last step)
+template <int KC> struct KGeom {
+  static constexpr int NCH = KSTEPS / KC;            // ring slots per pass
+  static constexpr int KQ = KC + 1 <= 4 ? 4 : 8;     // table entries per chunk
+  static constexpr int RING = KC * 3 * 1024;         // bytes per ring slot
+  static constexpr int TAB_BYTES = 4 * NCH * KQ * 4;
+  static_assert(KSTEPS % KC == 0, "KSTEPS must be a multiple of the chunk");
+};
+
+template <int KC, int TY, int TX>
+__device__ __forceinline__ unsigned kslot_entry(int idx) {
+  using G = KGeom<KC>;
+  const int g = idx / (G::NCH * G::KQ), ck = (idx / G::KQ) % G::NCH, q = idx % G::KQ;
+  int s = ck * KC + q;
+  s = s < KSTEPS ? s : KSTEPS - 1;
+  return kslot_offset<TY, TX>(s, g);
 }
+
+// One ring slot = KC K-steps x 3 fragments, contiguous in global memory.  A slot
+// is staged through REGISTERS: the global loads of slot ck+WDEPTH are issued
+// while slot ck is being multiplied, so WDEPTH slots (x 2 workgroups per CU) are
+// in flight - an LDS-DMA ring with one slot of lookahead left the MFMAs waiting
+// ~1 us per slot for L2.
+constexpr int WDEPTH = 4;
+
+template <int KC> struct WStage {
+  static constexpr int PIECES = KGeom<KC>::RING / 16;      // 16-B pieces per slot
+  static constexpr int PER = (PIECES + 255) / 256;         // per thread
+  u32x4 r[PER];
+  // branch-free: threads past the end re-load / re-store the last piece (same
+  // bytes, benign) so the compiler keeps counted vmcnt waits instead of vmcnt(0)
+  __device__ __forceinline__ void load(const unsigned char *wglobal, int chunk, int tid) {
+    const unsigned char *srcp = wglobal + (size_t)chunk * KGeom<KC>::RING;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int piece = tid + 256 * k;
+      piece = piece < PIECES ? piece : PIECES - 1;
+      r[k] = *reinterpret_cast<const u32x4 *>(srcp + (size_t)piece * 16);
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char *slot, int tid) const {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int piece = tid + 256 * k;
+      piece = piece < PIECES ? piece : PIECES - 1;
+      *reinterpret_cast<u32x4 *>(slot + (size_t)piece * 16) = r[k];
+    }
+  }
+};
 
 // fill the activation tile by LDS-DMA: tile is TZ*TY rows of TX voxels (96 B)
 template <int TZ, int TY, int TX>
@@ -195,47 +261,96 @@ __device__ __forceinline__ void stage_tile(const __bf16 *act, int AZ, int AY, in
   }
 }
 
-template <int NSUB, int TY, int TX, typename SubOff>
+template <int NSUB, int KC, bool DIAG = false, typename SubOff>
 __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
                                             unsigned char *ring,
                                             const unsigned *kofftab,
                                             const unsigned char *wglobal,
                                             unsigned vbase, SubOff sub_off,
-                                            f32x4 (&acc)[NSUB][3], int wave,
-                                            int lane) {
-  const int g = lane >> 4;
-  for (int ck = 0; ck < NCHUNK; ++ck) {
-    __syncthreads();          // slot ck landed (vmcnt(0) + barrier); slot ck^1 free
-    if (ck + 1 < NCHUNK)
-      stage_weights(wglobal, ring + ((ck + 1) & 1) * RING_BYTES, ck + 1, wave, lane);
-    const unsigned char *wslot = ring + (ck & 1) * RING_BYTES;
+                                            f32x4 (&acc)[NSUB][3], int tid,
+                                            unsigned long long *t_ready = nullptr) {
+  using G = KGeom<KC>;
+  const int lane = tid & 63, g = lane >> 4;
+  // weight slots 0..WDEPTH-1 start their trip from L2 right away
+  WStage<KC> wst[WDEPTH];
 #pragma unroll
-    for (int ks = 0; ks < KCHUNK; ++ks) {
-      const int s = ck * KCHUNK + ks;
-      const unsigned koff = kofftab[s * 4 + g];
-      bf16x8 wf[3];
+  for (int d = 0; d < WDEPTH; ++d)
+    if (d < G::NCH) wst[d].load(wglobal, d, tid);
+  wst[0].store(ring, tid);
+  if (WDEPTH < G::NCH) wst[0].load(wglobal, WDEPTH, tid);
+  __syncthreads();            // activation tile (LDS-DMA) + slot 0 + table visible
+  if (DIAG) *t_ready = __builtin_amdgcn_s_memtime();
+  // activation fragments run one K-step ahead of the MFMAs
+  bf16x8 bcur[NSUB], bnxt[NSUB];
+  const unsigned *ktab = kofftab + g * (G::NCH * G::KQ);
+  {
+    const unsigned koff = ktab[0];
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
-        wf[b] = *reinterpret_cast<const bf16x8 *>(wslot + (ks * 3 + b) * 1024 +
-                                                  lane * 16);
+    for (int sub = 0; sub < NSUB; ++sub)
+      bcur[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub_off(sub));
+  }
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(
-            tile + vbase + koff + sub_off(sub));
+  for (int ck = 0; ck < G::NCH; ++ck) {
+    // slot (ck+1)&1 was last read during chunk ck-1, which every wave has left
+    if (ck > 0) __syncthreads();
+    if (ck + 1 < G::NCH) {
+      wst[(ck + 1) % WDEPTH].store(ring + ((ck + 1) & 1) * G::RING, tid);
+      if (ck + 1 + WDEPTH < G::NCH)
+        wst[(ck + 1) % WDEPTH].load(wglobal, ck + 1 + WDEPTH, tid);
+    }
+    const unsigned char *wslot = ring + (ck & 1) * G::RING + lane * 16;
+    // k-slot offsets of steps 1..KC of this chunk (entry KC = next chunk's step 0)
+    unsigned kq[G::KQ];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wf[b], bf, acc[sub][b]);
+    for (int q4 = 0; q4 < G::KQ / 4; ++q4) {
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(ktab + ck * G::KQ + 4 * q4);
+      kq[4 * q4 + 0] = v[0]; kq[4 * q4 + 1] = v[1];
+      kq[4 * q4 + 2] = v[2]; kq[4 * q4 + 3] = v[3];
+    }
+    bf16x8 wcur[3], wnxt[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      wcur[b] = *reinterpret_cast<const bf16x8 *>(wslot + b * 1024);
+#pragma unroll
+    for (int ks = 0; ks < KC; ++ks) {
+      // prefetch K-step s+1 (the final prefetch re-reads step KSTEPS-1: harmless)
+      const unsigned koff = kq[ks + 1];
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+        bnxt[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub_off(sub));
+      if (ks + 1 < KC) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          wnxt[b] = *reinterpret_cast<const bf16x8 *>(wslot + ((ks + 1) * 3 + b) * 1024);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wcur[b], bcur[sub], acc[sub][b]);
+      __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) bcur[sub] = bnxt[sub];
+      if (ks + 1 < KC) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) wcur[b] = wnxt[b];
       }
     }
   }
 }
 
 // -------------------------------------------------------------------------------
-// K2: conv3 48->48 + conv1 48->48 + maxpool2.  WG = 4 waves, pooled block
-// 2 x 2 x 16; wave = one (pz,py) row; 8 sub-steps = pooling window positions.
+// K2: conv3 48->48 + conv1 48->48 + maxpool2.  WG = 4 waves, pre-pool block
+// 4 x 4 x 16 (pooled 2 x 2 x 8); wave = one pooled (pz,py) row; lanes = 16
+// consecutive pre-pool x; 4 sub-steps = the (dz,dy) pooling window positions, the
+// x pair is pooled across adjacent lanes at the very end.  80 KiB of LDS per WG
+// so two WGs share a CU: one fills its tile while the other computes.
 // -------------------------------------------------------------------------------
-constexpr int M_TZ = 6, M_TY = 6, M_TX = 34;
+constexpr int M_KC = 3;
+constexpr int M_TZ = 6, M_TY = 6, M_TX = 18;
 constexpr int M_TILE_BYTES = ((M_TZ * M_TY * M_TX * VOX_BYTES + 1023) / 1024) * 1024;
-constexpr int M_SMEM = M_TILE_BYTES + 2 * RING_BYTES + KSTEPS * 4 * 4;
+constexpr int M_SMEM = M_TILE_BYTES + 2 * KGeom<M_KC>::RING + KGeom<M_KC>::TAB_BYTES;
+static_assert(2 * M_SMEM <= 160 * 1024, "two mid workgroups must fit one CU");
 
 struct MidArgs {
   const __bf16 *p1;
@@ -245,75 +360,84 @@ struct MidArgs {
   const float *shift3, *shift4;
   __bf16 *p2;
   int P2Z, P2Y, P2X;
+  unsigned long long *dbg;       // diagnostic build only: 4 stamps per workgroup
 };
 
-__global__ __launch_bounds__(256) void vgg_mid_pool_bf16(MidArgs a) {
+template <bool DIAG>
+__global__ __launch_bounds__(256, 2) void vgg_mid_pool_bf16(MidArgs a) {
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (DIAG) t0 = __builtin_amdgcn_s_memtime();
+  using G = KGeom<M_KC>;
   unsigned char *tile = smem;
   unsigned char *ring = smem + M_TILE_BYTES;
-  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES + 2 * RING_BYTES);
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES + 2 * G::RING);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int px0 = blockIdx.x * 16, py0 = blockIdx.y * 2, pz0 = blockIdx.z * 2;
+  const int px0 = blockIdx.x * 8, py0 = blockIdx.y * 2, pz0 = blockIdx.z * 2;
 
-  if (tid < KSTEPS * 4) kofftab[tid] = kslot_offset<M_TY, M_TX>(tid >> 2, tid & 3);
+  if (tid < 4 * G::NCH * G::KQ) kofftab[tid] = kslot_entry<M_KC, M_TY, M_TX>(tid);
   stage_tile<M_TZ, M_TY, M_TX>(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0,
                                tile, wave, lane);
-  stage_weights(a.w3, ring, 0, wave, lane);
 
   const int pzl = wave >> 1, pyl = wave & 1;
   const unsigned vbase =
-      (unsigned)((((2 * pzl) * M_TY + 2 * pyl) * M_TX + 2 * c) * VOX_BYTES);
-  f32x4 acc[8][3];
+      (unsigned)((((2 * pzl) * M_TY + 2 * pyl) * M_TX + c) * VOX_BYTES);
+  f32x4 acc[4][3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     f32x4 sh;
 #pragma unroll
     for (int r = 0; r < 4; ++r) sh[r] = a.shift3[16 * b + 4 * g + r];
 #pragma unroll
-    for (int sub = 0; sub < 8; ++sub) acc[sub][b] = sh;
+    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
   }
   auto sub_off = [](int sub) -> unsigned {
-    return (unsigned)(((((sub >> 2) & 1) * M_TY + ((sub >> 1) & 1)) * M_TX + (sub & 1)) *
-                      VOX_BYTES);
+    return (unsigned)(((((sub >> 1) & 1) * M_TY + (sub & 1)) * M_TX) * VOX_BYTES);
   };
-  conv3_kloop<8, M_TY, M_TX>(tile, ring, kofftab, a.w3, vbase, sub_off, acc, wave, lane);
+  conv3_kloop<4, M_KC, DIAG>(tile, ring, kofftab, a.w3, vbase, sub_off, acc, tid, &t1);
+  if (DIAG) t2 = __builtin_amdgcn_s_memtime();
 
-  // conv1 48->48 chained in registers, pooled over the 8 window positions
+  // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions
   bf16x8 w4[2][3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     w4[0][b] = a.w4[(0 * 3 + b) * 64 + lane];
     w4[1][b] = a.w4[(1 * 3 + b) * 64 + lane];
   }
-  f32x4 pooled[3];
+  f32x4 sh4[3];
 #pragma unroll
-  for (int sub = 0; sub < 8; ++sub) {
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[16 * b + 4 * g + r];
+  u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
     const bf16x8 h0 = pack_relu(acc[sub][0], acc[sub][1]);
     const bf16x8 h1 = pack_relu_lo(acc[sub][2]);
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-      a4 = mfma16(w4[0][b], h0, a4);
+      f32x4 a4 = mfma16(w4[0][b], h0, sh4[b]);
       a4 = mfma16(w4[1][b], h1, a4);
-      if (sub == 0) {
-        pooled[b] = a4;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pooled[b][r] = max1(pooled[b][r], a4[r]);
-      }
+      pool_relu_bf16(pooled[b], a4);
     }
   }
-  const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + c;
-  if (pz < a.P2Z && py < a.P2Y && px < a.P2X) {
+  // pool the x pair: lanes c and c^1 hold neighbouring pre-pool x
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    pooled[b][0] = pk_max_i16(pooled[b][0], (unsigned)__shfl_xor((int)pooled[b][0], 1));
+    pooled[b][1] = pk_max_i16(pooled[b][1], (unsigned)__shfl_xor((int)pooled[b][1], 1));
+  }
+  const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + (c >> 1);
+  if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
     __bf16 *dst = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * CH + 4 * g;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      bf16x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        o[r] = (__bf16)relu1(pooled[b][r] + a.shift4[16 * b + 4 * g + r]);
-      *reinterpret_cast<bf16x4 *>(dst + 16 * b) = o;
-    }
+    for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
+  }
+  if (DIAG && tid == 0) {
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    a.dbg[4 * wg + 0] = t0; a.dbg[4 * wg + 1] = t1;
+    a.dbg[4 * wg + 2] = t2; a.dbg[4 * wg + 3] = t3;
   }
 }
 
@@ -326,7 +450,9 @@ constexpr int H_TZ = 6, H_TY = 6, H_TX = 18;
 constexpr int H_TILE_BYTES = ((H_TZ * H_TY * H_TX * VOX_BYTES + 1023) / 1024) * 1024;
 constexpr int H_W6 = 12, H_W7 = 18, H_W8 = 3;       // fragment counts
 constexpr int H_WTAIL_BYTES = (H_W6 + H_W7 + H_W8) * 1024;
-constexpr int H_SMEM = H_TILE_BYTES + 2 * RING_BYTES + H_WTAIL_BYTES + KSTEPS * 4 * 4;
+constexpr int H_KC = 6;
+constexpr int H_SMEM = H_TILE_BYTES + 2 * KGeom<H_KC>::RING + H_WTAIL_BYTES +
+                       KGeom<H_KC>::TAB_BYTES;
 
 struct HeadArgs {
   const __bf16 *p2;
@@ -342,21 +468,21 @@ struct HeadArgs {
   int64_t VZ, VY, VX;            // valid fine extents (dim - 14)
 };
 
-__global__ __launch_bounds__(256) void vgg_head_bf16(HeadArgs a) {
+__global__ __launch_bounds__(256, 2) void vgg_head_bf16(HeadArgs a) {
   unsigned char *tile = smem;
+  using G = KGeom<H_KC>;
   unsigned char *ring = smem + H_TILE_BYTES;
-  unsigned char *wtail = smem + H_TILE_BYTES + 2 * RING_BYTES;
+  unsigned char *wtail = smem + H_TILE_BYTES + 2 * G::RING;
   unsigned *kofftab =
-      reinterpret_cast<unsigned *>(smem + H_TILE_BYTES + 2 * RING_BYTES + H_WTAIL_BYTES);
+      reinterpret_cast<unsigned *>(smem + H_TILE_BYTES + 2 * G::RING + H_WTAIL_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int cx0 = blockIdx.x * 16, cy0 = blockIdx.y * 4, cz0 = blockIdx.z * 4;
 
-  if (tid < KSTEPS * 4) kofftab[tid] = kslot_offset<H_TY, H_TX>(tid >> 2, tid & 3);
+  if (tid < 4 * G::NCH * G::KQ) kofftab[tid] = kslot_entry<H_KC, H_TY, H_TX>(tid);
   stage_tile<H_TZ, H_TY, H_TX>(a.p2, a.P2Z, a.P2Y, a.P2X, cz0, cy0, cx0, tile, wave, lane);
   for (int i = wave; i < H_WTAIL_BYTES / 1024; i += 4)
     glds16(a.wtail + i * 1024 + lane * 16, wtail + i * 1024);
-  stage_weights(a.w5, ring, 0, wave, lane);
 
   const unsigned vbase = (unsigned)(((wave * H_TY) * H_TX + c) * VOX_BYTES);
   f32x4 acc[4][3];
@@ -369,7 +495,7 @@ __global__ __launch_bounds__(256) void vgg_head_bf16(HeadArgs a) {
     for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
   }
   auto sub_off = [](int sub) -> unsigned { return (unsigned)(sub * H_TX * VOX_BYTES); };
-  conv3_kloop<4, H_TY, H_TX>(tile, ring, kofftab, a.w5, vbase, sub_off, acc, wave, lane);
+  conv3_kloop<4, H_KC>(tile, ring, kofftab, a.w5, vbase, sub_off, acc, tid);
 
   const bf16x8 *w6 = reinterpret_cast<const bf16x8 *>(wtail);
   const bf16x8 *w7 = w6 + H_W6 * 64;
@@ -501,8 +627,11 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
     if (l == 7) {
       // sigmoid head: scale is 1 (no BN); keep it explicit anyway
     }
-    fpl_pack_frags(A + op.w_off, scale.data(), op.k * op.k * op.k, op.cin, op.cout,
-                   mblocks[l], ksteps[l], maps[l], &f);
+    if (l == 0)
+      fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f);
+    else
+      fpl_pack_frags(A + op.w_off, scale.data(), op.k * op.k * op.k, op.cin, op.cout,
+                     mblocks[l], ksteps[l], maps[l], &f);
     st->off_w[l] = all.size() * sizeof(uint16_t);
     all.insert(all.end(), f.begin(), f.end());
     st->off_s[l] = shifts.size();
@@ -520,7 +649,9 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
                          hipMemcpyHostToDevice));
   FPL_HIP(ctx, hipMemcpy(st->shifts, shifts.data(), shifts.size() * sizeof(float),
                          hipMemcpyHostToDevice));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vgg_mid_pool_bf16,
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vgg_mid_pool_bf16<false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vgg_mid_pool_bf16<true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vgg_head_bf16,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM));
@@ -590,10 +721,32 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
       a.w4 = (const bf16x8 *)(F + st->off_w[3]);
       a.shift3 = S + st->off_s[2]; a.shift4 = S + st->off_s[3];
       a.p2 = (__bf16 *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
-      dim3 grid((unsigned)ceil_div64(P2X, 16), (unsigned)ceil_div64(P2Y, 2),
+      dim3 grid((unsigned)ceil_div64(P2X, 8), (unsigned)ceil_div64(P2Y, 2),
                 (unsigned)ceil_div64(P2Z, 2));
-      TimedLaunch tl(ctx, "vgg_mid_pool_bf16");
-      vgg_mid_pool_bf16<<<grid, 256, M_SMEM, stream>>>(a);
+      a.dbg = nullptr;
+      if (getenv("FPL_DIAG_MID")) {
+        // diagnostic build: per-workgroup s_memtime stamps (never timed/shipped)
+        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+        void *dbg;
+        FPL_TRY(tmp.alloc(nwg * 32, &dbg));
+        a.dbg = (unsigned long long *)dbg;
+        vgg_mid_pool_bf16<true><<<grid, 256, M_SMEM, stream>>>(a);
+        std::vector<unsigned long long> h(nwg * 4);
+        FPL_HIP(ctx, hipMemcpyAsync(h.data(), dbg, nwg * 32, hipMemcpyDeviceToHost, stream));
+        FPL_HIP(ctx, hipStreamSynchronize(stream));
+        double fill = 0, loop = 0, epi = 0, tot = 0;
+        for (size_t i = 0; i < nwg; ++i) {
+          fill += (double)(h[4 * i + 1] - h[4 * i]);
+          loop += (double)(h[4 * i + 2] - h[4 * i + 1]);
+          epi += (double)(h[4 * i + 3] - h[4 * i + 2]);
+          tot += (double)(h[4 * i + 3] - h[4 * i]);
+        }
+        fprintf(stderr, "[FPL_DIAG_MID] %zu WGs: mean cycles fill %.0f  kloop %.0f  epilogue %.0f  total %.0f\n",
+                nwg, fill / nwg, loop / nwg, epi / nwg, tot / nwg);
+      } else {
+        TimedLaunch tl(ctx, "vgg_mid_pool_bf16");
+        vgg_mid_pool_bf16<false><<<grid, 256, M_SMEM, stream>>>(a);
+      }
     }
     {
       HeadArgs a;

@@ -13,7 +13,7 @@ from flypylib_amd import _capi, fplmodels, multi_gpu, synth
 from oracle import cnn_oracle, infer_oracle
 
 pytestmark = pytest.mark.gpu
-EMU_TOL = 4e-3       # bf16 one-ulp flips at rounding points, amplified by the net
+EMU_TOL = 1e-2       # worst voxel: bf16 one-ulp flips at rounding points, amplified
 BF16_TOL = 5e-2      # bf16 vs fp32 probabilities, max abs
 
 
@@ -53,6 +53,7 @@ def test_fused_bf16_matches_emulation_and_fp32(ctx, shape, tile):
     d_f32 = np.abs(got - f32)
     assert d_emu.max() < EMU_TOL, 'vs bf16 emulation: max %g' % d_emu.max()
     assert d_emu.mean() < 1e-4
+    assert np.mean(d_emu > 1e-3) < 1e-3       # 99.9 % of voxels within 1e-3
     assert d_f32.max() < BF16_TOL, 'vs fp32 oracle: max %g' % d_f32.max()
     assert f32[7:-7, 7:-7, 7:-7].std() > 1e-3
 
