@@ -155,6 +155,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # HBM bytes per launch of each kernel from the committed rocprofv3 --pmc pass
+    # (tools/profile_pmc.py; FETCH_SIZE doubled per the gfx950 correction) - only
+    # valid for the workload size it was collected on
+    traffic_by_kernel = {}
+    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_%d_%s.json'
+                            % (args.size, args.precision))
+    if world == 1 and os.path.exists(pmc_path):
+        for k, v in json.load(open(pmc_path))['kernels'].items():
+            if 'hbm_bytes_per_dispatch' in v:
+                traffic_by_kernel[k] = v['hbm_bytes_per_dispatch']
+
     # dominant kernel roofline (this rank; ranks are symmetric)
     roof = None
     if timings:
@@ -169,7 +180,8 @@ def main():
             peak = PEAK_TFLOPS[args.precision if 'generic' not in name else 'f32']
             roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 3),
                         peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 5), traffic=None,
+                        frac=round(achieved / peak, 5),
+                        traffic=traffic_by_kernel.get(name),
                         avg_launch_ms=round(avg_ms, 4), launches=tk['launches'],
                         algorithmic_flop_per_voxel=flop_per_vox,
                         kernel_ms_total={k: round(v['ms'], 3)

@@ -31,7 +31,9 @@ GROUPS = {
     'sq_mem': ['SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_SALU',
                'SQ_INSTS_SMEM', 'SQ_ACTIVE_INST_VMEM', 'SQ_INST_LEVEL_VMEM',
                'SQ_INST_LEVEL_LDS', 'SQ_LDS_UNALIGNED_STALL'],
-    'fetch': ['FETCH_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'],
+    'fetch': ['FETCH_SIZE'],
+    'rdreq': ['TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum'],
+    'l2hit': ['TCC_HIT_sum', 'TCC_MISS_sum'],
     'write': ['WRITE_SIZE', 'TCC_EA0_WRREQ_sum'],
 }
 
@@ -43,8 +45,13 @@ def run_group(name, counters, out, bench_args):
         '--kernel-trace', '--output-format', 'csv', '-d', d, '--',
         sys.executable, os.path.join(ROOT, 'bench.py')] + bench_args
     env = dict(os.environ, TMPDIR='/tmp')
-    r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True)
+    print('[pmc] group %s: %s' % (name, ' '.join(counters)), flush=True)
+    try:
+        r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        print('[pmc] group %s timed out' % name, flush=True)
+        return {}
     open(os.path.join(d, 'run.log'), 'w').write(r.stdout)
     if r.returncode != 0:
         print('group %s failed (rc %d); see %s/run.log' % (name, r.returncode, d))
