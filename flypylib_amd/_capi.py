@@ -29,6 +29,14 @@ class fpl_op(C.Structure):
                 ('p', C.c_int32 * 6)]
 
 
+class fpl_layer(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('src0', C.c_int32), ('src1', C.c_int32),
+                ('dst', C.c_int32), ('k', C.c_int32), ('cin', C.c_int32),
+                ('cout', C.c_int32), ('use_bias', C.c_int32), ('act', C.c_int32),
+                ('rate', C.c_float), ('p', C.c_int32 * 6),
+                ('w_off', C.c_int64 * 4)]
+
+
 _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 _pi32, _pi64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
 
@@ -57,6 +65,17 @@ SIGNATURES = {
                                  _pi64, _i32, _vp]),
     'fpl_v2o_nms': (C.c_int, [_vp, _f64, _vp, _i64, _pi64, _pi32]),
     'fpl_v2o_copy_smoothed': (C.c_int, [_vp, _vp, C.c_int]),
+    'fpl_trainer_create': (C.c_int, [_vp, C.POINTER(fpl_layer), _i32, _i32, _i32,
+                                     _vp, _i64, _f32, _f32, _f32, _f32,
+                                     C.POINTER(_vp)]),
+    'fpl_trainer_destroy': (C.c_int, [_vp]),
+    'fpl_trainer_step': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i32, _pi32,
+                                   C.c_uint64, C.POINTER(_f32), C.POINTER(_f32)]),
+    'fpl_trainer_apply': (C.c_int, [_vp, _f32]),
+    'fpl_trainer_grad_ptr': (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
+    'fpl_trainer_get_weights': (C.c_int, [_vp, _vp, _i64]),
+    'fpl_trainer_set_weights': (C.c_int, [_vp, _vp, _i64]),
+    'fpl_trainer_get_grads': (C.c_int, [_vp, _vp, _i64]),
     'fpl_synth_volume_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _vp,
                                       C.c_int]),
     'fpl_timing_enable': (C.c_int, [_vp, C.c_int]),
@@ -290,3 +309,88 @@ class Program:
             _arr(offset, C.c_int32), precision, int(z_range[0]),
             int(z_range[1]), _ptr(dst), _mem_of(dst)))
         return dst
+
+
+class Trainer:
+    """training engine for one LayerGraph on one GPU (fpl_trainer)"""
+
+    def __init__(self, ctx, graph, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+        from .program import lower_training
+        self.ctx = ctx
+        self.graph = graph
+        layers, arena, offsets, out_tensor, n_tensors = lower_training(graph)
+        self.offsets = offsets
+        self.n_w = int(arena.size)
+        c_layers = (fpl_layer * len(layers))()
+        for i, d in enumerate(layers):
+            c_layers[i] = fpl_layer(d['kind'], d['src0'], d['src1'], d['dst'],
+                                    d['k'], d['cin'], d['cout'], d['use_bias'],
+                                    d['act'], d['rate'],
+                                    (C.c_int32 * 6)(*[int(v) for v in d['p']]),
+                                    (C.c_int64 * 4)(*[int(v) for v in d['w_off']]))
+        h = _vp()
+        arena = np.ascontiguousarray(arena, np.float32)
+        ctx.check(ctx.lib.fpl_trainer_create(
+            ctx.h, c_layers, len(layers), n_tensors, out_tensor, _ptr(arena),
+            arena.size, lr, beta1, beta2, eps, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.lib.fpl_trainer_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, data, labels, seed=0):
+        """forward + loss + backward; data (B,D,H,W[,1]) f32, labels
+        (B,d,h,w[,1]) u8.  Returns (loss, accuracy); gradients stay on device."""
+        x = np.ascontiguousarray(data, np.float32)
+        if x.ndim == 5:
+            x = x[..., 0]
+        y = np.ascontiguousarray(labels, np.uint8)
+        if y.ndim == 5:
+            y = y[..., 0]
+        loss, acc = C.c_float(), C.c_float()
+        self.ctx.check(self.ctx.lib.fpl_trainer_step(
+            self.h, _ptr(x), MEM_HOST, _ptr(y), MEM_HOST, x.shape[0],
+            _arr(x.shape[1:], C.c_int32), C.c_uint64(int(seed)),
+            C.byref(loss), C.byref(acc)))
+        return loss.value, acc.value
+
+    def apply(self, grad_scale=1.0):
+        self.ctx.check(self.ctx.lib.fpl_trainer_apply(self.h, float(grad_scale)))
+
+    def grad_ptr(self):
+        p, n = _vp(), C.c_int64()
+        self.ctx.check(self.ctx.lib.fpl_trainer_grad_ptr(self.h, C.byref(p),
+                                                         C.byref(n)))
+        return p.value, n.value
+
+    def _split(self, flat):
+        out = []
+        for w, o in zip(self.graph.weights, self.offsets):
+            out.append(flat[o:o + w.size].reshape(w.shape).copy())
+        return out
+
+    def get_weights(self):
+        flat = np.empty(self.n_w, np.float32)
+        self.ctx.check(self.ctx.lib.fpl_trainer_get_weights(self.h, _ptr(flat),
+                                                            self.n_w))
+        return self._split(flat)
+
+    def get_grads(self):
+        flat = np.empty(self.n_w, np.float32)
+        self.ctx.check(self.ctx.lib.fpl_trainer_get_grads(self.h, _ptr(flat),
+                                                          self.n_w))
+        return self._split(flat)
+
+    def set_weights(self, weights):
+        flat = np.concatenate([np.asarray(w, np.float32).reshape(-1)
+                               for w in weights])
+        self.ctx.check(self.ctx.lib.fpl_trainer_set_weights(self.h, _ptr(flat),
+                                                            flat.size))

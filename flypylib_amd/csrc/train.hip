@@ -1,0 +1,876 @@
+// Training step engine: forward in training mode, binary cross-entropy, backward,
+// Adam.  Replaces the per-step work of `train_network.fit_generator`
+// (flypylib/fplnetwork.py:112-122) with the Keras-layer semantics of SURVEY.md
+// section 8a rows M3-M5:
+//   BatchNormalization: batch statistics over (N,D,H,W), biased variance,
+//     eps 1e-3, moving = 0.99*moving + 0.01*batch
+//   Dropout(rate): inverted scaling, mask from a counter-based hash of
+//     (seed, layer, element)  (flypylib_amd/synth.py::dropout_mask is the same)
+//   binary_crossentropy: p clipped to [1e-7, 1-1e-7], evaluated through logits
+//   Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)
+// fp32 throughout; one simple kernel per layer (round-1 correctness path - the
+// MFMA forward/backward kernels replace the convs later).
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+#include "conv_direct.h"
+
+namespace {
+
+struct TShape {
+  int d = 0, h = 0, w = 0, c = 0;
+  int64_t vox() const { return (int64_t)d * h * w; }
+  int64_t elems() const { return vox() * c; }
+};
+
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  uint64_t z = x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+inline unsigned g1(int64_t n) { return (unsigned)ceil_div64(n, 256); }
+
+// ---- per-channel reductions over rows of an [M][C] tensor -----------------------
+// block = (C, R) threads; each block covers rows blockIdx.x*ROWS .. ; partial
+// sums in double -> part[block][2][C]
+constexpr int RED_ROWS = 4096;
+
+template <int MODE>   // 0: (x, x^2)   1: (dy, dy*xhat)   2: (dy, 0)
+__global__ void chan_reduce_partial(const float *__restrict__ a,
+                                    const float *__restrict__ b,
+                                    const float *__restrict__ mean,
+                                    const float *__restrict__ invstd, int64_t M,
+                                    int C, double *__restrict__ part) {
+  extern __shared__ double red[];
+  const int c = threadIdx.x, r = threadIdx.y, R = blockDim.y;
+  const int64_t row0 = (int64_t)blockIdx.x * RED_ROWS;
+  const int64_t row1 = row0 + RED_ROWS < M ? row0 + RED_ROWS : M;
+  double s0 = 0.0, s1 = 0.0;
+  const float mu = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 0.f;
+  for (int64_t m = row0 + r; m < row1; m += R) {
+    const float v = a[m * C + c];
+    if (MODE == 0) {
+      s0 += v; s1 += (double)v * v;
+    } else if (MODE == 1) {
+      const float xh = (b[m * C + c] - mu) * is;
+      s0 += v; s1 += (double)v * xh;
+    } else {
+      s0 += v;
+    }
+  }
+  red[(r * C + c) * 2 + 0] = s0;
+  red[(r * C + c) * 2 + 1] = s1;
+  __syncthreads();
+  if (r == 0) {
+    for (int k = 1; k < R; ++k) {
+      s0 += red[(k * C + c) * 2 + 0];
+      s1 += red[(k * C + c) * 2 + 1];
+    }
+    part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s0;
+    part[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
+  }
+}
+
+// BN forward statistics from the partials: mean, invstd (biased var), and the
+// moving-average deltas into the gradient arena
+__global__ void bn_finish_stats(const double *__restrict__ part, int nb, int C,
+                                int64_t M, float eps, float momentum,
+                                const float *__restrict__ mov_mean,
+                                const float *__restrict__ mov_var,
+                                float *__restrict__ mean, float *__restrict__ invstd,
+                                float *__restrict__ d_mov_mean,
+                                float *__restrict__ d_mov_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    s0 += part[((int64_t)b * 2 + 0) * C + c];
+    s1 += part[((int64_t)b * 2 + 1) * C + c];
+  }
+  const double mu = s0 / (double)M;
+  double var = s1 / (double)M - mu * mu;
+  var = var > 0.0 ? var : 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  d_mov_mean[c] = ((float)mu - mov_mean[c]) * (1.f - momentum);
+  d_mov_var[c] = ((float)var - mov_var[c]) * (1.f - momentum);
+}
+
+__global__ void finish_sums(const double *__restrict__ part, int nb, int C,
+                            float *__restrict__ s0_out, float *__restrict__ s1_out,
+                            float scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    s0 += part[((int64_t)b * 2 + 0) * C + c];
+    s1 += part[((int64_t)b * 2 + 1) * C + c];
+  }
+  if (s0_out) s0_out[c] += (float)(s0 * scale);
+  if (s1_out) s1_out[c] += (float)(s1 * scale);
+}
+
+__global__ void bn_apply(const float *__restrict__ x, const float *__restrict__ mean,
+                         const float *__restrict__ invstd,
+                         const float *__restrict__ gamma,
+                         const float *__restrict__ beta, float *__restrict__ y,
+                         int64_t n, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  y[i] = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+}
+
+// dx += gamma*invstd/M * (M*dy - sum_dy - xhat*sum_dy_xhat)
+__global__ void bn_backward(const float *__restrict__ dy, const float *__restrict__ x,
+                            const float *__restrict__ mean,
+                            const float *__restrict__ invstd,
+                            const float *__restrict__ gamma,
+                            const float *__restrict__ sum_dy,
+                            const float *__restrict__ sum_dy_xhat,
+                            float *__restrict__ dx, int64_t n, int C, float inv_m) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float xh = (x[i] - mean[c]) * invstd[c];
+  dx[i] += gamma[c] * invstd[c] *
+           (dy[i] - inv_m * sum_dy[c] - xh * inv_m * sum_dy_xhat[c]);
+}
+
+__global__ void relu_fwd(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ void relu_bwd(const float *__restrict__ dy, const float *__restrict__ y,
+                         float *__restrict__ dx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] += y[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ void pool2_fwd(const float *__restrict__ x, float *__restrict__ y,
+                          uint8_t *__restrict__ arg, int64_t n_out, int D, int H,
+                          int W, int C, int od, int oh, int ow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  int64_t t = i;
+  const int c = (int)(t % C); t /= C;
+  const int ox = (int)(t % ow); t /= ow;
+  const int oy = (int)(t % oh); t /= oh;
+  const int oz = (int)(t % od); t /= od;
+  float m = -INFINITY;
+  int am = 0;
+  for (int p = 0; p < 8; ++p) {
+    const float v = x[((((t * D + 2 * oz + (p >> 2)) * H + 2 * oy + ((p >> 1) & 1)) *
+                        (int64_t)W + 2 * ox + (p & 1)) * C) + c];
+    if (v > m) { m = v; am = p; }      // first maximum wins (TF MaxPoolGrad)
+  }
+  y[i] = m;
+  arg[i] = (uint8_t)am;
+}
+__global__ void pool2_bwd(const float *__restrict__ dy, const uint8_t *__restrict__ arg,
+                          float *__restrict__ dx, int64_t n_out, int D, int H, int W,
+                          int C, int od, int oh, int ow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  int64_t t = i;
+  const int c = (int)(t % C); t /= C;
+  const int ox = (int)(t % ow); t /= ow;
+  const int oy = (int)(t % oh); t /= oh;
+  const int oz = (int)(t % od); t /= od;
+  const int p = arg[i];
+  dx[((((t * D + 2 * oz + (p >> 2)) * H + 2 * oy + ((p >> 1) & 1)) * (int64_t)W +
+       2 * ox + (p & 1)) * C) + c] += dy[i];      // windows do not overlap
+}
+
+__device__ __forceinline__ bool drop_keep(uint64_t seed, int layer, int64_t i,
+                                          float rate) {
+  const uint64_t h = splitmix64(seed ^ splitmix64(((uint64_t)layer << 48) ^ (uint64_t)i));
+  return (float)(h >> 40) * (1.f / 16777216.f) >= rate;
+}
+__global__ void dropout_fwd(const float *__restrict__ x, float *__restrict__ y,
+                            int64_t n, uint64_t seed, int layer, float rate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = drop_keep(seed, layer, i, rate) ? x[i] / (1.f - rate) : 0.f;
+}
+__global__ void dropout_bwd(const float *__restrict__ dy, float *__restrict__ dx,
+                            int64_t n, uint64_t seed, int layer, float rate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] += drop_keep(seed, layer, i, rate) ? dy[i] / (1.f - rate) : 0.f;
+}
+
+// y[b][z][y][x][c_off + c] = x[b][(z+lo)/f..][c]   (crop / upsample / concat half)
+__global__ void remap_fwd(const float *__restrict__ x, float *__restrict__ y,
+                          int64_t n, int D, int H, int W, int C, int od, int oh,
+                          int ow, int lo0, int lo1, int lo2, int f0, int f1, int f2,
+                          int c_off, int c_total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t t = i;
+  const int c = (int)(t % C); t /= C;
+  const int ox = (int)(t % ow); t /= ow;
+  const int oy = (int)(t % oh); t /= oh;
+  const int oz = (int)(t % od); t /= od;
+  y[((((t * od + oz) * oh + oy) * (int64_t)ow + ox) * c_total) + c_off + c] =
+      x[((((t * D + (oz + lo0) / f0) * H + (oy + lo1) / f1) * (int64_t)W +
+          (ox + lo2) / f2) * C) + c];
+}
+// transpose of remap_fwd: dx[src] += dy[dst] (atomic: upsampling maps many -> one)
+__global__ void remap_bwd(const float *__restrict__ dy, float *__restrict__ dx,
+                          int64_t n, int D, int H, int W, int C, int od, int oh,
+                          int ow, int lo0, int lo1, int lo2, int f0, int f1, int f2,
+                          int c_off, int c_total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t t = i;
+  const int c = (int)(t % C); t /= C;
+  const int ox = (int)(t % ow); t /= ow;
+  const int oy = (int)(t % oh); t /= oh;
+  const int oz = (int)(t % od); t /= od;
+  const float g =
+      dy[((((t * od + oz) * oh + oy) * (int64_t)ow + ox) * c_total) + c_off + c];
+  float *dst = &dx[((((t * D + (oz + lo0) / f0) * H + (oy + lo1) / f1) * (int64_t)W +
+                     (ox + lo2) / f2) * C) + c];
+  if (f0 * f1 * f2 == 1) *dst += g; else atomicAdd(dst, g);
+}
+__global__ void add_fwd(const float *a, const float *b, float *y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = a[i] + b[i];
+}
+__global__ void accum(const float *dy, float *dx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] += dy[i];
+}
+
+// sigmoid-output BCE: per-element loss, correct flag, and dL/dlogit (mean folded)
+__global__ void bce_loss_grad(const float *__restrict__ p, const uint8_t *__restrict__ lab,
+                              float *__restrict__ dlogit, int64_t n, float inv_n,
+                              double *__restrict__ sums) {
+  __shared__ double sl[256], sa[256];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double l = 0.0, a = 0.0;
+  if (i < n) {
+    const float y = (float)lab[i];
+    const float pi = p[i];
+    const float eps = 1e-7f;
+    const float pc = fminf(fmaxf(pi, eps), 1.f - eps);
+    const float z = logf(pc / (1.f - pc));
+    l = (double)(fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))));
+    a = (rintf(pi) == y) ? 1.0 : 0.0;
+    dlogit[i] = (pi > eps && pi < 1.f - eps) ? (pc - y) * inv_n : 0.f;
+  }
+  sl[threadIdx.x] = l; sa[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sl[threadIdx.x] += sl[threadIdx.x + s];
+      sa[threadIdx.x] += sa[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], sl[0]);
+    atomicAdd(&sums[1], sa[0]);
+  }
+}
+
+// dX[in][ci] += sum_tap sum_co dY[in - tap][co] * W[tap][ci][co]
+template <int CT>
+__global__ __launch_bounds__(256) void conv_dgrad_f32(
+    const float *__restrict__ dy, const float *__restrict__ w, float *__restrict__ dx,
+    int64_t n_vox, int D, int H, int W, int cin, int od, int oh, int ow, int cout,
+    int k) {
+  const int64_t vox = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vox >= n_vox) return;
+  const int ci0 = blockIdx.y * CT;
+  int64_t t = vox;
+  const int ix = (int)(t % W); t /= W;
+  const int iy = (int)(t % H); t /= H;
+  const int iz = (int)(t % D); t /= D;
+  float acc[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) acc[j] = 0.f;
+  for (int dz = 0; dz < k; ++dz) {
+    const int oz = iz - dz;
+    if (oz < 0 || oz >= od) continue;
+    for (int dyy = 0; dyy < k; ++dyy) {
+      const int oy = iy - dyy;
+      if (oy < 0 || oy >= oh) continue;
+      for (int dxx = 0; dxx < k; ++dxx) {
+        const int ox = ix - dxx;
+        if (ox < 0 || ox >= ow) continue;
+        const float *gp = dy + ((((t * od + oz) * oh + oy) * (int64_t)ow + ox) * cout);
+        const float *wp = w + ((int64_t)((dz * k + dyy) * k + dxx) * cin + ci0) * cout;
+        for (int co = 0; co < cout; ++co) {
+          const float g = gp[co];
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+            if (CT == 1 || ci0 + j < cin) acc[j] = fmaf(g, wp[(int64_t)j * cout + co], acc[j]);
+        }
+      }
+    }
+  }
+  float *xp = dx + vox * cin + ci0;
+#pragma unroll
+  for (int j = 0; j < CT; ++j)
+    if (ci0 + j < cin) xp[j] += acc[j];
+}
+
+// dW[tap][ci][co] += sum_m X[m+tap][ci] * dY[m][co].  Block = 16x16 threads, one
+// tap, one 48x48 (ci,co) tile, one chunk of output voxels; 3x3 register tile.
+constexpr int WG_VS = 16;            // voxels staged per LDS round
+constexpr int WG_CHUNK = 4096;       // output voxels per block
+__global__ __launch_bounds__(256) void conv_wgrad_f32(
+    const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dw,
+    int64_t n_vox, int D, int H, int W, int cin, int od, int oh, int ow, int cout,
+    int k, int ci_tiles, int co_tiles) {
+  __shared__ float xs[WG_VS][48], gs[WG_VS][48];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  int bid = blockIdx.x;
+  const int cot = bid % co_tiles; bid /= co_tiles;
+  const int cit = bid % ci_tiles; bid /= ci_tiles;
+  const int tap = bid;
+  const int dz = tap / (k * k), dyy = (tap / k) % k, dxx = tap % k;
+  const int ci0 = cit * 48, co0 = cot * 48;
+  const int64_t m0 = (int64_t)blockIdx.y * WG_CHUNK;
+  const int64_t m1 = m0 + WG_CHUNK < n_vox ? m0 + WG_CHUNK : n_vox;
+  float acc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  for (int64_t mb = m0; mb < m1; mb += WG_VS) {
+    // stage WG_VS rows: 16 x 48 values each for x and dy -> 3 per thread each
+    for (int e = threadIdx.x; e < WG_VS * 48; e += 256) {
+      const int v = e / 48, c = e % 48;
+      const int64_t m = mb + v;
+      float xv = 0.f, gv = 0.f;
+      if (m < m1) {
+        int64_t t = m;
+        const int ox = (int)(t % ow); t /= ow;
+        const int oy = (int)(t % oh); t /= oh;
+        const int oz = (int)(t % od); t /= od;
+        if (ci0 + c < cin)
+          xv = x[((((t * D + oz + dz) * H + oy + dyy) * (int64_t)W + ox + dxx) * cin) +
+                 ci0 + c];
+        if (co0 + c < cout) gv = dy[m * cout + co0 + c];
+      }
+      xs[v][c] = xv;
+      gs[v][c] = gv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < WG_VS; ++v) {
+      float xv[3], gv[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { xv[i] = xs[v][ty + 16 * i]; gv[i] = gs[v][tx + 16 * i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = fmaf(xv[i], gv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ci = ci0 + ty + 16 * i, co = co0 + tx + 16 * j;
+      if (ci < cin && co < cout && acc[i][j] != 0.f)
+        atomicAdd(&dw[((int64_t)tap * cin + ci) * cout + co], acc[i][j]);
+    }
+}
+
+__global__ void adam_update(float *__restrict__ w, const float *__restrict__ g,
+                            float *__restrict__ m, float *__restrict__ v,
+                            const uint8_t *__restrict__ kind, int64_t n,
+                            float grad_scale, float lr_t, float b1, float b2,
+                            float eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * grad_scale;
+  if (kind[i] == 1) {            // moving statistic: additive averaged delta
+    w[i] += gi;
+    return;
+  }
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  w[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+__global__ void fill_f32(float *p, float v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+struct fpl_trainer {
+  fpl_ctx *ctx = nullptr;
+  std::vector<fpl_layer> layers;
+  int n_tensors = 0, out_tensor = 0;
+  int64_t n_w = 0;
+  float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;
+  uint8_t *kind = nullptr;
+  float *ones = nullptr, *zeros = nullptr;        // 256 floats each
+  float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+  int64_t step_count = 0;
+};
+
+namespace {
+
+int shapes_for(fpl_ctx *ctx, const fpl_trainer *t, const int32_t patch[3],
+               std::vector<TShape> *shp) {
+  shp->assign(t->n_tensors, TShape());
+  (*shp)[0] = TShape{patch[0], patch[1], patch[2], 1};
+  for (size_t i = 0; i < t->layers.size(); ++i) {
+    const fpl_layer &L = t->layers[i];
+    const TShape a = (*shp)[L.src0];
+    FPL_REQUIRE(ctx, a.c > 0, "layer %zu reads tensor %d before it is produced", i, L.src0);
+    TShape o = a;
+    switch (L.kind) {
+      case FPL_L_CONV:
+        FPL_REQUIRE(ctx, a.c == L.cin, "layer %zu: conv cin mismatch", i);
+        o.d = a.d - L.k + 1; o.h = a.h - L.k + 1; o.w = a.w - L.k + 1; o.c = L.cout;
+        break;
+      case FPL_L_POOL:
+        FPL_REQUIRE(ctx, L.p[0] == 2 && L.p[1] == 2 && L.p[2] == 2,
+                    "layer %zu: only MaxPooling3D(2) is trainable", i);
+        o.d = a.d / 2; o.h = a.h / 2; o.w = a.w / 2;
+        break;
+      case FPL_L_UP: o.d = a.d * L.p[0]; o.h = a.h * L.p[1]; o.w = a.w * L.p[2]; break;
+      case FPL_L_CROP:
+        o.d = a.d - L.p[0] - L.p[1]; o.h = a.h - L.p[2] - L.p[3]; o.w = a.w - L.p[4] - L.p[5];
+        break;
+      case FPL_L_CONCAT: {
+        const TShape b = (*shp)[L.src1];
+        FPL_REQUIRE(ctx, a.d == b.d && a.h == b.h && a.w == b.w,
+                    "layer %zu: concatenate shape mismatch - patch size is not "
+                    "compatible with this architecture", i);
+        o.c = a.c + b.c;
+        break;
+      }
+      case FPL_L_ADD: case FPL_L_BN: case FPL_L_RELU: case FPL_L_DROPOUT: break;
+      default: return fpl_fail(ctx, "layer %zu: unknown kind %d", i, L.kind);
+    }
+    FPL_REQUIRE(ctx, o.d > 0 && o.h > 0 && o.w > 0, "layer %zu: patch too small", i);
+    (*shp)[L.dst] = o;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fpl_trainer_create(fpl_ctx *ctx, const fpl_layer *layers, int32_t n_layers,
+                       int32_t n_tensors, int32_t out_tensor, const float *weights,
+                       int64_t n_weights, float lr, float beta1, float beta2,
+                       float eps, fpl_trainer **out) {
+  if (!ctx || !layers || !weights || !out)
+    return fpl_fail(ctx, "fpl_trainer_create: NULL argument");
+  *out = nullptr;
+  FPL_REQUIRE(ctx, n_layers > 0 && n_tensors > 1 && out_tensor > 0 && out_tensor < n_tensors,
+              "fpl_trainer_create: bad sizes");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  std::vector<uint8_t> kind((size_t)n_weights, 0);
+  for (int i = 0; i < n_layers; ++i) {
+    const fpl_layer &L = layers[i];
+    FPL_REQUIRE(ctx, L.src0 >= 0 && L.src0 < n_tensors && L.dst > 0 && L.dst < n_tensors &&
+                         L.src1 < n_tensors, "fpl_trainer_create: layer %d tensor ids", i);
+    if (L.kind == FPL_L_CONV) {
+      FPL_REQUIRE(ctx, L.k == 1 || L.k == 3, "layer %d: conv kernel %d", i, L.k);
+      FPL_REQUIRE(ctx, L.cin <= 256 && L.cout <= 256, "layer %d: > 256 channels", i);
+      const int64_t kk = (int64_t)L.k * L.k * L.k * L.cin * L.cout;
+      FPL_REQUIRE(ctx, L.w_off[0] >= 0 && L.w_off[0] + kk <= n_weights &&
+                           (!L.use_bias || (L.w_off[1] >= 0 && L.w_off[1] + L.cout <= n_weights)),
+                  "layer %d: weight offsets exceed the arena", i);
+      FPL_REQUIRE(ctx, L.act == FPL_ACT_NONE || (L.act == FPL_ACT_SIGMOID && L.dst == out_tensor),
+                  "layer %d: only a sigmoid head may carry a conv activation", i);
+    } else if (L.kind == FPL_L_BN) {
+      FPL_REQUIRE(ctx, L.cin <= 256, "layer %d: > 256 channels", i);
+      for (int q = 0; q < 4; ++q)
+        FPL_REQUIRE(ctx, L.w_off[q] >= 0 && L.w_off[q] + L.cin <= n_weights,
+                    "layer %d: BN offsets exceed the arena", i);
+      for (int q = 2; q < 4; ++q)
+        for (int c = 0; c < L.cin; ++c) kind[L.w_off[q] + c] = 1;
+    }
+  }
+  fpl_trainer *t = new fpl_trainer();
+  t->ctx = ctx;
+  t->layers.assign(layers, layers + n_layers);
+  t->n_tensors = n_tensors;
+  t->out_tensor = out_tensor;
+  t->n_w = n_weights;
+  t->lr = lr; t->b1 = beta1; t->b2 = beta2; t->eps = eps;
+  const size_t nb = (size_t)n_weights * sizeof(float);
+  bool ok = hipMalloc((void **)&t->w, nb) == hipSuccess &&
+            hipMalloc((void **)&t->g, nb) == hipSuccess &&
+            hipMalloc((void **)&t->m, nb) == hipSuccess &&
+            hipMalloc((void **)&t->v, nb) == hipSuccess &&
+            hipMalloc((void **)&t->kind, (size_t)n_weights) == hipSuccess &&
+            hipMalloc((void **)&t->ones, 256 * sizeof(float)) == hipSuccess &&
+            hipMalloc((void **)&t->zeros, 256 * sizeof(float)) == hipSuccess;
+  if (!ok) {
+    fpl_trainer_destroy(t);
+    return fpl_fail(ctx, "fpl_trainer_create: device allocation failed");
+  }
+  hipStream_t st = ctx->stream;
+  FPL_HIP(ctx, hipMemcpyAsync(t->w, weights, nb, hipMemcpyHostToDevice, st));
+  FPL_HIP(ctx, hipMemcpyAsync(t->kind, kind.data(), (size_t)n_weights, hipMemcpyHostToDevice, st));
+  FPL_HIP(ctx, hipMemsetAsync(t->g, 0, nb, st));
+  FPL_HIP(ctx, hipMemsetAsync(t->m, 0, nb, st));
+  FPL_HIP(ctx, hipMemsetAsync(t->v, 0, nb, st));
+  FPL_HIP(ctx, hipMemsetAsync(t->zeros, 0, 256 * sizeof(float), st));
+  fill_f32<<<1, 256, 0, st>>>(t->ones, 1.f, 256);
+  FPL_HIP(ctx, hipStreamSynchronize(st));
+  *out = t;
+  return 0;
+}
+
+int fpl_trainer_destroy(fpl_trainer *t) {
+  if (!t) return 0;
+  hipSetDevice(t->ctx->device);
+  hipStreamSynchronize(t->ctx->stream);
+  for (void *p : {(void *)t->w, (void *)t->g, (void *)t->m, (void *)t->v, (void *)t->kind,
+                  (void *)t->ones, (void *)t->zeros})
+    if (p) hipFree(p);
+  delete t;
+  return 0;
+}
+
+int fpl_trainer_grad_ptr(fpl_trainer *t, void **dev_ptr, int64_t *n_floats) {
+  if (!t || !dev_ptr || !n_floats) return fpl_fail(nullptr, "fpl_trainer_grad_ptr: NULL");
+  *dev_ptr = t->g;
+  *n_floats = t->n_w;
+  return 0;
+}
+
+static int copy_arena(fpl_trainer *t, float *dev, float *host, int64_t n, bool to_host) {
+  fpl_ctx *ctx = t->ctx;
+  FPL_REQUIRE(ctx, n == t->n_w, "arena has %lld floats, trainer expects %lld",
+              (long long)n, (long long)t->n_w);
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  if (to_host)
+    FPL_HIP(ctx, hipMemcpyAsync(host, dev, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  else
+    FPL_HIP(ctx, hipMemcpyAsync(dev, host, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  FPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int fpl_trainer_get_weights(fpl_trainer *t, float *out, int64_t n) {
+  if (!t || !out) return fpl_fail(nullptr, "fpl_trainer_get_weights: NULL");
+  return copy_arena(t, t->w, out, n, true);
+}
+int fpl_trainer_get_grads(fpl_trainer *t, float *out, int64_t n) {
+  if (!t || !out) return fpl_fail(nullptr, "fpl_trainer_get_grads: NULL");
+  return copy_arena(t, t->g, out, n, true);
+}
+int fpl_trainer_set_weights(fpl_trainer *t, const float *w, int64_t n) {
+  if (!t || !w) return fpl_fail(nullptr, "fpl_trainer_set_weights: NULL");
+  return copy_arena(t, t->w, const_cast<float *>(w), n, false);
+}
+
+int fpl_trainer_apply(fpl_trainer *t, float grad_scale) {
+  if (!t) return fpl_fail(nullptr, "fpl_trainer_apply: NULL");
+  fpl_ctx *ctx = t->ctx;
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  t->step_count += 1;
+  const double tt = (double)t->step_count;
+  const float lr_t = (float)(t->lr * std::sqrt(1.0 - std::pow((double)t->b2, tt)) /
+                             (1.0 - std::pow((double)t->b1, tt)));
+  {
+    TimedLaunch tl(ctx, "train_adam");
+    adam_update<<<g1(t->n_w), 256, 0, ctx->stream>>>(t->w, t->g, t->m, t->v, t->kind, t->n_w,
+                                                     grad_scale, lr_t, t->b1, t->b2, t->eps);
+  }
+  FPL_HIP(ctx, hipGetLastError());
+  return 0;
+}
+
+int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
+                     const uint8_t *labels, int labels_mem, int32_t batch,
+                     const int32_t patch[3], uint64_t seed, float *loss,
+                     float *accuracy) {
+  if (!t || !data || !labels || !patch) return fpl_fail(nullptr, "fpl_trainer_step: NULL");
+  fpl_ctx *ctx = t->ctx;
+  FPL_REQUIRE(ctx, batch > 0, "fpl_trainer_step: batch %d", batch);
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  std::vector<TShape> shp;
+  FPL_TRY(shapes_for(ctx, t, patch, &shp));
+  const int nt = t->n_tensors;
+  const int nl = (int)t->layers.size();
+  DevTemp tmp(ctx);
+  std::vector<float *> val(nt, nullptr), grad(nt, nullptr);
+  std::vector<uint8_t *> arg(nl, nullptr);
+  std::vector<float *> bn_mean(nl, nullptr), bn_invstd(nl, nullptr);
+  auto alloc_f = [&](int64_t n, float **p) -> int {
+    void *q;
+    int rc = tmp.alloc((size_t)n * sizeof(float), &q);
+    *p = (float *)q;
+    return rc;
+  };
+  // input
+  const int64_t in_elems = (int64_t)batch * shp[0].elems();
+  if (data_mem == FPL_MEM_HOST) {
+    FPL_TRY(alloc_f(in_elems, &val[0]));
+    FPL_HIP(ctx, hipMemcpyAsync(val[0], data, (size_t)in_elems * 4, hipMemcpyHostToDevice, st));
+  } else {
+    val[0] = const_cast<float *>(data);
+  }
+  const TShape oshape = shp[t->out_tensor];
+  FPL_REQUIRE(ctx, oshape.c == 1, "fpl_trainer_step: network output has %d channels", oshape.c);
+  const int64_t n_out = (int64_t)batch * oshape.elems();
+  const uint8_t *lab_dev = labels;
+  if (labels_mem == FPL_MEM_HOST) {
+    void *q;
+    FPL_TRY(tmp.alloc((size_t)n_out, &q));
+    FPL_HIP(ctx, hipMemcpyAsync(q, labels, (size_t)n_out, hipMemcpyHostToDevice, st));
+    lab_dev = (const uint8_t *)q;
+  }
+  FPL_HIP(ctx, hipMemsetAsync(t->g, 0, (size_t)t->n_w * 4, st));
+  void *partv;
+  const int64_t max_rows = (int64_t)batch * shp[0].vox();
+  const int max_nb = (int)ceil_div64(max_rows, RED_ROWS);
+  FPL_TRY(tmp.alloc((size_t)max_nb * 2 * 256 * sizeof(double), &partv));
+  double *part = (double *)partv;
+  void *sumsv;
+  FPL_TRY(tmp.alloc(2 * sizeof(double), &sumsv));
+  double *sums = (double *)sumsv;
+  FPL_HIP(ctx, hipMemsetAsync(sums, 0, 2 * sizeof(double), st));
+
+  // ------------------------------ forward ------------------------------------
+  for (int li = 0; li < nl; ++li) {
+    const fpl_layer &L = t->layers[li];
+    const TShape a = shp[L.src0], o = shp[L.dst];
+    const int64_t n = (int64_t)batch * o.elems();
+    FPL_TRY(alloc_f(n, &val[L.dst]));
+    switch (L.kind) {
+      case FPL_L_CONV: {
+        const int64_t n_vox = (int64_t)batch * o.vox();
+        const float *bias = L.use_bias ? t->w + L.w_off[1] : t->zeros;
+        TimedLaunch tl(ctx, "train_conv_fwd");
+        if (L.cout % 16 == 0) {
+          dim3 g((unsigned)ceil_div64(n_vox, 256), L.cout / 16);
+          conv3d_direct_f32<16><<<g, 256, 0, st>>>(val[L.src0], t->w + L.w_off[0], t->ones, bias,
+              val[L.dst], n_vox, a.d, a.h, a.w, a.c, o.d, o.h, o.w, o.c, L.k, L.act);
+        } else {
+          dim3 g((unsigned)ceil_div64(n_vox, 256), L.cout);
+          conv3d_direct_f32<1><<<g, 256, 0, st>>>(val[L.src0], t->w + L.w_off[0], t->ones, bias,
+              val[L.dst], n_vox, a.d, a.h, a.w, a.c, o.d, o.h, o.w, o.c, L.k, L.act);
+        }
+        break;
+      }
+      case FPL_L_BN: {
+        const int C = a.c;
+        const int64_t M = (int64_t)batch * a.vox();
+        const int nb = (int)ceil_div64(M, RED_ROWS);
+        const int R = std::max(1, 256 / C);
+        FPL_TRY(alloc_f(C, &bn_mean[li]));
+        FPL_TRY(alloc_f(C, &bn_invstd[li]));
+        TimedLaunch tl(ctx, "train_bn_fwd");
+        chan_reduce_partial<0><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
+            val[L.src0], nullptr, nullptr, nullptr, M, C, part);
+        bn_finish_stats<<<(C + 63) / 64, 64, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
+            t->w + L.w_off[2], t->w + L.w_off[3], bn_mean[li], bn_invstd[li],
+            t->g + L.w_off[2], t->g + L.w_off[3]);
+        bn_apply<<<g1(n), 256, 0, st>>>(val[L.src0], bn_mean[li], bn_invstd[li],
+            t->w + L.w_off[0], t->w + L.w_off[1], val[L.dst], n, C);
+        break;
+      }
+      case FPL_L_RELU: {
+        TimedLaunch tl(ctx, "train_elementwise");
+        relu_fwd<<<g1(n), 256, 0, st>>>(val[L.src0], val[L.dst], n);
+        break;
+      }
+      case FPL_L_POOL: {
+        void *q;
+        FPL_TRY(tmp.alloc((size_t)n, &q));
+        arg[li] = (uint8_t *)q;
+        TimedLaunch tl(ctx, "train_pool");
+        pool2_fwd<<<g1(n), 256, 0, st>>>(val[L.src0], val[L.dst], arg[li], n, a.d, a.h, a.w,
+                                         a.c, o.d, o.h, o.w);
+        break;
+      }
+      case FPL_L_DROPOUT: {
+        TimedLaunch tl(ctx, "train_elementwise");
+        dropout_fwd<<<g1(n), 256, 0, st>>>(val[L.src0], val[L.dst], n, seed, li, L.rate);
+        break;
+      }
+      case FPL_L_UP: {
+        TimedLaunch tl(ctx, "train_elementwise");
+        remap_fwd<<<g1(n), 256, 0, st>>>(val[L.src0], val[L.dst], n, a.d, a.h, a.w, a.c, o.d,
+            o.h, o.w, 0, 0, 0, L.p[0], L.p[1], L.p[2], 0, o.c);
+        break;
+      }
+      case FPL_L_CROP: {
+        TimedLaunch tl(ctx, "train_elementwise");
+        remap_fwd<<<g1(n), 256, 0, st>>>(val[L.src0], val[L.dst], n, a.d, a.h, a.w, a.c, o.d,
+            o.h, o.w, L.p[0], L.p[2], L.p[4], 1, 1, 1, 0, o.c);
+        break;
+      }
+      case FPL_L_CONCAT: {
+        const TShape b = shp[L.src1];
+        const int64_t na = (int64_t)batch * a.elems(), nbb = (int64_t)batch * b.elems();
+        TimedLaunch tl(ctx, "train_elementwise");
+        remap_fwd<<<g1(na), 256, 0, st>>>(val[L.src0], val[L.dst], na, a.d, a.h, a.w, a.c, o.d,
+            o.h, o.w, 0, 0, 0, 1, 1, 1, 0, o.c);
+        remap_fwd<<<g1(nbb), 256, 0, st>>>(val[L.src1], val[L.dst], nbb, b.d, b.h, b.w, b.c, o.d,
+            o.h, o.w, 0, 0, 0, 1, 1, 1, a.c, o.c);
+        break;
+      }
+      case FPL_L_ADD: {
+        TimedLaunch tl(ctx, "train_elementwise");
+        add_fwd<<<g1(n), 256, 0, st>>>(val[L.src0], val[L.src1], val[L.dst], n);
+        break;
+      }
+    }
+    FPL_HIP(ctx, hipGetLastError());
+  }
+
+  // ------------------------------ loss ---------------------------------------
+  const fpl_layer *head = nullptr;
+  for (int li = 0; li < nl; ++li)
+    if (t->layers[li].dst == t->out_tensor) head = &t->layers[li];
+  FPL_REQUIRE(ctx, head && head->kind == FPL_L_CONV && head->act == FPL_ACT_SIGMOID,
+              "fpl_trainer_step: the output must be a sigmoid conv head");
+  for (int ti = 1; ti < nt; ++ti) {
+    if (!val[ti]) continue;
+    const int64_t n = (int64_t)batch * shp[ti].elems();
+    FPL_TRY(alloc_f(n, &grad[ti]));
+    FPL_HIP(ctx, hipMemsetAsync(grad[ti], 0, (size_t)n * 4, st));
+  }
+  {
+    TimedLaunch tl(ctx, "train_loss");
+    bce_loss_grad<<<g1(n_out), 256, 0, st>>>(val[t->out_tensor], lab_dev, grad[t->out_tensor],
+                                             n_out, 1.f / (float)n_out, sums);
+  }
+
+  // ------------------------------ backward -----------------------------------
+  for (int li = nl - 1; li >= 0; --li) {
+    const fpl_layer &L = t->layers[li];
+    const TShape a = shp[L.src0], o = shp[L.dst];
+    const int64_t n = (int64_t)batch * o.elems();
+    float *dy = grad[L.dst];
+    float *dx = L.src0 > 0 ? grad[L.src0] : nullptr;
+    switch (L.kind) {
+      case FPL_L_CONV: {
+        const int64_t n_vox = (int64_t)batch * o.vox();
+        const int taps = L.k * L.k * L.k;
+        {
+          const int cit = (L.cin + 47) / 48, cot = (L.cout + 47) / 48;
+          dim3 g((unsigned)(taps * cit * cot), (unsigned)ceil_div64(n_vox, WG_CHUNK));
+          TimedLaunch tl(ctx, "train_conv_wgrad");
+          conv_wgrad_f32<<<g, 256, 0, st>>>(val[L.src0], dy, t->g + L.w_off[0], n_vox, a.d, a.h,
+              a.w, a.c, o.d, o.h, o.w, o.c, L.k, cit, cot);
+        }
+        if (L.use_bias) {
+          const int nb = (int)ceil_div64(n_vox, RED_ROWS);
+          const int R = std::max(1, 256 / L.cout);
+          TimedLaunch tl(ctx, "train_bias_grad");
+          chan_reduce_partial<2><<<nb, dim3(L.cout, R), (size_t)L.cout * R * 2 * sizeof(double), st>>>(
+              dy, nullptr, nullptr, nullptr, n_vox, L.cout, part);
+          finish_sums<<<(L.cout + 63) / 64, 64, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
+                                                         nullptr, 1.f);
+        }
+        if (dx) {
+          const int64_t in_vox = (int64_t)batch * a.vox();
+          TimedLaunch tl(ctx, "train_conv_dgrad");
+          if (L.cin % 16 == 0) {
+            dim3 g((unsigned)ceil_div64(in_vox, 256), L.cin / 16);
+            conv_dgrad_f32<16><<<g, 256, 0, st>>>(dy, t->w + L.w_off[0], dx, in_vox, a.d, a.h,
+                a.w, a.c, o.d, o.h, o.w, o.c, L.k);
+          } else {
+            dim3 g((unsigned)ceil_div64(in_vox, 256), L.cin);
+            conv_dgrad_f32<1><<<g, 256, 0, st>>>(dy, t->w + L.w_off[0], dx, in_vox, a.d, a.h,
+                a.w, a.c, o.d, o.h, o.w, o.c, L.k);
+          }
+        }
+        break;
+      }
+      case FPL_L_BN: {
+        const int C = a.c;
+        const int64_t M = (int64_t)batch * a.vox();
+        const int nb = (int)ceil_div64(M, RED_ROWS);
+        const int R = std::max(1, 256 / C);
+        float *sdy, *sdyx;
+        FPL_TRY(alloc_f(C, &sdy));
+        FPL_TRY(alloc_f(C, &sdyx));
+        FPL_HIP(ctx, hipMemsetAsync(sdy, 0, (size_t)C * 4, st));
+        FPL_HIP(ctx, hipMemsetAsync(sdyx, 0, (size_t)C * 4, st));
+        TimedLaunch tl(ctx, "train_bn_bwd");
+        chan_reduce_partial<1><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
+            dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
+        finish_sums<<<(C + 63) / 64, 64, 0, st>>>(part, nb, C, sdy, sdyx, 1.f);
+        // dbeta = sum dy, dgamma = sum dy*xhat
+        accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
+        accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
+        if (dx)
+          bn_backward<<<g1(n), 256, 0, st>>>(dy, val[L.src0], bn_mean[li], bn_invstd[li],
+              t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M);
+        break;
+      }
+      case FPL_L_RELU:
+        if (dx) {
+          TimedLaunch tl(ctx, "train_elementwise");
+          relu_bwd<<<g1(n), 256, 0, st>>>(dy, val[L.dst], dx, n);
+        }
+        break;
+      case FPL_L_POOL:
+        if (dx) {
+          TimedLaunch tl(ctx, "train_pool");
+          pool2_bwd<<<g1(n), 256, 0, st>>>(dy, arg[li], dx, n, a.d, a.h, a.w, a.c, o.d, o.h, o.w);
+        }
+        break;
+      case FPL_L_DROPOUT:
+        if (dx) {
+          TimedLaunch tl(ctx, "train_elementwise");
+          dropout_bwd<<<g1(n), 256, 0, st>>>(dy, dx, n, seed, li, L.rate);
+        }
+        break;
+      case FPL_L_UP:
+        if (dx) {
+          TimedLaunch tl(ctx, "train_elementwise");
+          remap_bwd<<<g1(n), 256, 0, st>>>(dy, dx, n, a.d, a.h, a.w, a.c, o.d, o.h, o.w, 0, 0, 0,
+              L.p[0], L.p[1], L.p[2], 0, o.c);
+        }
+        break;
+      case FPL_L_CROP:
+        if (dx) {
+          TimedLaunch tl(ctx, "train_elementwise");
+          remap_bwd<<<g1(n), 256, 0, st>>>(dy, dx, n, a.d, a.h, a.w, a.c, o.d, o.h, o.w, L.p[0],
+              L.p[2], L.p[4], 1, 1, 1, 0, o.c);
+        }
+        break;
+      case FPL_L_CONCAT: {
+        const TShape b = shp[L.src1];
+        const int64_t na = (int64_t)batch * a.elems(), nbb = (int64_t)batch * b.elems();
+        TimedLaunch tl(ctx, "train_elementwise");
+        if (dx)
+          remap_bwd<<<g1(na), 256, 0, st>>>(dy, dx, na, a.d, a.h, a.w, a.c, o.d, o.h, o.w, 0, 0,
+              0, 1, 1, 1, 0, o.c);
+        if (L.src1 > 0)
+          remap_bwd<<<g1(nbb), 256, 0, st>>>(dy, grad[L.src1], nbb, b.d, b.h, b.w, b.c, o.d, o.h,
+              o.w, 0, 0, 0, 1, 1, 1, a.c, o.c);
+        break;
+      }
+      case FPL_L_ADD: {
+        TimedLaunch tl(ctx, "train_elementwise");
+        if (dx) accum<<<g1(n), 256, 0, st>>>(dy, dx, n);
+        if (L.src1 > 0) accum<<<g1(n), 256, 0, st>>>(dy, grad[L.src1], n);
+        break;
+      }
+    }
+    FPL_HIP(ctx, hipGetLastError());
+  }
+  double hs[2];
+  FPL_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(hs), hipMemcpyDeviceToHost, st));
+  FPL_HIP(ctx, hipStreamSynchronize(st));
+  if (loss) *loss = (float)(hs[0] / (double)n_out);
+  if (accuracy) *accuracy = (float)(hs[1] / (double)n_out);
+  return 0;
+}
+
+}  // extern "C"

@@ -356,3 +356,62 @@ class LayerGraph:
         arena = (np.concatenate(arena) if arena
                  else np.zeros(0, np.float32)).astype(np.float32)
         return ops, arena, out_tensor, n_tensors[0]
+
+
+# layer kinds shared with include/fplhip.h (enum fpl_layer_kind)
+L_CONV, L_BN, L_RELU, L_POOL, L_DROPOUT, L_UP, L_CROP, L_CONCAT, L_ADD = range(9)
+
+
+def lower_training(graph):
+    """Unfused layer list for the training engine (`fpl_trainer_create`).
+
+    Returns (layers, arena, offsets, out_tensor, n_tensors): one dict per Keras
+    layer with tensor ids (0 = input) and float offsets of its weights inside
+    `arena`, the flat concatenation of `graph.weights` (Keras order);
+    `offsets[i]` is where weight array i starts."""
+    offsets, tot = [], 0
+    for w in graph.weights:
+        offsets.append(tot)
+        tot += w.size
+    arena = (np.concatenate([w.reshape(-1) for w in graph.weights])
+             .astype(np.float32) if graph.weights else np.zeros(0, np.float32))
+    tensor_of = {graph.inputs_node.idx: 0}
+    layers, n_t = [], 1
+    kinds = {'conv': L_CONV, 'bn': L_BN, 'relu': L_RELU, 'pool': L_POOL,
+             'drop': L_DROPOUT, 'up': L_UP, 'crop': L_CROP, 'concat': L_CONCAT,
+             'add': L_ADD}
+    for n in graph.nodes:
+        if n.kind == 'input':
+            continue
+        src = [tensor_of[i] for i in n.inputs]
+        d = dict(kind=kinds[n.kind], src0=src[0], src1=src[1] if len(src) > 1 else -1,
+                 dst=n_t, k=0, cin=graph.nodes[n.inputs[0]].channels,
+                 cout=n.channels, use_bias=0, act=ACT_NONE, rate=0.0, p=(0,) * 6,
+                 w_off=[0, 0, 0, 0])
+        if n.kind == 'conv':
+            a = n.attrs['activation']
+            if a == 'relu':
+                raise NotImplementedError(
+                    'conv with a fused relu activation (unet_like_vol) is not '
+                    'trainable yet')
+            d.update(k=n.attrs['k'], use_bias=int(n.attrs['use_bias']),
+                     act={None: ACT_NONE, 'sigmoid': ACT_SIGMOID}[a])
+            d['w_off'][0] = offsets[n.weight_slots[0]]
+            if n.attrs['use_bias']:
+                d['w_off'][1] = offsets[n.weight_slots[1]]
+        elif n.kind == 'bn':
+            d['w_off'] = [offsets[s] for s in n.weight_slots]
+        elif n.kind == 'pool':
+            f = n.attrs['n']
+            d['p'] = (f, f, f, 0, 0, 0)
+        elif n.kind == 'up':
+            d['p'] = tuple(n.attrs['n']) + (0, 0, 0)
+        elif n.kind == 'crop':
+            c = n.attrs['c']
+            d['p'] = (c[0][0], c[0][1], c[1][0], c[1][1], c[2][0], c[2][1])
+        elif n.kind == 'drop':
+            d['rate'] = float(n.attrs['rate'])
+        layers.append(d)
+        tensor_of[n.idx] = n_t
+        n_t += 1
+    return layers, arena, offsets, tensor_of[graph.output.idx], n_t

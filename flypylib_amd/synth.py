@@ -105,3 +105,15 @@ def blob_prob_volume(seed, shape, period=24, radius=6.0, noise=0.05):
         v = height * fall * fall
         v = v + noise * hash_uniform_f32(seed + 1, shape).astype(np.float64)
         return np.minimum(v, 1.0).astype(np.float32)
+
+
+def dropout_keep_mask(seed, layer, n, rate):
+    """keep-mask of the training engine's Dropout (csrc/train.hip::drop_keep):
+    element i of lowered layer `layer` is kept iff u_i >= rate with
+    u_i = (splitmix64(seed ^ splitmix64((layer << 48) ^ i)) >> 40) / 2^24"""
+    with np.errstate(over='ignore'):
+        i = np.arange(n, dtype=np.uint64)
+        key = (np.uint64(layer) << np.uint64(48)) ^ i
+        h = _splitmix64(np.uint64(seed) ^ _splitmix64(key))
+        u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        return u >= np.float32(rate)

@@ -1,0 +1,124 @@
+"""Training loop of `FplNetwork.train` / `make_train_parallel`
+(reference `flypylib/fplnetwork.py:112-128`) on the HIP training engine.
+
+`fit_generator(network, generator, steps_per_epoch, epochs, log_file,
+save_filepath)` mirrors `train_network.fit_generator` with the reference's two
+callbacks: a CSV log (`CSVLogger`: epoch, acc, loss) and a per-epoch checkpoint
+'<save_filepath>_%03d' of the single-GPU weights (`multi_gpu_callback`,
+fplnetwork.py:9-17).
+
+Data parallelism (reference: in-graph towers slicing the batch,
+`flypylib/multi_gpu.py:20-61`): one process per GPU, every rank draws its own
+`batch_size` examples, gradients (and BN moving-average deltas) are summed with
+ONE all-reduce of the flat gradient arena over RCCL (`torch.distributed`, backend
+'nccl') and scaled by 1/world before the identical Adam update on every rank.
+BN batch statistics stay per GPU, as each tower normalises its own slice.
+"""
+import csv
+import os
+
+import numpy as np
+
+from . import _capi, runtime
+
+_OPTIMIZERS = {'adam': dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)}
+
+
+class ParallelTrainNetwork:
+    """what `network.train_network` holds after make_train_parallel"""
+
+    def __init__(self, single, n_gpu, batch_size, input_shape):
+        self.single, self.n_gpu = single, n_gpu
+        self.batch_size, self.input_shape = batch_size, tuple(input_shape)
+        self.compile_args = None
+
+    def compile(self, **kw):
+        self.compile_args = dict(kw)
+
+    def get_weights(self):
+        return self.single.get_weights()
+
+
+def make_parallel(train_single, n_gpu, batch_size, input_shape):
+    return ParallelTrainNetwork(train_single, n_gpu, batch_size, input_shape)
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except ImportError:
+        pass
+    return None
+
+
+def allreduce_grads(trainer):
+    """sum the flat gradient arena over all ranks (RCCL over xGMI); returns the
+    scale to apply (1/world).  No-op without an initialised process group."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return 1.0
+    import torch
+    ptr, n = trainer.grad_ptr()
+    # wrap the library-owned device arena without copying
+    arena = _DeviceArena(ptr, n)
+    t = torch.as_tensor(arena, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    torch.cuda.current_stream().synchronize()
+    return 1.0 / dist.get_world_size()
+
+
+class _DeviceArena:
+    """__cuda_array_interface__ view of `n` float32 at device address `ptr`"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {
+            'shape': (int(n),), 'typestr': '<f4', 'data': (int(ptr), False),
+            'version': 2}
+
+
+def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
+                  save_filepath, seed=0):
+    graph = network.train_single
+    args = network.compile_args or {}
+    loss = args.get('loss', 'binary_crossentropy')
+    if loss != 'binary_crossentropy':
+        raise NotImplementedError(
+            'loss %r: only binary_crossentropy is implemented in the training '
+            'engine (masked/focal losses: SURVEY 8f)' % (loss,))
+    opt = args.get('optimizer', 'adam')
+    if opt not in _OPTIMIZERS:
+        raise NotImplementedError('optimizer %r' % (opt,))
+    ctx = runtime.get_context(network._device)
+    trainer = _capi.Trainer(ctx, graph, **_OPTIMIZERS[opt])
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    writer = None
+    if rank == 0 and log_file:
+        f = open(log_file, 'w', newline='')
+        writer = csv.writer(f)
+        writer.writerow(['epoch', 'acc', 'loss'])
+    step_no = 0
+    history = []
+    for epoch in range(epochs):
+        tot_loss = tot_acc = 0.0
+        for _ in range(steps_per_epoch):
+            data, labels = next(generator)
+            l, a = trainer.step(data, labels, seed=seed + step_no)
+            trainer.apply(allreduce_grads(trainer))
+            tot_loss += l
+            tot_acc += a
+            step_no += 1
+        graph.set_weights(trainer.get_weights())
+        row = (epoch, tot_acc / steps_per_epoch, tot_loss / steps_per_epoch)
+        history.append(row)
+        if writer:
+            writer.writerow(row)
+            f.flush()
+        if rank == 0 and save_filepath:
+            graph.save('%s_%03d' % (save_filepath, epoch))
+    if writer:
+        f.close()
+    trainer.close()
+    return history

@@ -145,6 +145,57 @@ int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
 /* smoothed padded volume of the last fpl_v2o_smooth call (tests) */
 int fpl_v2o_copy_smoothed(fpl_ctx *ctx, float *dst, int dst_mem);
 
+/* ---- training -------------------------------------------------------------------- */
+/* replaces: train_network.fit_generator's per-step work (flypylib/fplnetwork.py:
+ * 112-122, default compile args :74-77): forward in training mode (BatchNorm
+ * batch statistics, momentum 0.99, eps 1e-3; inverted Dropout), binary
+ * cross-entropy on the sigmoid output (Keras clips p to [1e-7, 1-1e-7]), backward,
+ * Adam (Keras defaults).  The layer list is the UNFUSED graph of
+ * flypylib_amd/program.py (one entry per Keras layer). */
+enum fpl_layer_kind {
+  FPL_L_CONV = 0, FPL_L_BN = 1, FPL_L_RELU = 2, FPL_L_POOL = 3, FPL_L_DROPOUT = 4,
+  FPL_L_UP = 5, FPL_L_CROP = 6, FPL_L_CONCAT = 7, FPL_L_ADD = 8
+};
+typedef struct fpl_layer {
+  int32_t kind;        /* fpl_layer_kind                                       */
+  int32_t src0, src1;  /* tensor ids (0 = network input)                       */
+  int32_t dst;
+  int32_t k, cin, cout;/* conv                                                 */
+  int32_t use_bias;    /* conv                                                 */
+  int32_t act;         /* conv activation (fpl_act); sigmoid only on the head  */
+  float rate;          /* dropout                                              */
+  int32_t p[6];        /* pool/up factors or crop pairs                        */
+  int64_t w_off[4];    /* offsets (floats) into the weight arena: conv kernel,
+                        * bias | BN gamma, beta, moving_mean, moving_variance   */
+} fpl_layer;
+typedef struct fpl_trainer fpl_trainer;
+
+/* `weights`: flat fp32 concatenation of the Keras get_weights() list.  The
+ * trainer owns a gradient arena of the same layout (moving-statistics slots hold
+ * the pending moving-average delta); fpl_trainer_grad_ptr exposes it so the host
+ * can all-reduce it over RCCL between step and apply
+ * (replaces the implicit gradient sum over towers of multi_gpu.py:20-61). */
+int fpl_trainer_create(fpl_ctx *ctx, const fpl_layer *layers, int32_t n_layers,
+                       int32_t n_tensors, int32_t out_tensor, const float *weights,
+                       int64_t n_weights, float lr, float beta1, float beta2,
+                       float eps, fpl_trainer **out);
+int fpl_trainer_destroy(fpl_trainer *t);
+/* forward + loss + backward on one batch: data (batch, D,H,W) f32, labels
+ * (batch, d,h,w) u8 in {0,1} with (d,h,w) = the network output size.  Fills the
+ * gradient arena (mean over the batch).  `seed` drives the dropout masks. */
+int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
+                     const uint8_t *labels, int labels_mem, int32_t batch,
+                     const int32_t patch[3], uint64_t seed, float *loss,
+                     float *accuracy);
+/* Adam update (and moving-statistics update) from the gradient arena scaled by
+ * grad_scale (1/world_size after a sum all-reduce) */
+int fpl_trainer_apply(fpl_trainer *t, float grad_scale);
+int fpl_trainer_grad_ptr(fpl_trainer *t, void **dev_ptr, int64_t *n_floats);
+int fpl_trainer_get_weights(fpl_trainer *t, float *out, int64_t n_weights);
+int fpl_trainer_set_weights(fpl_trainer *t, const float *w, int64_t n_weights);
+/* tensors of the last step, for parity tests: grads (host copy of the arena) */
+int fpl_trainer_get_grads(fpl_trainer *t, float *out, int64_t n_weights);
+
 /* ---- synthetic data (bench / tests) -------------------- */
 /* EM-like uint8 volume from a counter-based hash; bit-identical to
  * flypylib_amd.synth.em_volume_u8 on the host */
