@@ -41,6 +41,7 @@ constexpr int S_TZ = 2 * S_PZ + 2, S_TY = 2 * S_PY + 2, S_TX = 2 * S_PX + 2;
 struct StemArgs {
   const void *src;
   int64_t SZ, SY, SX;      // volume dims
+  int64_t z_hi;            // rows >= z_hi are not needed (and may not be resident)
   float mean, sd;
   int64_t p1z0;            // global P1 row of chunk-local row 0
   const bf16x8 *w1, *w2;   // fragments [s][b][lane]
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
       const int i = tid + 256 * k;
       const int tx = i % S_TX, ty = (i / S_TX) % S_TY, tz = i / (S_TX * S_TY);
       const int64_t z = gz0 + tz, y = gy0 + ty, x = gx0 + tx;
-      inb[k] = i < N && z < a.SZ && y < a.SY && x < a.SX;
+      inb[k] = i < N && z < a.z_hi && y < a.SY && x < a.SX;
       raw[k] = inb[k] ? src[(z * a.SY + y) * a.SX + x] : (SRC)0;
     }
 #pragma unroll
@@ -702,6 +703,9 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
       StemArgs a;
       a.src = src; a.SZ = SZ; a.SY = SY; a.SX = SX; a.mean = mean; a.sd = sd;
       a.p1z0 = 2 * c0;
+      // block rounding may reach past the rows this slab stages: they only
+      // feed masked outputs, so they read as zero
+      a.z_hi = std::min<int64_t>(SZ, 4 * (c0 + CZ) + 14);
       a.w1 = (const bf16x8 *)(F + st->off_w[0]);
       a.w2 = (const bf16x8 *)(F + st->off_w[1]);
       a.shift1 = S + st->off_s[0]; a.shift2 = S + st->off_s[1];

@@ -124,3 +124,35 @@ def test_training_reduces_loss(ctx):
         tr.apply(1.0)
         first = loss if first is None else first
     assert loss < 0.7 * first
+
+
+def test_fplnetwork_train_api_end_to_end(ctx, tmp_path):
+    """FplNetwork.train(generator, steps, epochs, log, save) with gen_batches, as
+    in scripts/fpl_fib25_example.py:151-164 (tiny volume)"""
+    from flypylib_amd import FplNetwork, fplobjdetect
+    rng = np.random.RandomState(0)
+    img = rng.randn(48, 48, 48).astype(np.float32)
+    lab = np.zeros((48, 48, 48), np.uint8)
+    lab[20:28, 20:28, 20:28] = 1
+    img[lab == 1] += 2.0                       # learnable: bright cube = label 1
+    mask = np.ones((48, 48, 48), np.uint8)
+    net = FplNetwork(fplmodels.vgg_like)
+    gen = fplobjdetect.gen_batches([(img, lab, mask)], net.rf_size, 16, rng=rng)
+    data, labels = next(gen)
+    assert data.shape == (16, 18, 18, 18, 1) and labels.shape == (16, 1, 1, 1, 1)
+    assert labels[::2].max() == 0 and labels[1::2].min() == 1    # interleaved classes
+    log = str(tmp_path / 'log.csv')
+    net.train(gen, 12, 2, log, str(tmp_path / 'epoch'))
+    rows = open(log).read().strip().splitlines()
+    assert rows[0] == 'epoch,acc,loss' and len(rows) == 3
+    loss0, loss1 = float(rows[1].split(',')[2]), float(rows[2].split(',')[2])
+    assert loss1 < loss0
+    assert (tmp_path / 'epoch_000.npz').exists() and (tmp_path / 'epoch_001.npz').exists()
+    # the inference network was rebuilt from the trained weights
+    net.infer_sz = (30, 30, 30)
+    net._set_infer()
+    pred = net.infer(img)
+    assert pred.shape == img.shape and pred[12:36, 12:36, 12:36].std() > 0
+    inside = pred[22:26, 22:26, 22:26].mean()
+    outside = pred[8:12, 8:12, 8:12].mean()
+    assert inside > outside
