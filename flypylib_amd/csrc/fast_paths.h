@@ -14,3 +14,7 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                           const std::vector<int32_t> origins[3],
                           const int32_t out_sz[3], int32_t zb, int32_t ze,
                           float *dst, bool *handled);
+
+// true when fpl_fast_infer_volume will handle this program / precision / lattice
+bool fpl_fast_path_available(const fpl_program *prog, int precision,
+                             const int32_t offset[3], const int32_t out_sz[3]);

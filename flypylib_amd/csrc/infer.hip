@@ -58,6 +58,23 @@ __global__ void stitch_tiles(const float *__restrict__ tile_out, int o0, int o1,
       td.start[2] + off2 + x] = v;
 }
 
+// zero the rf_offset border shell of rows [z_lo, z_hi) of a (Z,Y,X) volume; one
+// wave per (z,y) row: full rows inside the z/y shell, else the two x margins
+__global__ void clear_shell(float *__restrict__ dst, int64_t Z, int64_t Y, int64_t X,
+                            int64_t z_lo, int64_t z_hi, int o0, int o1, int o2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= (z_hi - z_lo) * Y) return;
+  const int64_t z = z_lo + row / Y, y = row % Y;
+  float *p = dst + (z * Y + y) * X;
+  if (z < o0 || z >= Z - o0 || y < o1 || y >= Y - o1) {
+    for (int64_t x = lane; x < X; x += 64) p[x] = 0.f;
+  } else {
+    if (lane < o2) p[lane] = 0.f;
+    if (lane < o2) p[X - o2 + lane] = 0.f;
+  }
+}
+
 __global__ void upsample_out(const float *__restrict__ in, float *__restrict__ out,
                              int64_t n_total, int d, int h, int w, int c, int s0,
                              int s1, int s2) {
@@ -201,10 +218,22 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     dst_dev = (float *)p;
     dst_base = wr_lo;
   }
-  if (wr_hi > wr_lo)
-    FPL_HIP(ctx, hipMemsetAsync(dst_dev + (wr_lo - dst_base) * Y * X, 0,
-                                (size_t)(wr_hi - wr_lo) * Y * X * sizeof(float),
-                                st));
+  // the fused fast path writes every valid voxel itself: only the border shell
+  // needs clearing there; the per-op path stitches tiles into a zeroed volume
+  const bool fast = zb < ze && fpl_fast_path_available(prog, precision, offset, out_sz);
+  if (wr_hi > wr_lo) {
+    if (fast && offset[2] <= 64) {
+      TimedLaunch tl(ctx, "clear_shell");
+      const int64_t rows = (wr_hi - wr_lo) * Y;
+      clear_shell<<<(unsigned)ceil_div64(rows, 4), 256, 0, st>>>(
+          dst_dev - dst_base * Y * X, Z, Y, X, wr_lo, wr_hi, offset[0], offset[1],
+          offset[2]);
+      FPL_HIP(ctx, hipGetLastError());
+    } else {
+      FPL_HIP(ctx, hipMemsetAsync(dst_dev + (wr_lo - dst_base) * Y * X, 0,
+                                  (size_t)(wr_hi - wr_lo) * Y * X * sizeof(float), st));
+    }
+  }
   if (zb >= ze) {
     if (dst_mem == FPL_MEM_HOST && wr_hi > wr_lo)
       FPL_HIP(ctx, hipMemcpyAsync(dst + wr_lo * Y * X, dst_dev,

@@ -65,35 +65,46 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
 
   // ---- input tile: normalise, round to bf16; zero past the volume end.  For u8
   // sources the 256 possible values go through a per-WG lookup table, so the
-  // divide + convert happen once per value, not once per voxel.
+  // divide + convert happen once per value, not once per voxel.  One tile row
+  // (66 x) per wave iteration: the row address is wave-uniform (scalar math), a
+  // lane only adds its x.
   {
     const SRC *src = (const SRC *)a.src;
     const int64_t gz0 = 2 * (a.p1z0 + pz0), gy0 = 2 * (int64_t)py0, gx0 = 2 * (int64_t)px0;
-    constexpr int N = S_TZ * S_TY * S_TX;
-    constexpr int PER = (N + 255) / 256;
     if (sizeof(SRC) == 1) {
       lut[tid] = bf16_bits(((float)tid - a.mean) / a.sd);
       __syncthreads();
     }
-    // issue all loads first (PER independent loads in flight per thread)
-    SRC raw[PER];
-    bool inb[PER];
+    constexpr int ROWS = S_TZ * S_TY;            // 180 rows of 66
+    constexpr int RB = 9;                        // rows in flight per wave
+    const bool x0_ok = gx0 + lane < a.SX, x1_ok = lane < 2 && gx0 + 64 + lane < a.SX;
+    for (int r0 = wave * RB; r0 < ROWS; r0 += 4 * RB) {
+      SRC v0[RB], v1[RB];
+      bool ok[RB];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = tid + 256 * k;
-      const int tx = i % S_TX, ty = (i / S_TX) % S_TY, tz = i / (S_TX * S_TY);
-      const int64_t z = gz0 + tz, y = gy0 + ty, x = gx0 + tx;
-      inb[k] = i < N && z < a.z_hi && y < a.SY && x < a.SX;
-      raw[k] = inb[k] ? src[(z * a.SY + y) * a.SX + x] : (SRC)0;
-    }
+      for (int k = 0; k < RB; ++k) {
+        const int row = __builtin_amdgcn_readfirstlane(r0 + k);
+        const int64_t z = gz0 + row / S_TY, y = gy0 + row % S_TY;
+        ok[k] = row < ROWS && z < a.z_hi && y < a.SY;
+        const SRC *rp = src + (z * a.SY + y) * a.SX + gx0;
+        v0[k] = (ok[k] && x0_ok) ? rp[lane] : (SRC)0;
+        v1[k] = (ok[k] && x1_ok) ? rp[64 + lane] : (SRC)0;
+      }
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const int i = tid + 256 * k;
-      unsigned short v = 0;
-      if (inb[k])
-        v = sizeof(SRC) == 1 ? lut[(int)raw[k]]
-                             : bf16_bits(((float)raw[k] - a.mean) / a.sd);
-      if (i < N) tile[i] = v;
+      for (int k = 0; k < RB; ++k) {
+        const int row = r0 + k;
+        if (row >= ROWS) break;
+        unsigned short b0 = 0, b1 = 0;
+        if (sizeof(SRC) == 1) {
+          if (ok[k] && x0_ok) b0 = lut[(int)v0[k]];
+          if (ok[k] && x1_ok) b1 = lut[(int)v1[k]];
+        } else {
+          if (ok[k] && x0_ok) b0 = bf16_bits(((float)v0[k] - a.mean) / a.sd);
+          if (ok[k] && x1_ok) b1 = bf16_bits(((float)v1[k] - a.mean) / a.sd);
+        }
+        tile[row * S_TX + lane] = b0;
+        if (lane < 2) tile[row * S_TX + 64 + lane] = b1;
+      }
     }
   }
 
@@ -662,6 +673,14 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
 
 }  // namespace
 
+bool fpl_fast_path_available(const fpl_program *prog, int precision,
+                             const int32_t offset[3], const int32_t out_sz[3]) {
+  if (precision != FPL_PREC_BF16 || !is_vgg_like(prog)) return false;
+  for (int a = 0; a < 3; ++a)
+    if (offset[a] != 7 || out_sz[a] % 4 != 0) return false;
+  return true;
+}
+
 int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                           int src_dtype, float mean, float sd,
                           const int64_t dims[3], const int32_t tile_in[3],
@@ -670,9 +689,7 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                           const int32_t out_sz[3], int32_t zb, int32_t ze,
                           float *dst, bool *handled) {
   *handled = false;
-  if (precision != FPL_PREC_BF16 || !is_vgg_like(prog)) return 0;
-  for (int a = 0; a < 3; ++a)
-    if (offset[a] != 7 || out_sz[a] % 4 != 0) return 0;
+  if (!fpl_fast_path_available(prog, precision, offset, out_sz)) return 0;
   VggFastState *st;
   FPL_TRY(vgg_prepare(ctx, prog, &st));
   hipStream_t stream = ctx->stream;

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configs (run on the GPU box):
+
+    python tools/bench_configs.py --what unet,train,v2o,pipeline [--out file.json]
+
+  unet      configs[2] unet_like2 inference (reference lattice 100^3, pitch 82) on a
+            reduced volume (the fp32 per-op path; size via --unet-size)
+  train     configs[3] vgg_like training step, batch 32 of 64^3 patches (1 GPU)
+  v2o       voxel2obj on a 582^3 substack-sized probability volume (r=27, sigma=5)
+  pipeline  configs[4] shape at one substack: vgg_like bf16 inference of a 582^3
+            substack + voxel2obj, detections diffed against the CPU oracle on the
+            same prediction
+These are NOT the driver's bench line (bench.py); they document where the other
+rows of SURVEY section 8 stand.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--what', default='unet,train,v2o,pipeline')
+    ap.add_argument('--unet-size', type=int, default=264)
+    ap.add_argument('--sub', type=int, default=582)
+    ap.add_argument('--out', default=None)
+    a = ap.parse_args()
+    import torch
+    from flypylib_amd import _capi, fplmodels, fplobjdetect, runtime, synth
+    ctx = runtime.get_context(0)      # the context voxel2obj uses as well
+    res = {'device': ctx.device_info()['name']}
+    what = a.what.split(',')
+
+    if 'unet' in what:
+        g = fplmodels.unet_like2(100)[0]
+        synth.synthetic_weights(g, 7)
+        prog = _capi.Program(ctx, g, (1, 1, 1))
+        n = a.unet_size
+        src = torch.empty((n, n, n), dtype=torch.uint8, device='cuda')
+        dst = torch.empty((n, n, n), dtype=torch.float32, device='cuda')
+        ctx.synth_volume_u8(3, (n, n, n), out=src)
+        kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F32, dst=dst, dims=(n, n, n))
+        prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
+        ctx.synchronize()
+        ctx.timing(True); ctx.timing_reset()
+        t0 = time.perf_counter()
+        prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        vox = (n - 18) ** 3
+        res['unet_like2_f32_perop'] = dict(
+            volume=n, mvox_s=vox / dt / 1e6, seconds=dt,
+            tflops_algorithmic=vox * 350720 / dt / 1e12,
+            kernels={k: round(v['ms'], 2) for k, v in ctx.timing_get().items()})
+        ctx.timing(False)
+        print(json.dumps(res['unet_like2_f32_perop']), flush=True)
+
+    if 'train' in what:
+        g = fplmodels.vgg_like()[0]
+        synth.synthetic_weights(g, 8)
+        tr = _capi.Trainer(ctx, g)
+        rng = np.random.default_rng(0)
+        data = rng.standard_normal((32, 64, 64, 64)).astype(np.float32)
+        labels = (rng.random((32, 12, 12, 12)) > 0.9).astype(np.uint8)
+        tr.step(data, labels, 0); tr.apply(1.0)
+        ctx.synchronize()
+        ctx.timing(True); ctx.timing_reset()
+        t0 = time.perf_counter()
+        steps = 3
+        for s in range(steps):
+            tr.step(data, labels, s + 1); tr.apply(1.0)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res['vgg_train_b32_64cubed_f32'] = dict(
+            seconds_per_step=dt, steps_per_s=1 / dt,
+            tflops_algorithmic=492e9 / dt / 1e12, note='includes H2D of the batch',
+            kernels={k: round(v['ms'] / steps, 2) for k, v in ctx.timing_get().items()})
+        ctx.timing(False)
+        print(json.dumps(res['vgg_train_b32_64cubed_f32']), flush=True)
+
+    if 'v2o' in what or 'pipeline' in what:
+        n = a.sub
+        g = fplmodels.vgg_like(102)[0]
+        synth.synthetic_weights(g, 9)
+        prog = _capi.Program(ctx, g, (4, 4, 4))
+        src = torch.empty((n, n, n), dtype=torch.uint8, device='cuda')
+        pred = torch.empty((n, n, n), dtype=torch.float32, device='cuda')
+        ctx.synth_volume_u8(5, (n, n, n), out=src)
+        kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_BF16, dst=pred, dims=(n, n, n))
+        prog.infer_volume(src, (102,) * 3, (7,) * 3, **kw)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        prog.infer_volume(src, (102,) * 3, (7,) * 3, **kw)
+        ctx.synchronize()
+        t_inf = time.perf_counter() - t0
+        # blob-like probabilities make the NMS meaningful: add planted blobs
+        prob = synth.blob_prob_volume(11, (n, n, n), period=64, radius=9.0)
+        prob_dev = torch.from_numpy(prob).cuda()
+        fplobjdetect.voxel2obj(prob_dev, 27, 5, (0, 0, 0), 35, 0.1)      # warm-up
+        ctx.timing(True); ctx.timing_reset()
+        t0 = time.perf_counter()
+        out, info = fplobjdetect.voxel2obj(prob_dev, 27, 5, (0, 0, 0), 35, 0.1,
+                                           return_info=True)
+        t_v2o = time.perf_counter() - t0
+        kern = {k: round(v['ms'], 2) for k, v in ctx.timing_get().items()}
+        ctx.timing(False)
+        padded = (n + 54) ** 3
+        res['voxel2obj_sub%d' % n] = dict(
+            seconds=t_v2o, mvox_s=n ** 3 / t_v2o / 1e6, detections=len(out['conf']),
+            rounds=info['rounds'], gb_s_algorithmic=12 * padded / t_v2o / 1e9,
+            kernels=kern)
+        res['infer_sub%d_bf16' % n] = dict(seconds=t_inf,
+                                           mvox_s=(n - 14) ** 3 / t_inf / 1e6)
+        print(json.dumps(res['voxel2obj_sub%d' % n]), flush=True)
+        if 'pipeline' in what:
+            from oracle import voxel2obj_oracle
+            t0 = time.perf_counter()
+            ref = voxel2obj_oracle.voxel2obj(prob, 27, 5, (0, 0, 0), 35, 0.1)
+            t_cpu = time.perf_counter() - t0
+            same = (np.array_equal(ref['locs'], out['locs'])
+                    and np.array_equal(ref['conf'], out['conf']))
+            res['pipeline_sub%d' % n] = dict(
+                infer_s=t_inf, v2o_s=t_v2o, total_mvox_s=n ** 3 / (t_inf + t_v2o) / 1e6,
+                detections_identical_to_cpu_oracle=bool(same),
+                cpu_oracle_v2o_s=t_cpu, cpu_oracle_mvox_s=n ** 3 / t_cpu / 1e6)
+            print(json.dumps(res['pipeline_sub%d' % n]), flush=True)
+    if a.out:
+        json.dump(res, open(a.out, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
