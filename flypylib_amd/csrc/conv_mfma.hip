@@ -1,0 +1,632 @@
+// Generic bf16 MFMA convolution kernels (channels-last, batched tiles) and the
+// fused-op executor for unet_like2 inference (flypylib/fplmodels.py:258-304).
+//
+//   stem_cin1_bf16<COUT>      conv3 1->COUT + shift + ReLU          (f32 in, bf16 out)
+//   conv3_bf16<CC, MB>        conv3 CIN->16*MB, CIN = ncc chunks of CC channels,
+//                             input = concat of sources, each optionally nearest-
+//                             upsampled x2 or cropped (UpSampling3D / Cropping3D /
+//                             concatenate become an index remap in the tile loader)
+//   conv1_bf16<CIN, MB, TAIL> 1x1x1 conv as a voxel GEMM; TAIL chains a second
+//                             1x1 conv to one sigmoid channel in registers
+//   pool2_bf16                MaxPooling3D(2)
+//
+// conv3_bf16 follows vgg_mid (vgg_fused.hip): 4 waves, output block 4 x 4 x 16,
+// wave = z, sub-steps = y, lanes = x; activation tile (6 x 6 x 18 voxels, 96 B
+// pitch, one CC-channel chunk at a time) in LDS; flat k = (tap, channel) so a
+// lane's B fragment is one ds_read_b128; weight fragments stream through a 2-slot
+// LDS ring staged through registers; <= 80 KiB LDS so two workgroups share a CU.
+#include <algorithm>
+
+#include "fast_paths.h"
+#include "mfma_util.h"
+#include "pack_weights.h"
+
+namespace {
+
+constexpr int PITCH = 96;                 // LDS bytes per tile voxel (CC <= 48)
+constexpr int TZ = 6, TY = 6, TX = 18;    // input tile of a 4 x 4 x 16 output block
+constexpr int TILE_BYTES = TZ * TY * TX * PITCH;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+struct Src {             // one CC-channel chunk of the (virtual) concatenated input
+  const __bf16 *p;       // (n, D, H, W, C) bf16
+  int D, H, W, C;
+  int ch0;               // first channel of this chunk inside the source
+  int up;                // 1, or 2 = UpSampling3D(2) of the source
+  int crop;              // Cropping3D(crop) of the source
+};
+
+template <int CC, int KC> struct Geo {
+  static constexpr int KRAW = (27 * CC + 31) / 32;
+  static constexpr int KSTEPS = (KRAW + KC - 1) / KC * KC;
+  static constexpr int NCH = KSTEPS / KC;
+  static constexpr int KQ = 4;                      // KC <= 3
+  static constexpr int TAB_BYTES = 4 * NCH * KQ * 4;
+  static constexpr int WDEPTH = NCH % 3 == 0 ? 3 : 2;
+  static_assert(NCH % WDEPTH == 0, "ring state must be periodic per channel chunk");
+};
+
+template <int CC>
+__device__ __forceinline__ unsigned kslot_offset(int s, int g) {
+  const int f0 = 32 * s + 8 * g;
+  const int tap = f0 / CC, ch0 = f0 % CC;
+  if (tap >= 27) return 0u;
+  return (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PITCH + ch0 * 2);
+}
+
+template <int RING> struct WReg {
+  static constexpr int PIECES = RING / 16;
+  static constexpr int PER = (PIECES + 255) / 256;
+  u32x4 r[PER];
+  __device__ __forceinline__ void load(const unsigned char *w, int64_t chunk, int tid) {
+    const unsigned char *srcp = w + chunk * RING;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int piece = tid + 256 * k;
+      piece = piece < PIECES ? piece : PIECES - 1;
+      r[k] = *reinterpret_cast<const u32x4 *>(srcp + (size_t)piece * 16);
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char *slot, int tid) const {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int piece = tid + 256 * k;
+      piece = piece < PIECES ? piece : PIECES - 1;
+      *reinterpret_cast<u32x4 *>(slot + (size_t)piece * 16) = r[k];
+    }
+  }
+};
+
+struct Conv3Args {
+  Src src[6];
+  int ncc;                       // channel chunks
+  const unsigned char *w;        // fragments [cc][kstep][mb], 1 KiB each
+  const float *shift;
+  int relu;
+  __bf16 *out;                   // (n, OD, OH, OW, 16*MB)
+  int OD, OH, OW, zblocks;       // zblocks = ceil(OD/4); grid.z = n * zblocks
+};
+
+template <int CC, int MB>
+__global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
+  constexpr int KC = MB <= 2 ? 3 : 2;
+  using G = Geo<CC, KC>;
+  constexpr int RING = KC * MB * 1024;
+  constexpr int PPV = CC * 2 / 16;                  // 16-B pieces per voxel
+  constexpr int PIECES = TZ * TY * TX * PPV;
+  constexpr int NT = (PIECES + 255) / 256;
+  unsigned char *tile = smem;
+  unsigned char *ring = smem + TILE_BYTES;
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + TILE_BYTES + 2 * RING);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 4;
+  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * 4;
+
+  if (tid < 4 * G::NCH * G::KQ) {
+    const int gg = tid / (G::NCH * G::KQ), ck = (tid / G::KQ) % G::NCH, q = tid % G::KQ;
+    int s = ck * KC + q;
+    s = s < G::KSTEPS ? s : G::KSTEPS - 1;
+    kofftab[tid] = kslot_offset<CC>(s, gg);
+  }
+  const unsigned vbase = (unsigned)(((wave * TY) * TX + c) * PITCH);
+  const unsigned *ktab = kofftab + g * (G::NCH * G::KQ);
+  f32x4 acc[4][MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    f32x4 sh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = a.shift[16 * b + 4 * g + r];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
+  }
+  const int64_t total_chunks = (int64_t)a.ncc * G::NCH;
+  WReg<RING> wst[G::WDEPTH];
+#pragma unroll
+  for (int d = 0; d < G::WDEPTH; ++d) wst[d].load(a.w, d < total_chunks ? d : 0, tid);
+  wst[0].store(ring, tid);
+  wst[0].load(a.w, G::WDEPTH < total_chunks ? G::WDEPTH : 0, tid);
+
+  for (int cc = 0; cc < a.ncc; ++cc) {
+    const Src s = a.src[cc];
+    // ---- stage the CC-channel tile of this chunk through registers, NB pieces
+    // per thread at a time (the other workgroup on the CU computes meanwhile)
+    __syncthreads();              // every wave has left the previous chunk's tile
+    constexpr int NB = 8;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NT; j0 += NB) {
+      u32x4 nt[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int p = tid + 256 * (j0 + j);
+        p = p < PIECES ? p : PIECES - 1;
+        const int vox = p / PPV, pc = p % PPV;
+        int z = z0 + vox / (TY * TX), y = y0 + (vox / TX) % TY, x = x0 + vox % TX;
+        z = (z + s.crop) / s.up; y = (y + s.crop) / s.up; x = (x + s.crop) / s.up;
+        z = z < s.D ? z : s.D - 1;               // clamped reads only feed masked
+        y = y < s.H ? y : s.H - 1;               // outputs
+        x = x < s.W ? x : s.W - 1;
+        nt[j] = *reinterpret_cast<const u32x4 *>(
+            s.p + ((((int64_t)n * s.D + z) * s.H + y) * s.W + x) * s.C + s.ch0 + pc * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int p = tid + 256 * (j0 + j);
+        p = p < PIECES ? p : PIECES - 1;
+        *reinterpret_cast<u32x4 *>(tile + (size_t)(p / PPV) * PITCH + (p % PPV) * 16) = nt[j];
+      }
+    }
+    __syncthreads();              // tile (+ ring slot, table) visible
+    const int64_t gc0 = (int64_t)cc * G::NCH;
+    bf16x8 bcur[4], bnxt[4];
+    {
+      const unsigned koff = ktab[0];
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+        bcur[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub * TX * PITCH);
+    }
+#pragma unroll
+    for (int ck = 0; ck < G::NCH; ++ck) {
+      const int64_t gc = gc0 + ck;
+      if (ck > 0) __syncthreads();
+      {
+        int64_t nxt = gc + 1 + G::WDEPTH;
+        nxt = nxt < total_chunks ? nxt : 0;
+        wst[(ck + 1) % G::WDEPTH].store(ring + ((gc + 1) & 1) * RING, tid);
+        wst[(ck + 1) % G::WDEPTH].load(a.w, nxt, tid);
+      }
+      const unsigned char *wslot = ring + (gc & 1) * RING + lane * 16;
+      const u32x4 kq4 = *reinterpret_cast<const u32x4 *>(ktab + ck * G::KQ);
+      const unsigned kq[4] = {kq4[0], kq4[1], kq4[2], kq4[3]};
+      bf16x8 wcur[MB], wnxt[MB];
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+        wcur[b] = *reinterpret_cast<const bf16x8 *>(wslot + b * 1024);
+#pragma unroll
+      for (int ks = 0; ks < KC; ++ks) {
+        const unsigned koff = kq[ks + 1];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+          bnxt[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub * TX * PITCH);
+        if (ks + 1 < KC) {
+#pragma unroll
+          for (int b = 0; b < MB; ++b)
+            wnxt[b] = *reinterpret_cast<const bf16x8 *>(wslot + ((ks + 1) * MB + b) * 1024);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int b = 0; b < MB; ++b) acc[sub][b] = mfma16(wcur[b], bcur[sub], acc[sub][b]);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) bcur[sub] = bnxt[sub];
+        if (ks + 1 < KC) {
+#pragma unroll
+          for (int b = 0; b < MB; ++b) wcur[b] = wnxt[b];
+        }
+      }
+    }
+  }
+  // ---- epilogue: (ReLU) -> bf16, channels-last store
+  const int oz = z0 + wave, ox = x0 + c;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const int oy = y0 + sub;
+    if (oz < a.OD && oy < a.OH && ox < a.OW) {
+      __bf16 *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB) + 4 * g;
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        u32x2 o;
+        o[0] = cvt_pk_bf16(acc[sub][b][0], acc[sub][b][1]);
+        o[1] = cvt_pk_bf16(acc[sub][b][2], acc[sub][b][3]);
+        if (a.relu) { o[0] = pk_max_i16(o[0], 0u); o[1] = pk_max_i16(o[1], 0u); }
+        *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
+      }
+    }
+  }
+}
+
+// ---- conv3 1 -> 16*MB (+shift, ReLU): f32 (n,D,H,W) in, bf16 channels-last out ----
+constexpr int ST_Z = 4, ST_Y = 8, ST_X = 64;
+constexpr int ST_TZ = ST_Z + 2, ST_TY = ST_Y + 2, ST_TX = ST_X + 2;
+
+struct StemArgs1 {
+  const float *in; int D, H, W;
+  const bf16x8 *w;               // MB fragments (SLOT_STEM)
+  const float *shift;
+  __bf16 *out; int OD, OH, OW, zblocks;
+};
+
+template <int MB>
+__global__ __launch_bounds__(256) void stem_cin1_bf16(StemArgs1 a) {
+  __shared__ unsigned short tile[ST_TZ * ST_TY * ST_TX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int x0 = blockIdx.x * ST_X, y0 = blockIdx.y * ST_Y;
+  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * ST_Z;
+  for (int i = tid; i < ST_TZ * ST_TY * ST_TX; i += 256) {
+    const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
+    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+    float v = 0.f;
+    if (z < a.D && y < a.H && x < a.W) v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
+    tile[i] = bf16_bits(v);
+  }
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t = 8 * g + j;
+    toff[j] = t < 27 ? ((t / 9) * ST_TY + (t / 3) % 3) * ST_TX + t % 3 : 0;
+  }
+  bf16x8 w[MB];
+  f32x4 sh[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    w[b] = a.w[b * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[b][r] = a.shift[16 * b + 4 * g + r];
+  }
+  __syncthreads();
+  for (int task = wave; task < ST_Z * ST_Y * (ST_X / 16); task += 4) {
+    const int xg = task % (ST_X / 16), yl = (task / (ST_X / 16)) % ST_Y, zl = task / (ST_X / 16 * ST_Y);
+    const int base = (zl * ST_TY + yl) * ST_TX + 16 * xg + c;
+    u16x8 raw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = tile[base + toff[j]];
+    const bf16x8 bf = __builtin_bit_cast(bf16x8, raw);
+    const int oz = z0 + zl, oy = y0 + yl, ox = x0 + 16 * xg + c;
+    const bool ok = oz < a.OD && oy < a.OH && ox < a.OW;
+    __bf16 *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB) + 4 * g;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const f32x4 acc = mfma16(w[b], bf, sh[b]);
+      u32x2 o;
+      o[0] = pk_max_i16(cvt_pk_bf16(acc[0], acc[1]), 0u);
+      o[1] = pk_max_i16(cvt_pk_bf16(acc[2], acc[3]), 0u);
+      if (ok) *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
+    }
+  }
+}
+
+// ---- 1x1x1 conv as a voxel GEMM ---------------------------------------------------
+struct Conv1Args {
+  const __bf16 *in; int64_t M;   // voxels (n*D*H*W), CIN channels each
+  const unsigned char *w;        // [kstep][mb] fragments (SLOT_SPATIAL, 1 tap)
+  const float *shift;
+  __bf16 *out;                   // (M, 16*MB) bf16            (TAIL == 0)
+  const bf16x8 *w_tail;          // TAIL: [kstep] fragments of the 16*MB -> 1 conv
+  float bias_tail;
+  float *out_f32;                // TAIL: (M) sigmoid probabilities
+};
+
+template <int CIN, int MB, int TAIL>
+__global__ __launch_bounds__(256) void conv1_bf16(Conv1Args a) {
+  constexpr int KS = CIN / 32;
+  constexpr int NF = KS * MB;
+  unsigned char *wl = smem;                         // NF KiB of fragments
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  for (int i = tid; i < NF * 64; i += 256)
+    reinterpret_cast<u32x4 *>(wl)[i] = reinterpret_cast<const u32x4 *>(a.w)[i];
+  f32x4 sh[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[b][r] = a.shift[16 * b + 4 * g + r];
+  __syncthreads();
+  const int64_t groups = (a.M + 15) / 16;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
+    int64_t m = grp * 16 + c;
+    const bool ok = m < a.M;
+    m = ok ? m : a.M - 1;
+    bf16x8 bf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      bf[s] = *reinterpret_cast<const bf16x8 *>(a.in + m * CIN + 32 * s + 8 * g);
+    f32x4 acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      acc[b] = sh[b];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc[b] = mfma16(*reinterpret_cast<const bf16x8 *>(wl + ((s * MB + b) * 64 + lane) * 16),
+                        bf[s], acc[b]);
+    }
+    if (TAIL == 0) {
+      if (ok) {
+        __bf16 *dst = a.out + m * (16 * MB) + 4 * g;
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          u32x2 o;
+          o[0] = pk_max_i16(cvt_pk_bf16(acc[b][0], acc[b][1]), 0u);
+          o[1] = pk_max_i16(cvt_pk_bf16(acc[b][2], acc[b][3]), 0u);
+          *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
+        }
+      }
+    } else {
+      // chained 16*MB -> 1 conv (k-slots bound to the accumulator layout), sigmoid
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < MB / 2; ++s)
+        t = mfma16(a.w_tail[s * 64 + lane], pack_relu(acc[2 * s], acc[2 * s + 1]), t);
+      const float logit = __shfl(t[0], c) + a.bias_tail;
+      if (ok && g == 0) a.out_f32[m] = 1.f / (1.f + __expf(-logit));
+    }
+  }
+}
+
+__global__ void pool2_bf16(const __bf16 *__restrict__ x, __bf16 *__restrict__ y,
+                           int64_t n_out8, int D, int H, int W, int C8, int od, int oh, int ow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 8-channel groups
+  if (i >= n_out8) return;
+  int64_t t = i;
+  const int c8 = (int)(t % C8); t /= C8;
+  const int ox = (int)(t % ow); t /= ow;
+  const int oy = (int)(t % oh); t /= oh;
+  const int oz = (int)(t % od); t /= od;
+  u32x4 m = {0u, 0u, 0u, 0u};          // inputs are post-ReLU (>= 0): int16 max = float max
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(
+        x + (((((t * D + 2 * oz + (p >> 2)) * H + 2 * oy + ((p >> 1) & 1)) * (int64_t)W + 2 * ox + (p & 1)) * C8 + c8) * 8));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = pk_max_i16(m[k], v[k]);
+  }
+  *reinterpret_cast<u32x4 *>(y + i * 8) = m;
+}
+
+// ---- host: unet_like2 pattern + packed weights -------------------------------------
+struct UnetState {
+  uint64_t version = ~0ull;
+  unsigned char *frags = nullptr;
+  float *shifts = nullptr;
+  size_t off_w[12] = {0}, off_s[12] = {0};
+  float bias_tail = 0.f;
+};
+
+void unet_state_free(fpl_ctx *, void *p) {
+  UnetState *s = (UnetState *)p;
+  if (s->frags) hipFree(s->frags);
+  if (s->shifts) hipFree(s->shifts);
+  delete s;
+}
+
+// lowered unet_like2: conv,conv,pool,conv,conv,pool,conv1,up,concat,conv,conv1,
+//                     crop,up,concat,conv,conv1,conv1(sigmoid)     (17 ops; the crop
+// may be emitted before or after the up - match by kind counts + conv sequence)
+const int U_K[10] = {3, 3, 3, 3, 1, 3, 1, 3, 1, 1};
+const int U_CIN[10] = {1, 32, 32, 64, 64, 192, 64, 96, 32, 32};
+const int U_COUT[10] = {32, 32, 64, 64, 128, 64, 64, 32, 32, 1};
+
+bool is_unet_like2(const fpl_program *prog, int conv_idx[10]) {
+  int nc = 0, np = 0, nu = 0, ncat = 0, ncrop = 0;
+  for (size_t i = 0; i < prog->ops.size(); ++i) {
+    const fpl_op &op = prog->ops[i];
+    switch (op.kind) {
+      case FPL_OP_CONV:
+        if (nc >= 10 || op.k != U_K[nc] || op.cin != U_CIN[nc] || op.cout != U_COUT[nc]) return false;
+        if (op.act != (nc == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return false;
+        conv_idx[nc++] = (int)i;
+        break;
+      case FPL_OP_POOL: if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) return false; ++np; break;
+      case FPL_OP_UP: if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) return false; ++nu; break;
+      case FPL_OP_CONCAT: ++ncat; break;
+      case FPL_OP_CROP:
+        for (int q = 0; q < 6; ++q) if (op.p[q] != 6) return false;
+        ++ncrop;
+        break;
+      default: return false;
+    }
+  }
+  if (nc != 10 || np != 2 || nu != 2 || ncat != 2 || ncrop != 1) return false;
+  if (prog->stride[0] != 1 || prog->stride[1] != 1 || prog->stride[2] != 1) return false;
+  // dataflow: conv i (i>=1) reads conv i-1 except through pool / concat
+  const auto &o = prog->ops;
+  auto src_kind = [&](int tensor) -> int {
+    for (auto &op : o) if (op.dst == tensor) return op.kind;
+    return -1;
+  };
+  if (src_kind(o[conv_idx[2]].src0) != FPL_OP_POOL || src_kind(o[conv_idx[4]].src0) != FPL_OP_POOL)
+    return false;
+  if (src_kind(o[conv_idx[5]].src0) != FPL_OP_CONCAT || src_kind(o[conv_idx[7]].src0) != FPL_OP_CONCAT)
+    return false;
+  return prog->out_tensor == o[conv_idx[9]].dst;
+}
+
+int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetState **out) {
+  UnetState *st = (UnetState *)prog->fast_state;
+  if (!st) {
+    st = new UnetState();
+    prog->fast_state = st;
+    prog->fast_state_free = unet_state_free;
+  }
+  *out = st;
+  if (st->version == prog->arena_version) return 0;
+  std::vector<uint16_t> all;
+  std::vector<float> shifts;
+  const float *A = prog->arena_host.data();
+  for (int l = 0; l < 10; ++l) {
+    const fpl_op &op = prog->ops[conv_idx[l]];
+    std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
+    std::vector<uint16_t> f;
+    const int mb = (op.cout + 15) / 16;
+    if (l == 0) {
+      fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, mb, 1, SLOT_STEM, &f);
+    } else if (op.k == 3) {
+      // per CC-channel chunk: rows [tap][cin] -> sub-matrix of the chunk's channels
+      const int CC = 32, ncc = op.cin / CC;
+      const int kc = mb <= 2 ? 3 : 2;
+      const int ksteps = ((27 * CC + 31) / 32 + kc - 1) / kc * kc;
+      std::vector<float> sub((size_t)27 * CC * op.cout);
+      for (int cc = 0; cc < ncc; ++cc) {
+        for (int tap = 0; tap < 27; ++tap)
+          for (int ch = 0; ch < CC; ++ch)
+            memcpy(&sub[((size_t)tap * CC + ch) * op.cout],
+                   A + op.w_off + ((size_t)tap * op.cin + cc * CC + ch) * op.cout,
+                   op.cout * sizeof(float));
+        std::vector<uint16_t> fc;
+        fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, ksteps, SLOT_SPATIAL, &fc);
+        f.insert(f.end(), fc.begin(), fc.end());
+      }
+    } else if (l == 9) {
+      fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, 1, 1, SLOT_CHAIN, &f);
+    } else {
+      fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL, &f);
+    }
+    st->off_w[l] = all.size() * sizeof(uint16_t);
+    all.insert(all.end(), f.begin(), f.end());
+    st->off_s[l] = shifts.size();
+    shifts.insert(shifts.end(), A + op.shift_off, A + op.shift_off + op.cout);
+    while (shifts.size() % 4) shifts.push_back(0.f);
+  }
+  st->bias_tail = A[prog->ops[conv_idx[9]].shift_off];
+  if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
+  if (st->shifts) FPL_HIP(ctx, hipFree(st->shifts));
+  st->frags = nullptr; st->shifts = nullptr;
+  FPL_HIP(ctx, hipMalloc((void **)&st->frags, all.size() * sizeof(uint16_t)));
+  FPL_HIP(ctx, hipMalloc((void **)&st->shifts, shifts.size() * sizeof(float)));
+  FPL_HIP(ctx, hipMemcpy(st->frags, all.data(), all.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  FPL_HIP(ctx, hipMemcpy(st->shifts, shifts.data(), shifts.size() * sizeof(float), hipMemcpyHostToDevice));
+  st->version = prog->arena_version;
+  return 0;
+}
+
+template <int CC, int MB>
+int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
+  constexpr int KC = MB <= 2 ? 3 : 2;
+  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024 + Geo<CC, KC>::TAB_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<CC, MB>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  a.zblocks = (int)ceil_div64(a.OD, 4);
+  dim3 grid((unsigned)ceil_div64(a.OW, 16), (unsigned)ceil_div64(a.OH, 4), (unsigned)(n * a.zblocks));
+  TimedLaunch tl(ctx, name);
+  conv3_bf16<CC, MB><<<grid, 256, SMEM, ctx->stream>>>(a);
+  return 0;
+}
+
+Src make_src(const __bf16 *p, int dim, int C, int ch0, int up, int crop) {
+  Src s;
+  s.p = p; s.D = s.H = s.W = dim; s.C = C; s.ch0 = ch0; s.up = up; s.crop = crop;
+  return s;
+}
+
+}  // namespace
+
+bool fpl_unet_fast_available(const fpl_program *prog, int precision) {
+  int idx[10];
+  return precision == FPL_PREC_BF16 && is_unet_like2(prog, idx);
+}
+
+// in: (n, T,T,T) f32 normalised tiles on the device; out: (n, T-18, T-18, T-18) f32
+int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
+                          int T, float *out) {
+  int ci[10];
+  FPL_REQUIRE(ctx, is_unet_like2(prog, ci), "not a unet_like2 program");
+  FPL_REQUIRE(ctx, T % 4 == 0 && T >= 24, "unet_like2 tile edge %d must be 0 mod 4", T);
+  UnetState *st;
+  FPL_TRY(unet_prepare(ctx, prog, ci, &st));
+  DevTemp tmp(ctx);
+  const unsigned char *F = st->frags;
+  const float *S = st->shifts;
+  const int d1a = T - 2, d1 = T - 4, dp1 = d1 / 2, d2a = dp1 - 2, d2 = dp1 - 4, dp2 = d2 / 2;
+  const int d4a = 2 * dp2 - 2, d5a = 2 * d4a - 2;      // = T - 18
+  auto cube = [](int d) { return (int64_t)d * d * d; };
+  auto balloc = [&](int64_t elems, __bf16 **p) -> int {
+    void *q;
+    int rc = tmp.alloc((size_t)elems * 2 + 64, &q);
+    *p = (__bf16 *)q;
+    return rc;
+  };
+  __bf16 *c1a, *c1, *p1, *c2a, *c2, *p2, *c3, *c4a, *c4, *c5a;
+  FPL_TRY(balloc(n * cube(d1a) * 32, &c1a));
+  FPL_TRY(balloc(n * cube(d1) * 32, &c1));
+  FPL_TRY(balloc(n * cube(dp1) * 32, &p1));
+  FPL_TRY(balloc(n * cube(d2a) * 64, &c2a));
+  FPL_TRY(balloc(n * cube(d2) * 64, &c2));
+  FPL_TRY(balloc(n * cube(dp2) * 64, &p2));
+  FPL_TRY(balloc(n * cube(dp2) * 128, &c3));
+  FPL_TRY(balloc(n * cube(d4a) * 64, &c4a));
+  FPL_TRY(balloc(n * cube(d4a) * 64, &c4));
+  FPL_TRY(balloc(n * cube(d5a) * 32, &c5a));
+  hipStream_t stm = ctx->stream;
+  {  // L0: conv3 1->32
+    StemArgs1 a;
+    a.in = in; a.D = a.H = a.W = T;
+    a.w = (const bf16x8 *)(F + st->off_w[0]); a.shift = S + st->off_s[0];
+    a.out = c1a; a.OD = a.OH = a.OW = d1a; a.zblocks = (int)ceil_div64(d1a, ST_Z);
+    dim3 grid((unsigned)ceil_div64(d1a, ST_X), (unsigned)ceil_div64(d1a, ST_Y), (unsigned)(n * a.zblocks));
+    TimedLaunch tl(ctx, "unet_stem_bf16");
+    stem_cin1_bf16<2><<<grid, 256, 0, stm>>>(a);
+  }
+  auto conv3_args = [&](int l, __bf16 *outp, int od) {
+    Conv3Args a;
+    a.w = F + st->off_w[l]; a.shift = S + st->off_s[l]; a.relu = 1;
+    a.out = outp; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
+    return a;
+  };
+  auto pool = [&](const __bf16 *x, __bf16 *y, int d, int C) {
+    const int od = d / 2;
+    const int64_t n8 = (int64_t)n * cube(od) * (C / 8);
+    TimedLaunch tl(ctx, "unet_pool_bf16");
+    pool2_bf16<<<(unsigned)ceil_div64(n8, 256), 256, 0, stm>>>(x, y, n8, d, d, d, C / 8, od, od, od);
+  };
+  {  // L1: conv3 32->32
+    Conv3Args a = conv3_args(1, c1, d1);
+    a.ncc = 1; a.src[0] = make_src(c1a, d1a, 32, 0, 1, 0);
+    FPL_TRY((launch_conv3<32, 2>(ctx, a, n, "unet_conv3_32_32")));
+  }
+  pool(c1, p1, d1, 32);
+  {  // L2: conv3 32->64
+    Conv3Args a = conv3_args(2, c2a, d2a);
+    a.ncc = 1; a.src[0] = make_src(p1, dp1, 32, 0, 1, 0);
+    FPL_TRY((launch_conv3<32, 4>(ctx, a, n, "unet_conv3_32_64")));
+  }
+  {  // L3: conv3 64->64
+    Conv3Args a = conv3_args(3, c2, d2);
+    a.ncc = 2;
+    for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c2a, d2a, 64, 32 * cc, 1, 0);
+    FPL_TRY((launch_conv3<32, 4>(ctx, a, n, "unet_conv3_64_64")));
+  }
+  pool(c2, p2, d2, 64);
+  auto conv1 = [&](auto kern, int smem_frags, const __bf16 *x, int64_t M, int l, __bf16 *y,
+                   const char *name) {
+    Conv1Args a;
+    a.in = x; a.M = M; a.w = F + st->off_w[l]; a.shift = S + st->off_s[l];
+    a.out = y; a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(M, 64), (int64_t)ctx->n_cu * 8);
+    TimedLaunch tl(ctx, name);
+    kern<<<grid, 256, smem_frags * 1024, stm>>>(a);
+  };
+  conv1(conv1_bf16<64, 8, 0>, 16, p2, (int64_t)n * cube(dp2), 4, c3, "unet_conv1_64_128");
+  {  // L5: conv3 (up2(c3) 128 | c2 64) -> 64
+    Conv3Args a = conv3_args(5, c4a, d4a);
+    a.ncc = 6;
+    for (int cc = 0; cc < 4; ++cc) a.src[cc] = make_src(c3, dp2, 128, 32 * cc, 2, 0);
+    for (int cc = 0; cc < 2; ++cc) a.src[4 + cc] = make_src(c2, d2, 64, 32 * cc, 1, 0);
+    FPL_TRY((launch_conv3<32, 4>(ctx, a, n, "unet_conv3_192_64")));
+  }
+  conv1(conv1_bf16<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), 6, c4, "unet_conv1_64_64");
+  {  // L7: conv3 (up2(c4) 64 | crop6(c1) 32) -> 32
+    Conv3Args a = conv3_args(7, c5a, d5a);
+    a.ncc = 3;
+    for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c4, d4a, 64, 32 * cc, 2, 0);
+    a.src[2] = make_src(c1, d1, 32, 0, 1, 6);
+    FPL_TRY((launch_conv3<32, 2>(ctx, a, n, "unet_conv3_96_32")));
+  }
+  {  // L8 + L9: conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
+    Conv1Args a;
+    a.in = c5a; a.M = (int64_t)n * cube(d5a); a.w = F + st->off_w[8]; a.shift = S + st->off_s[8];
+    a.out = nullptr; a.w_tail = (const bf16x8 *)(F + st->off_w[9]); a.bias_tail = st->bias_tail;
+    a.out_f32 = out;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
+    TimedLaunch tl(ctx, "unet_head_bf16");
+    conv1_bf16<32, 2, 1><<<grid, 256, 2 * 1024, stm>>>(a);
+  }
+  FPL_HIP(ctx, hipGetLastError());
+  return 0;
+}

@@ -18,3 +18,8 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
 // true when fpl_fast_infer_volume will handle this program / precision / lattice
 bool fpl_fast_path_available(const fpl_program *prog, int precision,
                              const int32_t offset[3], const int32_t out_sz[3]);
+
+// unet_like2 bf16 MFMA executor (conv_mfma.hip): batch of n equal tiles
+bool fpl_unet_fast_available(const fpl_program *prog, int precision);
+int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
+                          int T, float *out);

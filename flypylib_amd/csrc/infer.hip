@@ -263,7 +263,10 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                                 precision, origins, out_sz, zb, ze,
                                 dst_dev - dst_base * Y * X, &handled));
   if (!handled) {
-    FPL_REQUIRE(ctx, precision == FPL_PREC_F32,
+    const bool unet_bf16 = precision == FPL_PREC_BF16 &&
+                           fpl_unet_fast_available(prog, precision) &&
+                           tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2];
+    FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || unet_bf16,
                 "fpl_infer_volume: no bf16 kernels for this architecture yet; "
                 "use precision f32");
     // tile list in the reference's order (z outer, x inner)
@@ -294,6 +297,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     const int64_t budget = (int64_t)24 << 30;
     int64_t B = std::max<int64_t>(1, std::min<int64_t>(n_tiles, budget / std::max<int64_t>(per_tile, 1)));
     B = std::min<int64_t>(B, 64);
+    if (unet_bf16) B = std::min<int64_t>(n_tiles, 48);
     const int64_t tile_elems = (int64_t)tile_in[0] * tile_in[1] * tile_in[2];
     void *in_batch, *out_batch;
     FPL_TRY(tmp.alloc(B * tile_elems * sizeof(float), &in_batch));
@@ -316,8 +320,12 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
               tot);
         FPL_HIP(ctx, hipGetLastError());
       }
-      FPL_TRY(fpl_forward_generic(ctx, prog, (const float *)in_batch, (int32_t)nb,
-                                  tile_in, (float *)out_batch));
+      if (unet_bf16)
+        FPL_TRY(fpl_unet_forward_bf16(ctx, prog, (const float *)in_batch, (int)nb,
+                                      tile_in[0], (float *)out_batch));
+      else
+        FPL_TRY(fpl_forward_generic(ctx, prog, (const float *)in_batch, (int32_t)nb,
+                                    tile_in, (float *)out_batch));
       {
         TimedLaunch tl(ctx, "stitch_tiles");
         const int64_t tot = nb * fine;

@@ -211,3 +211,28 @@ def vgg_like_forward_bf16emu(x, weights, upsample_stride=None):
     if upsample_stride is not None:
         h = upsample(h, upsample_stride)
     return h.permute(0, 2, 3, 4, 1).contiguous().numpy()
+
+
+def unet_like2_forward_bf16emu(x, weights):
+    """unet_like2 with the rounding points of the bf16 MFMA kernels
+    (csrc/conv_mfma.hip): input and every post-ReLU activation rounded to bf16,
+    BN scale folded into bf16 kernels, fp32 accumulation and shift."""
+    w = _W(weights, torch.float32)
+    h = _bf16_round(_t(x, torch.float32).permute(0, 4, 1, 2, 3))
+
+    def block(h):
+        kern = w.take()
+        g, b, m, v = w.take(4)
+        s = g / torch.sqrt(v + BN_EPS)
+        kf = _bf16_round(kern * s.view(1, 1, 1, 1, -1))
+        y = conv3d_valid(h, kf) + (b - m * s).view(1, -1, 1, 1, 1)
+        return _bf16_round(torch.relu(y))
+
+    c1 = block(block(h))
+    c2 = block(block(maxpool2(c1)))
+    c3 = block(maxpool2(c2))
+    c4 = block(block(torch.cat([upsample(c3, 2), c2], dim=1)))
+    c5 = block(block(torch.cat([upsample(c4, 2), crop(c1, 6)], dim=1)))
+    out = torch.sigmoid(conv3d_valid(c5, _bf16_round(w.take())))
+    w.done()
+    return out.permute(0, 2, 3, 4, 1).contiguous().numpy()
