@@ -36,6 +36,8 @@ VGG_FLOP_TOTAL = sum(VGG_FLOP.values())          # 25 707
 KERNEL_LAYERS = {
     'generic_conv3_f32': ('L1', 'L3', 'L5'),
     'generic_conv1_f32': ('L2', 'L4', 'L6', 'L7', 'L8'),
+    'mfma_conv3_f32': ('L3', 'L5'), 'mfma_stem_f32': ('L1',),
+    'mfma_conv1_f32': ('L2', 'L4', 'L6', 'L7', 'L8'),
     'vgg_stem_pool_bf16': ('L1', 'L2'), 'vgg_stem_pool_f32': ('L1', 'L2'),
     'vgg_mid_pool_bf16': ('L3', 'L4'), 'vgg_mid_pool_f32': ('L3', 'L4'),
     'vgg_head_bf16': ('L5', 'L6', 'L7', 'L8'),
@@ -177,7 +179,7 @@ def main():
         if flop_per_vox is not None:
             flops_per_launch = flop_per_vox * valid_local * args.steps / tk['launches']
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS[args.precision if 'generic' not in name else 'f32']
+            peak = PEAK_TFLOPS['f32' if ('generic' in name or 'f32' in name) else args.precision]
             roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 3),
                         peak=peak, unit='TFLOP/s',
                         frac=round(achieved / peak, 5),

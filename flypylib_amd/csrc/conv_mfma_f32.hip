@@ -1,0 +1,656 @@
+// fp32 MFMA (v_mfma_f32_16x16x4_f32: exact f32, k-ordered fmaf chain) kernels and a
+// generic executor over lowered layer programs.  This is the fast form of the
+// PARITY path (1e-3 gate of the north star): same arithmetic type as the
+// reference's fp32 Keras graph, ~30x the direct per-op kernels of generic.hip.
+//
+// Fragment maps (lane l: c = l & 15, g = l >> 4): A[row c][k = g], B[k = g][col c],
+// D[row 4g + r][col c].  Four consecutive K-steps form a K-block of 16 k-values;
+// k-slot (j, g) of a block is bound to k = 4g + j, so a lane's operands for the
+// whole block are ONE 16-byte read (4 consecutive channels of a tap / 4 floats of
+// a fragment).  conv3_f32 mirrors conv3_bf16 (conv_mfma.hip): LDS tile of 16
+// channels x (6 x 6 x 18) voxels at 96 B pitch, weight fragments through a 2-slot
+// LDS ring staged through registers, two workgroups per CU.
+#include <algorithm>
+
+#include "fast_paths.h"
+#include "mfma_util.h"
+
+namespace {
+
+constexpr int PITCH = 96;
+constexpr int TZ = 6, TY = 6, TX = 18;
+constexpr int TILE_BYTES = TZ * TY * TX * PITCH;
+constexpr int CC = 16;                    // channels per LDS tile chunk
+constexpr int KB = 27;                    // K-blocks (taps) per channel chunk
+constexpr int KC = 3;                     // K-blocks per weight ring slot
+constexpr int NCH = KB / KC;              // 9 ring slots per channel chunk
+constexpr int WDEPTH = 3;
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct SrcF {
+  const float *p;        // (n, D, H, W, C) f32
+  int D, H, W, C;
+  int ch0, up, crop;
+  int pad;               // zero padding around the source (dgrad: k-1)
+};
+
+struct Conv3F {
+  SrcF src[12];
+  int ncc;
+  const float *w;        // fragments [cc][tap][mb][lane][4]
+  const float *shift;
+  int act;               // fpl_act
+  float *out;            // (n, OD, OH, OW, cout)
+  int cout;              // real output channels (<= 16*MB)
+  int OD, OH, OW, zblocks;
+};
+
+template <int RING> struct WRegF {
+  static constexpr int PIECES = RING / 16;
+  static constexpr int PER = (PIECES + 255) / 256;
+  u32x4 r[PER];
+  __device__ __forceinline__ void load(const unsigned char *w, int64_t chunk, int tid) {
+    const unsigned char *srcp = w + chunk * RING;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int piece = tid + 256 * k;
+      piece = piece < PIECES ? piece : PIECES - 1;
+      r[k] = *reinterpret_cast<const u32x4 *>(srcp + (size_t)piece * 16);
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char *slot, int tid) const {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int piece = tid + 256 * k;
+      piece = piece < PIECES ? piece : PIECES - 1;
+      *reinterpret_cast<u32x4 *>(slot + (size_t)piece * 16) = r[k];
+    }
+  }
+};
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  if (act == FPL_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == FPL_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  return v;
+}
+
+template <int MB>
+__global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
+  constexpr int RING = KC * MB * 1024;
+  constexpr int PIECES = TZ * TY * TX * 4;          // 4 x 16 B per voxel (16 ch)
+  constexpr int NT = (PIECES + 255) / 256;
+  unsigned char *tile = smem;
+  unsigned char *ring = smem + TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 4;
+  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * 4;
+  const unsigned vbase = (unsigned)(((wave * TY) * TX + c) * PITCH + g * 16);
+  f32x4 acc[4][MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    f32x4 sh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * b + 4 * g + r;
+      sh[r] = co < a.cout ? a.shift[co] : 0.f;
+    }
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
+  }
+  const int64_t total_chunks = (int64_t)a.ncc * NCH;
+  const unsigned char *wg = reinterpret_cast<const unsigned char *>(a.w);
+  WRegF<RING> wst[WDEPTH];
+#pragma unroll
+  for (int d = 0; d < WDEPTH; ++d) wst[d].load(wg, d < total_chunks ? d : 0, tid);
+  wst[0].store(ring, tid);
+  wst[0].load(wg, WDEPTH < total_chunks ? WDEPTH : 0, tid);
+
+  for (int cc = 0; cc < a.ncc; ++cc) {
+    const SrcF s = a.src[cc];
+    __syncthreads();
+    constexpr int NB = 8;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NT; j0 += NB) {
+      u32x4 nt[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int p = tid + 256 * (j0 + j);
+        p = p < PIECES ? p : PIECES - 1;
+        const int vox = p >> 2, pc = p & 3;
+        int z = z0 + vox / (TY * TX) - s.pad, y = y0 + (vox / TX) % TY - s.pad,
+            x = x0 + vox % TX - s.pad;
+        const bool inside = z >= 0 && y >= 0 && x >= 0;
+        z = (z + s.crop) / s.up; y = (y + s.crop) / s.up; x = (x + s.crop) / s.up;
+        const bool ok = inside && z < s.D && y < s.H && x < s.W;
+        z = ok ? z : 0; y = ok ? y : 0; x = ok ? x : 0;
+        const int ch = s.ch0 + pc * 4;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        const float *gp = s.p + ((((int64_t)n * s.D + z) * s.H + y) * s.W + x) * s.C + ch;
+        if (ok) {
+          if (ch + 3 < s.C && (s.C & 3) == 0) {
+            v = *reinterpret_cast<const u32x4 *>(gp);
+          } else {                               // ragged channel tail (C = 1, ...)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (ch + q < s.C) v[q] = __float_as_uint(gp[q]);
+          }
+        }
+        nt[j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        int p = tid + 256 * (j0 + j);
+        p = p < PIECES ? p : PIECES - 1;
+        *reinterpret_cast<u32x4 *>(tile + (size_t)(p >> 2) * PITCH + (p & 3) * 16) = nt[j];
+      }
+    }
+    __syncthreads();
+    const int64_t gc0 = (int64_t)cc * NCH;
+#pragma unroll
+    for (int ck = 0; ck < NCH; ++ck) {
+      const int64_t gc = gc0 + ck;
+      if (ck > 0) __syncthreads();
+      {
+        int64_t nxt = gc + 1 + WDEPTH;
+        nxt = nxt < total_chunks ? nxt : 0;
+        wst[(ck + 1) % WDEPTH].store(ring + ((gc + 1) & 1) * RING, tid);
+        wst[(ck + 1) % WDEPTH].load(wg, nxt, tid);
+      }
+      const unsigned char *wslot = ring + (gc & 1) * RING + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < KC; ++ks) {
+        const int tap = ck * KC + ks;
+        const unsigned toff = (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PITCH);
+        f32x4 wf[MB], bf[4];
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+          wf[b] = *reinterpret_cast<const f32x4 *>(wslot + (ks * MB + b) * 1024);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+          bf[sub] = *reinterpret_cast<const f32x4 *>(tile + vbase + toff + sub * TX * PITCH);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+              acc[sub][b] = mfma4(wf[b][j], bf[sub][j], acc[sub][b]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  const int oz = z0 + wave, ox = x0 + c;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const int oy = y0 + sub;
+    if (oz < a.OD && oy < a.OH && ox < a.OW) {
+      float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.cout;
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * b + 4 * g + r;
+          if (co < a.cout) dst[co] = act_f(acc[sub][b][r], a.act);
+        }
+    }
+  }
+}
+
+// ---- 1x1x1 conv as a voxel GEMM (fp32) ----------------------------------------------
+struct Conv1F {
+  const float *in; int64_t M; int cin;     // cin padded to 16 in the fragments
+  const float *w;                          // fragments [kblock][mb][lane][4]
+  const float *shift;
+  int act;
+  float *out; int cout;
+};
+
+template <int MB>
+__global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int nkb = (a.cin + 15) / 16;
+  f32x4 sh[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * b + 4 * g + r;
+      sh[b][r] = co < a.cout ? a.shift[co] : 0.f;
+    }
+  const int64_t groups = (a.M + 15) / 16;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
+    int64_t m = grp * 16 + c;
+    const bool ok = m < a.M;
+    m = ok ? m : a.M - 1;
+    f32x4 acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = sh[b];
+    for (int kb = 0; kb < nkb; ++kb) {
+      const int ch = 16 * kb + 4 * g;
+      f32x4 bf = {0.f, 0.f, 0.f, 0.f};
+      const float *gp = a.in + m * a.cin + ch;
+      if (ch + 3 < a.cin && (a.cin & 3) == 0) {
+        bf = *reinterpret_cast<const f32x4 *>(gp);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (ch + q < a.cin) bf[q] = gp[q];
+      }
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const f32x4 wf = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)(kb * MB + b) * 64 + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b] = mfma4(wf[j], bf[j], acc[b]);
+      }
+    }
+    if (ok) {
+      float *dst = a.out + m * a.cout;
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * b + 4 * g + r;
+          if (co < a.cout) dst[co] = act_f(acc[b][r], a.act);
+        }
+    }
+  }
+}
+
+// ---- conv3 1 -> cout (fp32): 27 taps = 2 K-blocks (k-slot (j,g) of block q = tap
+// 16q + 4g + j), gathered straight from an f32 LDS tile ------------------------------
+constexpr int ST_Z = 4, ST_Y = 8, ST_X = 64;
+constexpr int ST_TZ = ST_Z + 2, ST_TY = ST_Y + 2, ST_TX = ST_X + 2;
+
+struct StemF {
+  const float *in; int D, H, W;
+  const float *w;                // fragments [2][mb][lane][4]
+  const float *shift;
+  int act;
+  float *out; int cout; int OD, OH, OW, zblocks;
+};
+
+template <int MB>
+__global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
+  __shared__ float tile[ST_TZ * ST_TY * ST_TX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int x0 = blockIdx.x * ST_X, y0 = blockIdx.y * ST_Y;
+  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * ST_Z;
+  for (int i = tid; i < ST_TZ * ST_TY * ST_TX; i += 256) {
+    const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
+    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+    float v = 0.f;
+    if (z < a.D && y < a.H && x < a.W) v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
+    tile[i] = v;
+  }
+  int toff[8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = 16 * q + 4 * g + j;
+      toff[4 * q + j] = t < 27 ? ((t / 9) * ST_TY + (t / 3) % 3) * ST_TX + t % 3 : 0;
+    }
+  f32x4 w[2][MB], sh[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    w[0][b] = *reinterpret_cast<const f32x4 *>(a.w + ((0 * MB + b) * 64 + lane) * 4);
+    w[1][b] = *reinterpret_cast<const f32x4 *>(a.w + ((1 * MB + b) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * b + 4 * g + r;
+      sh[b][r] = co < a.cout ? a.shift[co] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int task = wave; task < ST_Z * ST_Y * (ST_X / 16); task += 4) {
+    const int xg = task % (ST_X / 16), yl = (task / (ST_X / 16)) % ST_Y, zl = task / (ST_X / 16 * ST_Y);
+    const int base = (zl * ST_TY + yl) * ST_TX + 16 * xg + c;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = tile[base + toff[j]];
+    const int oz = z0 + zl, oy = y0 + yl, ox = x0 + 16 * xg + c;
+    const bool ok = oz < a.OD && oy < a.OH && ox < a.OW;
+    float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.cout;
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      f32x4 acc = sh[b];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma4(w[q][b][j], bv[4 * q + j], acc);
+      if (ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 16 * b + 4 * g + r;
+          if (co < a.cout) dst[co] = act_f(acc[r], a.act);
+        }
+      }
+    }
+  }
+}
+
+__global__ void pool2_f32v(const float *__restrict__ x, float *__restrict__ y, int64_t n_out,
+                           int D, int H, int W, int C, int od, int oh, int ow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  int64_t t = i;
+  const int c = (int)(t % C); t /= C;
+  const int ox = (int)(t % ow); t /= ow;
+  const int oy = (int)(t % oh); t /= oh;
+  const int oz = (int)(t % od); t /= od;
+  float m = -INFINITY;
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+    m = fmaxf(m, x[((((t * D + 2 * oz + (p >> 2)) * H + 2 * oy + ((p >> 1) & 1)) * (int64_t)W +
+                     2 * ox + (p & 1)) * C) + c]);
+  y[i] = m;
+}
+
+// ---- host: fragment packing + generic executor --------------------------------------
+// conv3 fragments: [cc][tap][mb][lane][j] = W[tap][16cc + 4g + j][16mb + (lane&15)] * scale
+void pack_conv3_f32(const float *W, const float *scale, int cin, int cout, int mb,
+                    std::vector<float> *out) {
+  const int ncc = (cin + 15) / 16;
+  out->assign((size_t)ncc * 27 * mb * 256, 0.f);
+  for (int cc = 0; cc < ncc; ++cc)
+    for (int tap = 0; tap < 27; ++tap)
+      for (int b = 0; b < mb; ++b)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = 16 * b + (lane & 15), g = lane >> 4;
+          if (co >= cout) continue;
+          for (int j = 0; j < 4; ++j) {
+            const int ci = 16 * cc + 4 * g + j;
+            if (ci >= cin) continue;
+            (*out)[((((size_t)cc * 27 + tap) * mb + b) * 64 + lane) * 4 + j] =
+                W[((size_t)tap * cin + ci) * cout + co] * scale[co];
+          }
+        }
+}
+
+void pack_conv1_f32(const float *W, const float *scale, int cin, int cout, int mb,
+                    std::vector<float> *out) {
+  const int nkb = (cin + 15) / 16;
+  out->assign((size_t)nkb * mb * 256, 0.f);
+  for (int kb = 0; kb < nkb; ++kb)
+    for (int b = 0; b < mb; ++b)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = 16 * b + (lane & 15), g = lane >> 4;
+        if (co >= cout) continue;
+        for (int j = 0; j < 4; ++j) {
+          const int ci = 16 * kb + 4 * g + j;
+          if (ci >= cin) continue;
+          (*out)[(((size_t)kb * mb + b) * 64 + lane) * 4 + j] = W[(size_t)ci * cout + co] * scale[co];
+        }
+      }
+}
+
+// stem fragments [q][mb][lane][j] = W[tap = 16q + 4g + j][0][16mb + (lane&15)] * scale
+void pack_stem_f32(const float *W, const float *scale, int cout, int mb, std::vector<float> *out) {
+  out->assign((size_t)2 * mb * 256, 0.f);
+  for (int q = 0; q < 2; ++q)
+    for (int b = 0; b < mb; ++b)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int co = 16 * b + (lane & 15), g = lane >> 4;
+        if (co >= cout) continue;
+        for (int j = 0; j < 4; ++j) {
+          const int tap = 16 * q + 4 * g + j;
+          if (tap < 27)
+            (*out)[(((size_t)q * mb + b) * 64 + lane) * 4 + j] = W[(size_t)tap * cout + co] * scale[co];
+        }
+      }
+}
+
+template <int MB>
+int launch_stem(fpl_ctx *ctx, StemF &a, int n) {
+  a.zblocks = (int)ceil_div64(a.OD, ST_Z);
+  dim3 grid((unsigned)ceil_div64(a.OW, ST_X), (unsigned)ceil_div64(a.OH, ST_Y), (unsigned)(n * a.zblocks));
+  TimedLaunch tl(ctx, "mfma_stem_f32");
+  stem_cin1_f32<MB><<<grid, 256, 0, ctx->stream>>>(a);
+  return 0;
+}
+
+struct F32State {
+  uint64_t version = ~0ull;
+  float *frags = nullptr;
+  std::vector<size_t> off;       // per op (float offset), conv ops only
+};
+
+void f32_state_free(fpl_ctx *, void *p) {
+  F32State *s = (F32State *)p;
+  if (s->frags) hipFree(s->frags);
+  delete s;
+}
+
+// virtual tensor view: a real f32 buffer seen through up / crop
+struct View {
+  const float *p = nullptr;
+  int D = 0, C = 0;              // real buffer dims (cubic tiles) and channels
+  int up = 1, crop = 0;
+  int dim = 0;                   // logical (viewed) edge
+};
+
+template <int MB>
+int launch3(fpl_ctx *ctx, Conv3F &a, int n) {
+  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_f32<MB>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  a.zblocks = (int)ceil_div64(a.OD, 4);
+  dim3 grid((unsigned)ceil_div64(a.OW, 16), (unsigned)ceil_div64(a.OH, 4), (unsigned)(n * a.zblocks));
+  TimedLaunch tl(ctx, "mfma_conv3_f32");
+  conv3_f32<MB><<<grid, 256, SMEM, ctx->stream>>>(a);
+  return 0;
+}
+
+template <int MB>
+int launch1(fpl_ctx *ctx, Conv1F &a) {
+  const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
+  TimedLaunch tl(ctx, "mfma_conv1_f32");
+  conv1_f32<MB><<<grid, 256, 0, ctx->stream>>>(a);
+  return 0;
+}
+
+}  // namespace
+
+// every op kind except ADD; conv3 needs cout <= 64 and <= 12 channel chunks
+bool fpl_mfma_f32_supported(const fpl_program *prog) {
+  // tensors that exist only as an index remap (up / crop / concat): consumable by a
+  // multi-channel conv3 (its tile loader applies the remap), nothing else
+  std::vector<char> is_view(prog->n_tensors, 0);
+  for (auto &op : prog->ops) {
+    const bool v0 = is_view[op.src0], v1 = op.src1 >= 0 && is_view[op.src1];
+    if (op.kind == FPL_OP_UP || op.kind == FPL_OP_CROP) {
+      if (v0) return false;
+      is_view[op.dst] = 1;
+    } else if (op.kind == FPL_OP_CONCAT) {
+      is_view[op.dst] = 1;
+    } else if (op.kind == FPL_OP_CONV && op.k == 3 && op.cin > 1) {
+      if (v1) return false;
+    } else if (v0 || v1) {
+      return false;
+    }
+    if (prog->out_tensor == op.dst && is_view[op.dst]) return false;
+  }
+  for (auto &op : prog->ops) {
+    if (op.kind == FPL_OP_ADD) return false;
+    if (op.kind == FPL_OP_POOL && (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2)) return false;
+    if (op.kind == FPL_OP_UP && (op.p[0] != op.p[1] || op.p[1] != op.p[2] || (op.p[0] != 1 && op.p[0] != 2)))
+      return false;
+    if (op.kind == FPL_OP_CROP && !(op.p[0] == op.p[1] && op.p[1] == op.p[2] && op.p[2] == op.p[3] &&
+                                    op.p[3] == op.p[4] && op.p[4] == op.p[5]))
+      return false;
+    if (op.kind == FPL_OP_CONV) {
+      if (op.k == 3 && (op.cout > 64 || op.cin > 12 * 16)) return false;
+      if (op.k == 1 && op.cout > 128) return false;
+    }
+  }
+  return true;
+}
+
+// in: (n, T,T,T) f32 on the device (cubic tiles); out: (n, d,d,d, c) f32
+int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T,
+                         float *out) {
+  FPL_REQUIRE(ctx, fpl_mfma_f32_supported(prog), "program has ops the fp32 MFMA executor lacks");
+  F32State *st = (F32State *)prog->fast_state_f32;
+  if (!st) {
+    st = new F32State();
+    prog->fast_state_f32 = st;
+    prog->fast_state_f32_free = f32_state_free;
+  }
+  const float *A = prog->arena_host.data();
+  if (st->version != prog->arena_version) {
+    std::vector<float> all;
+    st->off.assign(prog->ops.size(), 0);
+    for (size_t i = 0; i < prog->ops.size(); ++i) {
+      const fpl_op &op = prog->ops[i];
+      if (op.kind != FPL_OP_CONV) continue;
+      std::vector<float> f;
+      const int mb = (op.cout + 15) / 16;
+      if (op.k == 3 && op.cin == 1) pack_stem_f32(A + op.w_off, A + op.scale_off, op.cout, mb, &f);
+      else if (op.k == 3) pack_conv3_f32(A + op.w_off, A + op.scale_off, op.cin, op.cout, mb, &f);
+      else pack_conv1_f32(A + op.w_off, A + op.scale_off, op.cin, op.cout, mb, &f);
+      st->off[i] = all.size();
+      all.insert(all.end(), f.begin(), f.end());
+    }
+    if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
+    st->frags = nullptr;
+    FPL_HIP(ctx, hipMalloc((void **)&st->frags, all.size() * sizeof(float)));
+    FPL_HIP(ctx, hipMemcpy(st->frags, all.data(), all.size() * sizeof(float), hipMemcpyHostToDevice));
+    st->version = prog->arena_version;
+  }
+  DevTemp tmp(ctx);
+  std::vector<View> view(prog->n_tensors);
+  view[0].p = in; view[0].D = T; view[0].C = 1; view[0].dim = T;
+  hipStream_t stm = ctx->stream;
+  auto cube = [](int d) { return (int64_t)d * d * d; };
+  for (size_t i = 0; i < prog->ops.size(); ++i) {
+    const fpl_op &op = prog->ops[i];
+    const View a = view[op.src0];
+    FPL_REQUIRE(ctx, a.dim > 0, "op %zu reads a tensor before it is produced", i);
+    View o;
+    switch (op.kind) {
+      case FPL_OP_UP:
+        FPL_REQUIRE(ctx, a.up == 1 && a.crop == 0, "op %zu: nested views", i);
+        o = a; o.up = op.p[0]; o.dim = a.dim * op.p[0];
+        view[op.dst] = o;
+        continue;
+      case FPL_OP_CROP:
+        FPL_REQUIRE(ctx, a.up == 1 && a.crop == 0, "op %zu: nested views", i);
+        o = a; o.crop = op.p[0]; o.dim = a.dim - 2 * op.p[0];
+        view[op.dst] = o;
+        continue;
+      case FPL_OP_CONCAT: {
+        // kept virtual: remembered as two views; only a conv3 may consume it
+        const View b = view[op.src1];
+        FPL_REQUIRE(ctx, a.dim == b.dim, "op %zu: concatenate of %d^3 with %d^3 - input size is "
+                    "not compatible with this architecture", i, a.dim, b.dim);
+        o = a; o.p = nullptr; o.dim = a.dim; o.C = a.C + b.C;
+        view[op.dst] = o;
+        continue;
+      }
+      default: break;
+    }
+    float *dst;
+    int od = 0, oc = 0;
+    if (op.kind == FPL_OP_CONV) { od = a.dim - (op.k - 1); oc = op.cout; }
+    if (op.kind == FPL_OP_POOL) { od = a.dim / 2; oc = a.C; }
+    FPL_REQUIRE(ctx, od > 0, "op %zu: tile %d is too small for this architecture", i, T);
+    if (op.dst == prog->out_tensor) {
+      dst = out;
+    } else {
+      void *q;
+      FPL_TRY(tmp.alloc((size_t)n * cube(od) * oc * sizeof(float) + 64, &q));
+      dst = (float *)q;
+    }
+    o.p = dst; o.D = od; o.C = oc; o.dim = od;
+    if (op.kind == FPL_OP_POOL) {
+      FPL_REQUIRE(ctx, a.p && a.up == 1 && a.crop == 0, "op %zu: pool of a view", i);
+      const int64_t no = (int64_t)n * cube(od) * oc;
+      TimedLaunch tl(ctx, "mfma_pool_f32");
+      pool2_f32v<<<(unsigned)ceil_div64(no, 256), 256, 0, stm>>>(a.p, dst, no, a.D, a.D, a.D, a.C, od, od, od);
+    } else if (op.k == 1) {
+      FPL_REQUIRE(ctx, a.p && a.up == 1 && a.crop == 0, "op %zu: conv1 of a view", i);
+      Conv1F c;
+      c.in = a.p; c.M = (int64_t)n * cube(a.D); c.cin = op.cin;
+      c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
+      c.out = dst; c.cout = op.cout;
+      const int mb = (op.cout + 15) / 16;
+      switch (mb) {
+        case 1: FPL_TRY(launch1<1>(ctx, c)); break;
+        case 2: FPL_TRY(launch1<2>(ctx, c)); break;
+        case 3: FPL_TRY(launch1<3>(ctx, c)); break;
+        case 4: FPL_TRY(launch1<4>(ctx, c)); break;
+        case 6: FPL_TRY(launch1<6>(ctx, c)); break;
+        case 8: FPL_TRY(launch1<8>(ctx, c)); break;
+        default: return fpl_fail(ctx, "op %zu: conv1 with %d output channels", i, op.cout);
+      }
+    } else if (op.cin == 1) {
+      FPL_REQUIRE(ctx, a.p && a.up == 1 && a.crop == 0 && a.C == 1, "op %zu: stem of a view", i);
+      StemF c;
+      c.in = a.p; c.D = c.H = c.W = a.D;
+      c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
+      c.out = dst; c.cout = op.cout; c.OD = c.OH = c.OW = od;
+      const int mb = (op.cout + 15) / 16;
+      switch (mb) {
+        case 1: FPL_TRY(launch_stem<1>(ctx, c, n)); break;
+        case 2: FPL_TRY(launch_stem<2>(ctx, c, n)); break;
+        case 3: FPL_TRY(launch_stem<3>(ctx, c, n)); break;
+        case 4: FPL_TRY(launch_stem<4>(ctx, c, n)); break;
+        default: return fpl_fail(ctx, "op %zu: stem with %d output channels", i, op.cout);
+      }
+    } else {
+      Conv3F c;
+      c.ncc = 0;
+      auto add_src = [&](const View &v) {
+        const int chunks = (v.C + 15) / 16;
+        for (int q = 0; q < chunks; ++q) {
+          SrcF s;
+          s.p = v.p; s.D = s.H = s.W = v.D; s.C = v.C; s.ch0 = 16 * q;
+          s.up = v.up; s.crop = v.crop; s.pad = 0;
+          c.src[c.ncc++] = s;
+        }
+      };
+      // a concat input is resolved through the producing op
+      bool done = false;
+      for (size_t j = 0; j < i && !done; ++j)
+        if (prog->ops[j].dst == op.src0 && prog->ops[j].kind == FPL_OP_CONCAT) {
+          const View va = view[prog->ops[j].src0], vb = view[prog->ops[j].src1];
+          FPL_REQUIRE(ctx, va.p && vb.p && va.C % 16 == 0, "op %zu: unsupported concat", i);
+          add_src(va);
+          add_src(vb);
+          done = true;
+        }
+      if (!done) {
+        FPL_REQUIRE(ctx, a.p, "op %zu: conv3 of an unmaterialised tensor", i);
+        add_src(a);
+      }
+      // the packed fragments assume channel chunks of the concatenated tensor in
+      // order, each source starting on a 16-channel boundary
+      c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
+      c.out = dst; c.cout = op.cout; c.OD = c.OH = c.OW = od;
+      const int mb = (op.cout + 15) / 16;
+      switch (mb) {
+        case 1: FPL_TRY(launch3<1>(ctx, c, n)); break;
+        case 2: FPL_TRY(launch3<2>(ctx, c, n)); break;
+        case 3: FPL_TRY(launch3<3>(ctx, c, n)); break;
+        case 4: FPL_TRY(launch3<4>(ctx, c, n)); break;
+        default: return fpl_fail(ctx, "op %zu: conv3 with %d output channels", i, op.cout);
+      }
+    }
+    FPL_HIP(ctx, hipGetLastError());
+    view[op.dst] = o;
+  }
+  return 0;
+}

@@ -23,3 +23,9 @@ bool fpl_fast_path_available(const fpl_program *prog, int precision,
 bool fpl_unet_fast_available(const fpl_program *prog, int precision);
 int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
                           int T, float *out);
+
+// fp32 MFMA executor over any lowered program without ADD (conv_mfma_f32.hip):
+// cubic tiles (n, T,T,T) f32 -> network output (n, d,d,d, c) f32
+bool fpl_mfma_f32_supported(const fpl_program *prog);
+int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T,
+                         float *out);

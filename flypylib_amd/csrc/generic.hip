@@ -296,6 +296,8 @@ int fpl_program_destroy(fpl_program *prog) {
   hipStreamSynchronize(ctx->stream);
   if (prog->fast_state && prog->fast_state_free)
     prog->fast_state_free(ctx, prog->fast_state);
+  if (prog->fast_state_f32 && prog->fast_state_f32_free)
+    prog->fast_state_f32_free(ctx, prog->fast_state_f32);
   hipFree(prog->arena_dev);
   delete prog;
   return 0;

@@ -136,7 +136,11 @@ int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
     FPL_TRY(tmp.alloc(net_elems * sizeof(float), &p));
     net_out = (float *)p;
   }
-  FPL_TRY(fpl_forward_generic(ctx, prog, in_dev, n, in_dims, net_out));
+  const bool cubic = in_dims[0] == in_dims[1] && in_dims[1] == in_dims[2];
+  if (cubic && fpl_mfma_f32_supported(prog) && !getenv("FPL_FORCE_PEROP"))
+    FPL_TRY(fpl_forward_mfma_f32(ctx, prog, in_dev, n, in_dims[0], net_out));
+  else
+    FPL_TRY(fpl_forward_generic(ctx, prog, in_dev, n, in_dims, net_out));
   if (up) {
     TimedLaunch tl(ctx, "upsample_out");
     upsample_out<<<(unsigned)ceil_div64(out_elems, 256), 256, 0, ctx->stream>>>(
@@ -266,6 +270,9 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     const bool unet_bf16 = precision == FPL_PREC_BF16 &&
                            fpl_unet_fast_available(prog, precision) &&
                            tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2];
+    const bool f32_mfma = precision == FPL_PREC_F32 && fpl_mfma_f32_supported(prog) &&
+                          tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2] &&
+                          !getenv("FPL_FORCE_PEROP");
     FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || unet_bf16,
                 "fpl_infer_volume: no bf16 kernels for this architecture yet; "
                 "use precision f32");
@@ -323,6 +330,9 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
       if (unet_bf16)
         FPL_TRY(fpl_unet_forward_bf16(ctx, prog, (const float *)in_batch, (int)nb,
                                       tile_in[0], (float *)out_batch));
+      else if (f32_mfma)
+        FPL_TRY(fpl_forward_mfma_f32(ctx, prog, (const float *)in_batch, (int)nb,
+                                     tile_in[0], (float *)out_batch));
       else
         FPL_TRY(fpl_forward_generic(ctx, prog, (const float *)in_batch, (int32_t)nb,
                                     tile_in, (float *)out_batch));

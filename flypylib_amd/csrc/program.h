@@ -21,6 +21,9 @@ struct fpl_program {
   void *fast_state = nullptr;
   void (*fast_state_free)(fpl_ctx *, void *) = nullptr;
   uint64_t arena_version = 0;
+  // fp32 MFMA executor state (conv_mfma_f32.hip)
+  void *fast_state_f32 = nullptr;
+  void (*fast_state_f32_free)(fpl_ctx *, void *) = nullptr;
 };
 
 // shapes of every tensor for a given input size; returns non-zero + message on

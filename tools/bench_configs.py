@@ -46,21 +46,24 @@ def main():
         src = torch.empty((n, n, n), dtype=torch.uint8, device='cuda')
         dst = torch.empty((n, n, n), dtype=torch.float32, device='cuda')
         ctx.synth_volume_u8(3, (n, n, n), out=src)
-        kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F32, dst=dst, dims=(n, n, n))
-        prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
-        ctx.synchronize()
-        ctx.timing(True); ctx.timing_reset()
-        t0 = time.perf_counter()
-        prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
-        ctx.synchronize()
-        dt = time.perf_counter() - t0
-        vox = (n - 18) ** 3
-        res['unet_like2_f32_perop'] = dict(
-            volume=n, mvox_s=vox / dt / 1e6, seconds=dt,
-            tflops_algorithmic=vox * 350720 / dt / 1e12,
-            kernels={k: round(v['ms'], 2) for k, v in ctx.timing_get().items()})
-        ctx.timing(False)
-        print(json.dumps(res['unet_like2_f32_perop']), flush=True)
+        for pname, prec in (('bf16_mfma', _capi.PREC_BF16), ('f32_perop', _capi.PREC_F32)):
+            if pname == 'f32_perop' and n > 300:
+                continue
+            kw = dict(mean=128.0, std=33.0, precision=prec, dst=dst, dims=(n, n, n))
+            prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
+            ctx.synchronize()
+            ctx.timing(True); ctx.timing_reset()
+            t0 = time.perf_counter()
+            prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            vox = (n - 18) ** 3
+            res['unet_like2_' + pname] = dict(
+                volume=n, mvox_s=vox / dt / 1e6, seconds=dt,
+                tflops_algorithmic=vox * 350720 / dt / 1e12,
+                kernels={k: round(v['ms'], 2) for k, v in ctx.timing_get().items()})
+            ctx.timing(False)
+            print(json.dumps(res['unet_like2_' + pname]), flush=True)
 
     if 'train' in what:
         g = fplmodels.vgg_like()[0]
