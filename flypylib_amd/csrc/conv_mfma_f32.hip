@@ -654,3 +654,330 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
   }
   return 0;
 }
+
+// =====================================================================================
+// Training-side entry points (used by train.hip): forward / input-gradient / weight-
+// gradient convolutions on the fp32 MFMA kernels.  Weights change every step, so the
+// fragments are re-packed on the device per call (a few hundred KB).
+// =====================================================================================
+namespace {
+
+// mode 0: forward fragments of W[tap][cin][cout]
+// mode 1: input-gradient fragments: W'[tap'][cout][cin] with tap' the mirrored tap
+//         (dX = valid correlation of the (k-1)-padded dY with the flipped kernel)
+__global__ void pack_frags_dev(const float *__restrict__ W, float *__restrict__ out, int k3,
+                               int cin, int cout, int mb, int mode, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  int64_t t = i >> 8;
+  const int b = (int)(t % mb); t /= mb;
+  const int tap = (int)(t % k3); const int cc = (int)(t / k3);
+  const int g = lane >> 4;
+  const int kin = mode == 0 ? cin : cout, kout = mode == 0 ? cout : cin;
+  const int ci = 16 * cc + 4 * g + j, co = 16 * b + (lane & 15);
+  float v = 0.f;
+  if (ci < kin && co < kout) {
+    if (mode == 0) v = W[((int64_t)tap * cin + ci) * cout + co];
+    else v = W[((int64_t)(k3 - 1 - tap) * cin + co) * cout + ci];
+  }
+  out[i] = v;
+}
+
+__global__ void pack_stem_dev(const float *__restrict__ W, float *__restrict__ out, int cout,
+                              int mb, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  int64_t t = i >> 8;
+  const int b = (int)(t % mb); const int q = (int)(t / mb);
+  const int tap = 16 * q + 4 * (lane >> 4) + j, co = 16 * b + (lane & 15);
+  out[i] = (tap < 27 && co < cout) ? W[(int64_t)tap * cout + co] : 0.f;
+}
+
+// ---- weight gradient, 3x3x3: dW[tap][ci][co] += sum_m X[m + tap][ci] * dY[m][co].
+// One workgroup = one 4 x 4 x 16 block of output voxels x one 16-channel chunk of the
+// input x up to 48 output channels; the 27 taps are split over the 4 waves, each
+// wave sweeps all 16 K-blocks (rows of 16 x) for its taps.  A = X^T (ci x voxel),
+// B = dY (voxel x co), k-slot (j,g) of a K-block = voxel 4g + j of the row.
+constexpr int WG_YP = 48 * 4;                 // dY tile pitch (bytes): 48 floats
+struct WgradArgs {
+  const float *x; int D, H, W, cin;
+  const float *dy; int od, oh, ow, cout;
+  float *dw;
+  int zblocks, ncc, nco;                      // ci chunks of 16, co chunks of 48
+};
+
+__global__ __launch_bounds__(256) void conv3_wgrad_f32(WgradArgs a) {
+  unsigned char *xt = smem;                               // (6,6,18) x 96 B
+  unsigned char *yt = smem + TILE_BYTES;                  // 256 voxels x 192 B
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int bx = blockIdx.x;
+  const int coc = bx % a.nco; bx /= a.nco;
+  const int cc = bx % a.ncc; bx /= a.ncc;
+  const int x0 = bx * 16, y0 = blockIdx.y * 4;
+  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * 4;
+  const int co0 = coc * 48;
+  // stage X chunk (16 channels) and dY (48 channels), zero outside
+  for (int p = tid; p < TZ * TY * TX * 4; p += 256) {
+    const int vox = p >> 2, pc = p & 3;
+    const int z = z0 + vox / (TY * TX), y = y0 + (vox / TX) % TY, x = x0 + vox % TX;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (z < a.D && y < a.H && x < a.W) {
+      const float *gp = a.x + ((((int64_t)n * a.D + z) * a.H + y) * a.W + x) * a.cin;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = 16 * cc + 4 * pc + q;
+        if (ch < a.cin) v[q] = gp[ch];
+      }
+    }
+    *reinterpret_cast<f32x4 *>(xt + (size_t)vox * PITCH + pc * 16) = v;
+  }
+  for (int p = tid; p < 256 * 12; p += 256) {
+    const int vox = p / 12, pc = p % 12;
+    const int z = z0 + vox / 64, y = y0 + (vox / 16) % 4, x = x0 + vox % 16;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (z < a.od && y < a.oh && x < a.ow) {
+      const float *gp = a.dy + ((((int64_t)n * a.od + z) * a.oh + y) * a.ow + x) * a.cout;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ch = co0 + 4 * pc + q;
+        if (ch < a.cout) v[q] = gp[ch];
+      }
+    }
+    *reinterpret_cast<f32x4 *>(yt + (size_t)vox * WG_YP + pc * 16) = v;
+  }
+  __syncthreads();
+  const int tap0 = wave * 7, ntap = wave < 3 ? 7 : 6;
+  f32x4 acc[7][3];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int row = 0; row < 16; ++row) {             // (z,y) rows of 16 x
+    const int vz = row >> 2, vy = row & 3;
+    float bv[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        bv[b][j] = *reinterpret_cast<const float *>(
+            yt + (size_t)((vz * 4 + vy) * 16 + 4 * g + j) * WG_YP + (16 * b + c) * 4);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      if (t < ntap) {
+        const int tap = tap0 + t;
+        const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+        float av[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          av[j] = *reinterpret_cast<const float *>(
+              xt + (size_t)(((vz + tz) * TY + vy + ty) * TX + 4 * g + j + tx) * PITCH + c * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) acc[t][b] = mfma4(av[j], bv[b][j], acc[t][b]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    if (t < ntap) {
+      const int tap = tap0 + t;
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = 16 * cc + 4 * g + r, co = co0 + 16 * b + c;
+          if (ci < a.cin && co < a.cout && acc[t][b][r] != 0.f)
+            atomicAdd(&a.dw[((int64_t)tap * a.cin + ci) * a.cout + co], acc[t][b][r]);
+        }
+    }
+  }
+}
+
+// ---- weight gradient, 1x1x1: dW[ci][co] += sum_m X[m][ci] * dY[m][co]; one workgroup
+// = 1024 voxels (256 per wave) x one 16-channel input chunk x up to 48 output channels
+struct Wgrad1Args {
+  const float *x; const float *dy; int64_t M; int cin, cout;
+  float *dw; int ncc, nco;
+};
+
+__global__ __launch_bounds__(256) void conv1_wgrad_f32(Wgrad1Args a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int bx = blockIdx.x;
+  const int coc = bx % a.nco; bx /= a.nco;
+  const int cc = bx % a.ncc; bx /= a.ncc;
+  const int co0 = coc * 48;
+  const int64_t m0 = ((int64_t)bx * 4 + wave) * 256;
+  f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int ci = 16 * cc + c;
+  for (int kb = 0; kb < 16; ++kb) {
+    float av[4], bv[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = m0 + kb * 16 + 4 * g + j;
+      const bool ok = m < a.M;
+      av[j] = (ok && ci < a.cin) ? a.x[m * a.cin + ci] : 0.f;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int co = co0 + 16 * b + c;
+        bv[b][j] = (ok && co < a.cout) ? a.dy[m * a.cout + co] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) acc[b] = mfma4(av[j], bv[b][j], acc[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cir = 16 * cc + 4 * g + r, co = co0 + 16 * b + c;
+      if (cir < a.cin && co < a.cout && acc[b][r] != 0.f)
+        atomicAdd(&a.dw[(int64_t)cir * a.cout + co], acc[b][r]);
+    }
+}
+
+}  // namespace
+
+bool fpl_tm_supported(int k, int cin, int cout) {
+  if (k == 3) return cout <= 64 && cin <= 12 * 16;
+  return k == 1 && cout <= 128;
+}
+
+// y = act(conv(x, W) + bias); x (n,D,H,W,cin), W [k^3][cin][cout] on the device
+int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int k,
+                    int cout, const float *Wd, const float *bias, int act, float *y) {
+  DevTemp tmp(ctx);
+  const int mb = (cout + 15) / 16;
+  const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
+  void *fr;
+  if (k == 3 && cin == 1) {
+    const int64_t tot = (int64_t)2 * mb * 256;
+    FPL_TRY(tmp.alloc(tot * 4, &fr));
+    pack_stem_dev<<<(unsigned)ceil_div64(tot, 256), 256, 0, ctx->stream>>>(Wd, (float *)fr, cout, mb, tot);
+    StemF a;
+    a.in = x; a.D = D; a.H = H; a.W = W_; a.w = (const float *)fr; a.shift = bias; a.act = act;
+    a.out = y; a.cout = cout; a.OD = od; a.OH = oh; a.OW = ow;
+    switch (mb) {
+      case 1: return launch_stem<1>(ctx, a, n);
+      case 2: return launch_stem<2>(ctx, a, n);
+      case 3: return launch_stem<3>(ctx, a, n);
+      case 4: return launch_stem<4>(ctx, a, n);
+    }
+    return fpl_fail(ctx, "stem with %d channels", cout);
+  }
+  const int ncc = (cin + 15) / 16, k3 = k * k * k;
+  const int64_t tot = (int64_t)ncc * k3 * mb * 256;
+  FPL_TRY(tmp.alloc(tot * 4, &fr));
+  pack_frags_dev<<<(unsigned)ceil_div64(tot, 256), 256, 0, ctx->stream>>>(Wd, (float *)fr, k3, cin, cout, mb, 0, tot);
+  if (k == 1) {
+    Conv1F c;
+    c.in = x; c.M = (int64_t)n * D * H * W_; c.cin = cin; c.w = (const float *)fr; c.shift = bias;
+    c.act = act; c.out = y; c.cout = cout;
+    switch (mb) {
+      case 1: return launch1<1>(ctx, c);
+      case 2: return launch1<2>(ctx, c);
+      case 3: return launch1<3>(ctx, c);
+      case 4: return launch1<4>(ctx, c);
+      case 6: return launch1<6>(ctx, c);
+      case 8: return launch1<8>(ctx, c);
+    }
+    return fpl_fail(ctx, "conv1 with %d channels", cout);
+  }
+  Conv3F c;
+  c.ncc = ncc;
+  for (int q = 0; q < ncc; ++q) {
+    SrcF s;
+    s.p = x; s.D = D; s.H = H; s.W = W_; s.C = cin; s.ch0 = 16 * q; s.up = 1; s.crop = 0; s.pad = 0;
+    c.src[q] = s;
+  }
+  c.w = (const float *)fr; c.shift = bias; c.act = act; c.out = y; c.cout = cout;
+  c.OD = od; c.OH = oh; c.OW = ow;
+  switch (mb) {
+    case 1: return launch3<1>(ctx, c, n);
+    case 2: return launch3<2>(ctx, c, n);
+    case 3: return launch3<3>(ctx, c, n);
+    case 4: return launch3<4>(ctx, c, n);
+  }
+  return fpl_fail(ctx, "conv3 with %d channels", cout);
+}
+
+// dx (n,D,H,W,cin) = input gradient of the valid conv for dy (n,od,oh,ow,cout);
+// dx is OVERWRITTEN (the caller accumulates when a tensor has several consumers)
+int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
+                      int k, int cin, const float *Wd, const float *zeros, float *dx) {
+  DevTemp tmp(ctx);
+  const int mb = (cin + 15) / 16;              // outputs of this "conv" = cin
+  const int ncc = (cout + 15) / 16, k3 = k * k * k;
+  const int64_t tot = (int64_t)ncc * k3 * mb * 256;
+  void *fr;
+  FPL_TRY(tmp.alloc(tot * 4, &fr));
+  pack_frags_dev<<<(unsigned)ceil_div64(tot, 256), 256, 0, ctx->stream>>>(Wd, (float *)fr, k3, cin, cout, mb, 1, tot);
+  if (k == 1) {
+    Conv1F c;
+    c.in = dy; c.M = (int64_t)n * od * oh * ow; c.cin = cout; c.w = (const float *)fr;
+    c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin;
+    switch (mb) {
+      case 1: return launch1<1>(ctx, c);
+      case 2: return launch1<2>(ctx, c);
+      case 3: return launch1<3>(ctx, c);
+      case 4: return launch1<4>(ctx, c);
+      case 6: return launch1<6>(ctx, c);
+      case 8: return launch1<8>(ctx, c);
+    }
+    return fpl_fail(ctx, "conv1 dgrad with %d channels", cin);
+  }
+  Conv3F c;
+  c.ncc = ncc;
+  for (int q = 0; q < ncc; ++q) {
+    SrcF s;
+    s.p = dy; s.D = od; s.H = oh; s.W = ow; s.C = cout; s.ch0 = 16 * q; s.up = 1; s.crop = 0;
+    s.pad = k - 1;
+    c.src[q] = s;
+  }
+  c.w = (const float *)fr; c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin;
+  c.OD = od + k - 1; c.OH = oh + k - 1; c.OW = ow + k - 1;
+  switch (mb) {
+    case 1: return launch3<1>(ctx, c, n);
+    case 2: return launch3<2>(ctx, c, n);
+    case 3: return launch3<3>(ctx, c, n);
+    case 4: return launch3<4>(ctx, c, n);
+  }
+  return fpl_fail(ctx, "conv3 dgrad with %d channels", cin);
+}
+
+// dw [k^3][cin][cout] += weight gradient (float atomics)
+int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
+                      const float *dy, int k, int cout, float *dw) {
+  const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
+  const int ncc = (cin + 15) / 16, nco = (cout + 47) / 48;
+  if (k == 1) {
+    Wgrad1Args a;
+    a.x = x; a.dy = dy; a.M = (int64_t)n * D * H * W_; a.cin = cin; a.cout = cout; a.dw = dw;
+    a.ncc = ncc; a.nco = nco;
+    const int64_t vb = ceil_div64(a.M, 1024);
+    TimedLaunch tl(ctx, "mfma_wgrad1_f32");
+    conv1_wgrad_f32<<<(unsigned)(vb * ncc * nco), 256, 0, ctx->stream>>>(a);
+    return 0;
+  }
+  WgradArgs a;
+  a.x = x; a.D = D; a.H = H; a.W = W_; a.cin = cin; a.dy = dy; a.od = od; a.oh = oh; a.ow = ow;
+  a.cout = cout; a.dw = dw; a.zblocks = (int)ceil_div64(od, 4); a.ncc = ncc; a.nco = nco;
+  constexpr int SMEM = TILE_BYTES + 256 * WG_YP;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_wgrad_f32,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(ceil_div64(ow, 16) * ncc * nco), (unsigned)ceil_div64(oh, 4),
+            (unsigned)(n * a.zblocks));
+  TimedLaunch tl(ctx, "mfma_wgrad3_f32");
+  conv3_wgrad_f32<<<grid, 256, SMEM, ctx->stream>>>(a);
+  return 0;
+}

@@ -29,3 +29,12 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
 bool fpl_mfma_f32_supported(const fpl_program *prog);
 int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T,
                          float *out);
+
+// fp32 MFMA convolutions for the training engine (conv_mfma_f32.hip)
+bool fpl_tm_supported(int k, int cin, int cout);
+int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int k,
+                    int cout, const float *Wd, const float *bias, int act, float *y);
+int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
+                      int k, int cin, const float *Wd, const float *zeros, float *dx);
+int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
+                      const float *dy, int k, int cout, float *dw);

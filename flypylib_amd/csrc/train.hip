@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "conv_direct.h"
+#include "fast_paths.h"
 
 namespace {
 
@@ -598,6 +599,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   FPL_REQUIRE(ctx, batch > 0, "fpl_trainer_step: batch %d", batch);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  const bool use_mfma = getenv("FPL_TRAIN_DIRECT") == nullptr;   // fp32 MFMA convolutions
   std::vector<TShape> shp;
   FPL_TRY(shapes_for(ctx, t, patch, &shp));
   const int nt = t->n_tensors;
@@ -651,6 +653,11 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       case FPL_L_CONV: {
         const int64_t n_vox = (int64_t)batch * o.vox();
         const float *bias = L.use_bias ? t->w + L.w_off[1] : t->zeros;
+        if (use_mfma && fpl_tm_supported(L.k, L.cin, L.cout)) {
+          FPL_TRY(fpl_tm_conv_fwd(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, L.k, L.cout,
+                                  t->w + L.w_off[0], bias, L.act, val[L.dst]));
+          break;
+        }
         TimedLaunch tl(ctx, "train_conv_fwd");
         if (L.cout % 16 == 0) {
           dim3 g((unsigned)ceil_div64(n_vox, 256), L.cout / 16);
@@ -759,6 +766,31 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       case FPL_L_CONV: {
         const int64_t n_vox = (int64_t)batch * o.vox();
         const int taps = L.k * L.k * L.k;
+        if (use_mfma && fpl_tm_supported(L.k, L.cin, L.cout) &&
+            fpl_tm_supported(L.k, L.cout, L.cin)) {
+          FPL_TRY(fpl_tm_conv_wgrad(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, dy, L.k,
+                                    L.cout, t->g + L.w_off[0]));
+          if (L.use_bias) {
+            const int nb = (int)ceil_div64(n_vox, RED_ROWS);
+            const int R = std::max(1, 256 / L.cout);
+            TimedLaunch tl(ctx, "train_bias_grad");
+            chan_reduce_partial<2><<<nb, dim3(L.cout, R), (size_t)L.cout * R * 2 * sizeof(double), st>>>(
+                dy, nullptr, nullptr, nullptr, n_vox, L.cout, part);
+            finish_sums<<<(L.cout + 63) / 64, 64, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
+                                                           nullptr, 1.f);
+          }
+          if (dx) {
+            const int64_t in_el = (int64_t)batch * a.elems();
+            float *tmpdx;
+            FPL_TRY(alloc_f(in_el, &tmpdx));
+            FPL_TRY(fpl_tm_conv_dgrad(ctx, dy, batch, o.d, o.h, o.w, o.c, L.k, L.cin,
+                                      t->w + L.w_off[0], t->zeros, tmpdx));
+            TimedLaunch tl(ctx, "train_elementwise");
+            accum<<<g1(in_el), 256, 0, st>>>(tmpdx, dx, in_el);
+            tmp.release(tmpdx);
+          }
+          break;
+        }
         {
           const int cit = (L.cin + 47) / 48, cot = (L.cout + 47) / 48;
           dim3 g((unsigned)(taps * cit * cot), (unsigned)ceil_div64(n_vox, WG_CHUNK));
