@@ -68,6 +68,84 @@ __global__ __launch_bounds__(256) void gauss_pass(
   out[i] = v;
 }
 
+// Register-window form of one pass: a thread produces OUT consecutive outputs along
+// AXIS from OUT + 2*WR loaded values (3.5 loads per output for WR = 10 instead of
+// 21); lanes run along x, so the loads of passes 0 and 1 are coalesced.  Same
+// arithmetic order as gauss_pass.
+template <int AXIS, int WR>
+__global__ __launch_bounds__(256) void gauss_pass_win(
+    PadView pv, const float *__restrict__ in, float *__restrict__ out, int64_t P0,
+    int64_t P1, int64_t P2, const double *__restrict__ w, int r) {
+  constexpr int OUT = AXIS == 2 ? 4 : 8;
+  constexpr int NW = OUT + 2 * WR;
+  const int64_t PA = AXIS == 0 ? P0 : (AXIS == 1 ? P1 : P2);
+  const int64_t nblk = (PA + OUT - 1) / OUT;
+  // thread grid: (other two axes, x fastest) x blocks along AXIS
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t z, y, x, a0;
+  if (AXIS == 0) {
+    if (tid >= nblk * P1 * P2) return;
+    x = tid % P2; y = (tid / P2) % P1; a0 = (tid / (P2 * P1)) * OUT; z = a0;
+  } else if (AXIS == 1) {
+    if (tid >= P0 * nblk * P2) return;
+    x = tid % P2; a0 = ((tid / P2) % nblk) * OUT; z = tid / (P2 * nblk); y = a0;
+  } else {
+    if (tid >= P0 * P1 * nblk) return;
+    a0 = (tid % nblk) * OUT; y = (tid / nblk) % P1; z = tid / (nblk * P1); x = a0;
+  }
+  double win[NW];
+  const bool interior = a0 - WR >= 0 && a0 + OUT + WR <= PA;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    int64_t p = a0 - WR + i;
+    if (!interior) p = reflect_idx(p, PA);
+    float v;
+    if (AXIS == 0) v = pv.at(p, y, x);
+    else if (AXIS == 1) v = in[(z * P1 + p) * P2 + x];
+    else v = in[(z * P1 + y) * P2 + p];
+    win[i] = (double)v;
+  }
+  double wk[WR + 1];
+#pragma unroll
+  for (int j = 0; j <= WR; ++j) wk[j] = w[j];
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) {
+    if (a0 + o >= PA) break;
+    double acc = __dmul_rn(win[WR + o], wk[0]);
+#pragma unroll
+    for (int j = WR; j >= 1; --j)
+      acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
+    float v = (float)acc;
+    const int64_t oz = AXIS == 0 ? a0 + o : z, oy = AXIS == 1 ? a0 + o : y,
+                  ox = AXIS == 2 ? a0 + o : x;
+    if (AXIS == 2 && r > 0 &&
+        (oz < r || oy < r || ox < r || oz >= P0 - r || oy >= P1 - r || ox >= P2 - r))
+      v = 0.f;
+    out[(oz * P1 + oy) * P2 + ox] = v;
+  }
+}
+
+template <int WR>
+void launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t P[3],
+                      const double *w_dev, int r) {
+  hipStream_t st = ctx->stream;
+  {
+    const int64_t n = ((P[0] + 7) / 8) * P[1] * P[2];
+    TimedLaunch tl(ctx, "v2o_gauss_z");
+    gauss_pass_win<0, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(pv, nullptr, a, P[0], P[1], P[2], w_dev, r);
+  }
+  {
+    const int64_t n = P[0] * ((P[1] + 7) / 8) * P[2];
+    TimedLaunch tl(ctx, "v2o_gauss_y");
+    gauss_pass_win<1, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(pv, a, b, P[0], P[1], P[2], w_dev, r);
+  }
+  {
+    const int64_t n = P[0] * P[1] * ((P[2] + 3) / 4);
+    TimedLaunch tl(ctx, "v2o_gauss_x");
+    gauss_pass_win<2, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(pv, b, a, P[0], P[1], P[2], w_dev, r);
+  }
+}
+
 __device__ __forceinline__ uint32_t float_key(float f) {
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -264,20 +342,32 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
                               hipMemcpyHostToDevice, st));
   PadView pv{pred_dev, dims[0], dims[1], dims[2], r};
   const unsigned grid = (unsigned)ceil_div64(n_pad, 256);
-  {
-    TimedLaunch tl(ctx, "v2o_gauss_z");
-    gauss_pass<0><<<grid, 256, 0, st>>>(pv, nullptr, S.smoothed, P[0], P[1], P[2],
-                                        w_dev, wr, r);
+  // register-window kernels for the kernel radii flypylib's sigmas produce
+  // (sigma 1.5, 2, 3, 5 at truncate 2.0); the plain kernel covers the rest
+  bool windowed = true;
+  switch (wr) {
+    case 3: launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
+    case 4: launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
+    case 6: launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
+    case 10: launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
+    default: windowed = false;
   }
-  {
-    TimedLaunch tl(ctx, "v2o_gauss_y");
-    gauss_pass<1><<<grid, 256, 0, st>>>(pv, S.smoothed, scratch, P[0], P[1], P[2],
-                                        w_dev, wr, r);
-  }
-  {
-    TimedLaunch tl(ctx, "v2o_gauss_x");
-    gauss_pass<2><<<grid, 256, 0, st>>>(pv, scratch, S.smoothed, P[0], P[1], P[2],
-                                        w_dev, wr, r);
+  if (!windowed) {
+    {
+      TimedLaunch tl(ctx, "v2o_gauss_z");
+      gauss_pass<0><<<grid, 256, 0, st>>>(pv, nullptr, S.smoothed, P[0], P[1], P[2],
+                                          w_dev, wr, r);
+    }
+    {
+      TimedLaunch tl(ctx, "v2o_gauss_y");
+      gauss_pass<1><<<grid, 256, 0, st>>>(pv, S.smoothed, scratch, P[0], P[1], P[2],
+                                          w_dev, wr, r);
+    }
+    {
+      TimedLaunch tl(ctx, "v2o_gauss_x");
+      gauss_pass<2><<<grid, 256, 0, st>>>(pv, scratch, S.smoothed, P[0], P[1], P[2],
+                                          w_dev, wr, r);
+    }
   }
   FPL_HIP(ctx, hipGetLastError());
   for (int a = 0; a < 3; ++a) S.pdims[a] = P[a];
