@@ -53,11 +53,12 @@ def _dist():
     return None
 
 
-def allreduce_grads(trainer):
+def allreduce_grads(trainer, force=False):
     """sum the flat gradient arena over all ranks (RCCL over xGMI); returns the
-    scale to apply (1/world).  No-op without an initialised process group."""
+    scale to apply (1/world).  No-op without an initialised process group (or with
+    a single rank, unless `force`)."""
     dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
+    if dist is None or (dist.get_world_size() == 1 and not force):
         return 1.0
     import torch
     ptr, n = trainer.grad_ptr()

@@ -156,3 +156,37 @@ def test_fplnetwork_train_api_end_to_end(ctx, tmp_path):
     inside = pred[22:26, 22:26, 22:26].mean()
     outside = pred[8:12, 8:12, 8:12].mean()
     assert inside > outside
+
+
+def test_rccl_allreduce_on_the_gradient_arena(ctx):
+    """the library-owned gradient arena is wrapped zero-copy as a torch tensor and
+    all-reduced over RCCL ('nccl' backend); with one rank the sum is the identity"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from flypylib_amd import train
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        g = fplmodels.vgg_like()[0]
+        synth.synthetic_weights(g, 3)
+        tr = _capi.Trainer(ctx, g)
+        rng = np.random.default_rng(0)
+        data = rng.standard_normal((4, 18, 18, 18, 1)).astype(np.float32)
+        labels = (rng.random((4, 1, 1, 1, 1)) > 0.5).astype(np.uint8)
+        tr.step(data, labels, seed=1)
+        before = tr.get_grads()
+        scale = train.allreduce_grads(tr, force=True)
+        after = tr.get_grads()
+        assert scale == 1.0
+        for a, b in zip(before, after):
+            assert np.array_equal(a, b)
+        ptr, n = tr.grad_ptr()
+        assert n == g.count_params() and ptr != 0
+    finally:
+        dist.destroy_process_group()
