@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--tile', type=int, default=102,
                     help='reference infer_sz (tile lattice pitch = tile-14)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend (gloo only to rehearse N>1 on one GPU)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -98,10 +100,16 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # one rank per GPU; ranks beyond the visible devices wrap around (rehearsals of
+    # the N>1 path on a one-GPU box with --backend gloo)
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
 
     from flypylib_amd import _capi, fplmodels, multi_gpu, synth
     ctx = _capi.Context(local_rank)
@@ -153,7 +161,8 @@ def main():
     timings = ctx.timing_get()
     ctx.timing(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
