@@ -206,6 +206,8 @@ void fpl_dev_release(fpl_ctx *ctx, void *p) {
   ctx->free_blocks.emplace(it->second, p);
   ctx->cached_bytes += it->second;
   ctx->live_blocks.erase(it);
+  // keep the cache bounded (long-running services): past 96 GiB give it all back
+  if (ctx->cached_bytes > ((size_t)96 << 30)) fpl_dev_trim(ctx);
 }
 
 int fpl_dev_trim(fpl_ctx *ctx) {

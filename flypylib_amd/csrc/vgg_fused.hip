@@ -695,6 +695,10 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   hipStream_t stream = ctx->stream;
   const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];
   const int64_t VZ = SZ - 14, VY = SY - 14, VX = SX - 14;
+  if (VZ <= 0 || VY <= 0 || VX <= 0 || zb >= ze) {   // no valid output voxel
+    *handled = true;
+    return 0;
+  }
   // coarse rows this slab owns (tile rows zb..ze-1 of the reference lattice)
   const int64_t fz_lo = (int64_t)origins[0][zb] - 7;
   const int64_t fz_hi = std::min<int64_t>((int64_t)origins[0][ze - 1] - 7 + out_sz[0], VZ);

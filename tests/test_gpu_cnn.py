@@ -204,3 +204,44 @@ def test_fplnetwork_unet_reference_lattice(ctx):
                                              net.train_single.weights)
     ref = infer_oracle.infer_lattice(img, (28,) * 3, (9,) * 3, predict)
     assert np.max(np.abs(pred - ref)) < TOL
+
+
+@pytest.mark.parametrize('prec', [_capi.PREC_F32, _capi.PREC_BF16])
+@pytest.mark.parametrize('shape', [(12, 40, 40), (40, 14, 40), (40, 40, 13),
+                                   (15, 15, 15), (16, 40, 40), (14, 14, 14)])
+def test_volumes_with_no_or_one_valid_voxel_row(ctx, shape, prec):
+    """edge cases of the lattice (fplnetwork.py:151-155): an axis with
+    dim <= 2*rf_offset yields no tile at all -> an all-zero prediction; one with
+    dim = 2*offset + 1 yields a single (mostly padded) tile"""
+    g = fplmodels.vgg_like(30)[0]
+    synth.synthetic_weights(g, 13)
+    prog = _prog(ctx, g, (4, 4, 4))
+    img = synth.hash_uniform_f32(9, shape) - np.float32(0.5)
+
+    def predict(batch):
+        return cnn_oracle.vgg_like_forward(batch.astype(np.float32), g.weights, 4)
+    ref = infer_oracle.infer_lattice(img, (30,) * 3, (7,) * 3, predict)
+    got = prog.infer_volume(img, (30,) * 3, (7,) * 3, precision=prec)
+    assert got.shape == shape
+    tol = TOL if prec == _capi.PREC_F32 else 5e-2
+    assert np.max(np.abs(got - ref)) < tol
+    if min(shape) <= 14:
+        assert not got.any() and not ref.any()
+
+
+def test_bad_arguments_raise_library_errors(ctx):
+    g = fplmodels.vgg_like(30)[0]
+    prog = _prog(ctx, g, (4, 4, 4))
+    img = np.zeros((40, 40, 40), np.float32)
+    with pytest.raises(_capi.FplHipError, match='infer_sz'):
+        prog.infer_volume(img, (31,) * 3, (7,) * 3)          # 31-14 is not 4*n
+    with pytest.raises(_capi.FplHipError, match='std'):
+        prog.infer_volume(img, (30,) * 3, (7,) * 3, std=0.0)
+    with pytest.raises(_capi.FplHipError, match='too small'):
+        prog.forward(np.zeros((1, 10, 10, 10, 1), np.float32))
+    # unet tile that breaks the concat shapes, on every precision path
+    gu = fplmodels.unet_like2()[0]
+    pu = _prog(ctx, gu)
+    for prec in (_capi.PREC_F32, _capi.PREC_BF16):
+        with pytest.raises(_capi.FplHipError):
+            pu.infer_volume(img, (26,) * 3, (9,) * 3, precision=prec)
