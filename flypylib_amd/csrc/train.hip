@@ -41,22 +41,26 @@ inline unsigned g1(int64_t n) { return (unsigned)ceil_div64(n, 256); }
 constexpr int RED_ROWS = 4096;
 
 template <int MODE>   // 0: (x, x^2)   1: (dy, dy*xhat)   2: (dy, 0)
+                      // 3: as 1 with dy gated by the ReLU output y3 > 0
 __global__ void chan_reduce_partial(const float *__restrict__ a,
                                     const float *__restrict__ b,
                                     const float *__restrict__ mean,
                                     const float *__restrict__ invstd, int64_t M,
-                                    int C, double *__restrict__ part) {
+                                    int C, double *__restrict__ part,
+                                    const float *__restrict__ y3 = nullptr) {
   extern __shared__ double red[];
   const int c = threadIdx.x, r = threadIdx.y, R = blockDim.y;
   const int64_t row0 = (int64_t)blockIdx.x * RED_ROWS;
   const int64_t row1 = row0 + RED_ROWS < M ? row0 + RED_ROWS : M;
   double s0 = 0.0, s1 = 0.0;
-  const float mu = MODE == 1 ? mean[c] : 0.f, is = MODE == 1 ? invstd[c] : 0.f;
+  const float mu = (MODE == 1 || MODE == 3) ? mean[c] : 0.f,
+              is = (MODE == 1 || MODE == 3) ? invstd[c] : 0.f;
   for (int64_t m = row0 + r; m < row1; m += R) {
-    const float v = a[m * C + c];
+    float v = a[m * C + c];
+    if (MODE == 3) v = y3[m * C + c] > 0.f ? v : 0.f;
     if (MODE == 0) {
       s0 += v; s1 += (double)v * v;
-    } else if (MODE == 1) {
+    } else if (MODE == 1 || MODE == 3) {
       const float xh = (b[m * C + c] - mu) * is;
       s0 += v; s1 += (double)v * xh;
     } else {
@@ -140,6 +144,34 @@ __global__ void bn_backward(const float *__restrict__ dy, const float *__restric
   const float xh = (x[i] - mean[c]) * invstd[c];
   dx[i] += gamma[c] * invstd[c] *
            (dy[i] - inv_m * sum_dy[c] - xh * inv_m * sum_dy_xhat[c]);
+}
+
+// BatchNorm + ReLU in one pass (the pair always appears together, fplmodels.py:67-71)
+__global__ void bn_relu_apply(const float *__restrict__ x, const float *__restrict__ mean,
+                              const float *__restrict__ invstd,
+                              const float *__restrict__ gamma,
+                              const float *__restrict__ beta, float *__restrict__ y,
+                              int64_t n, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  y[i] = fmaxf((x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c], 0.f);
+}
+// backward of the pair: g = dy * (y > 0), then the BatchNorm input gradient
+__global__ void bn_relu_backward(const float *__restrict__ dy, const float *__restrict__ y,
+                                 const float *__restrict__ x,
+                                 const float *__restrict__ mean,
+                                 const float *__restrict__ invstd,
+                                 const float *__restrict__ gamma,
+                                 const float *__restrict__ sum_g,
+                                 const float *__restrict__ sum_g_xhat,
+                                 float *__restrict__ dx, int64_t n, int C, float inv_m) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float gg = y[i] > 0.f ? dy[i] : 0.f;
+  const float xh = (x[i] - mean[c]) * invstd[c];
+  dx[i] += gamma[c] * invstd[c] * (gg - inv_m * sum_g[c] - xh * inv_m * sum_g_xhat[c]);
 }
 
 __global__ void relu_fwd(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
@@ -643,12 +675,32 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   double *sums = (double *)sumsv;
   FPL_HIP(ctx, hipMemsetAsync(sums, 0, 2 * sizeof(double), st));
 
+  // BatchNorm directly followed by its only consumer ReLU runs as one fused pass
+  std::vector<int> n_cons(nt, 0);
+  for (int li = 0; li < nl; ++li) {
+    n_cons[t->layers[li].src0]++;
+    if (t->layers[li].src1 >= 0) n_cons[t->layers[li].src1]++;
+  }
+  std::vector<char> bn_fused(nl, 0), relu_fused(nl, 0);
+  for (int li = 0; li + 1 < nl; ++li)
+    if (t->layers[li].kind == FPL_L_BN && t->layers[li + 1].kind == FPL_L_RELU &&
+        t->layers[li + 1].src0 == t->layers[li].dst && n_cons[t->layers[li].dst] == 1 &&
+        t->layers[li].dst != t->out_tensor && !getenv("FPL_TRAIN_UNFUSED")) {
+      bn_fused[li] = 1;
+      relu_fused[li + 1] = 1;
+    }
+
   // ------------------------------ forward ------------------------------------
   for (int li = 0; li < nl; ++li) {
     const fpl_layer &L = t->layers[li];
     const TShape a = shp[L.src0], o = shp[L.dst];
     const int64_t n = (int64_t)batch * o.elems();
-    FPL_TRY(alloc_f(n, &val[L.dst]));
+    if (relu_fused[li]) continue;                 // produced by the BN before it
+    if (bn_fused[li]) {
+      FPL_TRY(alloc_f(n, &val[t->layers[li + 1].dst]));
+    } else {
+      FPL_TRY(alloc_f(n, &val[L.dst]));
+    }
     switch (L.kind) {
       case FPL_L_CONV: {
         const int64_t n_vox = (int64_t)batch * o.vox();
@@ -683,8 +735,12 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         bn_finish_stats<<<(C + 63) / 64, 64, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
             t->w + L.w_off[2], t->w + L.w_off[3], bn_mean[li], bn_invstd[li],
             t->g + L.w_off[2], t->g + L.w_off[3]);
-        bn_apply<<<g1(n), 256, 0, st>>>(val[L.src0], bn_mean[li], bn_invstd[li],
-            t->w + L.w_off[0], t->w + L.w_off[1], val[L.dst], n, C);
+        if (bn_fused[li])
+          bn_relu_apply<<<g1(n), 256, 0, st>>>(val[L.src0], bn_mean[li], bn_invstd[li],
+              t->w + L.w_off[0], t->w + L.w_off[1], val[t->layers[li + 1].dst], n, C);
+        else
+          bn_apply<<<g1(n), 256, 0, st>>>(val[L.src0], bn_mean[li], bn_invstd[li],
+              t->w + L.w_off[0], t->w + L.w_off[1], val[L.dst], n, C);
         break;
       }
       case FPL_L_RELU: {
@@ -760,7 +816,8 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
     const fpl_layer &L = t->layers[li];
     const TShape a = shp[L.src0], o = shp[L.dst];
     const int64_t n = (int64_t)batch * o.elems();
-    float *dy = grad[L.dst];
+    if (relu_fused[li]) continue;                 // handled with the BN before it
+    float *dy = bn_fused[li] ? grad[t->layers[li + 1].dst] : grad[L.dst];
     float *dx = L.src0 > 0 ? grad[L.src0] : nullptr;
     switch (L.kind) {
       case FPL_L_CONV: {
@@ -833,13 +890,21 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         FPL_HIP(ctx, hipMemsetAsync(sdy, 0, (size_t)C * 4, st));
         FPL_HIP(ctx, hipMemsetAsync(sdyx, 0, (size_t)C * 4, st));
         TimedLaunch tl(ctx, "train_bn_bwd");
-        chan_reduce_partial<1><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
-            dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
+        const float *yrelu = bn_fused[li] ? val[t->layers[li + 1].dst] : nullptr;
+        if (bn_fused[li])
+          chan_reduce_partial<3><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part, yrelu);
+        else
+          chan_reduce_partial<1><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
         finish_sums<<<(C + 63) / 64, 64, 0, st>>>(part, nb, C, sdy, sdyx, 1.f);
         // dbeta = sum dy, dgamma = sum dy*xhat
         accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
         accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
-        if (dx)
+        if (dx && bn_fused[li])
+          bn_relu_backward<<<g1(n), 256, 0, st>>>(dy, yrelu, val[L.src0], bn_mean[li],
+              bn_invstd[li], t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M);
+        else if (dx)
           bn_backward<<<g1(n), 256, 0, st>>>(dy, val[L.src0], bn_mean[li], bn_invstd[li],
               t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M);
         break;
