@@ -23,9 +23,14 @@
 
 namespace {
 
-constexpr int PITCH = 96;                 // LDS bytes per tile voxel (CC <= 48)
+constexpr int CC = 32;                    // channels per staged chunk = one K-step per tap
+constexpr int PITCH = 80;                 // LDS bytes per tile voxel: 64 B of data, 20-dword
+                                          // pitch keeps a 16-lane ds_read_b128 conflict-free
 constexpr int TZ = 6, TY = 6, TX = 18;    // input tile of a 4 x 4 x 16 output block
 constexpr int TILE_BYTES = TZ * TY * TX * PITCH;
+constexpr int NCH = 9;                    // ring chunks per channel chunk: (dz, dx)
+constexpr int KC = 3;                     // K-steps per ring chunk: dy
+constexpr int WDEPTH = 3;                 // weight chunks in flight in registers
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -33,27 +38,9 @@ struct Src {             // one CC-channel chunk of the (virtual) concatenated i
   const __bf16 *p;       // (n, D, H, W, C) bf16
   int D, H, W, C;
   int ch0;               // first channel of this chunk inside the source
-  int up;                // 1, or 2 = UpSampling3D(2) of the source
+  int ups;               // 0, or 1 = UpSampling3D(2) of the source (index >> ups)
   int crop;              // Cropping3D(crop) of the source
 };
-
-template <int CC, int KC> struct Geo {
-  static constexpr int KRAW = (27 * CC + 31) / 32;
-  static constexpr int KSTEPS = (KRAW + KC - 1) / KC * KC;
-  static constexpr int NCH = KSTEPS / KC;
-  static constexpr int KQ = 4;                      // KC <= 3
-  static constexpr int TAB_BYTES = 4 * NCH * KQ * 4;
-  static constexpr int WDEPTH = NCH % 3 == 0 ? 3 : 2;
-  static_assert(NCH % WDEPTH == 0, "ring state must be periodic per channel chunk");
-};
-
-template <int CC>
-__device__ __forceinline__ unsigned kslot_offset(int s, int g) {
-  const int f0 = 32 * s + 8 * g;
-  const int tap = f0 / CC, ch0 = f0 % CC;
-  if (tap >= 27) return 0u;
-  return (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PITCH + ch0 * 2);
-}
 
 template <int RING> struct WReg {
   static constexpr int PIECES = RING / 16;
@@ -81,150 +68,178 @@ template <int RING> struct WReg {
 struct Conv3Args {
   Src src[6];
   int ncc;                       // channel chunks
-  const unsigned char *w;        // fragments [cc][kstep][mb], 1 KiB each
+  const unsigned char *w;        // fragments [cc][dz][dx][dy][mb], 1 KiB each
   const float *shift;
   int relu;
   __bf16 *out;                   // (n, OD, OH, OW, 16*MB)
-  int OD, OH, OW, zblocks;       // zblocks = ceil(OD/4); grid.z = n * zblocks
+  int OD, OH, OW, zblocks;       // zblocks = ceil(OD/4)
+  int nbx, nby, nbz;             // blocks: ceil(OW/16), ceil(OH/4), n * zblocks
 };
 
-template <int CC, int MB>
+// K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
+// output rows y0..y0+3 of a wave and the three dy taps touch only six tile rows, so
+// a lane holds those six B fragments and every fragment feeds up to 3*MB MFMAs:
+// 6 + 3*MB LDS fragment reads per 12*MB MFMAs (12 + 3*MB without the reuse).
+//
+// Persistent: a workgroup walks output blocks wg, wg + G, ... and flattens
+// (block, channel chunk) into one sequence of tiles; the global loads of the next
+// tile are issued before the K loop of the current one and land in registers while
+// the MFMAs run (PF), so only the LDS store sits between two K loops.
+template <int MB, bool PF>
 __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
-  constexpr int KC = MB <= 2 ? 3 : 2;
-  using G = Geo<CC, KC>;
   constexpr int RING = KC * MB * 1024;
   constexpr int PPV = CC * 2 / 16;                  // 16-B pieces per voxel
   constexpr int PIECES = TZ * TY * TX * PPV;
   constexpr int NT = (PIECES + 255) / 256;
+  constexpr int ROW = TX * PITCH;
   unsigned char *tile = smem;
   unsigned char *ring = smem + TILE_BYTES;
-  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + TILE_BYTES + 2 * RING);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 4;
-  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * 4;
+  const int G = (int)gridDim.x;                     // multiple of 8 (host)
+  // consecutive logical workgroups share an XCD (and its L2): halo reuse
+  const int wg = ((int)blockIdx.x % 8) * (G / 8) + (int)blockIdx.x / 8;
+  const int64_t total_blocks = (int64_t)a.nbx * a.nby * a.nbz;
+  int64_t blk = wg;
+  if (blk >= total_blocks) return;
 
-  if (tid < 4 * G::NCH * G::KQ) {
-    const int gg = tid / (G::NCH * G::KQ), ck = (tid / G::KQ) % G::NCH, q = tid % G::KQ;
-    int s = ck * KC + q;
-    s = s < G::KSTEPS ? s : G::KSTEPS - 1;
-    kofftab[tid] = kslot_offset<CC>(s, gg);
-  }
-  const unsigned vbase = (unsigned)(((wave * TY) * TX + c) * PITCH);
-  const unsigned *ktab = kofftab + g * (G::NCH * G::KQ);
-  f32x4 acc[4][MB];
-#pragma unroll
-  for (int b = 0; b < MB; ++b) {
-    f32x4 sh;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = a.shift[16 * b + 4 * g + r];
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
-  }
-  const int64_t total_chunks = (int64_t)a.ncc * G::NCH;
-  WReg<RING> wst[G::WDEPTH];
-#pragma unroll
-  for (int d = 0; d < G::WDEPTH; ++d) wst[d].load(a.w, d < total_chunks ? d : 0, tid);
-  wst[0].store(ring, tid);
-  wst[0].load(a.w, G::WDEPTH < total_chunks ? G::WDEPTH : 0, tid);
-
-  for (int cc = 0; cc < a.ncc; ++cc) {
+  u32x4 nt[NT];
+  auto fetch = [&](int64_t fb, int cc) {
     const Src s = a.src[cc];
-    // ---- stage the CC-channel tile of this chunk through registers, NB pieces
-    // per thread at a time (the other workgroup on the CU computes meanwhile)
-    __syncthreads();              // every wave has left the previous chunk's tile
-    constexpr int NB = 8;
-#pragma unroll 1
-    for (int j0 = 0; j0 < NT; j0 += NB) {
-      u32x4 nt[NB];
+    const int bx = (int)(fb % a.nbx), by = (int)((fb / a.nbx) % a.nby);
+    const int bz = (int)(fb / ((int64_t)a.nbx * a.nby));
+    const int n = bz / a.zblocks, z0 = (bz % a.zblocks) * 4, y0 = by * 4, x0 = bx * 16;
+    const __bf16 *base = s.p + (int64_t)n * s.D * s.H * s.W * s.C + s.ch0;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        int p = tid + 256 * (j0 + j);
-        p = p < PIECES ? p : PIECES - 1;
-        const int vox = p / PPV, pc = p % PPV;
-        int z = z0 + vox / (TY * TX), y = y0 + (vox / TX) % TY, x = x0 + vox % TX;
-        z = (z + s.crop) / s.up; y = (y + s.crop) / s.up; x = (x + s.crop) / s.up;
-        z = z < s.D ? z : s.D - 1;               // clamped reads only feed masked
-        y = y < s.H ? y : s.H - 1;               // outputs
-        x = x < s.W ? x : s.W - 1;
-        nt[j] = *reinterpret_cast<const u32x4 *>(
-            s.p + ((((int64_t)n * s.D + z) * s.H + y) * s.W + x) * s.C + s.ch0 + pc * 8);
+    for (int j = 0; j < NT; ++j) {
+      int p = tid + 256 * j;
+      p = p < PIECES ? p : PIECES - 1;
+      const int vox = p / PPV, pc = p % PPV;
+      int z = z0 + vox / (TY * TX), y = y0 + (vox / TX) % TY, x = x0 + vox % TX;
+      z = (z + s.crop) >> s.ups; y = (y + s.crop) >> s.ups; x = (x + s.crop) >> s.ups;
+      z = z < s.D ? z : s.D - 1;                 // clamped reads only feed masked
+      y = y < s.H ? y : s.H - 1;                 // outputs
+      x = x < s.W ? x : s.W - 1;
+      nt[j] = *reinterpret_cast<const u32x4 *>(
+          base + (((int64_t)z * s.H + y) * s.W + x) * s.C + pc * 8);
+    }
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int p = tid + 256 * j;
+      p = p < PIECES ? p : PIECES - 1;
+      *reinterpret_cast<u32x4 *>(tile + (size_t)(p / PPV) * PITCH + (p % PPV) * 16) = nt[j];
+    }
+  };
+
+  const unsigned vbase = (unsigned)(((wave * TY) * TX + c) * PITCH + 16 * g);
+  f32x4 shv[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[16 * b + 4 * g + r];
+  f32x4 acc[4][MB];
+  const int total_chunks = a.ncc * NCH;
+  WReg<RING> wst[WDEPTH];
+#pragma unroll
+  for (int d = 0; d < WDEPTH; ++d) wst[d].load(a.w, d < total_chunks ? d : 0, tid);
+  wst[0].store(ring, tid);
+  wst[0].load(a.w, WDEPTH < total_chunks ? WDEPTH : 0, tid);
+  if (PF) fetch(blk, 0);
+
+  unsigned par = 0;                                 // ring slot of the current chunk
+  for (;;) {
+    for (int cc = 0; cc < a.ncc; ++cc) {
+      if (cc == 0) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) acc[sub][b] = shv[b];
       }
+      __syncthreads();            // every wave has left the previous tile
+      if (!PF) fetch(blk, cc);
+      put();
+      if (PF) {
+        const bool last_cc = cc + 1 == a.ncc;
+        int64_t nb = last_cc ? blk + G : blk;
+        nb = nb < total_blocks ? nb : blk;          // past the end: a harmless reload
+        fetch(nb, last_cc ? 0 : cc + 1);
+      }
+      __syncthreads();            // tile (+ ring slot) visible
+      bf16x8 brow[2][6];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        int p = tid + 256 * (j0 + j);
-        p = p < PIECES ? p : PIECES - 1;
-        *reinterpret_cast<u32x4 *>(tile + (size_t)(p / PPV) * PITCH + (p % PPV) * 16) = nt[j];
+      for (int r = 0; r < 6; ++r)
+        brow[0][r] = *reinterpret_cast<const bf16x8 *>(tile + vbase + r * ROW);
+#pragma unroll
+      for (int ck = 0; ck < NCH; ++ck) {
+        if (ck > 0) __syncthreads();
+        {
+          int nxt = cc * NCH + ck + 1 + WDEPTH;
+          nxt = nxt < total_chunks ? nxt : nxt - total_chunks;   // next block starts over
+          wst[(ck + 1) % WDEPTH].store(ring + (par ^ 1u) * RING, tid);
+          wst[(ck + 1) % WDEPTH].load(a.w, nxt, tid);
+        }
+        const unsigned char *wslot = ring + par * RING + lane * 16;
+        par ^= 1u;
+        bf16x8 wcur[MB], wnxt[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+          wcur[b] = *reinterpret_cast<const bf16x8 *>(wslot + b * 1024);
+        // next ring chunk's rows: (dz, dx) of chunk ck+1 (wraps to the tile origin;
+        // the wrapped read of the last chunk is unused)
+        const int nk = ck + 1 < NCH ? ck + 1 : 0;
+        const unsigned noff = (unsigned)(((nk / 3) * TY * TX + nk % 3) * PITCH);
+#pragma unroll
+        for (int dy = 0; dy < KC; ++dy) {
+          // spread the six prefetch reads over the three K-steps
+#pragma unroll
+          for (int r = 2 * dy; r < 2 * dy + 2; ++r)
+            brow[(ck + 1) & 1][r] =
+                *reinterpret_cast<const bf16x8 *>(tile + vbase + noff + r * ROW);
+          if (dy + 1 < KC) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+              wnxt[b] = *reinterpret_cast<const bf16x8 *>(wslot + ((dy + 1) * MB + b) * 1024);
+          }
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+              acc[sub][b] = mfma16(wcur[b], brow[ck & 1][sub + dy], acc[sub][b]);
+          __builtin_amdgcn_s_setprio(0);
+          if (dy + 1 < KC) {
+#pragma unroll
+            for (int b = 0; b < MB; ++b) wcur[b] = wnxt[b];
+          }
+        }
       }
     }
-    __syncthreads();              // tile (+ ring slot, table) visible
-    const int64_t gc0 = (int64_t)cc * G::NCH;
-    bf16x8 bcur[4], bnxt[4];
+    // ---- epilogue: (ReLU) -> bf16, channels-last store
     {
-      const unsigned koff = ktab[0];
+      const int bx = (int)(blk % a.nbx), by = (int)((blk / a.nbx) % a.nby);
+      const int bz = (int)(blk / ((int64_t)a.nbx * a.nby));
+      const int n = bz / a.zblocks;
+      const int oz = (bz % a.zblocks) * 4 + wave, ox = bx * 16 + c;
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub)
-        bcur[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub * TX * PITCH);
-    }
+      for (int sub = 0; sub < 4; ++sub) {
+        const int oy = by * 4 + sub;
+        if (oz < a.OD && oy < a.OH && ox < a.OW) {
+          __bf16 *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB) + 4 * g;
 #pragma unroll
-    for (int ck = 0; ck < G::NCH; ++ck) {
-      const int64_t gc = gc0 + ck;
-      if (ck > 0) __syncthreads();
-      {
-        int64_t nxt = gc + 1 + G::WDEPTH;
-        nxt = nxt < total_chunks ? nxt : 0;
-        wst[(ck + 1) % G::WDEPTH].store(ring + ((gc + 1) & 1) * RING, tid);
-        wst[(ck + 1) % G::WDEPTH].load(a.w, nxt, tid);
-      }
-      const unsigned char *wslot = ring + (gc & 1) * RING + lane * 16;
-      const u32x4 kq4 = *reinterpret_cast<const u32x4 *>(ktab + ck * G::KQ);
-      const unsigned kq[4] = {kq4[0], kq4[1], kq4[2], kq4[3]};
-      bf16x8 wcur[MB], wnxt[MB];
-#pragma unroll
-      for (int b = 0; b < MB; ++b)
-        wcur[b] = *reinterpret_cast<const bf16x8 *>(wslot + b * 1024);
-#pragma unroll
-      for (int ks = 0; ks < KC; ++ks) {
-        const unsigned koff = kq[ks + 1];
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-          bnxt[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub * TX * PITCH);
-        if (ks + 1 < KC) {
-#pragma unroll
-          for (int b = 0; b < MB; ++b)
-            wnxt[b] = *reinterpret_cast<const bf16x8 *>(wslot + ((ks + 1) * MB + b) * 1024);
-        }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-          for (int b = 0; b < MB; ++b) acc[sub][b] = mfma16(wcur[b], bcur[sub], acc[sub][b]);
-        __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) bcur[sub] = bnxt[sub];
-        if (ks + 1 < KC) {
-#pragma unroll
-          for (int b = 0; b < MB; ++b) wcur[b] = wnxt[b];
+          for (int b = 0; b < MB; ++b) {
+            u32x2 o;
+            o[0] = cvt_pk_bf16(acc[sub][b][0], acc[sub][b][1]);
+            o[1] = cvt_pk_bf16(acc[sub][b][2], acc[sub][b][3]);
+            if (a.relu) { o[0] = pk_max_i16(o[0], 0u); o[1] = pk_max_i16(o[1], 0u); }
+            *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
+          }
         }
       }
     }
-  }
-  // ---- epilogue: (ReLU) -> bf16, channels-last store
-  const int oz = z0 + wave, ox = x0 + c;
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
-    const int oy = y0 + sub;
-    if (oz < a.OD && oy < a.OH && ox < a.OW) {
-      __bf16 *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB) + 4 * g;
-#pragma unroll
-      for (int b = 0; b < MB; ++b) {
-        u32x2 o;
-        o[0] = cvt_pk_bf16(acc[sub][b][0], acc[sub][b][1]);
-        o[1] = cvt_pk_bf16(acc[sub][b][2], acc[sub][b][3]);
-        if (a.relu) { o[0] = pk_max_i16(o[0], 0u); o[1] = pk_max_i16(o[1], 0u); }
-        *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
-      }
-    }
+    blk += G;
+    if (blk >= total_blocks) break;
   }
 }
 
@@ -454,19 +469,20 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
     if (l == 0) {
       fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, mb, 1, SLOT_STEM, &f);
     } else if (op.k == 3) {
-      // per CC-channel chunk: rows [tap][cin] -> sub-matrix of the chunk's channels
-      const int CC = 32, ncc = op.cin / CC;
-      const int kc = mb <= 2 ? 3 : 2;
-      const int ksteps = ((27 * CC + 31) / 32 + kc - 1) / kc * kc;
+      // per CC-channel chunk, K-step order (dz, dx, dy): rows [kstep][channel]
+      const int ncc = op.cin / CC;
       std::vector<float> sub((size_t)27 * CC * op.cout);
       for (int cc = 0; cc < ncc; ++cc) {
-        for (int tap = 0; tap < 27; ++tap)
+        for (int ks = 0; ks < 27; ++ks) {
+          const int dz = ks / 9, dx = (ks / 3) % 3, dy = ks % 3;
+          const int tap = dz * 9 + dy * 3 + dx;
           for (int ch = 0; ch < CC; ++ch)
-            memcpy(&sub[((size_t)tap * CC + ch) * op.cout],
+            memcpy(&sub[((size_t)ks * CC + ch) * op.cout],
                    A + op.w_off + ((size_t)tap * op.cin + cc * CC + ch) * op.cout,
                    op.cout * sizeof(float));
+        }
         std::vector<uint16_t> fc;
-        fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, ksteps, SLOT_SPATIAL, &fc);
+        fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, 27, SLOT_SPATIAL, &fc);
         f.insert(f.end(), fc.begin(), fc.end());
       }
     } else if (l == 9) {
@@ -492,26 +508,31 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
   return 0;
 }
 
-template <int CC, int MB>
+template <int MB>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
-  constexpr int KC = MB <= 2 ? 3 : 2;
-  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024 + Geo<CC, KC>::TAB_BYTES;
+  constexpr bool PF = MB <= 2;     // MB = 4 has no registers left for the next tile
+  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024;
+  static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<CC, MB>,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<MB, PF>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
   }
   a.zblocks = (int)ceil_div64(a.OD, 4);
-  dim3 grid((unsigned)ceil_div64(a.OW, 16), (unsigned)ceil_div64(a.OH, 4), (unsigned)(n * a.zblocks));
+  a.nbx = (int)ceil_div64(a.OW, 16); a.nby = (int)ceil_div64(a.OH, 4); a.nbz = n * a.zblocks;
+  const int64_t total = (int64_t)a.nbx * a.nby * a.nbz;
+  // two workgroups per CU, rounded to a multiple of the 8 XCDs
+  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * 2, (total + 7) / 8 * 8);
+  grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
-  conv3_bf16<CC, MB><<<grid, 256, SMEM, ctx->stream>>>(a);
+  conv3_bf16<MB, PF><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
 
 Src make_src(const __bf16 *p, int dim, int C, int ch0, int up, int crop) {
   Src s;
-  s.p = p; s.D = s.H = s.W = dim; s.C = C; s.ch0 = ch0; s.up = up; s.crop = crop;
+  s.p = p; s.D = s.H = s.W = dim; s.C = C; s.ch0 = ch0; s.ups = up == 2 ? 1 : 0; s.crop = crop;
   return s;
 }
 
@@ -578,19 +599,19 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
   {  // L1: conv3 32->32
     Conv3Args a = conv3_args(1, c1, d1);
     a.ncc = 1; a.src[0] = make_src(c1a, d1a, 32, 0, 1, 0);
-    FPL_TRY((launch_conv3<32, 2>(ctx, a, n, "unet_conv3_32_32")));
+    FPL_TRY((launch_conv3<2>(ctx, a, n, "unet_conv3_32_32")));
   }
   pool(c1, p1, d1, 32);
   {  // L2: conv3 32->64
     Conv3Args a = conv3_args(2, c2a, d2a);
     a.ncc = 1; a.src[0] = make_src(p1, dp1, 32, 0, 1, 0);
-    FPL_TRY((launch_conv3<32, 4>(ctx, a, n, "unet_conv3_32_64")));
+    FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_32_64")));
   }
   {  // L3: conv3 64->64
     Conv3Args a = conv3_args(3, c2, d2);
     a.ncc = 2;
     for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c2a, d2a, 64, 32 * cc, 1, 0);
-    FPL_TRY((launch_conv3<32, 4>(ctx, a, n, "unet_conv3_64_64")));
+    FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_64_64")));
   }
   pool(c2, p2, d2, 64);
   auto conv1 = [&](auto kern, int smem_frags, const __bf16 *x, int64_t M, int l, __bf16 *y,
@@ -608,7 +629,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     a.ncc = 6;
     for (int cc = 0; cc < 4; ++cc) a.src[cc] = make_src(c3, dp2, 128, 32 * cc, 2, 0);
     for (int cc = 0; cc < 2; ++cc) a.src[4 + cc] = make_src(c2, d2, 64, 32 * cc, 1, 0);
-    FPL_TRY((launch_conv3<32, 4>(ctx, a, n, "unet_conv3_192_64")));
+    FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
   }
   conv1(conv1_bf16<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), 6, c4, "unet_conv1_64_64");
   {  // L7: conv3 (up2(c4) 64 | crop6(c1) 32) -> 32
@@ -616,7 +637,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     a.ncc = 3;
     for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c4, d4a, 64, 32 * cc, 2, 0);
     a.src[2] = make_src(c1, d1, 32, 0, 1, 6);
-    FPL_TRY((launch_conv3<32, 2>(ctx, a, n, "unet_conv3_96_32")));
+    FPL_TRY((launch_conv3<2>(ctx, a, n, "unet_conv3_96_32")));
   }
   {  // L8 + L9: conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
     Conv1Args a;
