@@ -24,10 +24,22 @@
 namespace {
 
 constexpr int CC = 32;                    // channels per staged chunk = one K-step per tap
-constexpr int PITCH = 80;                 // LDS bytes per tile voxel: 64 B of data, 20-dword
-                                          // pitch keeps a 16-lane ds_read_b128 conflict-free
 constexpr int TZ = 6, TY = 6, TX = 18;    // input tile of a 4 x 4 x 16 output block
-constexpr int TILE_BYTES = TZ * TY * TX * PITCH;
+// LDS tile layout: four planes, plane q = channels 8q..8q+7 of every tile voxel at a
+// 16-B pitch.  A lane (c, g) reads plane g, voxel v0 + c: the 16-lane groups of a
+// ds_read_b128 ({0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS) then cover 16
+// distinct 16-B slots when the plane size is a multiple of 256 B - conflict-free
+// with no padding per voxel (a 64-B voxel pitch would be 4-way conflicted, 80 B
+// 2-way on 3 of 16 slots; 96 B is clean but wastes a third of the tile).
+constexpr int PITCH = 16;
+constexpr int PLANE = (TZ * TY * TX * PITCH + 255) / 256 * 256;
+constexpr int TILE_BYTES = 4 * PLANE;
+constexpr int NPIECE = TZ * TY * TX * 4;  // 16-B pieces of a tile
+constexpr int NT = (NPIECE + 255) / 256;  // pieces per thread
+constexpr int MAXTAB = 2;                 // distinct source geometries per launch
+constexpr int TABN = NT * 64;              // voxel-offset table entries (>= tile voxels)
+constexpr int TAB_BYTES = MAXTAB * TABN * 4;
+static_assert(NPIECE % 32 == 0, "tile pieces come in groups of 32");
 constexpr int NCH = 9;                    // ring chunks per channel chunk: (dz, dx)
 constexpr int KC = 3;                     // K-steps per ring chunk: dy
 constexpr int WDEPTH = 3;                 // weight chunks in flight in registers
@@ -35,11 +47,12 @@ constexpr int WDEPTH = 3;                 // weight chunks in flight in register
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 struct Src {             // one CC-channel chunk of the (virtual) concatenated input
-  const __bf16 *p;       // (n, D, H, W, C) bf16
+  const __bf16 *p;       // (n, D, H, W, C) bf16, with read slack behind it (tile_slack)
   int D, H, W, C;
   int ch0;               // first channel of this chunk inside the source
   int ups;               // 0, or 1 = UpSampling3D(2) of the source (index >> ups)
-  int crop;              // Cropping3D(crop) of the source
+  int crop;              // Cropping3D(crop) of the source (only with ups == 0)
+  int tab;               // which offset table (geometry H, W, C, ups) this source uses
 };
 
 template <int RING> struct WReg {
@@ -68,6 +81,8 @@ template <int RING> struct WReg {
 struct Conv3Args {
   Src src[6];
   int ncc;                       // channel chunks
+  int ntab;                      // offset tables in use
+  int tabH[MAXTAB], tabW[MAXTAB], tabC[MAXTAB], tabU[MAXTAB];
   const unsigned char *w;        // fragments [cc][dz][dx][dy][mb], 1 KiB each
   const float *shift;
   int relu;
@@ -85,15 +100,20 @@ struct Conv3Args {
 // (block, channel chunk) into one sequence of tiles; the global loads of the next
 // tile are issued before the K loop of the current one and land in registers while
 // the MFMAs run (PF), so only the LDS store sits between two K loops.
+//
+// Tile addressing: block origins are even and the sources carry read slack, so a
+// piece's address is (uniform block/source base) + (per-thread offset that depends
+// only on the source geometry).  The offsets are tabulated once per workgroup in
+// LDS - a fetch is one ds_read_b32 and one saddr+voffset global load per piece, no
+// per-piece index arithmetic or clamping.  Reads past a source's edge land in its
+// neighbouring rows / the slack and only ever feed masked output voxels.
 template <int MB, bool PF>
 __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   constexpr int RING = KC * MB * 1024;
-  constexpr int PPV = CC * 2 / 16;                  // 16-B pieces per voxel
-  constexpr int PIECES = TZ * TY * TX * PPV;
-  constexpr int NT = (PIECES + 255) / 256;
   constexpr int ROW = TX * PITCH;
   unsigned char *tile = smem;
   unsigned char *ring = smem + TILE_BYTES;
+  unsigned *offtab = reinterpret_cast<unsigned *>(smem + TILE_BYTES + 2 * RING);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int G = (int)gridDim.x;                     // multiple of 8 (host)
@@ -103,37 +123,44 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   int64_t blk = wg;
   if (blk >= total_blocks) return;
 
+  // piece p = tid + 256 j of a tile is the 16-B piece pc = (tid / 8) % 4 of voxel
+  // vox0 + 64 j, vox0 = (tid / 32) * 8 + tid % 8: 8 consecutive lanes store the same
+  // piece of 8 consecutive voxels (a conflict-free 128-B LDS store) and a wave still
+  // reads 1 KiB contiguous.  offtab[t][v] = byte offset of tile voxel v in a source
+  // of geometry t.
+  for (int t = 0; t < a.ntab; ++t) {
+    const int H = a.tabH[t], W = a.tabW[t], C = a.tabC[t], U = a.tabU[t];
+    for (int i = tid; i < TABN; i += 256) {
+      const int vox = i < TZ * TY * TX ? i : TZ * TY * TX - 1;
+      const int tz = vox / (TY * TX), ty = (vox / TX) % TY, tx = vox % TX;
+      offtab[t * TABN + i] = (unsigned)(((((tz >> U) * H + (ty >> U)) * W + (tx >> U)) * C) * 2);
+    }
+  }
+  const int vox0 = (tid >> 5) * 8 + (tid & 7);
+  const unsigned pc = (unsigned)((tid >> 3) & 3);
   u32x4 nt[NT];
   auto fetch = [&](int64_t fb, int cc) {
     const Src s = a.src[cc];
     const int bx = (int)(fb % a.nbx), by = (int)((fb / a.nbx) % a.nby);
     const int bz = (int)(fb / ((int64_t)a.nbx * a.nby));
-    const int n = bz / a.zblocks, z0 = (bz % a.zblocks) * 4, y0 = by * 4, x0 = bx * 16;
-    const __bf16 *base = s.p + (int64_t)n * s.D * s.H * s.W * s.C + s.ch0;
+    const int n = bz / a.zblocks;
+    const int z0 = ((bz % a.zblocks) * 4 + s.crop) >> s.ups;
+    const int y0 = (by * 4 + s.crop) >> s.ups, x0 = (bx * 16 + s.crop) >> s.ups;
+    const unsigned char *base = reinterpret_cast<const unsigned char *>(
+        s.p + ((((int64_t)n * s.D + z0) * s.H + y0) * s.W + x0) * s.C + s.ch0);
+    const unsigned *tab = offtab + s.tab * TABN + vox0;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      int p = tid + 256 * j;
-      p = p < PIECES ? p : PIECES - 1;
-      const int vox = p / PPV, pc = p % PPV;
-      int z = z0 + vox / (TY * TX), y = y0 + (vox / TX) % TY, x = x0 + vox % TX;
-      z = (z + s.crop) >> s.ups; y = (y + s.crop) >> s.ups; x = (x + s.crop) >> s.ups;
-      z = z < s.D ? z : s.D - 1;                 // clamped reads only feed masked
-      y = y < s.H ? y : s.H - 1;                 // outputs
-      x = x < s.W ? x : s.W - 1;
-      nt[j] = *reinterpret_cast<const u32x4 *>(
-          base + (((int64_t)z * s.H + y) * s.W + x) * s.C + pc * 8);
-    }
+    for (int j = 0; j < NT; ++j)
+      nt[j] = *reinterpret_cast<const u32x4 *>(base + (tab[64 * j] + pc * 16));
   };
   auto put = [&]() {
+    unsigned char *dst = tile + pc * PLANE + vox0 * PITCH;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      int p = tid + 256 * j;
-      p = p < PIECES ? p : PIECES - 1;
-      *reinterpret_cast<u32x4 *>(tile + (size_t)(p / PPV) * PITCH + (p % PPV) * 16) = nt[j];
-    }
+    for (int j = 0; j < NT; ++j)
+      if (vox0 + 64 * j < TZ * TY * TX) *reinterpret_cast<u32x4 *>(dst + 64 * j * PITCH) = nt[j];
   };
 
-  const unsigned vbase = (unsigned)(((wave * TY) * TX + c) * PITCH + 16 * g);
+  const unsigned vbase = (unsigned)(((wave * TY) * TX + c) * PITCH + g * PLANE);
   f32x4 shv[MB];
 #pragma unroll
   for (int b = 0; b < MB; ++b)
@@ -146,6 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   for (int d = 0; d < WDEPTH; ++d) wst[d].load(a.w, d < total_chunks ? d : 0, tid);
   wst[0].store(ring, tid);
   wst[0].load(a.w, WDEPTH < total_chunks ? WDEPTH : 0, tid);
+  __syncthreads();                                  // offset tables visible
   if (PF) fetch(blk, 0);
 
   unsigned par = 0;                                 // ring slot of the current chunk
@@ -510,14 +538,30 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
 
 template <int MB>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
-  constexpr bool PF = MB <= 2;     // MB = 4 has no registers left for the next tile
-  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024;
+  constexpr bool PF = true;
+  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024 + TAB_BYTES;
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<MB, PF>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
+  }
+  // offset tables: one per distinct source geometry
+  a.ntab = 0;
+  for (int i = 0; i < a.ncc; ++i) {
+    Src &s = a.src[i];
+    FPL_REQUIRE(ctx, !(s.ups && s.crop), "conv3_bf16: crop of an upsampled source");
+    FPL_REQUIRE(ctx, s.crop % 2 == 0, "conv3_bf16: odd crop");
+    int t = 0;
+    for (; t < a.ntab; ++t)
+      if (a.tabH[t] == s.H && a.tabW[t] == s.W && a.tabC[t] == s.C && a.tabU[t] == s.ups) break;
+    if (t == a.ntab) {
+      FPL_REQUIRE(ctx, a.ntab < MAXTAB, "conv3_bf16: more than %d source geometries", MAXTAB);
+      a.tabH[t] = s.H; a.tabW[t] = s.W; a.tabC[t] = s.C; a.tabU[t] = s.ups;
+      ++a.ntab;
+    }
+    s.tab = t;
   }
   a.zblocks = (int)ceil_div64(a.OD, 4);
   a.nbx = (int)ceil_div64(a.OW, 16); a.nby = (int)ceil_div64(a.OH, 4); a.nbz = n * a.zblocks;
@@ -532,7 +576,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
 
 Src make_src(const __bf16 *p, int dim, int C, int ch0, int up, int crop) {
   Src s;
-  s.p = p; s.D = s.H = s.W = dim; s.C = C; s.ch0 = ch0; s.ups = up == 2 ? 1 : 0; s.crop = crop;
+  s.p = p; s.D = s.H = s.W = dim; s.C = C; s.ch0 = ch0; s.ups = up == 2 ? 1 : 0; s.crop = crop; s.tab = 0;
   return s;
 }
 
@@ -557,23 +601,25 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
   const int d1a = T - 2, d1 = T - 4, dp1 = d1 / 2, d2a = dp1 - 2, d2 = dp1 - 4, dp2 = d2 / 2;
   const int d4a = 2 * dp2 - 2, d5a = 2 * d4a - 2;      // = T - 18
   auto cube = [](int d) { return (int64_t)d * d * d; };
-  auto balloc = [&](int64_t elems, __bf16 **p) -> int {
+  // conv3 tiles read up to 5 planes + 5 rows + 17 voxels past a source's last voxel
+  auto balloc = [&](int64_t elems, int dim, int C, __bf16 **p) -> int {
     void *q;
-    int rc = tmp.alloc((size_t)elems * 2 + 64, &q);
+    const size_t slack = ((size_t)5 * dim * dim + 5 * dim + 18) * C * 2;
+    int rc = tmp.alloc((size_t)elems * 2 + slack + 64, &q);
     *p = (__bf16 *)q;
     return rc;
   };
   __bf16 *c1a, *c1, *p1, *c2a, *c2, *p2, *c3, *c4a, *c4, *c5a;
-  FPL_TRY(balloc(n * cube(d1a) * 32, &c1a));
-  FPL_TRY(balloc(n * cube(d1) * 32, &c1));
-  FPL_TRY(balloc(n * cube(dp1) * 32, &p1));
-  FPL_TRY(balloc(n * cube(d2a) * 64, &c2a));
-  FPL_TRY(balloc(n * cube(d2) * 64, &c2));
-  FPL_TRY(balloc(n * cube(dp2) * 64, &p2));
-  FPL_TRY(balloc(n * cube(dp2) * 128, &c3));
-  FPL_TRY(balloc(n * cube(d4a) * 64, &c4a));
-  FPL_TRY(balloc(n * cube(d4a) * 64, &c4));
-  FPL_TRY(balloc(n * cube(d5a) * 32, &c5a));
+  FPL_TRY(balloc(n * cube(d1a) * 32, d1a, 32, &c1a));
+  FPL_TRY(balloc(n * cube(d1) * 32, d1, 32, &c1));
+  FPL_TRY(balloc(n * cube(dp1) * 32, dp1, 32, &p1));
+  FPL_TRY(balloc(n * cube(d2a) * 64, d2a, 64, &c2a));
+  FPL_TRY(balloc(n * cube(d2) * 64, d2, 64, &c2));
+  FPL_TRY(balloc(n * cube(dp2) * 64, dp2, 64, &p2));
+  FPL_TRY(balloc(n * cube(dp2) * 128, dp2, 128, &c3));
+  FPL_TRY(balloc(n * cube(d4a) * 64, d4a, 64, &c4a));
+  FPL_TRY(balloc(n * cube(d4a) * 64, d4a, 64, &c4));
+  FPL_TRY(balloc(n * cube(d5a) * 32, d5a, 32, &c5a));
   hipStream_t stm = ctx->stream;
   {  // L0: conv3 1->32
     StemArgs1 a;

@@ -38,12 +38,12 @@ GROUPS = {
 }
 
 
-def run_group(name, counters, out, bench_args):
+def run_group(name, counters, out, bench_args, script='bench.py'):
     d = os.path.join(out, name)
     os.makedirs(d, exist_ok=True)
     cmd = ['rocprofv3', '--pmc'] + counters + [
         '--kernel-trace', '--output-format', 'csv', '-d', d, '--',
-        sys.executable, os.path.join(ROOT, 'bench.py')] + bench_args
+        sys.executable, os.path.join(ROOT, script)] + bench_args
     env = dict(os.environ, TMPDIR='/tmp')
     print('[pmc] group %s: %s' % (name, ' '.join(counters)), flush=True)
     try:
@@ -66,6 +66,11 @@ def run_group(name, counters, out, bench_args):
 
 
 def short(name):
+    for key in ('conv3_bf16', 'conv1_bf16', 'stem_cin1_bf16', 'pool2_bf16',
+                'vgg_c5', 'vgg_tail', 'gather_tiles', 'stitch_tiles'):
+        if key in name:
+            i = name.index(key)
+            return name[i:].split('(')[0].replace('(anonymous namespace)::', '')
     for key in ('vgg_stem_pool', 'vgg_mid_pool', 'vgg_head', 'generic_conv',
                 'synth_u8', 'v2o_', 'gauss_pass', 'fillBuffer'):
         if key in name:
@@ -81,14 +86,21 @@ def main():
     ap.add_argument('--precision', default='bf16')
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--groups', default=','.join(GROUPS))
+    ap.add_argument('--target', default='bench', choices=['bench', 'unet'],
+                    help="bench = bench.py (vgg_like); unet = tools/bench_configs.py "
+                         "--what unet --unet-size SIZE")
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)
     os.makedirs(a.out, exist_ok=True)
     bench_args = ['--size', str(a.size), '--precision', a.precision, '--steps',
                   str(a.steps), '--warmup', '1', '--no-cpu-baseline']
+    script = 'bench.py'
+    if a.target == 'unet':
+        script = os.path.join('tools', 'bench_configs.py')
+        bench_args = ['--what', 'unet', '--unet-size', str(a.size)]
     summary = defaultdict(dict)
     for gname in a.groups.split(','):
-        acc = run_group(gname, GROUPS[gname], a.out, bench_args)
+        acc = run_group(gname, GROUPS[gname], a.out, bench_args, script)
         for k, cs in acc.items():
             for c, vals in cs.items():
                 summary[short(k)][c] = sum(vals) / len(vals)
@@ -103,8 +115,8 @@ def main():
     json.dump({'bench_args': bench_args, 'kernels': summary},
               open(os.path.join(a.out, 'summary.json'), 'w'), indent=1)
     with open(os.path.join(a.out, 'summary.md'), 'w') as f:
-        f.write('# rocprofv3 PMC summary (mean per dispatch)\n\n`bench.py %s`\n\n'
-                % ' '.join(bench_args))
+        f.write('# rocprofv3 PMC summary (mean per dispatch)\n\n`%s %s`\n\n'
+                % (script, ' '.join(bench_args)))
         for k, cs in sorted(summary.items()):
             f.write('## %s\n\n| counter | value |\n|---|---|\n' % k)
             for c, v in sorted(cs.items()):
