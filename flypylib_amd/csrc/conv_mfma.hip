@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   auto put = [&]() {
     unsigned char *dst = tile + pc * PLANE + vox0 * PITCH;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-      if (vox0 + 64 * j < TZ * TY * TX) *reinterpret_cast<u32x4 *>(dst + 64 * j * PITCH) = nt[j];
+    for (int j = 0; j < NT - 1; ++j) *reinterpret_cast<u32x4 *>(dst + 64 * j * PITCH) = nt[j];
+    if (vox0 < TZ * TY * TX - 64 * (NT - 1))       // the last round is partial
+      *reinterpret_cast<u32x4 *>(dst + 64 * (NT - 1) * PITCH) = nt[NT - 1];
   };
 
   const unsigned vbase = (unsigned)(((wave * TY) * TX + c) * PITCH + g * PLANE);
@@ -168,13 +169,17 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
     for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[16 * b + 4 * g + r];
   f32x4 acc[4][MB];
   const int total_chunks = a.ncc * NCH;
+  __syncthreads();                                  // offset tables visible
+  // The tile loads go out BEFORE the weight loads, as in the steady state of the
+  // loop below: vmcnt retires in order, and with this order the waits hipcc derives
+  // for put() leave the youngest weight loads in flight instead of draining them.
+  if (PF) fetch(blk, 0);
+  __builtin_amdgcn_sched_barrier(0);                // keep that issue order
   WReg<RING> wst[WDEPTH];
 #pragma unroll
   for (int d = 0; d < WDEPTH; ++d) wst[d].load(a.w, d < total_chunks ? d : 0, tid);
   wst[0].store(ring, tid);
   wst[0].load(a.w, WDEPTH < total_chunks ? WDEPTH : 0, tid);
-  __syncthreads();                                  // offset tables visible
-  if (PF) fetch(blk, 0);
 
   unsigned par = 0;                                 // ring slot of the current chunk
   for (;;) {
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
         int64_t nb = last_cc ? blk + G : blk;
         nb = nb < total_blocks ? nb : blk;          // past the end: a harmless reload
         fetch(nb, last_cc ? 0 : cc + 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();            // tile (+ ring slot) visible
       bf16x8 brow[2][6];
