@@ -55,6 +55,28 @@ struct Src {             // one CC-channel chunk of the (virtual) concatenated i
   int tab;               // which offset table (geometry H, W, C, ups) this source uses
 };
 
+// Epilogue store for interleaved output channels (pack_weights.h, fpl_out_channel):
+// lane (c, g) writes the 4*MB contiguous channels [4*MB*g, ...) of its voxel.
+template <int MB, bool RELU_ALWAYS>
+__device__ __forceinline__ void store_il(__bf16 *vox_out, int g, const f32x4 (&acc)[MB], int relu) {
+  static_assert(MB % 2 == 0, "16-B pieces");
+  __bf16 *dst = vox_out + 4 * MB * g;
+#pragma unroll
+  for (int h = 0; h < MB / 2; ++h) {
+    u32x4 o;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      o[2 * q] = cvt_pk_bf16(acc[2 * h + q][0], acc[2 * h + q][1]);
+      o[2 * q + 1] = cvt_pk_bf16(acc[2 * h + q][2], acc[2 * h + q][3]);
+    }
+    if (RELU_ALWAYS || relu) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = pk_max_i16(o[q], 0u);
+    }
+    *reinterpret_cast<u32x4 *>(dst + 8 * h) = o;
+  }
+}
+
 template <int RING> struct WReg {
   static constexpr int PIECES = RING / 16;
   static constexpr int PER = (PIECES + 255) / 256;
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
 #pragma unroll
   for (int b = 0; b < MB; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[16 * b + 4 * g + r];
+    for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[4 * MB * g + 4 * b + r];
   f32x4 acc[4][MB];
   const int total_chunks = a.ncc * NCH;
   __syncthreads();                                  // offset tables visible
@@ -259,17 +281,9 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         const int oy = by * 4 + sub;
-        if (oz < a.OD && oy < a.OH && ox < a.OW) {
-          __bf16 *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB) + 4 * g;
-#pragma unroll
-          for (int b = 0; b < MB; ++b) {
-            u32x2 o;
-            o[0] = cvt_pk_bf16(acc[sub][b][0], acc[sub][b][1]);
-            o[1] = cvt_pk_bf16(acc[sub][b][2], acc[sub][b][3]);
-            if (a.relu) { o[0] = pk_max_i16(o[0], 0u); o[1] = pk_max_i16(o[1], 0u); }
-            *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
-          }
-        }
+        if (oz < a.OD && oy < a.OH && ox < a.OW)
+          store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB),
+                              g, acc[sub], a.relu);
       }
     }
     blk += G;
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(256) void stem_cin1_bf16(StemArgs1 a) {
   for (int b = 0; b < MB; ++b) {
     w[b] = a.w[b * 64 + lane];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[b][r] = a.shift[16 * b + 4 * g + r];
+    for (int r = 0; r < 4; ++r) sh[b][r] = a.shift[4 * MB * g + 4 * b + r];
   }
   __syncthreads();
   for (int task = wave; task < ST_Z * ST_Y * (ST_X / 16); task += 4) {
@@ -326,15 +340,12 @@ __global__ __launch_bounds__(256) void stem_cin1_bf16(StemArgs1 a) {
     const bf16x8 bf = __builtin_bit_cast(bf16x8, raw);
     const int oz = z0 + zl, oy = y0 + yl, ox = x0 + 16 * xg + c;
     const bool ok = oz < a.OD && oy < a.OH && ox < a.OW;
-    __bf16 *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB) + 4 * g;
+    f32x4 acc[MB];
 #pragma unroll
-    for (int b = 0; b < MB; ++b) {
-      const f32x4 acc = mfma16(w[b], bf, sh[b]);
-      u32x2 o;
-      o[0] = pk_max_i16(cvt_pk_bf16(acc[0], acc[1]), 0u);
-      o[1] = pk_max_i16(cvt_pk_bf16(acc[2], acc[3]), 0u);
-      if (ok) *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
-    }
+    for (int b = 0; b < MB; ++b) acc[b] = mfma16(w[b], bf, sh[b]);
+    if (ok)
+      store_il<MB, true>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB),
+                         g, acc, 1);
   }
 }
 
@@ -362,7 +373,8 @@ __global__ __launch_bounds__(256) void conv1_bf16(Conv1Args a) {
 #pragma unroll
   for (int b = 0; b < MB; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh[b][r] = a.shift[16 * b + 4 * g + r];
+    for (int r = 0; r < 4; ++r)
+      sh[b][r] = a.shift[TAIL ? 16 * b + 4 * g + r : 4 * MB * g + 4 * b + r];
   __syncthreads();
   const int64_t groups = (a.M + 15) / 16;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
@@ -383,16 +395,7 @@ __global__ __launch_bounds__(256) void conv1_bf16(Conv1Args a) {
                         bf[s], acc[b]);
     }
     if (TAIL == 0) {
-      if (ok) {
-        __bf16 *dst = a.out + m * (16 * MB) + 4 * g;
-#pragma unroll
-        for (int b = 0; b < MB; ++b) {
-          u32x2 o;
-          o[0] = pk_max_i16(cvt_pk_bf16(acc[b][0], acc[b][1]), 0u);
-          o[1] = pk_max_i16(cvt_pk_bf16(acc[b][2], acc[b][3]), 0u);
-          *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
-        }
-      }
+      if (ok) store_il<MB, true>(a.out + m * (16 * MB), g, acc, 1);
     } else {
       // chained 16*MB -> 1 conv (k-slots bound to the accumulator layout), sigmoid
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -501,7 +504,7 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
     std::vector<uint16_t> f;
     const int mb = (op.cout + 15) / 16;
     if (l == 0) {
-      fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, mb, 1, SLOT_STEM, &f);
+      fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, mb, 1, SLOT_STEM, &f, true);
     } else if (op.k == 3) {
       // per CC-channel chunk, K-step order (dz, dx, dy): rows [kstep][channel]
       const int ncc = op.cin / CC;
@@ -516,13 +519,14 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
                    op.cout * sizeof(float));
         }
         std::vector<uint16_t> fc;
-        fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, 27, SLOT_SPATIAL, &fc);
+        fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, 27, SLOT_SPATIAL, &fc, true);
         f.insert(f.end(), fc.begin(), fc.end());
       }
     } else if (l == 9) {
       fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, 1, 1, SLOT_CHAIN, &f);
     } else {
-      fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL, &f);
+      // l == 8 feeds the register-chained tail: plain row order there
+      fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL, &f, l != 8);
     }
     st->off_w[l] = all.size() * sizeof(uint16_t);
     all.insert(all.end(), f.begin(), f.end());

@@ -21,16 +21,26 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// Output channel computed by row m of M-block b.  Plain: 16b + m.  Interleaved
+// (il): 4*MB*(m/4) + 4b + m%4 - lane (c, g) of the accumulators (rows 4g..4g+3 of
+// every block) then owns the 4*MB CONTIGUOUS channels [4*MB*g, 4*MB*(g+1)) of its
+// voxel, so an epilogue stores 16-B pieces and a wave writes whole lines.
+static inline int fpl_out_channel(int b, int m, int n_mblocks, bool il) {
+  return il ? 4 * n_mblocks * (m >> 2) + 4 * b + (m & 3) : 16 * b + m;
+}
+
 // W: [ntaps * cin][cout] fp32 (Keras memory order), scale[cout] folded in.
 // out: n_ksteps * n_mblocks fragments.
 static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
                                   int cin, int cout, int n_mblocks, int n_ksteps,
-                                  FplSlotMap map, std::vector<uint16_t> *out) {
+                                  FplSlotMap map, std::vector<uint16_t> *out,
+                                  bool il = false) {
   out->assign((size_t)n_ksteps * n_mblocks * 512, 0);
   for (int s = 0; s < n_ksteps; ++s)
     for (int b = 0; b < n_mblocks; ++b)
       for (int lane = 0; lane < 64; ++lane) {
-        const int m = lane & 15, g = lane >> 4, co = 16 * b + m;
+        const int m = lane & 15, g = lane >> 4;
+        const int co = fpl_out_channel(b, m, n_mblocks, il);
         if (co >= cout) continue;
         for (int j = 0; j < 8; ++j) {
           int kidx = -1;
