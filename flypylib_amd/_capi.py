@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREC_F32, PREC_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FplHipError(RuntimeError):
@@ -71,6 +71,8 @@ SIGNATURES = {
     'fpl_trainer_destroy': (C.c_int, [_vp]),
     'fpl_trainer_step': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _i32, _pi32,
                                    C.c_uint64, C.POINTER(_f32), C.POINTER(_f32)]),
+    'fpl_trainer_set_loss': (C.c_int, [_vp, C.c_int]),
+    'fpl_trainer_metric_sums': (C.c_int, [_vp, C.POINTER(C.c_double)]),
     'fpl_trainer_apply': (C.c_int, [_vp, _f32]),
     'fpl_trainer_grad_ptr': (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     'fpl_trainer_get_weights': (C.c_int, [_vp, _vp, _i64]),
@@ -311,10 +313,25 @@ class Program:
         return dst
 
 
+# include/fplhip.h fpl_loss; names are the reference's (fplnetwork.py:74-77,
+# fplmodels.py:28-50)
+LOSS_KINDS = {'binary_crossentropy': 0, 'masked_binary_crossentropy': 1,
+              'masked_weighted_binary_crossentropy': 2, 'masked_focal_loss': 3}
+
+
+def metrics_from_sums(s):
+    """the reference's metrics (fplmodels.py:52-65 + Keras 'accuracy') of one batch
+    from fpl_trainer_metric_sums"""
+    n = max(s[7], 1.0)
+    return {'loss': s[0] / n, 'acc': s[1] / n, 'masked_accuracy': s[2] / n,
+            'lb0l1err': s[3] / max(s[4], 1.0), 'lb1l1err': s[5] / max(s[6], 1.0)}
+
+
 class Trainer:
     """training engine for one LayerGraph on one GPU (fpl_trainer)"""
 
-    def __init__(self, ctx, graph, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, ctx, graph, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8,
+                 loss='binary_crossentropy'):
         from .program import lower_training
         self.ctx = ctx
         self.graph = graph
@@ -334,6 +351,10 @@ class Trainer:
             ctx.h, c_layers, len(layers), n_tensors, out_tensor, _ptr(arena),
             arena.size, lr, beta1, beta2, eps, C.byref(h)))
         self.h = h
+        loss = getattr(loss, '__name__', loss)
+        if loss not in LOSS_KINDS:
+            raise NotImplementedError('loss %r (have %s)' % (loss, sorted(LOSS_KINDS)))
+        ctx.check(ctx.lib.fpl_trainer_set_loss(h, LOSS_KINDS[loss]))
 
     def close(self):
         if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
@@ -361,6 +382,12 @@ class Trainer:
             _arr(x.shape[1:], C.c_int32), C.c_uint64(int(seed)),
             C.byref(loss), C.byref(acc)))
         return loss.value, acc.value
+
+    def metrics(self):
+        """metrics of the last step by the reference's names"""
+        sums = (C.c_double * 8)()
+        self.ctx.check(self.ctx.lib.fpl_trainer_metric_sums(self.h, sums))
+        return metrics_from_sums(list(sums))
 
     def apply(self, grad_scale=1.0):
         self.ctx.check(self.ctx.lib.fpl_trainer_apply(self.h, float(grad_scale)))

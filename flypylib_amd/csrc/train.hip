@@ -278,36 +278,76 @@ __global__ void accum(const float *dy, float *dx, int64_t n) {
   if (i < n) dx[i] += dy[i];
 }
 
-// sigmoid-output BCE: per-element loss, correct flag, and dL/dlogit (mean folded)
-__global__ void bce_loss_grad(const float *__restrict__ p, const uint8_t *__restrict__ lab,
-                              float *__restrict__ dlogit, int64_t n, float inv_n,
-                              double *__restrict__ sums) {
-  __shared__ double sl[256], sa[256];
+// Sigmoid-output losses (include/fplhip.h fpl_loss): per-element loss, metric sums
+// and dL/dlogit with the 1/n of the mean folded in.  The network's last op is the
+// sigmoid, so dL/dlogit = dL/dp * p (1 - p).
+//   BCE (Keras K.binary_crossentropy): p clipped to [1e-7, 1-1e-7], re-expressed
+//     through the logit as TF does; zero gradient where the clip is active.
+//   MASKED_BCE (fplmodels.py:41-44): the same on (p * mask, y * mask), mask = y != 2;
+//     a masked voxel contributes -log(1 - 1e-7) and no gradient.
+//   MASKED_WEIGHTED_BCE (fplmodels.py:28-39): tf.nn.weighted_cross_entropy_with_logits
+//     with pos_weight q = 100 on z = logit(clip(p * mask)):
+//     (1 - t) z + (1 + (q - 1) t) (log1p(exp(-|z|)) + max(-z, 0)).
+//   MASKED_FOCAL (fplmodels.py:45-50): -mask (1 - pt)^2 log(pt + 1e-7),
+//     pt = p where y == 1, else 1 - p; mask = y < 2.
+template <int KIND>
+__global__ void loss_grad(const float *__restrict__ p, const uint8_t *__restrict__ lab,
+                          float *__restrict__ dlogit, int64_t n, float inv_n,
+                          double *__restrict__ sums) {
+  __shared__ double sh[7][256];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double l = 0.0, a = 0.0;
+  double v[7] = {0, 0, 0, 0, 0, 0, 0};
   if (i < n) {
-    const float y = (float)lab[i];
+    const int yl = lab[i];
+    const float y = (float)yl;
     const float pi = p[i];
     const float eps = 1e-7f;
-    const float pc = fminf(fmaxf(pi, eps), 1.f - eps);
-    const float z = logf(pc / (1.f - pc));
-    l = (double)(fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))));
-    a = (rintf(pi) == y) ? 1.0 : 0.0;
-    dlogit[i] = (pi > eps && pi < 1.f - eps) ? (pc - y) * inv_n : 0.f;
+    const float mask = KIND == FPL_LOSS_BCE ? 1.f : (yl != 2 ? 1.f : 0.f);
+    float l, d;
+    if (KIND == FPL_LOSS_MASKED_FOCAL) {
+      const float m = yl < 2 ? 1.f : 0.f;
+      const bool pos = yl == 1;
+      const float pt = pos ? pi : 1.f - pi;
+      const float lg = logf(pt + eps);
+      l = -m * (1.f - pt) * (1.f - pt) * lg;
+      // d/dpt of -(1-pt)^2 log(pt+eps); dpt/dp = +-1
+      const float dpt = 2.f * (1.f - pt) * lg - (1.f - pt) * (1.f - pt) / (pt + eps);
+      d = m * (pos ? dpt : -dpt) * pi * (1.f - pi);
+    } else {
+      const float t = y * mask, pm = pi * mask;
+      const float pc = fminf(fmaxf(pm, eps), 1.f - eps);
+      const float z = logf(pc / (1.f - pc));
+      const bool open = pm > eps && pm < 1.f - eps;     // clip inactive
+      if (KIND == FPL_LOSS_MASKED_WEIGHTED_BCE) {
+        const float w = 1.f + 99.f * t;
+        l = (1.f - t) * z + w * (log1pf(expf(-fabsf(z))) + fmaxf(-z, 0.f));
+        d = open ? ((1.f - t) - w * (1.f - pc)) : 0.f;
+      } else {
+        l = fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z)));
+        d = open ? (pc - t) : 0.f;
+      }
+    }
+    dlogit[i] = d * inv_n;
+    const float mk = yl != 2 ? 1.f : 0.f;
+    v[0] = (double)l;
+    v[1] = (rintf(pi) == y) ? 1.0 : 0.0;
+    v[2] = (rintf(pi * mk) == y * mk) ? 1.0 : 0.0;
+    v[3] = yl == 0 ? (double)pi : 0.0;
+    v[4] = yl == 0 ? 1.0 : 0.0;
+    v[5] = yl == 1 ? (double)(1.f - pi) : 0.0;
+    v[6] = yl == 1 ? 1.0 : 0.0;
   }
-  sl[threadIdx.x] = l; sa[threadIdx.x] = a;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) sh[k][threadIdx.x] = v[k];
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
-      sl[threadIdx.x] += sl[threadIdx.x + s];
-      sa[threadIdx.x] += sa[threadIdx.x + s];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + s];
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], sl[0]);
-    atomicAdd(&sums[1], sa[0]);
-  }
+  if (threadIdx.x < 7) atomicAdd(&sums[threadIdx.x], sh[threadIdx.x][0]);
 }
 
 // dX[in][ci] += sum_tap sum_co dY[in - tap][co] * W[tap][ci][co]
@@ -449,6 +489,8 @@ struct fpl_trainer {
   float *ones = nullptr, *zeros = nullptr;        // 256 floats each
   float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
   int64_t step_count = 0;
+  int loss_kind = FPL_LOSS_BCE;
+  double last_sums[FPL_N_METRIC_SUMS] = {0};
 };
 
 namespace {
@@ -631,7 +673,11 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   FPL_REQUIRE(ctx, batch > 0, "fpl_trainer_step: batch %d", batch);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const bool use_mfma = getenv("FPL_TRAIN_DIRECT") == nullptr;   // fp32 MFMA convolutions
+  // fp32 MFMA convolutions; FPL_TRAIN_DIRECT = bitmask of what falls back to the
+  // direct kernels (1 forward, 2 backward; anything else = both) - a debug switch
+  const char *direct_env = getenv("FPL_TRAIN_DIRECT");
+  const int direct_mask = direct_env ? ((atoi(direct_env) & 3) ? (atoi(direct_env) & 3) : 3) : 0;
+  const bool use_mfma = !(direct_mask & 1), use_mfma_bwd = !(direct_mask & 2);
   std::vector<TShape> shp;
   FPL_TRY(shapes_for(ctx, t, patch, &shp));
   const int nt = t->n_tensors;
@@ -671,9 +717,9 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   FPL_TRY(tmp.alloc((size_t)max_nb * 2 * 256 * sizeof(double), &partv));
   double *part = (double *)partv;
   void *sumsv;
-  FPL_TRY(tmp.alloc(2 * sizeof(double), &sumsv));
+  FPL_TRY(tmp.alloc(8 * sizeof(double), &sumsv));
   double *sums = (double *)sumsv;
-  FPL_HIP(ctx, hipMemsetAsync(sums, 0, 2 * sizeof(double), st));
+  FPL_HIP(ctx, hipMemsetAsync(sums, 0, 8 * sizeof(double), st));
 
   // BatchNorm directly followed by its only consumer ReLU runs as one fused pass
   std::vector<int> n_cons(nt, 0);
@@ -807,8 +853,21 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   }
   {
     TimedLaunch tl(ctx, "train_loss");
-    bce_loss_grad<<<g1(n_out), 256, 0, st>>>(val[t->out_tensor], lab_dev, grad[t->out_tensor],
-                                             n_out, 1.f / (float)n_out, sums);
+    const float inv_n = 1.f / (float)n_out;
+    float *po = val[t->out_tensor], *go = grad[t->out_tensor];
+    switch (t->loss_kind) {
+      case FPL_LOSS_MASKED_BCE:
+        loss_grad<FPL_LOSS_MASKED_BCE><<<g1(n_out), 256, 0, st>>>(po, lab_dev, go, n_out, inv_n, sums);
+        break;
+      case FPL_LOSS_MASKED_WEIGHTED_BCE:
+        loss_grad<FPL_LOSS_MASKED_WEIGHTED_BCE><<<g1(n_out), 256, 0, st>>>(po, lab_dev, go, n_out, inv_n, sums);
+        break;
+      case FPL_LOSS_MASKED_FOCAL:
+        loss_grad<FPL_LOSS_MASKED_FOCAL><<<g1(n_out), 256, 0, st>>>(po, lab_dev, go, n_out, inv_n, sums);
+        break;
+      default:
+        loss_grad<FPL_LOSS_BCE><<<g1(n_out), 256, 0, st>>>(po, lab_dev, go, n_out, inv_n, sums);
+    }
   }
 
   // ------------------------------ backward -----------------------------------
@@ -823,7 +882,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       case FPL_L_CONV: {
         const int64_t n_vox = (int64_t)batch * o.vox();
         const int taps = L.k * L.k * L.k;
-        if (use_mfma && fpl_tm_supported(L.k, L.cin, L.cout) &&
+        if (use_mfma_bwd && fpl_tm_supported(L.k, L.cin, L.cout) &&
             fpl_tm_supported(L.k, L.cout, L.cin)) {
           FPL_TRY(fpl_tm_conv_wgrad(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, dy, L.k,
                                     L.cout, t->g + L.w_off[0]));
@@ -962,11 +1021,43 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
     }
     FPL_HIP(ctx, hipGetLastError());
   }
-  double hs[2];
+  if (const char *dump = getenv("FPL_TRAIN_DUMP")) {
+    // debug: raw fp32 dump of every activation / activation-gradient tensor
+    FPL_HIP(ctx, hipStreamSynchronize(st));
+    for (int ti = 1; ti < nt; ++ti) {
+      for (int which = 0; which < 2; ++which) {
+        const float *src = which ? grad[ti] : val[ti];
+        if (!src) continue;
+        const int64_t n = (int64_t)batch * shp[ti].elems();
+        std::vector<float> h((size_t)n);
+        FPL_HIP(ctx, hipMemcpy(h.data(), src, (size_t)n * 4, hipMemcpyDeviceToHost));
+        char path[512];
+        snprintf(path, sizeof(path), "%s/%s_%03d_c%d.f32", dump, which ? "grad" : "val", ti, shp[ti].c);
+        if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), 4, (size_t)n, f); fclose(f); }
+      }
+    }
+  }
+  double hs[8];
   FPL_HIP(ctx, hipMemcpyAsync(hs, sums, sizeof(hs), hipMemcpyDeviceToHost, st));
   FPL_HIP(ctx, hipStreamSynchronize(st));
+  hs[7] = (double)n_out;
+  memcpy(t->last_sums, hs, sizeof(hs));
   if (loss) *loss = (float)(hs[0] / (double)n_out);
   if (accuracy) *accuracy = (float)(hs[1] / (double)n_out);
+  return 0;
+}
+
+int fpl_trainer_set_loss(fpl_trainer *t, int loss_kind) {
+  if (!t) return fpl_fail(nullptr, "fpl_trainer_set_loss: trainer is NULL");
+  FPL_REQUIRE(t->ctx, loss_kind >= FPL_LOSS_BCE && loss_kind <= FPL_LOSS_MASKED_FOCAL,
+              "fpl_trainer_set_loss: unknown loss %d", loss_kind);
+  t->loss_kind = loss_kind;
+  return 0;
+}
+
+int fpl_trainer_metric_sums(fpl_trainer *t, double out[FPL_N_METRIC_SUMS]) {
+  if (!t || !out) return fpl_fail(nullptr, "fpl_trainer_metric_sums: NULL argument");
+  memcpy(out, t->last_sums, sizeof(t->last_sums));
   return 0;
 }
 

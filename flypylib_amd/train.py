@@ -84,35 +84,41 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
     graph = network.train_single
     args = network.compile_args or {}
     loss = args.get('loss', 'binary_crossentropy')
-    if loss != 'binary_crossentropy':
-        raise NotImplementedError(
-            'loss %r: only binary_crossentropy is implemented in the training '
-            'engine (masked/focal losses: SURVEY 8f)' % (loss,))
+    loss = getattr(loss, '__name__', loss)
+    # Keras names a metric column after the function ('accuracy' -> 'acc')
+    metric_names = ['acc' if m in ('accuracy', 'acc') else getattr(m, '__name__', m)
+                    for m in args.get('metrics', ['accuracy'])]
     opt = args.get('optimizer', 'adam')
     if opt not in _OPTIMIZERS:
         raise NotImplementedError('optimizer %r' % (opt,))
     ctx = runtime.get_context(network._device)
-    trainer = _capi.Trainer(ctx, graph, **_OPTIMIZERS[opt])
+    trainer = _capi.Trainer(ctx, graph, loss=loss, **_OPTIMIZERS[opt])
     dist = _dist()
     rank = dist.get_rank() if dist else 0
+    cols = sorted(set(metric_names + ['loss']))
+    for k in cols:
+        if k not in ('loss', 'acc', 'masked_accuracy', 'lb0l1err', 'lb1l1err'):
+            raise NotImplementedError('metric %r' % (k,))
     writer = None
     if rank == 0 and log_file:
         f = open(log_file, 'w', newline='')
         writer = csv.writer(f)
-        writer.writerow(['epoch', 'acc', 'loss'])
+        # CSVLogger: 'epoch' then the log keys in sorted order
+        writer.writerow(['epoch'] + cols)
     step_no = 0
     history = []
     for epoch in range(epochs):
-        tot_loss = tot_acc = 0.0
+        tot = dict.fromkeys(cols, 0.0)
         for _ in range(steps_per_epoch):
             data, labels = next(generator)
-            l, a = trainer.step(data, labels, seed=seed + step_no)
+            trainer.step(data, labels, seed=seed + step_no)
             trainer.apply(allreduce_grads(trainer))
-            tot_loss += l
-            tot_acc += a
+            m = trainer.metrics()
+            for k in cols:
+                tot[k] += m[k]
             step_no += 1
         graph.set_weights(trainer.get_weights())
-        row = (epoch, tot_acc / steps_per_epoch, tot_loss / steps_per_epoch)
+        row = (epoch,) + tuple(tot[k] / steps_per_epoch for k in cols)
         history.append(row)
         if writer:
             writer.writerow(row)

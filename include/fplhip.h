@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 1
+#define FPL_ABI_VERSION 2
 
 typedef struct fpl_ctx fpl_ctx;
 typedef struct fpl_program fpl_program;
@@ -170,6 +170,18 @@ typedef struct fpl_layer {
 } fpl_layer;
 typedef struct fpl_trainer fpl_trainer;
 
+/* losses of the reference: Keras 'binary_crossentropy' (fplnetwork.py:74-77) and
+ * the custom ones of fplmodels.py:28-50.  Label 2 = "don't care" for the masked
+ * kinds.  Every loss is the mean over all output voxels of the batch (Keras
+ * means the per-voxel values whatever their mask). */
+typedef enum fpl_loss {
+  FPL_LOSS_BCE = 0,                 /* clip p to [1e-7, 1-1e-7], -y log p - (1-y) log(1-p) */
+  FPL_LOSS_MASKED_BCE = 1,          /* BCE of (p*mask, y*mask), fplmodels.py:41-44 */
+  FPL_LOSS_MASKED_WEIGHTED_BCE = 2, /* pos_weight 100 on logits, fplmodels.py:28-39 */
+  FPL_LOSS_MASKED_FOCAL = 3         /* gamma 2, alpha 1, fplmodels.py:45-50 */
+} fpl_loss;
+#define FPL_N_METRIC_SUMS 8
+
 /* `weights`: flat fp32 concatenation of the Keras get_weights() list.  The
  * trainer owns a gradient arena of the same layout (moving-statistics slots hold
  * the pending moving-average delta); fpl_trainer_grad_ptr exposes it so the host
@@ -187,6 +199,13 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
                      const uint8_t *labels, int labels_mem, int32_t batch,
                      const int32_t patch[3], uint64_t seed, float *loss,
                      float *accuracy);
+/* loss used by the following steps (default FPL_LOSS_BCE) */
+int fpl_trainer_set_loss(fpl_trainer *t, int loss_kind);
+/* raw sums of the last step, from which the host forms the reference's metrics
+ * (fplmodels.py:52-65): [0] sum of per-voxel loss, [1] #(round(p) == y),
+ * [2] #(round(p*mask) == y*mask)  (masked_accuracy numerator), [3] sum p over
+ * y==0, [4] #(y==0), [5] sum (1-p) over y==1, [6] #(y==1), [7] #voxels */
+int fpl_trainer_metric_sums(fpl_trainer *t, double out[FPL_N_METRIC_SUMS]);
 /* Adam update (and moving-statistics update) from the gradient arena scaled by
  * grad_scale (1/world_size after a sum all-reduce) */
 int fpl_trainer_apply(fpl_trainer *t, float grad_scale);

@@ -24,10 +24,52 @@ from flypylib_amd import synth
 BN_EPS, BN_MOMENTUM = 1e-3, 0.99
 
 
-def train_step(graph, weights, data, labels, seed, dtype=torch.float64):
+def loss_value(p, y, kind):
+    """Scalar loss of the reference for sigmoid outputs p and labels y (same shape,
+    last axis = 1): Keras means the per-voxel loss over everything.
+    binary_crossentropy: fplnetwork.py:74-77 (Keras/TF: clip to [1e-7, 1-1e-7],
+    sigmoid cross-entropy on the recovered logit); masked_*: fplmodels.py:28-50,
+    label 2 = don't care."""
+    eps = 1e-7
+    if kind == 'masked_focal_loss':
+        pt = torch.where(y == 1, p, 1 - p)
+        mask = (y < 2).to(p.dtype)
+        return (-(mask * (1 - pt) ** 2 * torch.log(pt + eps))).mean()
+    mask = torch.ones_like(p) if kind == 'binary_crossentropy' else (y != 2).to(p.dtype)
+    t, pm = y * mask, p * mask
+    pc = pm.clamp(eps, 1 - eps)
+    z = torch.log(pc / (1 - pc))
+    if kind == 'masked_weighted_binary_crossentropy':
+        w = 1 + 99 * t                        # pos_weight = 100
+        return ((1 - t) * z + w * (torch.log1p(torch.exp(-z.abs())) + torch.relu(-z))).mean()
+    if kind in ('binary_crossentropy', 'masked_binary_crossentropy'):
+        return (torch.relu(z) - z * t + torch.log1p(torch.exp(-z.abs()))).mean()
+    raise NotImplementedError(kind)
+
+
+def metric_values(p, y):
+    """Keras 'accuracy' and the reference's metrics (fplmodels.py:52-65)"""
+    mask = (y != 2).to(p.dtype)
+    m0, m1 = (y == 0).to(p.dtype), (y == 1).to(p.dtype)
+    return {
+        'acc': float((torch.round(p) == y).to(p.dtype).mean()),
+        'masked_accuracy': float((y * mask == torch.round(p * mask)).to(p.dtype).mean()),
+        'lb0l1err': float((p * m0).sum() / torch.clamp(m0.sum(), min=1)),
+        'lb1l1err': float(((1 - p) * m1).sum() / torch.clamp(m1.sum(), min=1)),
+    }
+
+
+def train_step(graph, weights, data, labels, seed, dtype=torch.float64,
+               loss='binary_crossentropy', return_metrics=False, info=None):
     """-> (loss, accuracy, grads) where `grads` follows the weight list order;
     for BN moving_mean / moving_variance the entry is the pending delta
-    (1-momentum)*(batch_stat - moving)."""
+    (1-momentum)*(batch_stat - moving).
+
+    `info` (a dict) receives 'min_pool_gap': the smallest relative gap between the
+    two largest values of any max-pool window with a positive maximum.  Max-pool
+    routes the whole gradient of a window to its argmax, so a gap at rounding level
+    (~1e-6) lets two correct fp32 implementations disagree on every gradient
+    upstream; parity tests pick inputs whose gap is far above that."""
     W = [torch.tensor(np.asarray(w), dtype=dtype) for w in weights]
     trainable = []
     for n in graph.nodes:
@@ -68,6 +110,15 @@ def train_step(graph, weights, data, labels, seed, dtype=torch.float64):
             v = torch.relu(a[0])
         elif n.kind == 'pool':
             v = F.max_pool3d(a[0], 2, 2)
+            if info is not None:
+                x_ = a[0].detach()
+                d_, h_, w_ = (x_.shape[2] // 2 * 2, x_.shape[3] // 2 * 2, x_.shape[4] // 2 * 2)
+                win = x_[:, :, :d_, :h_, :w_].unfold(2, 2, 2).unfold(3, 2, 2).unfold(4, 2, 2)
+                top = win.reshape(*win.shape[:5], 8).topk(2, dim=-1).values
+                pos = top[..., 0] > 0
+                if pos.any():
+                    gap = ((top[..., 0] - top[..., 1]) / top[..., 0])[pos].min()
+                    info['min_pool_gap'] = min(info.get('min_pool_gap', 1.0), float(gap))
         elif n.kind == 'drop':
             rate = n.attrs['rate']
             cl = a[0].permute(0, 2, 3, 4, 1)               # channels-last order
@@ -92,10 +143,9 @@ def train_step(graph, weights, data, labels, seed, dtype=torch.float64):
         vals[n.idx] = v
     p = vals[graph.output.idx].permute(0, 2, 3, 4, 1)
     y = torch.tensor(np.asarray(labels), dtype=dtype).reshape(p.shape)
-    pc = p.clamp(1e-7, 1 - 1e-7)
-    z = torch.log(pc / (1 - pc))
-    loss = (torch.relu(z) - z * y + torch.log1p(torch.exp(-z.abs()))).mean()
+    loss = loss_value(p, y, loss)
     acc = (torch.round(p.detach()) == y).to(dtype).mean()
+    metrics = metric_values(p.detach(), y)
     loss.backward()
     grads = []
     for i, w in enumerate(W):
@@ -105,6 +155,8 @@ def train_step(graph, weights, data, labels, seed, dtype=torch.float64):
             grads.append(w.grad.numpy())
         else:
             grads.append(np.zeros(tuple(w.shape)))
+    if return_metrics:
+        return float(loss.detach()), metrics, grads
     return float(loss.detach()), float(acc), grads
 
 

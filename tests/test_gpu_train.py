@@ -15,18 +15,60 @@ def _rel(a, b):
     return np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-12)
 
 
-def _check_step(ctx, graph, data, labels, seed=5, tol=2e-3):
-    tr = _capi.Trainer(ctx, graph)
-    loss, acc = tr.step(data, labels, seed=seed)
-    rl, ra, rg = train_oracle.train_step(graph, graph.weights, data, labels, seed)
-    assert abs(loss - rl) < 1e-4 * max(1.0, abs(rl)), (loss, rl)
-    assert abs(acc - ra) < 1e-6
-    grads = tr.get_grads()
+FLIP_GAP = 5e-6      # top-2 gap of a max-pool window below which fp32 rounding may flip it
+
+
+def _oracle_step(graph, shape, data_seed, loss='binary_crossentropy', labels=None,
+                 step_seed=5, tries=8):
+    """Seeded normal input + the float64 oracle's step on it.  Max-pool routes a
+    window's whole gradient to its argmax, so a window whose two largest values
+    differ at fp32 rounding level (the MFMA and the direct fp32 convolutions
+    themselves differ by ~2e-6 relative) can be routed differently by two correct
+    fp32 implementations, which moves every gradient UPSTREAM of that pool (observed:
+    one flipped window of unet_like2's 3^3 pool -> 5 % on the encoder gradients).  A
+    few seeds are tried for an input without such windows; the returned flag says
+    whether one was found."""
+    best = None
+    for k in range(tries):
+        rng = np.random.default_rng(data_seed + 1000 * k)
+        data = rng.standard_normal(shape).astype(np.float32)
+        info = {}
+        rl, rm, rg = train_oracle.train_step(graph, graph.weights, data, labels, step_seed,
+                                             loss=loss, return_metrics=True, info=info)
+        gap = info.get('min_pool_gap', 1.0)
+        if best is None or gap > best[0]:
+            best = (gap, data, rl, rm, rg)
+        if gap > FLIP_GAP:
+            break
+    gap, data, rl, rm, rg = best
+    return data, rl, rm, rg, gap > FLIP_GAP
+
+
+def _check_grads(graph, grads, rg, separated, tol_flip):
+    """tight (2e-4) on every gradient when no pool window is flip-prone, and always
+    on the layers after the last pool (no pool backward upstream of them);
+    `tol_flip` on the rest otherwise"""
+    last_pool = max([n.idx for n in graph.nodes if n.kind == 'pool'] or [-1])
+    after = set()
+    for n in graph.nodes:
+        if n.idx > last_pool:
+            after.update(n.weight_slots)
     for i, (g, r) in enumerate(zip(grads, rg)):
         if np.max(np.abs(r)) < 1e-12:
             assert np.max(np.abs(g)) < 1e-7, graph.weight_names[i]
             continue
-        assert _rel(g, r) < tol, '%s: rel err %g' % (graph.weight_names[i], _rel(g, r))
+        tol = 2e-4 if (separated or i in after) else tol_flip
+        assert _rel(g, r) < tol, '%s: rel err %g (tol %g)' % (graph.weight_names[i], _rel(g, r), tol)
+
+
+def _check_step(ctx, graph, shape, labels, seed=5, tol_flip=2e-3, data_seed=0):
+    data, rl, rm, rg, separated = _oracle_step(graph, shape, data_seed, labels=labels,
+                                               step_seed=seed)
+    tr = _capi.Trainer(ctx, graph)
+    loss, acc = tr.step(data, labels, seed=seed)
+    assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)), (loss, rl)
+    assert abs(acc - rm['acc']) < 1e-6
+    _check_grads(graph, tr.get_grads(), rg, separated, tol_flip)
     return tr, rg
 
 
@@ -36,9 +78,8 @@ def test_vgg_like_step_reference_shape(ctx):
     g = fplmodels.vgg_like()[0]
     synth.synthetic_weights(g, 3)
     rng = np.random.default_rng(0)
-    data = rng.standard_normal((8, 18, 18, 18, 1)).astype(np.float32)
     labels = (rng.random((8, 1, 1, 1, 1)) > 0.5).astype(np.uint8)
-    _check_step(ctx, g, data, labels)
+    _check_step(ctx, g, (8, 18, 18, 18, 1), labels)
 
 
 def test_vgg_like_step_dense_patch(ctx):
@@ -46,19 +87,59 @@ def test_vgg_like_step_dense_patch(ctx):
     g = fplmodels.vgg_like()[0]
     synth.synthetic_weights(g, 4)
     rng = np.random.default_rng(1)
-    data = rng.standard_normal((3, 30, 30, 30, 1)).astype(np.float32)
     labels = (rng.random((3, 4, 4, 4, 1)) > 0.7).astype(np.uint8)
-    _check_step(ctx, g, data, labels)
+    _check_step(ctx, g, (3, 30, 30, 30, 1), labels, data_seed=1)
 
 
 def test_unet_like2_step(ctx):
     g = fplmodels.unet_like2()[0]
     synth.synthetic_weights(g, 5)
     rng = np.random.default_rng(2)
-    data = rng.standard_normal((2, 24, 24, 24, 1)).astype(np.float32)
     labels = (rng.random((2, 6, 6, 6, 1)) > 0.5).astype(np.uint8)
-    # deepest backward path (10 BN layers, batch 2): fp32 vs the fp64 oracle
-    _check_step(ctx, g, data, labels, tol=1e-2)
+    _check_step(ctx, g, (2, 24, 24, 24, 1), labels, data_seed=2, tol_flip=1e-1)
+
+
+@pytest.mark.parametrize('loss', ['masked_focal_loss', 'masked_binary_crossentropy',
+                                  'masked_weighted_binary_crossentropy'])
+def test_masked_losses_and_metrics(ctx, loss):
+    """the reference's custom losses / metrics (fplmodels.py:28-65); label 2 =
+    don't care.  unet_like2 is compiled with masked_focal_loss (fplmodels.py:300)"""
+    g = fplmodels.unet_like2()[0]
+    synth.synthetic_weights(g, 6)
+    rng = np.random.default_rng(8)
+    labels = rng.integers(0, 3, (2, 6, 6, 6, 1)).astype(np.uint8)      # {0, 1, 2}
+    data, rl, rm, rg, separated = _oracle_step(g, (2, 24, 24, 24, 1), 8, loss=loss,
+                                               labels=labels)
+    tr = _capi.Trainer(ctx, g, loss=loss)
+    lv, _ = tr.step(data, labels, seed=5)
+    assert abs(lv - rl) < 1e-5 * max(1.0, abs(rl)), (lv, rl)
+    m = tr.metrics()
+    assert abs(m['loss'] - rl) < 1e-5 * max(1.0, abs(rl))
+    for k, v in rm.items():
+        assert abs(m[k] - v) < 1e-5, (k, m[k], v)
+    _check_grads(g, tr.get_grads(), rg, separated, 1e-1)
+    tr.close()
+
+
+def test_unet_trains_with_its_reference_compile_args(ctx, tmp_path):
+    """FplNetwork(unet_like2).train runs with the loss / metrics the reference
+    compiles it with; the CSV has CSVLogger's sorted columns"""
+    from flypylib_amd import FplNetwork
+    net = FplNetwork(fplmodels.unet_like2)
+    assert net.compile_args['loss'] == 'masked_focal_loss'
+    rng = np.random.default_rng(4)
+
+    def gen():
+        while True:
+            x = rng.standard_normal((2, 24, 24, 24, 1)).astype(np.float32)
+            y = rng.integers(0, 3, (2, 6, 6, 6, 1)).astype(np.uint8)
+            x[:, 9:15, 9:15, 9:15][y == 1] += 2.0
+            yield x, y
+    log = str(tmp_path / 'unet.csv')
+    net.train(gen(), 6, 2, log, None)
+    rows = open(log).read().strip().splitlines()
+    assert rows[0] == 'epoch,lb0l1err,lb1l1err,loss,masked_accuracy'
+    assert len(rows) == 3 and float(rows[2].split(',')[3]) < float(rows[1].split(',')[3])
 
 
 def test_small_graph_with_bias_and_dropout(ctx):
@@ -69,9 +150,8 @@ def test_small_graph_with_bias_and_dropout(ctx):
     g.finish(g.conv(x, 1, 1, use_bias=True, activation='sigmoid'))
     g.randomize_bn(9)
     rng = np.random.default_rng(3)
-    data = rng.standard_normal((4, 10, 10, 10, 1)).astype(np.float32)
     labels = (rng.random((4, 4, 4, 4, 1)) > 0.5).astype(np.uint8)
-    _check_step(ctx, g, data, labels, seed=77)
+    _check_step(ctx, g, (4, 10, 10, 10, 1), labels, seed=77, data_seed=3)
 
 
 def test_adam_updates_match_oracle_over_steps(ctx):

@@ -115,3 +115,33 @@ def test_unet_output_is_shift_equivariant_only_mod_4():
     o0, o2, o4 = f(0), f(2), f(4)
     assert np.allclose(o0[0, 4:], o4[0, :-4], atol=1e-5)
     assert not np.allclose(o0[0, 2:], o2[0, :-2], atol=1e-3)
+
+
+def test_oracle_losses_known_answers():
+    """hand-derived values of the reference's losses (fplnetwork.py:74-77,
+    fplmodels.py:28-65) on a 4-voxel example: p = [.9, .2, .6, .3], y = [1, 0, 2, 1]"""
+    import math
+    import torch
+    from oracle import train_oracle
+    p = torch.tensor([0.9, 0.2, 0.6, 0.3], dtype=torch.float64).reshape(1, 1, 1, 4, 1)
+    y = torch.tensor([1.0, 0.0, 2.0, 1.0], dtype=torch.float64).reshape(1, 1, 1, 4, 1)
+    eps = 1e-7
+    # focal: -(1-pt)^2 log(pt + eps), masked voxel contributes 0, mean over all 4
+    pts = [0.9, 0.8, None, 0.3]
+    focal = sum(-(1 - q) ** 2 * math.log(q + eps) for q in pts if q is not None) / 4
+    assert abs(float(train_oracle.loss_value(p, y, 'masked_focal_loss')) - focal) < 1e-12
+    # masked BCE: masked voxel -> BCE(0 clipped to eps, 0) = -log(1 - eps)
+    bce = (-math.log(0.9) - math.log(0.8) - math.log(1 - eps) - math.log(0.3)) / 4
+    assert abs(float(train_oracle.loss_value(p, y, 'masked_binary_crossentropy')) - bce) < 1e-9
+    # weighted: positives x100
+    wbce = (-100 * math.log(0.9) - math.log(0.8) - math.log(1 - eps) - 100 * math.log(0.3)) / 4
+    got = float(train_oracle.loss_value(p, y, 'masked_weighted_binary_crossentropy'))
+    assert abs(got - wbce) < 1e-6
+    # plain BCE on {0,1} labels
+    y01 = torch.tensor([1.0, 0.0, 0.0, 1.0], dtype=torch.float64).reshape(p.shape)
+    b = (-math.log(0.9) - math.log(0.8) - math.log(0.4) - math.log(0.3)) / 4
+    assert abs(float(train_oracle.loss_value(p, y01, 'binary_crossentropy')) - b) < 1e-9
+    m = train_oracle.metric_values(p, y)
+    assert m['masked_accuracy'] == 0.75          # voxel 3 (p=.3, y=1) is the only miss
+    assert abs(m['lb0l1err'] - 0.2) < 1e-12 and abs(m['lb1l1err'] - (0.1 + 0.7) / 2) < 1e-12
+    assert m['acc'] == 0.5                        # label 2 never equals round(p)
