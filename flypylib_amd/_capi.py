@@ -80,6 +80,8 @@ SIGNATURES = {
     'fpl_trainer_get_grads': (C.c_int, [_vp, _vp, _i64]),
     'fpl_synth_volume_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _vp,
                                       C.c_int]),
+    'fpl_synth_substack_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _pi64, _vp, C.c_int]),
+    'fpl_histogram_u8': (C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(C.c_uint64)]),
     'fpl_timing_enable': (C.c_int, [_vp, C.c_int]),
     'fpl_timing_reset': (C.c_int, [_vp]),
     'fpl_timing_get': (C.c_int, [_vp, _vp, _vp, _vp, _i32, _pi32]),
@@ -204,6 +206,30 @@ class Context:
             _arr(origin, C.c_int64), _ptr(out), _mem_of(out)))
         return out
 
+    # ---- raw device memory (the pipeline keeps substacks / predictions resident)
+    def malloc(self, shape, dtype):
+        return DeviceBuffer(self, shape, dtype)
+
+    def memcpy(self, dst, src, nbytes):
+        self.check(self.lib.fpl_memcpy(self.h, _ptr(dst), _mem_of(dst), _ptr(src),
+                                       _mem_of(src), int(nbytes)))
+
+    def synth_substack_u8(self, seed, extent, dims, origin, out):
+        self.check(self.lib.fpl_synth_substack_u8(
+            self.h, C.c_uint64(int(seed)), _arr(extent, C.c_int64), _arr(dims, C.c_int64),
+            _arr(origin, C.c_int64), _ptr(out), _mem_of(out)))
+        return out
+
+    def histogram_u8(self, src, n=None):
+        if isinstance(src, np.ndarray):
+            src = np.ascontiguousarray(src, np.uint8)
+            n = src.size
+        elif n is None:
+            n = int(np.prod(src.shape))
+        out = (C.c_uint64 * 256)()
+        self.check(self.lib.fpl_histogram_u8(self.h, _ptr(src), _mem_of(src), int(n), out))
+        return np.array(out[:], np.int64)
+
     # ---- voxel2obj stages
     def v2o_smooth(self, pred, dims, r, weights, ranks):
         weights = np.ascontiguousarray(weights, np.float64)
@@ -227,6 +253,58 @@ class Context:
         out = np.empty(tuple(int(d) for d in pdims), np.float32)
         self.check(self.lib.fpl_v2o_copy_smoothed(self.h, _ptr(out), MEM_HOST))
         return out
+
+
+class DeviceBuffer:
+    """`shape` x `dtype` in the HBM of one context (fpl_malloc / fpl_free); accepted
+    wherever the bindings take a device array"""
+    is_cuda = True
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(d) for d in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = _vp()
+        ctx.check(ctx.lib.fpl_malloc(ctx.h, max(self.nbytes, 16), C.byref(p)))
+        self.ptr = p.value
+
+    def data_ptr(self):
+        return self.ptr
+
+    def view(self, shape, dtype=None):
+        """the leading bytes of this buffer under another shape (no copy)"""
+        v = object.__new__(DeviceBuffer)
+        v.ctx, v.ptr = self.ctx, self.ptr
+        v.shape = tuple(int(d) for d in shape)
+        v.dtype = np.dtype(dtype or self.dtype)
+        v.nbytes = int(np.prod(v.shape)) * v.dtype.itemsize
+        assert v.nbytes <= self.nbytes
+        v._base = self
+        return v
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        self.ctx.memcpy(out, self, self.nbytes)
+        return out
+
+    def from_host(self, a):
+        a = np.ascontiguousarray(a, self.dtype)
+        assert a.nbytes == self.nbytes
+        self.ctx.memcpy(self, a, self.nbytes)
+        return self
+
+    def free(self):
+        if getattr(self, 'ptr', None) and not hasattr(self, '_base') \
+                and getattr(self.ctx, 'h', None):
+            self.ctx.lib.fpl_free(self.ctx.h, _vp(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Program:

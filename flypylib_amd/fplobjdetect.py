@@ -199,3 +199,8 @@ def gen_batches(train_data, context_sz, batch_sz, is_mask=False, rng=None):
                 a[ii, :, :, :, 0] = v
         yield data, labels
         vi = (vi + 1) % len(vols)
+
+
+# the substack pipeline of the reference's fplobjdetect (fplobjdetect.py:841-1216)
+from .fplpipeline import (szyx, roi_from_txt, gen_full_tab_roi, fri_filename,  # noqa: E402,F401
+                          fri_get_image, full_roi_inference)

@@ -1,0 +1,343 @@
+"""Substack pipeline: `full_roi_inference` and its helpers
+(reference `flypylib/fplobjdetect.py:841-1216`).
+
+The reference streams substacks (size + 2*buffer cubes) out of DVID / DICED / n5,
+normalises each one on the host (`fri_get_image`), runs `network.infer` and hands
+the prediction to a forked `voxel2obj` worker, with one pickle per substack as
+the resume point.  Here a substack never leaves the GPU between those steps:
+
+    uint8 cube (HBM)  ->  histogram -> mn_use          (fpl_histogram_u8)
+                      ->  fpl_infer_volume(u8, mn_use, std) -> float32 prediction (HBM)
+                      ->  fpl_v2o_smooth / fpl_v2o_nms  -> points (host, a few KB)
+
+and only the point list and the normalisation record go back to the host.  The
+next substack's cube is cut (or synthesised) while the current one computes.
+File formats (ROI text, `<size>_<z>_<y>_<x>.p` pickles, `norm/*.txt`, `all.p`)
+are the reference's, so an interrupted run resumes and downstream tools read the
+results unchanged.
+
+Data sources.  DVID, DICED and n5 readers (`libdvid`, `diced`, `z5py`) are not
+available offline; `data_source` is instead
+  * an array-like `(Z,Y,X)` uint8 with numpy slicing (ndarray, `np.memmap`, ...),
+  * `'npy://<file>'` (opened with `np.load(mmap_mode='r')`), or
+  * `'synth://<seed>,<Z>,<Y>,<X>'`, the counter-hash EM volume of `synth.py`,
+    generated on the device substack by substack (nothing is stored);
+any other URL raises `NotImplementedError` naming the missing reader.
+Multi-GPU: one process per GPU (`torch.distributed` if initialised, else
+RANK/WORLD_SIZE); substacks go round-robin to ranks, no collective on the data
+path; rank 0 merges the per-substack pickles.
+"""
+import os
+import pickle
+import sys
+import threading
+from collections import namedtuple
+
+import numpy as np
+
+from . import fplobjdetect
+
+szyx = namedtuple('szyx', 'size z y x')          # fplobjdetect.py:24-25
+
+
+# ---- ROI text files (fplobjdetect.py:1172-1216) ------------------------------------
+def roi_from_txt(filename):
+    with open(filename, 'r') as f_in:
+        substacks = f_in.read().splitlines()
+    roi = []
+    for ss in substacks:
+        roi.append(szyx(*[int(nn) for nn in ss.split(',')]))
+    return [roi, ]
+
+
+def gen_full_tab_roi(filename, store_name, repo_uuid=None,
+                     crop=(None, None, None), n_splits=1, step_size=512):
+    """write '<filename>_%02d.txt' ROI files covering the volume in `step_size`
+    substacks, split into `n_splits` files (reference :1172-1208; `store_name` is
+    a data source as in `full_roi_inference`, whose extents start at 0)"""
+    extents = _open_source(store_name).extent
+    crop = [list(c) if c is not None else [0, int(e)] for c, e in zip(crop, extents)]
+    file_idx = 0
+    f_out = open('%s_%02d.txt' % (filename, file_idx), 'w')
+    count_idx = 0
+    max_count = int(np.ceil((
+        np.ceil((crop[0][1] - crop[0][0]) / float(step_size)) *
+        np.ceil((crop[1][1] - crop[1][0]) / float(step_size)) *
+        np.ceil((crop[2][1] - crop[2][0]) / float(step_size))) / n_splits))
+    for zz in range(crop[0][0], crop[0][1], step_size):
+        for yy in range(crop[1][0], crop[1][1], step_size):
+            for xx in range(crop[2][0], crop[2][1], step_size):
+                f_out.write('%d,%d,%d,%d\n' % (step_size, zz, yy, xx))
+                count_idx += 1
+                if count_idx == max_count:
+                    count_idx = 0
+                    file_idx += 1
+                    f_out.close()
+                    f_out = open('%s_%02d.txt' % (filename, file_idx), 'w')
+    f_out.close()
+
+
+def fri_filename(working_dir, substack):
+    return '%s/%d_%d_%d_%d.p' % (working_dir, substack.size,
+                                 substack.z, substack.y, substack.x)
+
+
+# ---- data sources ------------------------------------------------------------------
+class _ArraySource:
+    def __init__(self, arr):
+        assert len(arr.shape) == 3, 'volume must be (Z,Y,X)'
+        self.arr = arr
+        self.extent = tuple(int(s) for s in arr.shape)
+
+    def cube_host(self, origin, size):
+        """uint8 (size,)*3 cube at `origin`, zeros outside the extents; None if the
+        box does not meet the volume (reference :1053-1070)"""
+        lo = np.maximum(origin, 0)
+        hi = np.minimum(np.asarray(origin) + size, self.extent)
+        if np.any(lo > hi):
+            return None
+        image = np.zeros((size,) * 3, np.uint8)
+        image[lo[0] - origin[0]:hi[0] - origin[0],
+              lo[1] - origin[1]:hi[1] - origin[1],
+              lo[2] - origin[2]:hi[2] - origin[2]] = self.arr[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        return image
+
+
+
+class _SynthSource:
+    def __init__(self, seed, extent):
+        self.seed = int(seed)
+        self.extent = tuple(int(e) for e in extent)
+
+    def cube_host(self, origin, size):
+        from . import synth
+        lo = np.maximum(origin, 0)
+        hi = np.minimum(np.asarray(origin) + size, self.extent)
+        if np.any(lo > hi):
+            return None
+        image = np.zeros((size,) * 3, np.uint8)
+        if np.all(hi > lo):
+            image[lo[0] - origin[0]:hi[0] - origin[0],
+                  lo[1] - origin[1]:hi[1] - origin[1],
+                  lo[2] - origin[2]:hi[2] - origin[2]] = synth.em_volume_u8(
+                      self.seed, tuple(int(v) for v in hi - lo), tuple(int(v) for v in lo))
+        return image
+
+    def cube_device(self, ctx, origin, size, dst):
+        lo = np.maximum(origin, 0)
+        hi = np.minimum(np.asarray(origin) + size, self.extent)
+        if np.any(lo > hi):
+            return False
+        ctx.synth_substack_u8(self.seed, self.extent, (size,) * 3, origin, dst)
+        return True
+
+
+def _open_source(data_source):
+    if isinstance(data_source, (_ArraySource, _SynthSource)):
+        return data_source
+    if isinstance(data_source, str):
+        if data_source.startswith('npy://'):
+            return _ArraySource(np.load(data_source[6:], mmap_mode='r'))
+        if data_source.startswith('synth://'):
+            seed, z, y, x = (int(v) for v in data_source[8:].split(','))
+            return _SynthSource(seed, (z, y, x))
+        reader = ('z5py' if data_source.startswith('n5://') else
+                  'diced' if data_source.startswith('gs://') else 'libdvid')
+        raise NotImplementedError(
+            'data source %r needs %s, which is not installed; pass an array, '
+            "'npy://file' or 'synth://seed,Z,Y,X'" % (data_source, reader))
+    return _ArraySource(data_source)
+
+
+# ---- substack normalisation (fri_get_image, fplobjdetect.py:1088-1124) ----------------
+def normalisation_from_histogram(hist, image_normalize):
+    """-> dict(mn_use, global_frac, im_flt_mn, im_flt_std, im_raw_mn, im_raw_std).
+    np.mean of a uint8 array (and of its 1 < v < 200 subset) is the exact integer
+    sum over the count, so the 256-bin histogram reproduces it bit for bit."""
+    hist = np.asarray(hist, np.float64)
+    v = np.arange(256, dtype=np.float64)
+
+    def stats(h):
+        n = h.sum()
+        mn = (h * v).sum() / n
+        return mn, np.sqrt((h * (v - mn) ** 2).sum() / n)
+    im_raw_mn, im_raw_std = stats(hist)
+    flt = hist.copy()
+    flt[:2] = 0                       # image > 1
+    flt[200:] = 0                     # image < 200
+    if flt.sum() > 0:
+        im_flt_mn, im_flt_std = stats(flt)
+    else:
+        im_flt_mn, im_flt_std = image_normalize[0], image_normalize[1]
+    global_frac = 1. if len(image_normalize) < 3 else image_normalize[2]
+    mn_use = global_frac * image_normalize[0] + (1 - global_frac) * im_flt_mn
+    return dict(mn_use=mn_use, global_frac=global_frac, im_flt_mn=im_flt_mn,
+                im_flt_std=im_flt_std, im_raw_mn=im_raw_mn, im_raw_std=im_raw_std)
+
+
+def _write_norm(norm_dir, substack, buffer_sz, image_normalize, st):
+    norm_fn = '%s/%d_%d_%d_%d.txt' % (norm_dir, substack.size, substack.z,
+                                      substack.y, substack.x)
+    with open(norm_fn, 'w') as f_out:
+        f_out.write('%d,%d,%d,%d,%d,%g,%g,%g,%g,%g,%g,%g,%g\n' %
+                    (substack.size, buffer_sz, substack.z, substack.y, substack.x,
+                     image_normalize[0], image_normalize[1], st['global_frac'],
+                     st['mn_use'], st['im_flt_mn'], st['im_flt_std'],
+                     st['im_raw_mn'], st['im_raw_std']))
+
+
+def fri_get_image(substack_info, dvid_node, using_diced=True, instance_name='grayscale'):
+    """host form of the reference's reader (:1023-1124): -> (float32 normalised image
+    or None, substack).  `substack_info` = [substack, data_source, uuid,
+    image_normalize, buffer_sz, local_cache_dir, norm_dir, instance_name];
+    `dvid_node` is a data source (see module docstring).  `full_roi_inference`
+    does the same on the device and never materialises this array."""
+    substack, image_normalize, buffer_sz = substack_info[0], substack_info[3], substack_info[4]
+    norm_dir = substack_info[6]
+    src = _open_source(dvid_node)
+    image_sz = substack.size + 2 * buffer_sz
+    image_offset = [substack.z - buffer_sz, substack.y - buffer_sz, substack.x - buffer_sz]
+    image = src.cube_host(image_offset, image_sz)
+    if image is None:
+        return (None, substack)
+    st = normalisation_from_histogram(np.bincount(image.reshape(-1), minlength=256),
+                                      image_normalize)
+    image = (image.astype('float32') - np.float32(st['mn_use'])) / np.float32(image_normalize[1])
+    if norm_dir is not None:
+        _write_norm(norm_dir, substack, buffer_sz, image_normalize, st)
+    return (image, substack)
+
+
+# ---- the pipeline ------------------------------------------------------------------------
+def _rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size(), dist
+    except ImportError:
+        pass
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), None
+
+
+def full_roi_inference(data_source, dvid_uuid, dvid_roi,
+                       network, thd, working_dir,
+                       image_normalize,
+                       obj_min_dist=27, smoothing_sigma=5,
+                       buffer_sz=35, partition_size=16,
+                       local_cache_dir=None,
+                       roi_force_file=False,
+                       instance_name='grayscale',
+                       dvid_seg_info=None, precision=None, timings=None):
+    """Predictions of a trained network within the substacks of an ROI, cached per
+    substack in `working_dir` (reference :841-986; same arguments).  `dvid_roi` is
+    an ROI text file (`roi_from_txt`) or a list of `szyx`; `precision` overrides the
+    network's ('f32' / 'bf16').  Returns {'locs': (N,3) x/y/z, 'conf': (N,)} (all
+    ranks return the merged result once every rank's substacks are on disk)."""
+    if dvid_seg_info is not None:
+        raise NotImplementedError('segmentation-aware post-processing (SURVEY 8f-4)')
+    for d in (working_dir, '%s/norm' % working_dir):
+        os.makedirs(d, exist_ok=True)
+    norm_dir = '%s/norm' % working_dir
+    src = _open_source(data_source)
+    roi = roi_from_txt(dvid_roi) if isinstance(dvid_roi, str) else [[szyx(*r) for r in dvid_roi]]
+    rank, world, dist = _rank_world()
+
+    todo = []
+    num_processed = 0
+    for rr in roi[0]:
+        if os.path.isfile(fri_filename(working_dir, rr)):
+            num_processed += 1
+            continue
+        todo.append(szyx(rr.size, rr.z, rr.y, rr.x))
+    mine = todo[rank::world]
+    if rank == 0:
+        print('already processed: %d' % num_processed)
+        print('to process: %d' % len(todo))
+
+    assert network.infer_network is not None, 'network has not been trained'
+    prog = network.infer_network.program
+    ctx = prog.ctx
+    prec = fplobjdetect_precision(network, precision)
+    bufs = {}
+
+    def buffers(size):
+        if size not in bufs:
+            bufs[size] = (ctx.malloc((size,) * 3, np.uint8), ctx.malloc((size,) * 3, np.float32))
+        return bufs[size]
+
+    # host-side prefetch of the next cube (array sources); synthetic cubes are made
+    # on the device and need none
+    staged = {}
+
+    def stage(i):
+        if i < len(mine) and isinstance(src, _ArraySource):
+            ss = mine[i]
+            sz = ss.size + 2 * buffer_sz
+            staged[i] = src.cube_host([ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz], sz)
+
+    stage(0)
+    n_done = 0
+    for i, ss in enumerate(mine):
+        th = threading.Thread(target=stage, args=(i + 1,))
+        th.start()
+        image_sz = ss.size + 2 * buffer_sz
+        origin = [ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz]
+        cube, pred = buffers(image_sz)
+        if isinstance(src, _ArraySource):
+            image = staged.pop(i)
+            have = image is not None
+            if have:
+                cube.from_host(image)
+        else:
+            have = src.cube_device(ctx, origin, image_sz, cube)
+        if not have:
+            out = {'locs': np.zeros((0, 3)), 'conf': np.zeros(0)}
+        else:
+            st = normalisation_from_histogram(ctx.histogram_u8(cube), image_normalize)
+            _write_norm(norm_dir, ss, buffer_sz, image_normalize, st)
+            prog.infer_volume(cube, network.infer_sz, network.rf_offset,
+                              mean=st['mn_use'], std=image_normalize[1],
+                              precision=prec, dst=pred, dims=(image_sz,) * 3)
+            out = fplobjdetect.voxel2obj(
+                pred, obj_min_dist, smoothing_sigma,
+                (ss.x - buffer_sz, ss.y - buffer_sz, ss.z - buffer_sz),
+                buffer_sz, thd, device=ctx.device)
+        tmp_fn = fri_filename(working_dir, ss) + '.tmp%d' % rank
+        with open(tmp_fn, 'wb') as f_out:
+            pickle.dump(out, f_out)
+        os.replace(tmp_fn, fri_filename(working_dir, ss))     # a resume never sees half a file
+        th.join()
+        n_done += 1
+        if rank == 0 and sys.stdout.isatty():
+            sys.stdout.write('\r%d' % n_done)
+            sys.stdout.flush()
+    for cube, pred in bufs.values():
+        cube.free()
+        pred.free()
+    if timings is not None:
+        timings['substacks'] = n_done
+
+    if dist is not None and world > 1:
+        dist.barrier()
+    locs, conf = [], []
+    for rr in roi[0]:
+        ff = fri_filename(working_dir, rr)
+        if not os.path.isfile(ff):
+            if dist is None and world > 1:
+                continue              # another rank's substack, no rendezvous to wait on
+            raise RuntimeError('substack result %s is missing' % ff)
+        with open(ff, 'rb') as f_in:
+            obj = pickle.load(f_in)
+        locs.append(obj['locs'])
+        conf.append(obj['conf'])
+    obj = {'locs': np.concatenate(locs) if locs else np.zeros((0, 3)),
+           'conf': np.concatenate(conf) if conf else np.zeros(0)}
+    if rank == 0:
+        with open('%s/all.p' % working_dir, 'wb') as f_out:
+            pickle.dump(obj, f_out)
+    return obj
+
+
+def fplobjdetect_precision(network, precision):
+    from .fplnetwork import _PRECISIONS
+    return _PRECISIONS[precision or network.precision]

@@ -221,6 +221,18 @@ int fpl_trainer_get_grads(fpl_trainer *t, float *out, int64_t n_weights);
 int fpl_synth_volume_u8(fpl_ctx *ctx, uint64_t seed, const int64_t dims[3],
                         const int64_t origin[3], uint8_t *dst, int dst_mem);
 
+/* the same volume read as a substack + buffer: dims/origin may reach outside
+ * [0, extent); voxels there are 0, as fri_get_image pads (fplobjdetect.py:1044-1070) */
+int fpl_synth_substack_u8(fpl_ctx *ctx, uint64_t seed, const int64_t extent[3],
+                          const int64_t dims[3], const int64_t origin[3],
+                          uint8_t *dst, int dst_mem);
+
+/* ---- substack normalisation (fri_get_image, fplobjdetect.py:1088-1107) -------- */
+/* exact 256-bin histogram of a uint8 buffer; the raw / filtered (1 < v < 200) means
+ * the reference takes with np.mean are exact functions of it */
+int fpl_histogram_u8(fpl_ctx *ctx, const uint8_t *src, int src_mem, int64_t n,
+                     uint64_t out[256]);
+
 /* ---- timing ------------------------------------------------------------------ */
 /* per-kernel accumulated HIP-event time since the last reset.  Names are
  * NUL-terminated, up to `cap` entries of 64 bytes each. */

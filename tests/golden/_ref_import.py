@@ -20,6 +20,8 @@ def import_reference(path='/root/reference'):
         if name not in sys.modules:
             sys.modules[name] = mock.MagicMock()
     sys.modules['keras.callbacks'].Callback = object
+    # fri_get_image does isinstance(node, z5py.dataset.Dataset): needs a type
+    sys.modules['z5py'].dataset.Dataset = type('Dataset', (), {})
     sys.dont_write_bytecode = True
     if path not in sys.path:
         sys.path.insert(0, path)

@@ -150,7 +150,66 @@ def gen_infer():
     np.savez_compressed(os.path.join(HERE, 'infer_lattice.npz'), **out)
 
 
+# ---- fri_get_image (fplobjdetect.py:1023-1124): substack + buffer read, zero fill
+# outside the extents, normalisation by the interpolated filtered mean ---------------
+FRI_VOLUME = (11, (20, 24, 28))         # em_volume_u8 seed, shape
+# (name, size, z, y, x, buffer, image_normalize)
+FRI_CASES = [
+    ('interior', 8, 6, 8, 10, 4, [128., 33.]),
+    ('interior_frac', 8, 6, 8, 10, 4, [128., 33., 0.3]),
+    ('clip_low', 8, 0, 0, 0, 4, [120., 30., 0.5]),
+    ('clip_high', 8, 16, 16, 24, 4, [128., 33., 0.0]),
+    ('outside', 8, 200, 0, 0, 4, [128., 33.]),
+]
+
+
+def fri_volume():
+    """the synthetic EM volume with planted 0 / 1 / 200 / 255 voxels, so that the
+    1 < v < 200 filter of the normalisation matters"""
+    vol = synth.em_volume_u8(FRI_VOLUME[0], FRI_VOLUME[1])
+    vol[::5, ::3, ::7] = 0
+    vol[1::4, ::5, 2::3] = 255
+    vol[2::6, 1::4, ::5] = 1
+    vol[::7, 2::5, 1::3] = 200
+    return vol
+
+
+class _FakeNode:
+    """what the reference's DICED branch needs of an array: extents + slicing"""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def get_extents(self):
+        return [slice(0, s) for s in self.arr.shape]
+
+    def __getitem__(self, key):
+        return self.arr[key]
+
+
+def gen_fri_get_image():
+    import tempfile
+    vol = fri_volume()
+    out = {'volume_sha': np.array(sha(vol))}
+    with tempfile.TemporaryDirectory() as norm_dir:
+        for name, size, z, y, x, buf, norm in FRI_CASES:
+            ss = fplobjdetect.szyx(size, z, y, x)
+            info = [ss, 'gs://unused', 'uuid', norm, buf, None, norm_dir, 'grayscale']
+            image, ss_out = fplobjdetect.fri_get_image(info, _FakeNode(vol), True)
+            assert ss_out == ss
+            if image is None:
+                out[name + '/none'] = np.array(1)
+                continue
+            # numpy >= 2 makes this float64 (np.float64 mean); the reference's numpy
+            # 1.13 kept float32 - store the values, compare to float32 rounding
+            out[name + '/image'] = np.asarray(image, np.float64)
+            line = open('%s/%d_%d_%d_%d.txt' % (norm_dir, size, z, y, x)).read()
+            out[name + '/norm_line'] = np.array(line)
+    np.savez_compressed(os.path.join(HERE, 'fri_get_image.npz'), **out)
+
+
 if __name__ == '__main__':
+    gen_fri_get_image()
     gen_set_filter()
     gen_voxel2obj()
     gen_infer()

@@ -1,0 +1,177 @@
+"""Substack pipeline (reference fplobjdetect.py:841-1216): the host pieces and the
+oracle against the reference's own fri_get_image outputs (CPU), and the
+device-resident full_roi_inference against the oracle (GPU)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from flypylib_amd import fplobjdetect, fplpipeline, synth
+from oracle import pipeline_oracle
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'fri_get_image.npz'))
+FRI_VOLUME = (11, (20, 24, 28))
+FRI_CASES = [
+    ('interior', 8, 6, 8, 10, 4, [128., 33.]),
+    ('interior_frac', 8, 6, 8, 10, 4, [128., 33., 0.3]),
+    ('clip_low', 8, 0, 0, 0, 4, [120., 30., 0.5]),
+    ('clip_high', 8, 16, 16, 24, 4, [128., 33., 0.0]),
+    ('outside', 8, 200, 0, 0, 4, [128., 33.]),
+]
+
+
+def fri_volume():
+    vol = synth.em_volume_u8(FRI_VOLUME[0], FRI_VOLUME[1])
+    vol[::5, ::3, ::7] = 0
+    vol[1::4, ::5, 2::3] = 255
+    vol[2::6, 1::4, ::5] = 1
+    vol[::7, 2::5, 1::3] = 200
+    return vol
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize('case', FRI_CASES, ids=[c[0] for c in FRI_CASES])
+def test_fri_get_image_matches_the_reference(case, tmp_path):
+    name, size, z, y, x, buf, norm = case
+    vol = fri_volume()
+    assert _sha(vol) == str(GOLD['volume_sha'])
+    o_img, o_rec = pipeline_oracle.fri_get_image(vol, size, z, y, x, buf, norm, float32_math=False)
+    info = [fplobjdetect.szyx(size, z, y, x), 'unused', 'uuid', norm, buf, None,
+            str(tmp_path), 'grayscale']
+    h_img, ss = fplobjdetect.fri_get_image(info, vol)
+    assert ss == fplobjdetect.szyx(size, z, y, x)
+    if name + '/none' in GOLD:
+        assert o_img is None and h_img is None
+        return
+    ref = GOLD[name + '/image']
+    # oracle in the reference's arithmetic as run here (numpy 2: float64)
+    assert np.array_equal(np.asarray(o_img, np.float64), ref)
+    line = str(GOLD[name + '/norm_line'])
+    assert pipeline_oracle.norm_line(size, buf, z, y, x, norm, o_rec) == line
+    # the host function computes in float32 (the reference's numpy-1.13 semantics and
+    # what the device does): equal to the float64 result rounded, within one ulp
+    assert h_img.dtype == np.float32
+    # (mn_use ~ 128 rounds to float32 with up to 3.8e-6 error, / std)
+    np.testing.assert_allclose(h_img, ref, rtol=2e-7, atol=3e-7)
+    o32, _ = pipeline_oracle.fri_get_image(vol, size, z, y, x, buf, norm)
+    assert np.array_equal(h_img, o32)
+    got_line = open('%s/%d_%d_%d_%d.txt' % (tmp_path, size, z, y, x)).read()
+    assert got_line == line
+
+
+def test_normalisation_from_histogram_is_exact():
+    vol = fri_volume()
+    for norm in ([128., 33.], [100., 20., 0.25]):
+        st = fplpipeline.normalisation_from_histogram(np.bincount(vol.reshape(-1), minlength=256), norm)
+        idx = (vol < 200) & (vol > 1)
+        g = 1. if len(norm) < 3 else norm[2]
+        assert st['im_raw_mn'] == np.mean(vol) and st['im_flt_mn'] == np.mean(vol[idx])
+        assert st['mn_use'] == g * norm[0] + (1 - g) * np.mean(vol[idx])
+        assert abs(st['im_flt_std'] - np.std(vol[idx])) < 1e-9
+    empty = fplpipeline.normalisation_from_histogram(np.bincount([0, 1, 255], minlength=256), [5., 2., 0.5])
+    assert empty['im_flt_mn'] == 5. and empty['mn_use'] == 5.
+
+
+def test_roi_files_round_trip(tmp_path):
+    vol = np.zeros((100, 130, 64), np.uint8)
+    base = str(tmp_path / 'roi')
+    fplobjdetect.gen_full_tab_roi(base, vol, None, n_splits=2, step_size=48)
+    a = fplobjdetect.roi_from_txt(base + '_00.txt')[0]
+    b = fplobjdetect.roi_from_txt(base + '_01.txt')[0]
+    assert len(a) + len(b) == 3 * 3 * 2 and len(a) == 9
+    assert a[0] == fplobjdetect.szyx(48, 0, 0, 0) and a[1] == fplobjdetect.szyx(48, 0, 0, 48)
+    assert b[-1] == fplobjdetect.szyx(48, 96, 96, 48)
+    assert fplobjdetect.fri_filename('/w', a[1]) == '/w/48_0_0_48.p'
+    with pytest.raises(NotImplementedError, match='libdvid'):
+        fplobjdetect.gen_full_tab_roi(base, 'http://dvid:8000', 'uuid')
+    with pytest.raises(NotImplementedError, match='z5py'):
+        fplpipeline._open_source('n5://some/where')
+
+
+def test_synth_source_matches_the_host_generator():
+    src = fplpipeline._open_source('synth://7,40,50,60')
+    cube = src.cube_host([-4, 30, 50], 24)
+    ref = np.zeros((24, 24, 24), np.uint8)
+    ref[4:, :20, :10] = synth.em_volume_u8(7, (20, 20, 10), (0, 30, 50))
+    assert np.array_equal(cube, ref)
+    assert src.cube_host([41, 0, 0], 8) is None
+
+
+# ---- GPU --------------------------------------------------------------------------
+def _small_setup():
+    from flypylib_amd import FplNetwork, fplmodels
+    net = FplNetwork(fplmodels.vgg_like)
+    synth.synthetic_weights(net.train_single, 21)
+    net.infer_sz = (38, 38, 38)           # small tiles: 24^3 outputs
+    net._set_infer()
+    vol = synth.em_volume_u8(5, (70, 90, 80))
+    roi = [(32, z, y, x) for z in (0, 32, 64) for y in (0, 32, 64) for x in (0, 32, 64)]
+    roi.append((32, 400, 0, 0))            # outside the volume: an empty result
+    return net, vol, roi
+
+
+@pytest.mark.gpu
+def test_full_roi_inference_matches_the_oracle(ctx, tmp_path):
+    """device-resident pipeline vs the CPU oracle on a 70x90x80 volume cut into 28
+    substacks of 32 + buffer 10 (faces clipped, one substack outside): the fp32
+    predictions agree to 1e-5, and on each substack's device prediction the oracle's
+    voxel2obj returns the identical point list"""
+    from oracle import cnn_oracle
+    net, vol, roi = _small_setup()
+    wd = str(tmp_path / 'work')
+    kw = dict(obj_min_dist=5, smoothing_sigma=1.5, buffer_sz=10)
+    norm = [128., 33., 0.7]
+    got = fplobjdetect.full_roi_inference(vol, None, roi, net, 0.2, wd, norm, precision='f32', **kw)
+    assert os.path.isfile(wd + '/all.p') and os.path.isfile(wd + '/norm/32_0_0_0.txt')
+    graph = net.train_single
+
+    def predict(batch):
+        return cnn_oracle.graph_forward(graph, batch.astype(np.float32), upsample_stride=net.rf_stride)
+    # (a) end to end through the oracle CNN
+    want, per = pipeline_oracle.full_roi_inference(vol, roi, predict, net.infer_sz, net.rf_offset,
+                                                   0.2, norm, **kw)
+    assert got['locs'].shape == want['locs'].shape and got['locs'].shape[0] > 20
+    assert np.array_equal(got['locs'], want['locs'])
+    np.testing.assert_allclose(got['conf'], want['conf'], rtol=0, atol=2e-6)
+    # per-substack files hold the same as the oracle's per-substack results
+    for (size, z, y, x), o in per.items():
+        with open(fplobjdetect.fri_filename(wd, fplobjdetect.szyx(size, z, y, x)), 'rb') as f:
+            g = pickle.load(f)
+        assert np.array_equal(g['locs'], o['locs'])
+    # the norm record is the reference's line
+    _, rec = pipeline_oracle.fri_get_image(vol, 32, 0, 0, 0, 10, norm)
+    assert open(wd + '/norm/32_0_0_0.txt').read() == pipeline_oracle.norm_line(32, 10, 0, 0, 0, norm, rec)
+
+
+@pytest.mark.gpu
+def test_full_roi_inference_resumes_and_bf16_synth_source(ctx, tmp_path):
+    """(1) finished substacks are not recomputed (their pickles are read back);
+    (2) the synthetic device source + bf16 path give the oracle's points when the
+    oracle post-processes the device predictions (bit-exact voxel2obj)"""
+    net, vol, roi = _small_setup()
+    wd = str(tmp_path / 'work')
+    kw = dict(obj_min_dist=5, smoothing_sigma=1.5, buffer_sz=10)
+    norm = [128., 33.]
+    src = 'synth://5,70,90,80'
+    first = fplobjdetect.full_roi_inference(src, None, roi[:5], net, 0.2, wd, norm, precision='bf16', **kw)
+    # plant a marker in a finished substack: a resumed run must keep it
+    ff = fplobjdetect.fri_filename(wd, fplobjdetect.szyx(*roi[0]))
+    with open(ff, 'rb') as f:
+        obj = pickle.load(f)
+    obj['conf'] = obj['conf'] + 100.0
+    with open(ff, 'wb') as f:
+        pickle.dump(obj, f)
+    full = fplobjdetect.full_roi_inference(src, None, roi, net, 0.2, wd, norm, precision='bf16', **kw)
+    n0 = len(obj['conf'])
+    assert n0 > 0 and np.all(full['conf'][:n0] > 100.0) and np.all(full['conf'][n0:] < 2.0)
+    assert len(full['conf']) > len(first['conf'])
+    # same volume from the host array == the synthetic source (bit-identical generator)
+    wd2 = str(tmp_path / 'work2')
+    again = fplobjdetect.full_roi_inference(vol, None, roi, net, 0.2, wd2, norm, precision='bf16', **kw)
+    assert np.array_equal(again['locs'][n0:], full['locs'][n0:])
+    assert np.array_equal(again['conf'][n0:], full['conf'][n0:])

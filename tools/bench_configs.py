@@ -7,6 +7,9 @@
             reduced volume (the fp32 per-op path; size via --unet-size)
   train     configs[3] vgg_like training step, batch 32 of 64^3 patches (1 GPU)
   v2o       voxel2obj on a 582^3 substack-sized probability volume (r=27, sigma=5)
+  roi       configs[4] end to end: fplobjdetect.full_roi_inference over a synthetic
+            --roi-size^3 volume (512-substacks + 35 buffer), one substack's points
+            diffed against the CPU oracle
   pipeline  configs[4] shape at one substack: vgg_like bf16 inference of a 582^3
             substack + voxel2obj, detections diffed against the CPU oracle on the
             same prediction
@@ -30,6 +33,7 @@ def main():
     ap.add_argument('--what', default='unet,train,v2o,pipeline')
     ap.add_argument('--unet-size', type=int, default=264)
     ap.add_argument('--sub', type=int, default=582)
+    ap.add_argument('--roi-size', type=int, default=1536)
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
     import torch
@@ -134,6 +138,55 @@ def main():
                 detections_identical_to_cpu_oracle=bool(same),
                 cpu_oracle_v2o_s=t_cpu, cpu_oracle_mvox_s=n ** 3 / t_cpu / 1e6)
             print(json.dumps(res['pipeline_sub%d' % n]), flush=True)
+    if 'roi' in what:
+        # configs[4] end to end on one GPU: full_roi_inference over a synthetic
+        # volume cut into 512-substacks + 35 buffer (582^3 cubes), bf16, r 27, sigma 5
+        import pickle
+        import shutil
+        import tempfile
+        from flypylib_amd import FplNetwork
+        from oracle import voxel2obj_oracle
+        n = a.roi_size
+        net = FplNetwork(fplmodels.vgg_like, precision='bf16')
+        synth.synthetic_weights(net.train_single, 9)
+        net._set_infer()
+        wd = tempfile.mkdtemp(prefix='fri_')
+        src = 'synth://5,%d,%d,%d' % (n, n, n)
+        fplobjdetect.gen_full_tab_roi(wd + '/roi', src, None, step_size=512)
+        roi = fplobjdetect.roi_from_txt(wd + '/roi_00.txt')[0]
+        norm = [128., 33., 0.5]
+        fplobjdetect.full_roi_inference(src, None, roi[:1], net, 0.1, wd + '/warm', norm)
+        ctx.timing(True); ctx.timing_reset()
+        t0 = time.perf_counter()
+        out = fplobjdetect.full_roi_inference(src, None, wd + '/roi_00.txt', net, 0.1,
+                                              wd + '/work', norm)
+        dt = time.perf_counter() - t0
+        kern = {k: round(v['ms'], 2) for k, v in ctx.timing_get().items()}
+        ctx.timing(False)
+        # one substack re-derived and post-processed by the CPU oracle
+        ss = roi[len(roi) // 2]
+        sz = ss.size + 70
+        cube = ctx.malloc((sz,) * 3, np.uint8)
+        pred = ctx.malloc((sz,) * 3, np.float32)
+        ctx.synth_substack_u8(5, (n, n, n), (sz,) * 3, [ss.z - 35, ss.y - 35, ss.x - 35], cube)
+        from flypylib_amd import fplpipeline
+        st = fplpipeline.normalisation_from_histogram(ctx.histogram_u8(cube), norm)
+        net.infer_network.program.infer_volume(cube, net.infer_sz, net.rf_offset, mean=st['mn_use'],
+                                               std=norm[1], precision=_capi.PREC_BF16, dst=pred,
+                                               dims=(sz,) * 3)
+        t0 = time.perf_counter()
+        ref = voxel2obj_oracle.voxel2obj(pred.to_host(), 27, 5, (ss.x - 35, ss.y - 35, ss.z - 35), 35, 0.1)
+        t_cpu = time.perf_counter() - t0
+        got = pickle.load(open(fplobjdetect.fri_filename(wd + '/work', ss), 'rb'))
+        same = np.array_equal(ref['locs'], got['locs']) and np.array_equal(ref['conf'], got['conf'])
+        res['full_roi_inference_%d' % n] = dict(
+            substacks=len(roi), seconds=dt, mvox_s=n ** 3 / dt / 1e6,
+            detections=int(len(out['conf'])), checked_substack=list(ss),
+            checked_substack_detections=int(len(got['conf'])),
+            detections_identical_to_cpu_oracle=bool(same), cpu_oracle_v2o_s=t_cpu,
+            kernel_ms_total=kern)
+        print(json.dumps(res['full_roi_inference_%d' % n]), flush=True)
+        shutil.rmtree(wd, ignore_errors=True)
     if a.out:
         json.dump(res, open(a.out, 'w'), indent=1)
 
