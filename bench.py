@@ -171,9 +171,11 @@ def main():
     # (tools/profile_pmc.py; FETCH_SIZE doubled per the gfx950 correction) - only
     # valid for the workload size it was collected on
     traffic_by_kernel = {}
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_%d_%s.json'
-                            % (args.size, args.precision))
-    if world == 1 and os.path.exists(pmc_path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_%d_%s.json'
+                                          % (args.size, args.precision))))
+    pmc_path = cands[-1] if cands else ''       # the latest round's pass
+    if world == 1 and pmc_path:
         for k, v in json.load(open(pmc_path))['kernels'].items():
             if 'hbm_bytes_per_dispatch' in v:
                 traffic_by_kernel[k] = v['hbm_bytes_per_dispatch']
