@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256) void gauss_pass_win(
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t z, y, x, a0;
   if (AXIS == 0) {
+    // x fastest, then the blocks of one (y) row along z, then y: consecutive
+    // workgroups share their z halo planes of that row through L2
     if (tid >= nblk * P1 * P2) return;
-    x = tid % P2; y = (tid / P2) % P1; a0 = (tid / (P2 * P1)) * OUT; z = a0;
+    x = tid % P2; a0 = ((tid / P2) % nblk) * OUT; y = tid / (P2 * nblk); z = a0;
   } else if (AXIS == 1) {
     if (tid >= P0 * nblk * P2) return;
     x = tid % P2; a0 = ((tid / P2) % nblk) * OUT; z = tid / (P2 * nblk); y = a0;
@@ -95,15 +97,35 @@ __global__ __launch_bounds__(256) void gauss_pass_win(
   }
   double win[NW];
   const bool interior = a0 - WR >= 0 && a0 + OUT + WR <= PA;
+  if (AXIS == 0) {
+    // the (y, x) column of the unpadded prediction is fixed per thread: one bounds
+    // test and one base pointer, then a constant plane stride along z
+    const int64_t yy = y - pv.r, xx = x - pv.r;
+    const bool col_ok = yy >= 0 && xx >= 0 && yy < pv.D1 && xx < pv.D2;
+    const int64_t plane = pv.D1 * pv.D2;
+    const float *col = pv.pred + (col_ok ? yy * pv.D2 + xx : 0);
+    const int64_t z_lo = a0 - WR - pv.r;                 // unpadded z of win[0]
+    if (col_ok && interior && z_lo >= 0 && z_lo + NW <= pv.D0) {
+      const float *q = col + z_lo * plane;
 #pragma unroll
-  for (int i = 0; i < NW; ++i) {
-    int64_t p = a0 - WR + i;
-    if (!interior) p = reflect_idx(p, PA);
-    float v;
-    if (AXIS == 0) v = pv.at(p, y, x);
-    else if (AXIS == 1) v = in[(z * P1 + p) * P2 + x];
-    else v = in[(z * P1 + y) * P2 + p];
-    win[i] = (double)v;
+      for (int i = 0; i < NW; ++i) win[i] = (double)q[i * plane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        int64_t p = a0 - WR + i;
+        if (!interior) p = reflect_idx(p, PA);
+        const int64_t zz = p - pv.r;
+        win[i] = (col_ok && zz >= 0 && zz < pv.D0) ? (double)col[zz * plane] : 0.0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      int64_t p = a0 - WR + i;
+      if (!interior) p = reflect_idx(p, PA);
+      const float v = AXIS == 1 ? in[(z * P1 + p) * P2 + x] : in[(z * P1 + y) * P2 + p];
+      win[i] = (double)v;
+    }
   }
   double wk[WR + 1];
 #pragma unroll
@@ -125,9 +147,162 @@ __global__ __launch_bounds__(256) void gauss_pass_win(
   }
 }
 
+// x pass through LDS: a workgroup takes GX_ROWS (z,y) rows x GX_SEG outputs; each
+// row segment + 2*WR halo (reflected at the row ends) is loaded coalesced once, a
+// thread then reads its 4 + 2*WR inputs as aligned 16-B LDS pieces - one global
+// load per input instead of (4 + 2*WR) / 4 strided ones.  Arithmetic as gauss_pass;
+// the outer r shell is zeroed on store.
+constexpr int GX_ROWS = 8, GX_SEG = 128;
+
+__device__ __forceinline__ uint32_t float_key(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int WR>
+__global__ __launch_bounds__(256) void gauss_x_lds(
+    const float *__restrict__ in, float *__restrict__ out, int64_t P0, int64_t P1,
+    int64_t P2, const double *__restrict__ w, int r,
+    unsigned long long *__restrict__ hist11) {
+  constexpr int NW = 4 + 2 * WR;
+  constexpr int LROW = (GX_SEG + 2 * WR + 3) / 4 * 4 + 4;     // floats, 16-B multiple
+  __shared__ __attribute__((aligned(16))) float tile[GX_ROWS][LROW];
+  // first level of the radix select (top 11 key bits of every smoothed voxel),
+  // taken while the values are in registers: saves one scan of the volume
+  __shared__ unsigned int lh[2048];
+  const int t = threadIdx.x, rl = t >> 5, tx = t & 31;
+  for (int b = t; b < 2048; b += 256) lh[b] = 0u;
+  double wk[WR + 1];
+#pragma unroll
+  for (int j = 0; j <= WR; ++j) wk[j] = w[j];
+  const int64_t nseg = (P2 + GX_SEG - 1) / GX_SEG;
+  const int64_t nrows = P0 * P1;
+  const int64_t ntiles = ((nrows + GX_ROWS - 1) / GX_ROWS) * nseg;
+  for (int64_t tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
+    const int64_t seg0 = (tileid % nseg) * GX_SEG;
+    const int64_t row = (tileid / nseg) * GX_ROWS + rl;
+    __syncthreads();                       // previous tile consumed (and lh zeroed)
+    if (row < nrows) {
+      const float *src = in + row * P2;
+      for (int i = tx; i < GX_SEG + 2 * WR; i += 32) {
+        int64_t p = seg0 - WR + i;
+        if (p < 0 || p >= P2) p = reflect_idx(p, P2);
+        tile[rl][i] = src[p];
+      }
+    }
+    __syncthreads();
+    const int64_t x0 = seg0 + 4 * tx;
+    if (row >= nrows || x0 >= P2) continue;
+    double win[NW];
+#pragma unroll
+    for (int q = 0; q < (NW + 3) / 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(&tile[rl][4 * tx + 4 * q]);
+      if (4 * q + 0 < NW) win[4 * q + 0] = (double)v.x;
+      if (4 * q + 1 < NW) win[4 * q + 1] = (double)v.y;
+      if (4 * q + 2 < NW) win[4 * q + 2] = (double)v.z;
+      if (4 * q + 3 < NW) win[4 * q + 3] = (double)v.w;
+    }
+    const int64_t z = row / P1, y = row % P1;
+    const bool edge_zy = r > 0 && (z < r || y < r || z >= P0 - r || y >= P1 - r);
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double acc = __dmul_rn(win[WR + k], wk[0]);
+#pragma unroll
+      for (int j = WR; j >= 1; --j)
+        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
+      const int64_t x = x0 + k;
+      o[k] = (edge_zy || (r > 0 && (x < r || x >= P2 - r))) ? 0.f : (float)acc;
+    }
+    float *dst = out + row * P2 + x0;
+    if (x0 + 4 <= P2 && ((row * P2 + x0) & 3) == 0) {
+      *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (x0 + k < P2) dst[k] = o[k];
+    }
+    if (hist11) {
+      // runs of equal bins (zeros of the shell, flat regions) cost one atomic
+      uint32_t kb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) kb[k] = float_key(o[k]) >> 21;
+      const int nv = (int)(P2 - x0 < 4 ? P2 - x0 : 4);
+      // a wave whose 256 values share one bin (shell zeros, smooth regions): one atomic
+      const uint32_t first = __shfl(kb[0], 0);
+      const bool same = nv == 4 && kb[0] == first && kb[1] == first && kb[2] == first &&
+                        kb[3] == first;
+      if (__ballot(same) == ~0ull) {
+        if ((t & 63) == 0) atomicAdd(&lh[first], 256u);
+        continue;
+      }
+      int run = 1;
+#pragma unroll
+      for (int k = 1; k <= 4; ++k) {
+        if (k < nv && kb[k] == kb[k - 1]) { ++run; continue; }
+        if (k <= nv) atomicAdd(&lh[kb[k - 1]], (unsigned)run);
+        run = 1;
+      }
+    }
+  }
+  __syncthreads();
+  if (hist11)
+    for (int b = t; b < 2048; b += 256)
+      if (lh[b]) atomicAdd(&hist11[b], (unsigned long long)lh[b]);
+}
+
+// Compaction without global atomics: workgroup b scans elements [b*chunk, (b+1)*chunk)
+// and packs those whose key matches (key & mask) == want to the front of the same
+// range of `list` (as floats); counts[b] = how many.
+__global__ __launch_bounds__(256) void compact_prefix(
+    const float *__restrict__ v, int64_t n, int64_t chunk, uint32_t mask, uint32_t want,
+    float *__restrict__ list, unsigned int *__restrict__ counts) {
+  __shared__ unsigned int cnt;
+  if (threadIdx.x == 0) cnt = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  const int64_t hi = lo + chunk < n ? lo + chunk : n;
+  float *dst = list + lo;
+  for (int64_t i0 = lo; i0 < hi; i0 += 256) {
+    const int64_t i = i0 + threadIdx.x;
+    const float f = i < hi ? v[i] : 0.f;
+    const bool hit = i < hi && (float_key(f) & mask) == want;
+    const unsigned long long m = __ballot(hit);
+    if (m == 0ull) continue;
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(&cnt, (unsigned)__popcll(m));
+    base = __shfl(base, 0);
+    // a hit is written at or before its own position of the range (in-place safe
+    // even if list aliased v, which it does not)
+    if (hit) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = cnt;
+}
+
+// key_histogram over the compacted chunks
+__global__ __launch_bounds__(256) void key_histogram_chunks(
+    const float *__restrict__ list, const unsigned int *__restrict__ counts, int64_t chunk,
+    uint32_t mask, uint32_t want, int shift, int bits, unsigned long long *__restrict__ hist) {
+  __shared__ unsigned int lh[2048];
+  const int nb = 1 << bits;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) lh[b] = 0;
+  __syncthreads();
+  const float *src = list + (int64_t)blockIdx.x * chunk;
+  const unsigned int m = counts[blockIdx.x];
+  for (unsigned int i = threadIdx.x; i < m; i += blockDim.x) {
+    const uint32_t k = float_key(src[i]);
+    if ((k & mask) == want) atomicAdd(&lh[(k >> shift) & (nb - 1)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += blockDim.x)
+    if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
 template <int WR>
 void launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t P[3],
-                      const double *w_dev, int r) {
+                      const double *w_dev, int r, unsigned long long *hist11) {
   hipStream_t st = ctx->stream;
   {
     const int64_t n = ((P[0] + 7) / 8) * P[1] * P[2];
@@ -140,15 +315,11 @@ void launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_
     gauss_pass_win<1, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(pv, a, b, P[0], P[1], P[2], w_dev, r);
   }
   {
-    const int64_t n = P[0] * P[1] * ((P[2] + 3) / 4);
+    const int64_t ntiles = ceil_div64(P[0] * P[1], GX_ROWS) * ceil_div64(P[2], GX_SEG);
+    const int64_t nblk = std::min<int64_t>(ntiles, (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, "v2o_gauss_x");
-    gauss_pass_win<2, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(pv, b, a, P[0], P[1], P[2], w_dev, r);
+    gauss_x_lds<WR><<<(unsigned)nblk, 256, 0, st>>>(b, a, P[0], P[1], P[2], w_dev, r, hist11);
   }
-}
-
-__device__ __forceinline__ uint32_t float_key(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
 // histogram of `bits` key bits at `shift` over the elements whose key matches
@@ -342,14 +513,18 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
                               hipMemcpyHostToDevice, st));
   PadView pv{pred_dev, dims[0], dims[1], dims[2], r};
   const unsigned grid = (unsigned)ceil_div64(n_pad, 256);
+  // [0..2047] histogram, [2048] compaction counter
+  FPL_TRY(tmp.alloc(2049 * sizeof(unsigned long long), &p));
+  unsigned long long *hist_dev = (unsigned long long *)p;
+  FPL_HIP(ctx, hipMemsetAsync(hist_dev, 0, 2049 * sizeof(unsigned long long), st));
   // register-window kernels for the kernel radii flypylib's sigmas produce
   // (sigma 1.5, 2, 3, 5 at truncate 2.0); the plain kernel covers the rest
   bool windowed = true;
   switch (wr) {
-    case 3: launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
-    case 4: launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
-    case 6: launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
-    case 10: launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r); break;
+    case 3: launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    case 4: launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    case 6: launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    case 10: launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
     default: windowed = false;
   }
   if (!windowed) {
@@ -373,51 +548,82 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
   for (int a = 0; a < 3; ++a) S.pdims[a] = P[a];
   S.r = r;
 
-  // exact order statistics: 3-level radix select on the monotone float key
+  // exact order statistics: 3-level radix select (11 / 11 / 10 bits) on the monotone
+  // float key.  Level 0 comes out of the x pass; the elements of the selected
+  // level-0 bin are then compacted (one filtered scan) and levels 1-2 run on that
+  // short list.
   if (n_ranks > 0) {
     FPL_REQUIRE(ctx, rank_values, "fpl_v2o_smooth: rank_values is NULL");
-    FPL_TRY(tmp.alloc(2048 * sizeof(unsigned long long), &p));
-    unsigned long long *hist_dev = (unsigned long long *)p;
     std::vector<unsigned long long> hist(2048);
     std::vector<RankQuery> q(n_ranks);
     for (int i = 0; i < n_ranks; ++i) q[i] = RankQuery{ranks[i], 0u};
     const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
-    uint32_t mask = 0;
-    const unsigned hgrid = (unsigned)std::min<int64_t>(ceil_div64(n_pad, 256 * 8),
-                                                      (int64_t)ctx->n_cu * 16);
-    for (int lvl = 0; lvl < 3; ++lvl) {
-      std::vector<bool> done(n_ranks, false);
-      for (int i = 0; i < n_ranks; ++i) {
-        if (done[i]) continue;
+    auto hgrid_for = [&](int64_t n) {
+      return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(n, 256 * 8),
+                                                              (int64_t)ctx->n_cu * 16));
+    };
+    // compaction geometry: one chunk per workgroup
+    const int64_t cgrid = std::max<int64_t>(1, std::min<int64_t>(ceil_div64(n_pad, 4096),
+                                                                 (int64_t)ctx->n_cu * 16));
+    const int64_t chunk = ceil_div64(ceil_div64(n_pad, cgrid), 256) * 256;
+    const int64_t nchunks = ceil_div64(n_pad, chunk);
+    FPL_TRY(tmp.alloc((size_t)nchunks * sizeof(unsigned int), &p));
+    unsigned int *counts_dev = (unsigned int *)p;
+    // one level for the queries `idx` that share a prefix: histogram (already in
+    // hist_dev if `have`; of the compacted chunks if `chunks`), then rank -> bin
+    auto resolve = [&](int lvl, uint32_t mask, const std::vector<int> &idx, bool have,
+                       bool chunks) -> int {
+      const uint32_t pref = q[idx[0]].prefix;
+      if (!have) {
         FPL_HIP(ctx, hipMemsetAsync(hist_dev, 0, 2048 * sizeof(unsigned long long), st));
-        {
-          TimedLaunch tl(ctx, "v2o_key_histogram");
-          key_histogram<<<hgrid ? hgrid : 1, 256, 0, st>>>(
-              S.smoothed, n_pad, mask, q[i].prefix, shifts[lvl], nbits[lvl],
-              hist_dev);
-        }
-        FPL_HIP(ctx, hipMemcpyAsync(hist.data(), hist_dev,
-                                    2048 * sizeof(unsigned long long),
-                                    hipMemcpyDeviceToHost, st));
-        FPL_HIP(ctx, hipStreamSynchronize(st));
-        const uint32_t pref = q[i].prefix;
-        for (int j = i; j < n_ranks; ++j) {
-          if (done[j] || q[j].prefix != pref) continue;
-          int64_t k = q[j].rank;
-          int b = 0;
-          const int nb = 1 << nbits[lvl];
-          for (; b < nb; ++b) {
-            if (k < (int64_t)hist[b]) break;
-            k -= (int64_t)hist[b];
-          }
-          FPL_REQUIRE(ctx, b < nb, "fpl_v2o_smooth: radix select ran off the "
-                                   "histogram (NaN in the volume?)");
-          q[j].rank = k;
-          q[j].prefix = pref | ((uint32_t)b << shifts[lvl]);
-          done[j] = true;
-        }
+        TimedLaunch tl(ctx, "v2o_key_histogram");
+        if (chunks)
+          key_histogram_chunks<<<(unsigned)nchunks, 256, 0, st>>>(
+              scratch, counts_dev, chunk, mask, pref, shifts[lvl], nbits[lvl], hist_dev);
+        else
+          key_histogram<<<hgrid_for(n_pad), 256, 0, st>>>(S.smoothed, n_pad, mask, pref,
+                                                          shifts[lvl], nbits[lvl], hist_dev);
       }
-      mask |= (uint32_t)((1u << nbits[lvl]) - 1) << shifts[lvl];
+      FPL_HIP(ctx, hipMemcpyAsync(hist.data(), hist_dev, 2048 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, st));
+      FPL_HIP(ctx, hipStreamSynchronize(st));
+      const int nb = 1 << nbits[lvl];
+      for (int j : idx) {
+        int64_t k = q[j].rank;
+        int b = 0;
+        for (; b < nb; ++b) {
+          if (k < (int64_t)hist[b]) break;
+          k -= (int64_t)hist[b];
+        }
+        FPL_REQUIRE(ctx, b < nb, "fpl_v2o_smooth: radix select ran off the histogram "
+                                 "(NaN in the volume?)");
+        q[j].rank = k;
+        q[j].prefix = pref | ((uint32_t)b << shifts[lvl]);
+      }
+      return 0;
+    };
+    auto groups_of = [&](const std::vector<int> &idx) {
+      std::vector<std::vector<int>> g;
+      for (int j : idx) {
+        bool placed = false;
+        for (auto &v : g)
+          if (q[v[0]].prefix == q[j].prefix) { v.push_back(j); placed = true; break; }
+        if (!placed) g.push_back({j});
+      }
+      return g;
+    };
+    std::vector<int> all(n_ranks);
+    for (int i = 0; i < n_ranks; ++i) all[i] = i;
+    FPL_TRY(resolve(0, 0u, all, windowed, false));
+    const uint32_t mask0 = 0x7FFu << 21, mask1 = mask0 | (0x7FFu << 10);
+    for (auto &grp : groups_of(all)) {
+      {
+        TimedLaunch tl(ctx, "v2o_compact_bin");
+        compact_prefix<<<(unsigned)nchunks, 256, 0, st>>>(S.smoothed, n_pad, chunk, mask0,
+                                                          q[grp[0]].prefix, scratch, counts_dev);
+      }
+      FPL_TRY(resolve(1, mask0, grp, false, true));
+      for (auto &g2 : groups_of(grp)) FPL_TRY(resolve(2, mask1, g2, false, true));
     }
     for (int i = 0; i < n_ranks; ++i) {
       const uint32_t k = q[i].prefix;
