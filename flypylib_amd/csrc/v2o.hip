@@ -357,35 +357,46 @@ __global__ void build_live(const float *__restrict__ s, int64_t P0, int64_t P1,
   live[i] = k;
 }
 
-// best live key per 4x4x4 cell: (value bits << 32) | ~flat_index(padded volume)
+// best live key per 4x4x4 cell: (value bits << 32) | ~flat_index(padded volume).
+// After the first round only the cells a cleared ball touched (marked CELL_DIRTY by
+// clear_balls) are re-scanned; the others keep their key.
+constexpr unsigned long long CELL_DIRTY = 1ull;    // no live key has value bits 0
+
 __global__ void cell_best(const uint32_t *__restrict__ live, int64_t L1,
                           int64_t L2, int64_t P1, int64_t P2, int64_t C0,
                           int64_t C1, int64_t C2,
                           unsigned long long *__restrict__ best,
-                          unsigned long long *__restrict__ counters) {
+                          unsigned long long *__restrict__ counters, int first_round) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C0 * C1 * C2) return;
-  const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
+  const bool in = c < C0 * C1 * C2;
   unsigned long long b = 0;
+  if (in) {
+    b = first_round ? CELL_DIRTY : best[c];
+    if (b == CELL_DIRTY) {
+      b = 0;
+      const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
 #pragma unroll
-  for (int dz = 0; dz < CELL; ++dz)
+      for (int dz = 0; dz < CELL; ++dz)
 #pragma unroll
-    for (int dy = 0; dy < CELL; ++dy) {
-      const int64_t z = cz * CELL + dz, y = cy * CELL + dy;
-      const uint4 q =
-          *reinterpret_cast<const uint4 *>(live + (z * L1 + y) * L2 + cx * CELL);
-      const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+        for (int dy = 0; dy < CELL; ++dy) {
+          const int64_t z = cz * CELL + dz, y = cy * CELL + dy;
+          const uint4 q =
+              *reinterpret_cast<const uint4 *>(live + (z * L1 + y) * L2 + cx * CELL);
+          const uint32_t v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-      for (int dx = 0; dx < CELL; ++dx)
-        if (v[dx]) {
-          const uint32_t flat = (uint32_t)((z * P1 + y) * P2 + cx * CELL + dx);
-          const unsigned long long k =
-              ((unsigned long long)v[dx] << 32) | (0xFFFFFFFFu - flat);
-          b = k > b ? k : b;
+          for (int dx = 0; dx < CELL; ++dx)
+            if (v[dx]) {
+              const uint32_t flat = (uint32_t)((z * P1 + y) * P2 + cx * CELL + dx);
+              const unsigned long long k =
+                  ((unsigned long long)v[dx] << 32) | (0xFFFFFFFFu - flat);
+              b = k > b ? k : b;
+            }
         }
+      best[c] = b;
     }
-  best[c] = b;
-  if (b) atomicAdd(&counters[0], 1ull);
+  }
+  const unsigned long long m = __ballot(in && b != 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[0], (unsigned long long)__popcll(m));
 }
 
 template <int AXIS>
@@ -430,7 +441,8 @@ __global__ void pick_winners(const unsigned long long *__restrict__ best,
 __global__ __launch_bounds__(256) void clear_balls(
     const unsigned long long *__restrict__ round_list,
     const unsigned long long *__restrict__ counters, uint32_t *__restrict__ live,
-    int64_t L1, int64_t L2, int64_t P1, int64_t P2, int r) {
+    int64_t L1, int64_t L2, int64_t P1, int64_t P2, int r,
+    unsigned long long *__restrict__ best, int64_t C1, int64_t C2) {
   const unsigned long long nwin = counters[1];
   for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
     const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(round_list[wi] & 0xFFFFFFFFu);
@@ -446,6 +458,15 @@ __global__ __launch_bounds__(256) void clear_balls(
       while (hx * hx > rem) --hx;
       uint32_t *rowp = live + ((z + dz) * L1 + (y + dy)) * L2 + x;
       for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0;
+    }
+    // cells of the ball's bounding box lose their cached key (the r shell of the
+    // padded volume keeps every ball inside it)
+    const int64_t cz0 = (z - r) / CELL, cy0 = (y - r) / CELL, cx0 = (x - r) / CELL;
+    const int nz = (int)((z + r) / CELL - cz0 + 1), ny = (int)((y + r) / CELL - cy0 + 1),
+              nx = (int)((x + r) / CELL - cx0 + 1);
+    for (int i = threadIdx.x; i < nz * ny * nx; i += blockDim.x) {
+      const int64_t cz = cz0 + i / (ny * nx), cy = cy0 + (i / nx) % ny, cx = cx0 + i % nx;
+      best[(cz * C1 + cy) * C2 + cx] = CELL_DIRTY;
     }
   }
 }
@@ -698,7 +719,7 @@ int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
     {
       TimedLaunch tl(ctx, "v2o_cell_best");
       cell_best<<<cgrid, 256, 0, st>>>(live, L1, L2, P1, P2, C0, C1, C2, best,
-                                       counters);
+                                       counters, rounds == 0);
     }
     {
       TimedLaunch tl(ctx, "v2o_window_max");
@@ -714,7 +735,7 @@ int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
     {
       TimedLaunch tl(ctx, "v2o_clear_balls");
       clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, L1, L2, P1, P2,
-                                        r);
+                                        r, best, C1, C2);
     }
     FPL_HIP(ctx, hipGetLastError());
     FPL_HIP(ctx, hipMemcpyAsync(host_cnt, counters, 4 * 8, hipMemcpyDeviceToHost, st));
