@@ -1,20 +1,21 @@
 // Generic bf16 MFMA convolution kernels (channels-last, batched tiles) and the
 // fused-op executor for unet_like2 inference (flypylib/fplmodels.py:258-304).
 //
-//   stem_cin1_bf16<COUT>      conv3 1->COUT + shift + ReLU          (f32 in, bf16 out)
-//   conv3_bf16<CC, MB>        conv3 CIN->16*MB, CIN = ncc chunks of CC channels,
+//   conv3_bf16<MB, PF, STEM>  conv3 CIN->16*MB, CIN = ncc chunks of 32 channels,
 //                             input = concat of sources, each optionally nearest-
 //                             upsampled x2 or cropped (UpSampling3D / Cropping3D /
-//                             concatenate become an index remap in the tile loader)
+//                             concatenate become an index remap in the tile loader);
+//                             STEM: the source is conv3 1->32 of the raw f32 tiles,
+//                             computed straight into the LDS tile
 //   conv1_bf16<CIN, MB, TAIL> 1x1x1 conv as a voxel GEMM; TAIL chains a second
 //                             1x1 conv to one sigmoid channel in registers
 //   pool2_bf16                MaxPooling3D(2)
 //
-// conv3_bf16 follows vgg_mid (vgg_fused.hip): 4 waves, output block 4 x 4 x 16,
-// wave = z, sub-steps = y, lanes = x; activation tile (6 x 6 x 18 voxels, 96 B
-// pitch, one CC-channel chunk at a time) in LDS; flat k = (tap, channel) so a
-// lane's B fragment is one ds_read_b128; weight fragments stream through a 2-slot
-// LDS ring staged through registers; <= 80 KiB LDS so two workgroups share a CU.
+// conv3_bf16: 4 waves, output block 4 x 4 x 16, wave = z, sub-steps = y, lanes = x;
+// persistent over blocks; planar activation tile (6 x 6 x 18 voxels, one 32-channel
+// chunk at a time) in LDS; K order (chunk, dz, dx, dy) with y-row fragment reuse;
+// weight fragments stream through a 2-slot LDS ring staged through registers;
+// <= 80 KiB LDS so two workgroups share a CU.  Details at the kernel.
 #include <algorithm>
 
 #include "fast_paths.h"
@@ -111,6 +112,11 @@ struct Conv3Args {
   __bf16 *out;                   // (n, OD, OH, OW, 16*MB)
   int OD, OH, OW, zblocks;       // zblocks = ceil(OD/4)
   int nbx, nby, nbz;             // blocks: ceil(OW/16), ceil(OH/4), n * zblocks
+  // STEM variant: the (single) source is conv3 1->32 + shift + ReLU of this raw
+  // (n, T, T, T) f32 volume, computed into the tile instead of being read
+  const float *raw; int T;
+  const bf16x8 *wstem;           // 2 fragments (SLOT_STEM, interleaved rows)
+  const float *shstem;
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -129,13 +135,26 @@ struct Conv3Args {
 // LDS - a fetch is one ds_read_b32 and one saddr+voffset global load per piece, no
 // per-piece index arithmetic or clamping.  Reads past a source's edge land in its
 // neighbouring rows / the slack and only ever feed masked output voxels.
-template <int MB, bool PF>
+//
+// STEM (unet_like2's first pair conv3 1->32, conv3 32->32): the 32-channel tile is
+// not read but COMPUTED from the raw (TZ+2, TY+2, TX+2) f32 tile - 41 groups of 16
+// tile voxels, two MFMAs each (27 taps in one K-step); with interleaved weight rows
+// a lane's 8 outputs are exactly one 16-B piece of plane g.  The 98^3 x 32 stem
+// output (44 GB per 729 tiles) never exists in HBM.
+constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
+constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
+
+template <int MB, bool PF, bool STEM = false>
 __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
+  static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
+  static_assert(NRAW % 256 == 0, "raw tile pieces per thread");
   constexpr int RING = KC * MB * 1024;
   constexpr int ROW = TX * PITCH;
   unsigned char *tile = smem;
   unsigned char *ring = smem + TILE_BYTES;
   unsigned *offtab = reinterpret_cast<unsigned *>(smem + TILE_BYTES + 2 * RING);
+  // STEM: [0, TABN) = raw-tile offset of tile voxel v; then the bf16 raw tile
+  unsigned short *rawt = reinterpret_cast<unsigned short *>(offtab + TABN);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int G = (int)gridDim.x;                     // multiple of 8 (host)
@@ -150,7 +169,14 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   // piece of 8 consecutive voxels (a conflict-free 128-B LDS store) and a wave still
   // reads 1 KiB contiguous.  offtab[t][v] = byte offset of tile voxel v in a source
   // of geometry t.
-  for (int t = 0; t < a.ntab; ++t) {
+  if (STEM) {
+    for (int i = tid; i < TABN; i += 256) {
+      const int vox = i < TZ * TY * TX ? i : TZ * TY * TX - 1;
+      const int tz = vox / (TY * TX), ty = (vox / TX) % TY, tx = vox % TX;
+      offtab[i] = (unsigned)((tz * RY + ty) * RX + tx);
+    }
+  }
+  for (int t = 0; t < (STEM ? 0 : a.ntab); ++t) {
     const int H = a.tabH[t], W = a.tabW[t], C = a.tabC[t], U = a.tabU[t];
     for (int i = tid; i < TABN; i += 256) {
       const int vox = i < TZ * TY * TX ? i : TZ * TY * TX - 1;
@@ -160,22 +186,77 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   }
   const int vox0 = (tid >> 5) * 8 + (tid & 7);
   const unsigned pc = (unsigned)((tid >> 3) & 3);
-  u32x4 nt[NT];
+  u32x4 nt[STEM ? 1 : NT];
+  float rawv[STEM ? NRAW / 256 : 1];
   auto fetch = [&](int64_t fb, int cc) {
-    const Src s = a.src[cc];
     const int bx = (int)(fb % a.nbx), by = (int)((fb / a.nbx) % a.nby);
     const int bz = (int)(fb / ((int64_t)a.nbx * a.nby));
     const int n = bz / a.zblocks;
+    if (STEM) {
+      const int z0 = (bz % a.zblocks) * 4, y0 = by * 4, x0 = bx * 16;
+      const float *base = a.raw + (int64_t)n * a.T * a.T * a.T;
+#pragma unroll
+      for (int j = 0; j < NRAW / 256; ++j) {
+        const int p = tid + 256 * j;
+        int z = z0 + p / (RY * RX), y = y0 + (p / RX) % RY, x = x0 + p % RX;
+        z = z < a.T ? z : a.T - 1;                 // clamped reads only feed masked
+        y = y < a.T ? y : a.T - 1;                 // outputs
+        x = x < a.T ? x : a.T - 1;
+        rawv[j] = base[((int64_t)z * a.T + y) * a.T + x];
+      }
+      return;
+    }
+    const Src s = a.src[cc];
     const int z0 = ((bz % a.zblocks) * 4 + s.crop) >> s.ups;
     const int y0 = (by * 4 + s.crop) >> s.ups, x0 = (bx * 16 + s.crop) >> s.ups;
     const unsigned char *base = reinterpret_cast<const unsigned char *>(
         s.p + ((((int64_t)n * s.D + z0) * s.H + y0) * s.W + x0) * s.C + s.ch0);
     const unsigned *tab = offtab + s.tab * TABN + vox0;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < (STEM ? 1 : NT); ++j)
       nt[j] = *reinterpret_cast<const u32x4 *>(base + (tab[64 * j] + pc * 16));
   };
+  // STEM: lane constants of the gather (tap 8g+j of the 27, k-slots 27..31 unused)
+  int toff[8];
+  bf16x8 wsf[2];
+  f32x4 shs[2];
+  if (STEM) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 8 * g + j;
+      toff[j] = t < 27 ? ((t / 9) * RY + (t / 3) % 3) * RX + t % 3 : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      wsf[b] = a.wstem[b * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) shs[b][r] = a.shstem[8 * g + 4 * b + r];
+    }
+  }
   auto put = [&]() {
+    if (STEM) {
+#pragma unroll
+      for (int j = 0; j < NRAW / 256; ++j) rawt[tid + 256 * j] = bf16_bits(rawv[j]);
+      __syncthreads();                              // raw tile visible
+      constexpr int NGRP = (TZ * TY * TX + 15) / 16;
+      for (int grp = wave; grp < NGRP; grp += 4) {
+        const int v = 16 * grp + c;
+        const unsigned ro = offtab[v];              // TABN >= 16 * NGRP, tail clamped
+        u16x8 rw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rw[j] = rawt[ro + toff[j]];
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, rw);
+        const f32x4 a0 = mfma16(wsf[0], bf, shs[0]);
+        const f32x4 a1 = mfma16(wsf[1], bf, shs[1]);
+        u32x4 o;
+        o[0] = pk_max_i16(cvt_pk_bf16(a0[0], a0[1]), 0u);
+        o[1] = pk_max_i16(cvt_pk_bf16(a0[2], a0[3]), 0u);
+        o[2] = pk_max_i16(cvt_pk_bf16(a1[0], a1[1]), 0u);
+        o[3] = pk_max_i16(cvt_pk_bf16(a1[2], a1[3]), 0u);
+        if (v < TZ * TY * TX) *reinterpret_cast<u32x4 *>(tile + g * PLANE + v * PITCH) = o;
+      }
+      return;
+    }
     unsigned char *dst = tile + pc * PLANE + vox0 * PITCH;
 #pragma unroll
     for (int j = 0; j < NT - 1; ++j) *reinterpret_cast<u32x4 *>(dst + 64 * j * PITCH) = nt[j];
@@ -288,64 +369,6 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
     }
     blk += G;
     if (blk >= total_blocks) break;
-  }
-}
-
-// ---- conv3 1 -> 16*MB (+shift, ReLU): f32 (n,D,H,W) in, bf16 channels-last out ----
-constexpr int ST_Z = 4, ST_Y = 8, ST_X = 64;
-constexpr int ST_TZ = ST_Z + 2, ST_TY = ST_Y + 2, ST_TX = ST_X + 2;
-
-struct StemArgs1 {
-  const float *in; int D, H, W;
-  const bf16x8 *w;               // MB fragments (SLOT_STEM)
-  const float *shift;
-  __bf16 *out; int OD, OH, OW, zblocks;
-};
-
-template <int MB>
-__global__ __launch_bounds__(256) void stem_cin1_bf16(StemArgs1 a) {
-  __shared__ unsigned short tile[ST_TZ * ST_TY * ST_TX];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  const int x0 = blockIdx.x * ST_X, y0 = blockIdx.y * ST_Y;
-  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * ST_Z;
-  for (int i = tid; i < ST_TZ * ST_TY * ST_TX; i += 256) {
-    const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
-    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-    float v = 0.f;
-    if (z < a.D && y < a.H && x < a.W) v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
-    tile[i] = bf16_bits(v);
-  }
-  int toff[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int t = 8 * g + j;
-    toff[j] = t < 27 ? ((t / 9) * ST_TY + (t / 3) % 3) * ST_TX + t % 3 : 0;
-  }
-  bf16x8 w[MB];
-  f32x4 sh[MB];
-#pragma unroll
-  for (int b = 0; b < MB; ++b) {
-    w[b] = a.w[b * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh[b][r] = a.shift[4 * MB * g + 4 * b + r];
-  }
-  __syncthreads();
-  for (int task = wave; task < ST_Z * ST_Y * (ST_X / 16); task += 4) {
-    const int xg = task % (ST_X / 16), yl = (task / (ST_X / 16)) % ST_Y, zl = task / (ST_X / 16 * ST_Y);
-    const int base = (zl * ST_TY + yl) * ST_TX + 16 * xg + c;
-    u16x8 raw;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) raw[j] = tile[base + toff[j]];
-    const bf16x8 bf = __builtin_bit_cast(bf16x8, raw);
-    const int oz = z0 + zl, oy = y0 + yl, ox = x0 + 16 * xg + c;
-    const bool ok = oz < a.OD && oy < a.OH && ox < a.OW;
-    f32x4 acc[MB];
-#pragma unroll
-    for (int b = 0; b < MB; ++b) acc[b] = mfma16(w[b], bf, sh[b]);
-    if (ok)
-      store_il<MB, true>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB),
-                         g, acc, 1);
   }
 }
 
@@ -546,20 +569,21 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
   return 0;
 }
 
-template <int MB>
+template <int MB, bool STEM = false>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   constexpr bool PF = true;
-  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024 + TAB_BYTES;
+  // STEM keeps the bf16 raw tile behind the (single) offset table
+  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024 + (STEM ? TABN * 4 + NRAW * 2 : TAB_BYTES);
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<MB, PF>,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<MB, PF, STEM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
   }
   // offset tables: one per distinct source geometry
   a.ntab = 0;
-  for (int i = 0; i < a.ncc; ++i) {
+  for (int i = 0; i < (STEM ? 0 : a.ncc); ++i) {
     Src &s = a.src[i];
     FPL_REQUIRE(ctx, !(s.ups && s.crop), "conv3_bf16: crop of an upsampled source");
     FPL_REQUIRE(ctx, s.crop % 2 == 0, "conv3_bf16: odd crop");
@@ -580,7 +604,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * 2, (total + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
-  conv3_bf16<MB, PF><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
+  conv3_bf16<MB, PF, STEM><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
 
@@ -619,8 +643,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     *p = (__bf16 *)q;
     return rc;
   };
-  __bf16 *c1a, *c1, *p1, *c2a, *c2, *p2, *c3, *c4a, *c4, *c5a;
-  FPL_TRY(balloc(n * cube(d1a) * 32, d1a, 32, &c1a));
+  __bf16 *c1, *p1, *c2a, *c2, *p2, *c3, *c4a, *c4, *c5a;
   FPL_TRY(balloc(n * cube(d1) * 32, d1, 32, &c1));
   FPL_TRY(balloc(n * cube(dp1) * 32, dp1, 32, &p1));
   FPL_TRY(balloc(n * cube(d2a) * 64, d2a, 64, &c2a));
@@ -631,19 +654,11 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
   FPL_TRY(balloc(n * cube(d4a) * 64, d4a, 64, &c4));
   FPL_TRY(balloc(n * cube(d5a) * 32, d5a, 32, &c5a));
   hipStream_t stm = ctx->stream;
-  {  // L0: conv3 1->32
-    StemArgs1 a;
-    a.in = in; a.D = a.H = a.W = T;
-    a.w = (const bf16x8 *)(F + st->off_w[0]); a.shift = S + st->off_s[0];
-    a.out = c1a; a.OD = a.OH = a.OW = d1a; a.zblocks = (int)ceil_div64(d1a, ST_Z);
-    dim3 grid((unsigned)ceil_div64(d1a, ST_X), (unsigned)ceil_div64(d1a, ST_Y), (unsigned)(n * a.zblocks));
-    TimedLaunch tl(ctx, "unet_stem_bf16");
-    stem_cin1_bf16<2><<<grid, 256, 0, stm>>>(a);
-  }
   auto conv3_args = [&](int l, __bf16 *outp, int od) {
     Conv3Args a;
     a.w = F + st->off_w[l]; a.shift = S + st->off_s[l]; a.relu = 1;
     a.out = outp; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
+    a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr;
     return a;
   };
   auto pool = [&](const __bf16 *x, __bf16 *y, int d, int C) {
@@ -652,10 +667,12 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     TimedLaunch tl(ctx, "unet_pool_bf16");
     pool2_bf16<<<(unsigned)ceil_div64(n8, 256), 256, 0, stm>>>(x, y, n8, d, d, d, C / 8, od, od, od);
   };
-  {  // L1: conv3 32->32
+  {  // L0 + L1: conv3 1->32 computed into the tile of conv3 32->32
     Conv3Args a = conv3_args(1, c1, d1);
-    a.ncc = 1; a.src[0] = make_src(c1a, d1a, 32, 0, 1, 0);
-    FPL_TRY((launch_conv3<2>(ctx, a, n, "unet_conv3_32_32")));
+    a.ncc = 1; a.src[0] = make_src(nullptr, d1a, 32, 0, 1, 0);
+    a.raw = in; a.T = T;
+    a.wstem = (const bf16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
+    FPL_TRY((launch_conv3<2, true>(ctx, a, n, "unet_stem_conv3_32_32")));
   }
   pool(c1, p1, d1, 32);
   {  // L2: conv3 32->64
