@@ -9,7 +9,7 @@
 //                             computed straight into the LDS tile
 //   conv1_bf16<CIN, MB, TAIL> 1x1x1 conv as a voxel GEMM; TAIL chains a second
 //                             1x1 conv to one sigmoid channel in registers
-//   pool2_bf16                MaxPooling3D(2)
+//   (MaxPooling3D(2) is an epilogue option of conv3_bf16)
 //
 // conv3_bf16: 4 waves, output block 4 x 4 x 16, wave = z, sub-steps = y, lanes = x;
 // persistent over blocks; planar activation tile (6 x 6 x 18 voxels, one 32-channel
@@ -117,6 +117,8 @@ struct Conv3Args {
   const float *raw; int T;
   const bf16x8 *wstem;           // 2 fragments (SLOT_STEM, interleaved rows)
   const float *shstem;
+  // optional fused MaxPooling3D(2) of the (ReLU) output: (n, OD/2, OH/2, OW/2, 16*MB)
+  __bf16 *pool_out;
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -144,7 +146,7 @@ struct Conv3Args {
 constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
 constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
-template <int MB, bool PF, bool STEM = false>
+template <int MB, bool PF, bool STEM = false, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
   static_assert(NRAW % 256 == 0, "raw tile pieces per thread");
@@ -367,6 +369,59 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
                               g, acc[sub], a.relu);
       }
     }
+    // ---- fused 2x2x2 max pool of the block (4 x 4 x 16 -> 2 x 2 x 8): y pairs are
+    // sub-steps of a lane, x pairs neighbouring lanes, z pairs neighbouring waves
+    // (through the tile's LDS, free until the next put).  ReLU output is >= 0, so
+    // the bf16 order is the int16 order.
+    if (POOL) {
+      u32x4 pm[2][MB / 2];                          // [y half][16-B piece]
+#pragma unroll
+      for (int yh = 0; yh < 2; ++yh)
+#pragma unroll
+        for (int h = 0; h < MB / 2; ++h) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b = 2 * h + (q >> 1), r0 = (q & 1) * 2;
+            const unsigned lo = pk_max_i16(cvt_pk_bf16(acc[2 * yh][b][r0], acc[2 * yh][b][r0 + 1]), 0u);
+            const unsigned hi = pk_max_i16(cvt_pk_bf16(acc[2 * yh + 1][b][r0], acc[2 * yh + 1][b][r0 + 1]), 0u);
+            unsigned m = pk_max_i16(lo, hi);
+            m = pk_max_i16(m, (unsigned)__shfl_xor((int)m, 1));      // x pair (c ^ 1)
+            pm[yh][h][q] = m;
+          }
+        }
+      u32x4 *xch = reinterpret_cast<u32x4 *>(tile);          // [wave pair][yh][h][lane]
+      __syncthreads();                              // every wave is done with the tile
+      if (wave & 1) {
+#pragma unroll
+        for (int yh = 0; yh < 2; ++yh)
+#pragma unroll
+          for (int h = 0; h < MB / 2; ++h)
+            xch[(((wave >> 1) * 2 + yh) * (MB / 2) + h) * 64 + lane] = pm[yh][h];
+      }
+      __syncthreads();
+      if (!(wave & 1) && !(c & 1)) {
+        const int bx = (int)(blk % a.nbx), by = (int)((blk / a.nbx) % a.nby);
+        const int bz = (int)(blk / ((int64_t)a.nbx * a.nby));
+        const int n = bz / a.zblocks;
+        const int PD = a.OD / 2, PH = a.OH / 2, PW = a.OW / 2;
+        const int pz = (bz % a.zblocks) * 2 + (wave >> 1), px = bx * 8 + (c >> 1);
+#pragma unroll
+        for (int yh = 0; yh < 2; ++yh) {
+          const int py = by * 2 + yh;
+          if (pz < PD && py < PH && px < PW) {
+            __bf16 *dst = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (16 * MB) + 4 * MB * g;
+#pragma unroll
+            for (int h = 0; h < MB / 2; ++h) {
+              const u32x4 o = xch[(((wave >> 1) * 2 + yh) * (MB / 2) + h) * 64 + lane];
+              u32x4 m;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) m[q] = pk_max_i16(pm[yh][h][q], o[q]);
+              *reinterpret_cast<u32x4 *>(dst + 8 * h) = m;
+            }
+          }
+        }
+      }
+    }
     blk += G;
     if (blk >= total_blocks) break;
   }
@@ -429,26 +484,6 @@ __global__ __launch_bounds__(256) void conv1_bf16(Conv1Args a) {
       if (ok && g == 0) a.out_f32[m] = 1.f / (1.f + __expf(-logit));
     }
   }
-}
-
-__global__ void pool2_bf16(const __bf16 *__restrict__ x, __bf16 *__restrict__ y,
-                           int64_t n_out8, int D, int H, int W, int C8, int od, int oh, int ow) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 8-channel groups
-  if (i >= n_out8) return;
-  int64_t t = i;
-  const int c8 = (int)(t % C8); t /= C8;
-  const int ox = (int)(t % ow); t /= ow;
-  const int oy = (int)(t % oh); t /= oh;
-  const int oz = (int)(t % od); t /= od;
-  u32x4 m = {0u, 0u, 0u, 0u};          // inputs are post-ReLU (>= 0): int16 max = float max
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const u32x4 v = *reinterpret_cast<const u32x4 *>(
-        x + (((((t * D + 2 * oz + (p >> 2)) * H + 2 * oy + ((p >> 1) & 1)) * (int64_t)W + 2 * ox + (p & 1)) * C8 + c8) * 8));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) m[k] = pk_max_i16(m[k], v[k]);
-  }
-  *reinterpret_cast<u32x4 *>(y + i * 8) = m;
 }
 
 // ---- host: unet_like2 pattern + packed weights -------------------------------------
@@ -569,7 +604,7 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
   return 0;
 }
 
-template <int MB, bool STEM = false>
+template <int MB, bool STEM = false, bool POOL = false>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   constexpr bool PF = true;
   // STEM keeps the bf16 raw tile behind the (single) offset table
@@ -577,7 +612,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<MB, PF, STEM>,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<MB, PF, STEM, POOL>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
   }
@@ -604,7 +639,9 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * 2, (total + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
-  conv3_bf16<MB, PF, STEM><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
+  FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
+              "conv3_bf16: pool output / template mismatch");
+  conv3_bf16<MB, PF, STEM, POOL><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
 
@@ -658,23 +695,17 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     Conv3Args a;
     a.w = F + st->off_w[l]; a.shift = S + st->off_s[l]; a.relu = 1;
     a.out = outp; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
-    a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr;
+    a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr; a.pool_out = nullptr;
     return a;
-  };
-  auto pool = [&](const __bf16 *x, __bf16 *y, int d, int C) {
-    const int od = d / 2;
-    const int64_t n8 = (int64_t)n * cube(od) * (C / 8);
-    TimedLaunch tl(ctx, "unet_pool_bf16");
-    pool2_bf16<<<(unsigned)ceil_div64(n8, 256), 256, 0, stm>>>(x, y, n8, d, d, d, C / 8, od, od, od);
   };
   {  // L0 + L1: conv3 1->32 computed into the tile of conv3 32->32
     Conv3Args a = conv3_args(1, c1, d1);
     a.ncc = 1; a.src[0] = make_src(nullptr, d1a, 32, 0, 1, 0);
     a.raw = in; a.T = T;
     a.wstem = (const bf16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
-    FPL_TRY((launch_conv3<2, true>(ctx, a, n, "unet_stem_conv3_32_32")));
+    a.pool_out = p1;                               // MaxPooling3D(2) in the epilogue
+    FPL_TRY((launch_conv3<2, true, true>(ctx, a, n, "unet_stem_conv3_32_32_pool")));
   }
-  pool(c1, p1, d1, 32);
   {  // L2: conv3 32->64
     Conv3Args a = conv3_args(2, c2a, d2a);
     a.ncc = 1; a.src[0] = make_src(p1, dp1, 32, 0, 1, 0);
@@ -684,9 +715,9 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     Conv3Args a = conv3_args(3, c2, d2);
     a.ncc = 2;
     for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c2a, d2a, 64, 32 * cc, 1, 0);
-    FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_64_64")));
+    a.pool_out = p2;
+    FPL_TRY((launch_conv3<4, false, true>(ctx, a, n, "unet_conv3_64_64_pool")));
   }
-  pool(c2, p2, d2, 64);
   auto conv1 = [&](auto kern, int smem_frags, const __bf16 *x, int64_t M, int l, __bf16 *y,
                    const char *name) {
     Conv1Args a;
