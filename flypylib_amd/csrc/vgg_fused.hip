@@ -143,30 +143,46 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
     const int row = task >> 1, xh = task & 1;
     const int pzl = row / S_PY, pyl = row % S_PY;
     const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TX + 2 * (16 * xh + c));
-    u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+    // max-pool in fp32, two window positions per v_max3_f32 (rounding to bf16 is
+    // monotonic, so rounding the fp32 max equals the max of the rounded values);
+    // the initial 0 is the ReLU
+    f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int sub = 0; sub < 8; ++sub) {
-      const int e = sub & 1;
-      const int so = 2 * ((((sub >> 2) & 1) * S_TY + ((sub >> 1) & 1)) * S_TX);
-      u32x4 raw;
+    for (int sp = 0; sp < 4; ++sp) {
+      f32x4 a2[2][3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-        raw[i] = *reinterpret_cast<const unsigned *>(tb + base + so + offP[e][i]);
-      const unsigned s0 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][0]);
-      const unsigned s1 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][1]);
-      raw[3] = s0 | (s1 << 16);
-      const bf16x8 bfrag = __builtin_bit_cast(bf16x8, raw);
-      f32x4 a1[3];
+      for (int e = 0; e < 2; ++e) {                 // sub = 2 sp + e: x parity e
+        const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TX);
+        u32x4 raw;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[e][b], bfrag, sh1[b]);
-      const bf16x8 h0 = pack_relu(a1[0], a1[1]);
-      const bf16x8 h1 = pack_relu_lo(a1[2]);
+        for (int i = 0; i < 3; ++i)
+          raw[i] = *reinterpret_cast<const unsigned *>(tb + base + so + offP[e][i]);
+        const unsigned s0 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][0]);
+        const unsigned s1 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][1]);
+        raw[3] = s0 | (s1 << 16);
+        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, raw);
+        f32x4 a1[3];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        f32x4 a2 = mfma16(w2[0][b], h0, sh2[b]);
-        a2 = mfma16(w2[1][b], h1, a2);
-        pool_relu_bf16(pooled[b], a2);
+        for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[e][b], bfrag, sh1[b]);
+        const bf16x8 h0 = pack_relu(a1[0], a1[1]);
+        const bf16x8 h1 = pack_relu_lo(a1[2]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          a2[e][b] = mfma16(w2[0][b], h0, sh2[b]);
+          a2[e][b] = mfma16(w2[1][b], h1, a2[e][b]);
+        }
       }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
+    }
+    u32x2 pooled[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      pooled[b][0] = cvt_pk_bf16(poolf[b][0], poolf[b][1]);
+      pooled[b][1] = cvt_pk_bf16(poolf[b][2], poolf[b][3]);
     }
     const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + 16 * xh + c;
     if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
