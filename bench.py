@@ -42,9 +42,11 @@ KERNEL_LAYERS = {
     'vgg_mid_pool_bf16': ('L3', 'L4'), 'vgg_mid_pool_f32': ('L3', 'L4'),
     'vgg_head_bf16': ('L5', 'L6', 'L7', 'L8'),
     'vgg_c5_bf16': ('L5',), 'vgg_tail_bf16': ('L6', 'L7', 'L8'),
+    'vgg_stem_pool_f16': ('L1', 'L2'), 'vgg_mid_pool_f16': ('L3', 'L4'),
+    'vgg_c5_f16': ('L5',), 'vgg_tail_f16': ('L6', 'L7', 'L8'),
     'vgg_head_f32': ('L5', 'L6', 'L7', 'L8'),
 }
-PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -86,7 +88,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--size', type=int, default=1024,
                     help='volume edge per GPU (Z is size*gpus)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16', 'f32'],
+                    help='bf16 = the configuration BASELINE.json names; f16 = the same '
+                         'kernels on IEEE-half operands (same rate, meets the 1e-3 gate)')
     ap.add_argument('--tile', type=int, default=102,
                     help='reference infer_sz (tile lattice pitch = tile-14)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -120,7 +124,7 @@ def main():
     graph = fplmodels.vgg_like(tile)[0]
     synth.synthetic_weights(graph, 1234)
     prog = _capi.Program(ctx, graph, (4, 4, 4))
-    prec = _capi.PREC_BF16 if args.precision == 'bf16' else _capi.PREC_F32
+    prec = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16, 'f32': _capi.PREC_F32}[args.precision]
 
     # global volume (size*N, size, size); rank slab = contiguous tile rows, which
     # is itself a standalone volume whose lattice coincides with the global one
@@ -191,7 +195,7 @@ def main():
         if flop_per_vox is not None:
             flops_per_launch = flop_per_vox * valid_local * args.steps / tk['launches']
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_TFLOPS['f32' if ('generic' in name or 'f32' in name) else args.precision]
+            peak = PEAK_TFLOPS['f32' if ('generic' in name or name.endswith('f32')) else args.precision]
             roof = dict(bound='mfma', kernel=name, achieved=round(achieved, 3),
                         peak=peak, unit='TFLOP/s',
                         frac=round(achieved / peak, 5),

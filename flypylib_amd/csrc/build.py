@@ -25,8 +25,20 @@ CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC',
             '-Wno-unused-value', '-Wno-unused-result']
 
 
+# translation units built a second time with -DFPL_F16 (IEEE-half operands instead of
+# bfloat16; mfma_util.h)
+DUAL_PRECISION = ('vgg_fused.hip', 'conv_mfma.hip')
+
+
 def _sources():
-    return sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+    """(source file, object stem, extra flags)"""
+    out = []
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.hip'):
+            out.append((f, f[:-4], []))
+            if f in DUAL_PRECISION:
+                out.append((f, f[:-4] + '_f16', ['-DFPL_F16=1']))
+    return out
 
 
 def _headers_mtime():
@@ -35,17 +47,18 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src, force, hdr_m):
-    obj = os.path.join(OBJ_DIR, src[:-4] + '.o')
+def _compile(unit, force, hdr_m):
+    src, stem, extra = unit
+    obj = os.path.join(OBJ_DIR, stem + '.o')
     sp = os.path.join(HERE, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_m)):
         return obj, None
-    cmd = [HIPCC] + CXXFLAGS + ['-c', sp, '-o', obj]
+    cmd = [HIPCC] + CXXFLAGS + extra + ['-c', sp, '-o', obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True)
     if r.returncode != 0:
-        raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout))
+        raise RuntimeError('hipcc failed for %s:\n%s' % (stem, r.stdout))
     return obj, r.stdout
 
 
@@ -57,10 +70,10 @@ def build(force=False, jobs=4, verbose=True):
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         results = list(ex.map(lambda s: _compile(s, force, hdr_m), srcs))
     objs = [o for o, _ in results]
-    rebuilt = [s for s, (_, out) in zip(srcs, results) if out is not None]
-    for s, (_, out) in zip(srcs, results):
+    rebuilt = [u[1] for u, (_, out) in zip(srcs, results) if out is not None]
+    for u, (_, out) in zip(srcs, results):
         if out and verbose and out.strip():
-            print('[%s]\n%s' % (s, out.strip()))
+            print('[%s]\n%s' % (u[1], out.strip()))
     if (rebuilt or not os.path.exists(LIB)
             or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs

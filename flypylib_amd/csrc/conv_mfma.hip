@@ -48,7 +48,7 @@ constexpr int WDEPTH = 3;                 // weight chunks in flight in register
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
 struct Src {             // one CC-channel chunk of the (virtual) concatenated input
-  const __bf16 *p;       // (n, D, H, W, C) bf16, with read slack behind it (tile_slack)
+  const h16_t *p;       // (n, D, H, W, C) bf16, with read slack behind it (tile_slack)
   int D, H, W, C;
   int ch0;               // first channel of this chunk inside the source
   int ups;               // 0, or 1 = UpSampling3D(2) of the source (index >> ups)
@@ -59,16 +59,16 @@ struct Src {             // one CC-channel chunk of the (virtual) concatenated i
 // Epilogue store for interleaved output channels (pack_weights.h, fpl_out_channel):
 // lane (c, g) writes the 4*MB contiguous channels [4*MB*g, ...) of its voxel.
 template <int MB, bool RELU_ALWAYS>
-__device__ __forceinline__ void store_il(__bf16 *vox_out, int g, const f32x4 (&acc)[MB], int relu) {
+__device__ __forceinline__ void store_il(h16_t *vox_out, int g, const f32x4 (&acc)[MB], int relu) {
   static_assert(MB % 2 == 0, "16-B pieces");
-  __bf16 *dst = vox_out + 4 * MB * g;
+  h16_t *dst = vox_out + 4 * MB * g;
 #pragma unroll
   for (int h = 0; h < MB / 2; ++h) {
     u32x4 o;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      o[2 * q] = cvt_pk_bf16(acc[2 * h + q][0], acc[2 * h + q][1]);
-      o[2 * q + 1] = cvt_pk_bf16(acc[2 * h + q][2], acc[2 * h + q][3]);
+      o[2 * q] = cvt_pk_h16(acc[2 * h + q][0], acc[2 * h + q][1]);
+      o[2 * q + 1] = cvt_pk_h16(acc[2 * h + q][2], acc[2 * h + q][3]);
     }
     if (RELU_ALWAYS || relu) {
 #pragma unroll
@@ -109,16 +109,16 @@ struct Conv3Args {
   const unsigned char *w;        // fragments [cc][dz][dx][dy][mb], 1 KiB each
   const float *shift;
   int relu;
-  __bf16 *out;                   // (n, OD, OH, OW, 16*MB)
+  h16_t *out;                   // (n, OD, OH, OW, 16*MB)
   int OD, OH, OW, zblocks;       // zblocks = ceil(OD/4)
   int nbx, nby, nbz;             // blocks: ceil(OW/16), ceil(OH/4), n * zblocks
   // STEM variant: the (single) source is conv3 1->32 + shift + ReLU of this raw
   // (n, T, T, T) f32 volume, computed into the tile instead of being read
   const float *raw; int T;
-  const bf16x8 *wstem;           // 2 fragments (SLOT_STEM, interleaved rows)
+  const h16x8 *wstem;           // 2 fragments (SLOT_STEM, interleaved rows)
   const float *shstem;
   // optional fused MaxPooling3D(2) of the (ReLU) output: (n, OD/2, OH/2, OW/2, 16*MB)
-  __bf16 *pool_out;
+  h16_t *pool_out;
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -147,7 +147,7 @@ constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
 constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
 template <int MB, bool PF, bool STEM = false, bool POOL = false>
-__global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
+__global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
   static_assert(NRAW % 256 == 0, "raw tile pieces per thread");
   constexpr int RING = KC * MB * 1024;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   };
   // STEM: lane constants of the gather (tap 8g+j of the 27, k-slots 27..31 unused)
   int toff[8];
-  bf16x8 wsf[2];
+  h16x8 wsf[2];
   f32x4 shs[2];
   if (STEM) {
 #pragma unroll
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
   auto put = [&]() {
     if (STEM) {
 #pragma unroll
-      for (int j = 0; j < NRAW / 256; ++j) rawt[tid + 256 * j] = bf16_bits(rawv[j]);
+      for (int j = 0; j < NRAW / 256; ++j) rawt[tid + 256 * j] = h16_bits(rawv[j]);
       __syncthreads();                              // raw tile visible
       constexpr int NGRP = (TZ * TY * TX + 15) / 16;
       for (int grp = wave; grp < NGRP; grp += 4) {
@@ -247,14 +247,14 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
         u16x8 rw;
 #pragma unroll
         for (int j = 0; j < 8; ++j) rw[j] = rawt[ro + toff[j]];
-        const bf16x8 bf = __builtin_bit_cast(bf16x8, rw);
+        const h16x8 bf = __builtin_bit_cast(h16x8, rw);
         const f32x4 a0 = mfma16(wsf[0], bf, shs[0]);
         const f32x4 a1 = mfma16(wsf[1], bf, shs[1]);
         u32x4 o;
-        o[0] = pk_max_i16(cvt_pk_bf16(a0[0], a0[1]), 0u);
-        o[1] = pk_max_i16(cvt_pk_bf16(a0[2], a0[3]), 0u);
-        o[2] = pk_max_i16(cvt_pk_bf16(a1[0], a1[1]), 0u);
-        o[3] = pk_max_i16(cvt_pk_bf16(a1[2], a1[3]), 0u);
+        o[0] = pk_max_i16(cvt_pk_h16(a0[0], a0[1]), 0u);
+        o[1] = pk_max_i16(cvt_pk_h16(a0[2], a0[3]), 0u);
+        o[2] = pk_max_i16(cvt_pk_h16(a1[0], a1[1]), 0u);
+        o[3] = pk_max_i16(cvt_pk_h16(a1[2], a1[3]), 0u);
         if (v < TZ * TY * TX) *reinterpret_cast<u32x4 *>(tile + g * PLANE + v * PITCH) = o;
       }
       return;
@@ -306,10 +306,10 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();            // tile (+ ring slot) visible
-      bf16x8 brow[2][6];
+      h16x8 brow[2][6];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
-        brow[0][r] = *reinterpret_cast<const bf16x8 *>(tile + vbase + r * ROW);
+        brow[0][r] = *reinterpret_cast<const h16x8 *>(tile + vbase + r * ROW);
 #pragma unroll
       for (int ck = 0; ck < NCH; ++ck) {
         if (ck > 0) __syncthreads();
@@ -321,10 +321,10 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
         }
         const unsigned char *wslot = ring + par * RING + lane * 16;
         par ^= 1u;
-        bf16x8 wcur[MB], wnxt[MB];
+        h16x8 wcur[MB], wnxt[MB];
 #pragma unroll
         for (int b = 0; b < MB; ++b)
-          wcur[b] = *reinterpret_cast<const bf16x8 *>(wslot + b * 1024);
+          wcur[b] = *reinterpret_cast<const h16x8 *>(wslot + b * 1024);
         // next ring chunk's rows: (dz, dx) of chunk ck+1 (wraps to the tile origin;
         // the wrapped read of the last chunk is unused)
         const int nk = ck + 1 < NCH ? ck + 1 : 0;
@@ -335,11 +335,11 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
 #pragma unroll
           for (int r = 2 * dy; r < 2 * dy + 2; ++r)
             brow[(ck + 1) & 1][r] =
-                *reinterpret_cast<const bf16x8 *>(tile + vbase + noff + r * ROW);
+                *reinterpret_cast<const h16x8 *>(tile + vbase + noff + r * ROW);
           if (dy + 1 < KC) {
 #pragma unroll
             for (int b = 0; b < MB; ++b)
-              wnxt[b] = *reinterpret_cast<const bf16x8 *>(wslot + ((dy + 1) * MB + b) * 1024);
+              wnxt[b] = *reinterpret_cast<const h16x8 *>(wslot + ((dy + 1) * MB + b) * 1024);
           }
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int b = 2 * h + (q >> 1), r0 = (q & 1) * 2;
-            const unsigned lo = pk_max_i16(cvt_pk_bf16(acc[2 * yh][b][r0], acc[2 * yh][b][r0 + 1]), 0u);
-            const unsigned hi = pk_max_i16(cvt_pk_bf16(acc[2 * yh + 1][b][r0], acc[2 * yh + 1][b][r0 + 1]), 0u);
+            const unsigned lo = pk_max_i16(cvt_pk_h16(acc[2 * yh][b][r0], acc[2 * yh][b][r0 + 1]), 0u);
+            const unsigned hi = pk_max_i16(cvt_pk_h16(acc[2 * yh + 1][b][r0], acc[2 * yh + 1][b][r0 + 1]), 0u);
             unsigned m = pk_max_i16(lo, hi);
             m = pk_max_i16(m, (unsigned)__shfl_xor((int)m, 1));      // x pair (c ^ 1)
             pm[yh][h][q] = m;
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
         for (int yh = 0; yh < 2; ++yh) {
           const int py = by * 2 + yh;
           if (pz < PD && py < PH && px < PW) {
-            __bf16 *dst = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (16 * MB) + 4 * MB * g;
+            h16_t *dst = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (16 * MB) + 4 * MB * g;
 #pragma unroll
             for (int h = 0; h < MB / 2; ++h) {
               const u32x4 o = xch[(((wave >> 1) * 2 + yh) * (MB / 2) + h) * 64 + lane];
@@ -429,17 +429,17 @@ __global__ __launch_bounds__(256, 2) void conv3_bf16(Conv3Args a) {
 
 // ---- 1x1x1 conv as a voxel GEMM ---------------------------------------------------
 struct Conv1Args {
-  const __bf16 *in; int64_t M;   // voxels (n*D*H*W), CIN channels each
+  const h16_t *in; int64_t M;   // voxels (n*D*H*W), CIN channels each
   const unsigned char *w;        // [kstep][mb] fragments (SLOT_SPATIAL, 1 tap)
   const float *shift;
-  __bf16 *out;                   // (M, 16*MB) bf16            (TAIL == 0)
-  const bf16x8 *w_tail;          // TAIL: [kstep] fragments of the 16*MB -> 1 conv
+  h16_t *out;                   // (M, 16*MB) bf16            (TAIL == 0)
+  const h16x8 *w_tail;          // TAIL: [kstep] fragments of the 16*MB -> 1 conv
   float bias_tail;
   float *out_f32;                // TAIL: (M) sigmoid probabilities
 };
 
 template <int CIN, int MB, int TAIL>
-__global__ __launch_bounds__(256) void conv1_bf16(Conv1Args a) {
+__global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
   constexpr int KS = CIN / 32;
   constexpr int NF = KS * MB;
   unsigned char *wl = smem;                         // NF KiB of fragments
@@ -459,17 +459,17 @@ __global__ __launch_bounds__(256) void conv1_bf16(Conv1Args a) {
     int64_t m = grp * 16 + c;
     const bool ok = m < a.M;
     m = ok ? m : a.M - 1;
-    bf16x8 bf[KS];
+    h16x8 bf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      bf[s] = *reinterpret_cast<const bf16x8 *>(a.in + m * CIN + 32 * s + 8 * g);
+      bf[s] = *reinterpret_cast<const h16x8 *>(a.in + m * CIN + 32 * s + 8 * g);
     f32x4 acc[MB];
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
       acc[b] = sh[b];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        acc[b] = mfma16(*reinterpret_cast<const bf16x8 *>(wl + ((s * MB + b) * 64 + lane) * 16),
+        acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wl + ((s * MB + b) * 64 + lane) * 16),
                         bf[s], acc[b]);
     }
     if (TAIL == 0) {
@@ -545,11 +545,11 @@ bool is_unet_like2(const fpl_program *prog, int conv_idx[10]) {
 }
 
 int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetState **out) {
-  UnetState *st = (UnetState *)prog->fast_state;
+  UnetState *st = (UnetState *)prog->fast_state_h16[FPL_H16_SLOT];
   if (!st) {
     st = new UnetState();
-    prog->fast_state = st;
-    prog->fast_state_free = unet_state_free;
+    prog->fast_state_h16[FPL_H16_SLOT] = st;
+    prog->fast_state_h16_free[FPL_H16_SLOT] = unet_state_free;
   }
   *out = st;
   if (st->version == prog->arena_version) return 0;
@@ -592,6 +592,12 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
     shifts.insert(shifts.end(), A + op.shift_off, A + op.shift_off + op.cout);
     while (shifts.size() % 4) shifts.push_back(0.f);
   }
+#ifdef FPL_F16
+  for (uint16_t h : all)
+    FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
+                "a folded weight exceeds the IEEE-half range (65504); use precision "
+                "bf16 or f32 for this network");
+#endif
   st->bias_tail = A[prog->ops[conv_idx[9]].shift_off];
   if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
   if (st->shifts) FPL_HIP(ctx, hipFree(st->shifts));
@@ -612,7 +618,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_bf16<MB, PF, STEM, POOL>,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
   }
@@ -620,13 +626,13 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   a.ntab = 0;
   for (int i = 0; i < (STEM ? 0 : a.ncc); ++i) {
     Src &s = a.src[i];
-    FPL_REQUIRE(ctx, !(s.ups && s.crop), "conv3_bf16: crop of an upsampled source");
-    FPL_REQUIRE(ctx, s.crop % 2 == 0, "conv3_bf16: odd crop");
+    FPL_REQUIRE(ctx, !(s.ups && s.crop), "FPLK(conv3): crop of an upsampled source");
+    FPL_REQUIRE(ctx, s.crop % 2 == 0, "FPLK(conv3): odd crop");
     int t = 0;
     for (; t < a.ntab; ++t)
       if (a.tabH[t] == s.H && a.tabW[t] == s.W && a.tabC[t] == s.C && a.tabU[t] == s.ups) break;
     if (t == a.ntab) {
-      FPL_REQUIRE(ctx, a.ntab < MAXTAB, "conv3_bf16: more than %d source geometries", MAXTAB);
+      FPL_REQUIRE(ctx, a.ntab < MAXTAB, "FPLK(conv3): more than %d source geometries", MAXTAB);
       a.tabH[t] = s.H; a.tabW[t] = s.W; a.tabC[t] = s.C; a.tabU[t] = s.ups;
       ++a.ntab;
     }
@@ -640,12 +646,12 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
   FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
-              "conv3_bf16: pool output / template mismatch");
-  conv3_bf16<MB, PF, STEM, POOL><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
+              "FPLK(conv3): pool output / template mismatch");
+  FPLK(conv3)<MB, PF, STEM, POOL><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
 
-Src make_src(const __bf16 *p, int dim, int C, int ch0, int up, int crop) {
+Src make_src(const h16_t *p, int dim, int C, int ch0, int up, int crop) {
   Src s;
   s.p = p; s.D = s.H = s.W = dim; s.C = C; s.ch0 = ch0; s.ups = up == 2 ? 1 : 0; s.crop = crop; s.tab = 0;
   return s;
@@ -653,13 +659,13 @@ Src make_src(const __bf16 *p, int dim, int C, int ch0, int up, int crop) {
 
 }  // namespace
 
-bool fpl_unet_fast_available(const fpl_program *prog, int precision) {
+bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
   int idx[10];
-  return precision == FPL_PREC_BF16 && is_unet_like2(prog, idx);
+  return precision == FPL_THIS_PREC && is_unet_like2(prog, idx);
 }
 
 // in: (n, T,T,T) f32 normalised tiles on the device; out: (n, T-18, T-18, T-18) f32
-int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
+int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
                           int T, float *out) {
   int ci[10];
   FPL_REQUIRE(ctx, is_unet_like2(prog, ci), "not a unet_like2 program");
@@ -673,14 +679,14 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
   const int d4a = 2 * dp2 - 2, d5a = 2 * d4a - 2;      // = T - 18
   auto cube = [](int d) { return (int64_t)d * d * d; };
   // conv3 tiles read up to 5 planes + 5 rows + 17 voxels past a source's last voxel
-  auto balloc = [&](int64_t elems, int dim, int C, __bf16 **p) -> int {
+  auto balloc = [&](int64_t elems, int dim, int C, h16_t **p) -> int {
     void *q;
     const size_t slack = ((size_t)5 * dim * dim + 5 * dim + 18) * C * 2;
     int rc = tmp.alloc((size_t)elems * 2 + slack + 64, &q);
-    *p = (__bf16 *)q;
+    *p = (h16_t *)q;
     return rc;
   };
-  __bf16 *c1, *p1, *c2a, *c2, *p2, *c3, *c4a, *c4, *c5a;
+  h16_t *c1, *p1, *c2a, *c2, *p2, *c3, *c4a, *c4, *c5a;
   FPL_TRY(balloc(n * cube(d1) * 32, d1, 32, &c1));
   FPL_TRY(balloc(n * cube(dp1) * 32, dp1, 32, &p1));
   FPL_TRY(balloc(n * cube(d2a) * 64, d2a, 64, &c2a));
@@ -691,7 +697,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
   FPL_TRY(balloc(n * cube(d4a) * 64, d4a, 64, &c4));
   FPL_TRY(balloc(n * cube(d5a) * 32, d5a, 32, &c5a));
   hipStream_t stm = ctx->stream;
-  auto conv3_args = [&](int l, __bf16 *outp, int od) {
+  auto conv3_args = [&](int l, h16_t *outp, int od) {
     Conv3Args a;
     a.w = F + st->off_w[l]; a.shift = S + st->off_s[l]; a.relu = 1;
     a.out = outp; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
@@ -702,7 +708,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     Conv3Args a = conv3_args(1, c1, d1);
     a.ncc = 1; a.src[0] = make_src(nullptr, d1a, 32, 0, 1, 0);
     a.raw = in; a.T = T;
-    a.wstem = (const bf16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
+    a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
     a.pool_out = p1;                               // MaxPooling3D(2) in the epilogue
     FPL_TRY((launch_conv3<2, true, true>(ctx, a, n, "unet_stem_conv3_32_32_pool")));
   }
@@ -718,7 +724,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     a.pool_out = p2;
     FPL_TRY((launch_conv3<4, false, true>(ctx, a, n, "unet_conv3_64_64_pool")));
   }
-  auto conv1 = [&](auto kern, int smem_frags, const __bf16 *x, int64_t M, int l, __bf16 *y,
+  auto conv1 = [&](auto kern, int smem_frags, const h16_t *x, int64_t M, int l, h16_t *y,
                    const char *name) {
     Conv1Args a;
     a.in = x; a.M = M; a.w = F + st->off_w[l]; a.shift = S + st->off_s[l];
@@ -727,7 +733,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     TimedLaunch tl(ctx, name);
     kern<<<grid, 256, smem_frags * 1024, stm>>>(a);
   };
-  conv1(conv1_bf16<64, 8, 0>, 16, p2, (int64_t)n * cube(dp2), 4, c3, "unet_conv1_64_128");
+  conv1(FPLK(conv1)<64, 8, 0>, 16, p2, (int64_t)n * cube(dp2), 4, c3, "unet_conv1_64_128");
   {  // L5: conv3 (up2(c3) 128 | c2 64) -> 64
     Conv3Args a = conv3_args(5, c4a, d4a);
     a.ncc = 6;
@@ -735,7 +741,7 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
     for (int cc = 0; cc < 2; ++cc) a.src[4 + cc] = make_src(c2, d2, 64, 32 * cc, 1, 0);
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
   }
-  conv1(conv1_bf16<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), 6, c4, "unet_conv1_64_64");
+  conv1(FPLK(conv1)<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), 6, c4, "unet_conv1_64_64");
   {  // L7: conv3 (up2(c4) 64 | crop6(c1) 32) -> 32
     Conv3Args a = conv3_args(7, c5a, d5a);
     a.ncc = 3;
@@ -746,11 +752,11 @@ int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int 
   {  // L8 + L9: conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
     Conv1Args a;
     a.in = c5a; a.M = (int64_t)n * cube(d5a); a.w = F + st->off_w[8]; a.shift = S + st->off_s[8];
-    a.out = nullptr; a.w_tail = (const bf16x8 *)(F + st->off_w[9]); a.bias_tail = st->bias_tail;
+    a.out = nullptr; a.w_tail = (const h16x8 *)(F + st->off_w[9]); a.bias_tail = st->bias_tail;
     a.out_f32 = out;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, "unet_head_bf16");
-    conv1_bf16<32, 2, 1><<<grid, 256, 2 * 1024, stm>>>(a);
+    FPLK(conv1)<32, 2, 1><<<grid, 256, 2 * 1024, stm>>>(a);
   }
   FPL_HIP(ctx, hipGetLastError());
   return 0;

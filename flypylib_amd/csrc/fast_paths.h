@@ -4,25 +4,31 @@
 
 #include "program.h"
 
-// Tries to run the slab [zb, ze) of the tile lattice with fused kernels.  Sets
-// *handled = false (and returns 0) when the program / precision has no fast path.
-// `src` / `dst` point at row 0 of the (Z,Y,X) volume on the device.
-int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
-                          int src_dtype, float mean, float sd,
-                          const int64_t dims[3], const int32_t tile_in[3],
-                          const int32_t offset[3], int precision,
-                          const std::vector<int32_t> origins[3],
-                          const int32_t out_sz[3], int32_t zb, int32_t ze,
-                          float *dst, bool *handled);
-
-// true when fpl_fast_infer_volume will handle this program / precision / lattice
-bool fpl_fast_path_available(const fpl_program *prog, int precision,
-                             const int32_t offset[3], const int32_t out_sz[3]);
-
-// unet_like2 bf16 MFMA executor (conv_mfma.hip): batch of n equal tiles
-bool fpl_unet_fast_available(const fpl_program *prog, int precision);
-int fpl_unet_forward_bf16(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
-                          int T, float *out);
+// The fused 16-bit paths exist twice, built from the same sources (mfma_util.h):
+// *_bf16 (FPL_PREC_BF16) and *_f16 (FPL_PREC_F16).
+//
+// fpl_fast_infer_volume_*: tries to run the slab [zb, ze) of the tile lattice with
+// the fused vgg_like kernels.  Sets *handled = false (and returns 0) when the
+// program / precision has no fast path.  `src` / `dst` point at row 0 of the (Z,Y,X)
+// volume on the device.
+// fpl_fast_path_available_*: true when fpl_fast_infer_volume_* will handle this
+// program / precision / lattice.
+// fpl_unet_*: unet_like2 MFMA executor (conv_mfma.hip): batch of n equal tiles.
+#define FPL_DECLARE_H16_PATHS(sfx)                                                      \
+  int fpl_fast_infer_volume_##sfx(fpl_ctx *ctx, fpl_program *prog, const void *src,     \
+                                  int src_dtype, float mean, float sd,                  \
+                                  const int64_t dims[3], const int32_t tile_in[3],      \
+                                  const int32_t offset[3], int precision,               \
+                                  const std::vector<int32_t> origins[3],                \
+                                  const int32_t out_sz[3], int32_t zb, int32_t ze,      \
+                                  float *dst, bool *handled);                           \
+  bool fpl_fast_path_available_##sfx(const fpl_program *prog, int precision,            \
+                                     const int32_t offset[3], const int32_t out_sz[3]); \
+  bool fpl_unet_fast_available_##sfx(const fpl_program *prog, int precision);           \
+  int fpl_unet_forward_##sfx(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,   \
+                             int T, float *out);
+FPL_DECLARE_H16_PATHS(bf16)
+FPL_DECLARE_H16_PATHS(f16)
 
 // fp32 MFMA executor over any lowered program without ADD (conv_mfma_f32.hip):
 // cubic tiles (n, T,T,T) f32 -> network output (n, d,d,d, c) f32

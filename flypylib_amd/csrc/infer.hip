@@ -164,7 +164,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   FPL_REQUIRE(ctx, src_dtype == FPL_U8 || src_dtype == FPL_F32,
               "fpl_infer_volume: src dtype must be u8 or f32");
   FPL_REQUIRE(ctx, sd != 0.f, "fpl_infer_volume: std is 0");
-  FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || precision == FPL_PREC_BF16,
+  FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || precision == FPL_PREC_BF16 ||
+                       precision == FPL_PREC_F16,
               "fpl_infer_volume: unknown precision %d", precision);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   int32_t out_sz[3];
@@ -224,7 +225,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   }
   // the fused fast path writes every valid voxel itself: only the border shell
   // needs clearing there; the per-op path stitches tiles into a zeroed volume
-  const bool fast = zb < ze && fpl_fast_path_available(prog, precision, offset, out_sz);
+  const bool fast = zb < ze && (fpl_fast_path_available_bf16(prog, precision, offset, out_sz) ||
+                                fpl_fast_path_available_f16(prog, precision, offset, out_sz));
   if (wr_hi > wr_lo) {
     if (fast && offset[2] <= 64) {
       TimedLaunch tl(ctx, "clear_shell");
@@ -262,19 +264,18 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
 
   // fused whole-slab fast paths (vgg_like): no tile batch, no stitch
   bool handled = false;
-  FPL_TRY(fpl_fast_infer_volume(ctx, prog, src_dev - src_base * Y * X * esz,
-                                src_dtype, mean, sd, dims, tile_in, offset,
-                                precision, origins, out_sz, zb, ze,
-                                dst_dev - dst_base * Y * X, &handled));
+  FPL_TRY((precision == FPL_PREC_F16 ? fpl_fast_infer_volume_f16 : fpl_fast_infer_volume_bf16)(
+      ctx, prog, src_dev - src_base * Y * X * esz, src_dtype, mean, sd, dims, tile_in,
+      offset, precision, origins, out_sz, zb, ze, dst_dev - dst_base * Y * X, &handled));
   if (!handled) {
-    const bool unet_bf16 = precision == FPL_PREC_BF16 &&
-                           fpl_unet_fast_available(prog, precision) &&
+    const bool unet_bf16 = (fpl_unet_fast_available_bf16(prog, precision) ||
+                            fpl_unet_fast_available_f16(prog, precision)) &&
                            tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2];
     const bool f32_mfma = precision == FPL_PREC_F32 && fpl_mfma_f32_supported(prog) &&
                           tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2] &&
                           !getenv("FPL_FORCE_PEROP");
     FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || unet_bf16,
-                "fpl_infer_volume: no bf16 kernels for this architecture yet; "
+                "fpl_infer_volume: no 16-bit MFMA kernels for this architecture yet; "
                 "use precision f32");
     // tile list in the reference's order (z outer, x inner)
     std::vector<TileDesc> tiles;
@@ -328,8 +329,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
         FPL_HIP(ctx, hipGetLastError());
       }
       if (unet_bf16)
-        FPL_TRY(fpl_unet_forward_bf16(ctx, prog, (const float *)in_batch, (int)nb,
-                                      tile_in[0], (float *)out_batch));
+        FPL_TRY((precision == FPL_PREC_F16 ? fpl_unet_forward_f16 : fpl_unet_forward_bf16)(
+            ctx, prog, (const float *)in_batch, (int)nb, tile_in[0], (float *)out_batch));
       else if (f32_mfma)
         FPL_TRY(fpl_forward_mfma_f32(ctx, prog, (const float *)in_batch, (int)nb,
                                      tile_in[0], (float *)out_batch));

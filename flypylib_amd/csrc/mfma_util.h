@@ -14,30 +14,53 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// 16-bit operand type of the fused kernels.  Each fused translation unit is built
+// twice (csrc/build.py): bfloat16 (default; FPL_PREC_BF16) and, with -DFPL_F16, IEEE
+// half (FPL_PREC_F16).  Same MFMA rate; half keeps 11 significant bits instead of 8
+// (probabilities within ~1e-4 of fp32 instead of ~1e-3) at a 65504 range, which the
+// weight packer checks.  FPLK(name) = name_bf16 / name_f16 keeps the two builds'
+// kernels and entry points apart.
+#ifdef FPL_F16
+typedef _Float16 h16_t;
+#define FPLK(name) name##_f16
+#define FPL_PREC_STR "f16"
+#define FPL_THIS_PREC FPL_PREC_F16
+#define FPL_H16_SLOT 1
+#else
+typedef __bf16 h16_t;
+#define FPLK(name) name##_bf16
+#define FPL_PREC_STR "bf16"
+#define FPL_THIS_PREC FPL_PREC_BF16
+#define FPL_H16_SLOT 0
+#endif
+typedef h16_t h16x8 __attribute__((ext_vector_type(8)));
+typedef h16_t h16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+__device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
+#ifdef FPL_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef h16_t h16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// two f32 -> packed bf16 pair (one v_cvt_pk_bf16_f32, RNE)
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+// two f32 -> packed 16-bit pair, RNE (one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned cvt_pk_h16(float a, float b) {
   f32x2 f = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, h16x2));
 }
 
-// max of packed bf16 pairs AS SIGNED INT16 (one v_pk_max_i16).  Against 0 this
-// is ReLU on both halves (negative bf16 = negative int16, -0.0 included);
+// max of packed 16-bit float pairs AS SIGNED INT16 (one v_pk_max_i16).  Against 0 this
+// is ReLU on both halves (negative float16/bfloat16 = negative int16, -0.0 included);
 // between non-negative values it is the float max - which is all a max-pool of
 // post-ReLU activations needs.
 __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
@@ -48,34 +71,34 @@ __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
 
 // two accumulator tiles (M-blocks 2s and 2s+1 of the previous layer) -> the B
 // fragment of K-step s of the next layer, ReLU applied: 4 cvt_pk + 4 pk_max
-__device__ __forceinline__ bf16x8 pack_relu(const f32x4 &lo, const f32x4 &hi) {
+__device__ __forceinline__ h16x8 pack_relu(const f32x4 &lo, const f32x4 &hi) {
   u32x4 v;
-  v[0] = pk_max_i16(cvt_pk_bf16(lo[0], lo[1]), 0u);
-  v[1] = pk_max_i16(cvt_pk_bf16(lo[2], lo[3]), 0u);
-  v[2] = pk_max_i16(cvt_pk_bf16(hi[0], hi[1]), 0u);
-  v[3] = pk_max_i16(cvt_pk_bf16(hi[2], hi[3]), 0u);
-  return __builtin_bit_cast(bf16x8, v);
+  v[0] = pk_max_i16(cvt_pk_h16(lo[0], lo[1]), 0u);
+  v[1] = pk_max_i16(cvt_pk_h16(lo[2], lo[3]), 0u);
+  v[2] = pk_max_i16(cvt_pk_h16(hi[0], hi[1]), 0u);
+  v[3] = pk_max_i16(cvt_pk_h16(hi[2], hi[3]), 0u);
+  return __builtin_bit_cast(h16x8, v);
 }
 
 // same with the upper block missing (48 channels = 3 blocks): zeros
-__device__ __forceinline__ bf16x8 pack_relu_lo(const f32x4 &lo) {
+__device__ __forceinline__ h16x8 pack_relu_lo(const f32x4 &lo) {
   u32x4 v;
-  v[0] = pk_max_i16(cvt_pk_bf16(lo[0], lo[1]), 0u);
-  v[1] = pk_max_i16(cvt_pk_bf16(lo[2], lo[3]), 0u);
+  v[0] = pk_max_i16(cvt_pk_h16(lo[0], lo[1]), 0u);
+  v[1] = pk_max_i16(cvt_pk_h16(lo[2], lo[3]), 0u);
   v[2] = 0u;
   v[3] = 0u;
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(h16x8, v);
 }
 
 // running max-pool of relu(acc) in packed bf16: pooled = max(pooled, bf16(acc))
 // with pooled initialised to 0 (rounding is monotonic, so this equals rounding
 // the fp32 max)
-__device__ __forceinline__ void pool_relu_bf16(u32x2 &pooled, const f32x4 &acc) {
-  pooled[0] = pk_max_i16(pooled[0], cvt_pk_bf16(acc[0], acc[1]));
-  pooled[1] = pk_max_i16(pooled[1], cvt_pk_bf16(acc[2], acc[3]));
+__device__ __forceinline__ void pool_relu_h16(u32x2 &pooled, const f32x4 &acc) {
+  pooled[0] = pk_max_i16(pooled[0], cvt_pk_h16(acc[0], acc[1]));
+  pooled[1] = pk_max_i16(pooled[1], cvt_pk_h16(acc[2], acc[3]));
 }
 
-__device__ __forceinline__ unsigned short bf16_bits(float f) {
-  __bf16 b = (__bf16)f;
+__device__ __forceinline__ unsigned short h16_bits(float f) {
+  h16_t b = (h16_t)f;
   return __builtin_bit_cast(unsigned short, b);
 }

@@ -1,5 +1,5 @@
-// Host-side packing of folded conv weights into MFMA A-fragment order (bf16).
-// One fragment = 64 lanes x 8 bf16 = 1 KiB, stored [kstep][mblock][lane][8] so a
+// Host-side packing of folded conv weights into MFMA A-fragment order (bf16 or, with
+// -DFPL_F16, IEEE half).  One fragment = 64 lanes x 8 x 16 bit = 1 KiB, stored [kstep][mblock][lane][8] so a
 // wave fetches a fragment with one coalesced 16-B-per-lane load (or one
 // ds_read_b128 per lane from an LDS copy).  Slot maps: see mfma_util.h.
 #pragma once
@@ -13,13 +13,25 @@ enum FplSlotMap {
   SLOT_CHAIN = 2     // k-slot (s,g,j) -> channel 16(2s + (j>>2)) + 4g + (j&3)
 };
 
-static inline uint16_t f32_to_bf16_rne(float f) {
+// float -> the 16-bit operand type of this build (mfma_util.h), round to nearest even
+#ifdef FPL_F16
+static inline uint16_t fpl_f32_to_h16(float f) {
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+constexpr float FPL_H16_MAX = 65504.f;
+#else
+static inline uint16_t fpl_f32_to_h16(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
   if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
   u += 0x7FFFu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+constexpr float FPL_H16_MAX = 3.3e38f;
+#endif
 
 // Output channel computed by row m of M-block b.  Plain: 16b + m.  Interleaved
 // (il): 4*MB*(m/4) + 4b + m%4 - lane (c, g) of the accumulators (rows 4g..4g+3 of
@@ -55,7 +67,7 @@ static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
           if (kidx < 0) continue;
           const float v = W[(size_t)kidx * cout + co] * scale[co];
           (*out)[(((size_t)s * n_mblocks + b) * 64 + lane) * 8 + j] =
-              f32_to_bf16_rne(v);
+              fpl_f32_to_h16(v);
         }
       }
 }
@@ -96,7 +108,7 @@ static inline void fpl_pack_stem(const float *W, const float *scale, int cout,
           const int tap = fpl_stem_slot_tap(e, g, j);
           if (tap < 0) continue;
           (*out)[(((size_t)e * 3 + b) * 64 + lane) * 8 + j] =
-              f32_to_bf16_rne(W[(size_t)tap * cout + co] * scale[co]);
+              fpl_f32_to_h16(W[(size_t)tap * cout + co] * scale[co]);
         }
       }
 }

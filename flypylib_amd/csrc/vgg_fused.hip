@@ -45,9 +45,9 @@ struct StemArgs {
   int64_t z_hi;            // rows >= z_hi are not needed (and may not be resident)
   float mean, sd;
   int64_t p1z0;            // global P1 row of chunk-local row 0
-  const bf16x8 *w1, *w2;   // fragments [s][b][lane]
+  const h16x8 *w1, *w2;   // fragments [s][b][lane]
   const float *shift1, *shift2;
-  __bf16 *p1;
+  h16_t *p1;
   int P1Z, P1Y, P1X;       // chunk-local dims
 };
 
@@ -57,7 +57,7 @@ __device__ __forceinline__ int stem_row_off(int row) {
 }
 
 template <typename SRC>
-__global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
+__global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned short tile[S_TZ * S_TY * S_TX];
   __shared__ unsigned short lut[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
     const SRC *src = (const SRC *)a.src;
     const int64_t gz0 = 2 * (a.p1z0 + pz0), gy0 = 2 * (int64_t)py0, gx0 = 2 * (int64_t)px0;
     if (sizeof(SRC) == 1) {
-      lut[tid] = bf16_bits(((float)tid - a.mean) / a.sd);
+      lut[tid] = h16_bits(((float)tid - a.mean) / a.sd);
       __syncthreads();
     }
     constexpr int ROWS = S_TZ * S_TY;            // 180 rows of 66
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
           if (ok[k] && x0_ok) b0 = lut[(int)v0[k]];
           if (ok[k] && x1_ok) b1 = lut[(int)v1[k]];
         } else {
-          if (ok[k] && x0_ok) b0 = bf16_bits(((float)v0[k] - a.mean) / a.sd);
-          if (ok[k] && x1_ok) b1 = bf16_bits(((float)v1[k] - a.mean) / a.sd);
+          if (ok[k] && x0_ok) b0 = h16_bits(((float)v0[k] - a.mean) / a.sd);
+          if (ok[k] && x1_ok) b1 = h16_bits(((float)v1[k] - a.mean) / a.sd);
         }
         tile[row * S_TX + lane] = b0;
         if (lane < 2) tile[row * S_TX + 64 + lane] = b1;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
     for (int h = 0; h < 2; ++h)
       offS[e][h] = g < 3 ? 2 * (stem_row_off(2 * g + h) + (e == 0 ? 2 : 1)) : 0;
   }
-  bf16x8 w1[2][3], w2[2][3];
+  h16x8 w1[2][3], w2[2][3];
   f32x4 sh1[3], sh2[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
@@ -160,12 +160,12 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
         const unsigned s0 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][0]);
         const unsigned s1 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][1]);
         raw[3] = s0 | (s1 << 16);
-        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, raw);
+        const h16x8 bfrag = __builtin_bit_cast(h16x8, raw);
         f32x4 a1[3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[e][b], bfrag, sh1[b]);
-        const bf16x8 h0 = pack_relu(a1[0], a1[1]);
-        const bf16x8 h1 = pack_relu_lo(a1[2]);
+        const h16x8 h0 = pack_relu(a1[0], a1[1]);
+        const h16x8 h1 = pack_relu_lo(a1[2]);
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
           a2[e][b] = mfma16(w2[0][b], h0, sh2[b]);
@@ -181,12 +181,12 @@ __global__ __launch_bounds__(256, 2) void vgg_stem_pool_bf16(StemArgs a) {
     u32x2 pooled[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      pooled[b][0] = cvt_pk_bf16(poolf[b][0], poolf[b][1]);
-      pooled[b][1] = cvt_pk_bf16(poolf[b][2], poolf[b][3]);
+      pooled[b][0] = cvt_pk_h16(poolf[b][0], poolf[b][1]);
+      pooled[b][1] = cvt_pk_h16(poolf[b][2], poolf[b][3]);
     }
     const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + 16 * xh + c;
     if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
-      __bf16 *dst = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * CH + 4 * g;
+      h16_t *dst = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * CH + 4 * g;
 #pragma unroll
       for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
     }
@@ -271,7 +271,7 @@ template <int KC> struct WStage {
 
 // fill the activation tile by LDS-DMA: tile is TZ*TY rows of TX voxels (96 B)
 template <int TZ, int TY, int TX>
-__device__ __forceinline__ void stage_tile(const __bf16 *act, int AZ, int AY, int AX,
+__device__ __forceinline__ void stage_tile(const h16_t *act, int AZ, int AY, int AX,
                                            int z0, int y0, int x0,
                                            unsigned char *tile, int wave, int lane) {
   constexpr int ROW_CHUNKS = TX * VOX_BYTES / 16;          // 16-B pieces per row
@@ -285,7 +285,7 @@ __device__ __forceinline__ void stage_tile(const __bf16 *act, int AZ, int AY, in
     z = z < AZ ? z : AZ - 1;                               // clamp: edge blocks
     y = y < AY ? y : AY - 1;                               // only feed masked
     x = x < AX ? x : AX - 1;                               // outputs
-    const __bf16 *gp = act + (((int64_t)z * AY + y) * AX + x) * CH + (cw % 6) * 8;
+    const h16_t *gp = act + (((int64_t)z * AY + y) * AX + x) * CH + (cw % 6) * 8;
     glds16(gp, tile + (size_t)p * 1024);
   }
 }
@@ -310,13 +310,13 @@ __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
   __syncthreads();            // activation tile (LDS-DMA) + slot 0 + table visible
   if (DIAG) *t_ready = __builtin_amdgcn_s_memtime();
   // activation fragments run one K-step ahead of the MFMAs
-  bf16x8 bcur[NSUB], bnxt[NSUB];
+  h16x8 bcur[NSUB], bnxt[NSUB];
   const unsigned *ktab = kofftab + g * (G::NCH * G::KQ);
   {
     const unsigned koff = ktab[0];
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
-      bcur[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub_off(sub));
+      bcur[sub] = *reinterpret_cast<const h16x8 *>(tile + vbase + koff + sub_off(sub));
   }
 #pragma unroll
   for (int ck = 0; ck < G::NCH; ++ck) {
@@ -336,21 +336,21 @@ __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
       kq[4 * q4 + 0] = v[0]; kq[4 * q4 + 1] = v[1];
       kq[4 * q4 + 2] = v[2]; kq[4 * q4 + 3] = v[3];
     }
-    bf16x8 wcur[3], wnxt[3];
+    h16x8 wcur[3], wnxt[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b)
-      wcur[b] = *reinterpret_cast<const bf16x8 *>(wslot + b * 1024);
+      wcur[b] = *reinterpret_cast<const h16x8 *>(wslot + b * 1024);
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
       // prefetch K-step s+1 (the final prefetch re-reads step KSTEPS-1: harmless)
       const unsigned koff = kq[ks + 1];
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub)
-        bnxt[sub] = *reinterpret_cast<const bf16x8 *>(tile + vbase + koff + sub_off(sub));
+        bnxt[sub] = *reinterpret_cast<const h16x8 *>(tile + vbase + koff + sub_off(sub));
       if (ks + 1 < KC) {
 #pragma unroll
         for (int b = 0; b < 3; ++b)
-          wnxt[b] = *reinterpret_cast<const bf16x8 *>(wslot + ((ks + 1) * 3 + b) * 1024);
+          wnxt[b] = *reinterpret_cast<const h16x8 *>(wslot + ((ks + 1) * 3 + b) * 1024);
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -382,18 +382,18 @@ constexpr int M_SMEM = M_TILE_BYTES + 2 * KGeom<M_KC>::RING + KGeom<M_KC>::TAB_B
 static_assert(2 * M_SMEM <= 160 * 1024, "two mid workgroups must fit one CU");
 
 struct MidArgs {
-  const __bf16 *p1;
+  const h16_t *p1;
   int P1Z, P1Y, P1X;
   const unsigned char *w3;       // 42 x 3 fragments
-  const bf16x8 *w4;              // [s][b][lane]
+  const h16x8 *w4;              // [s][b][lane]
   const float *shift3, *shift4;
-  __bf16 *p2;
+  h16_t *p2;
   int P2Z, P2Y, P2X;
   unsigned long long *dbg;       // diagnostic build only: 4 stamps per workgroup
 };
 
 template <bool DIAG>
-__global__ __launch_bounds__(256, 2) void vgg_mid_pool_bf16(MidArgs a) {
+__global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
   if (DIAG) t0 = __builtin_amdgcn_s_memtime();
   using G = KGeom<M_KC>;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void vgg_mid_pool_bf16(MidArgs a) {
   if (DIAG) t2 = __builtin_amdgcn_s_memtime();
 
   // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions
-  bf16x8 w4[2][3];
+  h16x8 w4[2][3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     w4[0][b] = a.w4[(0 * 3 + b) * 64 + lane];
@@ -441,13 +441,13 @@ __global__ __launch_bounds__(256, 2) void vgg_mid_pool_bf16(MidArgs a) {
   u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
-    const bf16x8 h0 = pack_relu(acc[sub][0], acc[sub][1]);
-    const bf16x8 h1 = pack_relu_lo(acc[sub][2]);
+    const h16x8 h0 = pack_relu(acc[sub][0], acc[sub][1]);
+    const h16x8 h1 = pack_relu_lo(acc[sub][2]);
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
       f32x4 a4 = mfma16(w4[0][b], h0, sh4[b]);
       a4 = mfma16(w4[1][b], h1, a4);
-      pool_relu_bf16(pooled[b], a4);
+      pool_relu_h16(pooled[b], a4);
     }
   }
   // pool the x pair: lanes c and c^1 hold neighbouring pre-pool x
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void vgg_mid_pool_bf16(MidArgs a) {
   }
   const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + (c >> 1);
   if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
-    __bf16 *dst = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * CH + 4 * g;
+    h16_t *dst = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * CH + 4 * g;
 #pragma unroll
     for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
   }
@@ -482,15 +482,15 @@ constexpr int H_SMEM = H_TILE_BYTES + 2 * KGeom<H_KC>::RING + KGeom<H_KC>::TAB_B
 static_assert(2 * H_SMEM <= 160 * 1024, "two c5 workgroups must fit one CU");
 
 struct C5Args {
-  const __bf16 *p2;
+  const h16_t *p2;
   int P2Z, P2Y, P2X;
   const unsigned char *w5;       // 42 x 3 fragments
   const float *shift5;
-  __bf16 *c5;
+  h16_t *c5;
   int CZ, CY, CX;                // chunk-local coarse dims (= c5 dims)
 };
 
-__global__ __launch_bounds__(256, 2) void vgg_c5_bf16(C5Args a) {
+__global__ __launch_bounds__(256, 2) void FPLK(vgg_c5)(C5Args a) {
   using G = KGeom<H_KC>;
   unsigned char *tile = smem;
   unsigned char *ring = smem + H_TILE_BYTES;
@@ -520,12 +520,12 @@ __global__ __launch_bounds__(256, 2) void vgg_c5_bf16(C5Args a) {
   for (int sub = 0; sub < 4; ++sub) {
     const int cy = cy0 + sub;
     if (cz < a.CZ && cy < a.CY && cx < a.CX) {
-      __bf16 *dst = a.c5 + (((int64_t)cz * a.CY + cy) * a.CX + cx) * CH + 4 * g;
+      h16_t *dst = a.c5 + (((int64_t)cz * a.CY + cy) * a.CX + cx) * CH + 4 * g;
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         u32x2 o;
-        o[0] = pk_max_i16(cvt_pk_bf16(acc[sub][b][0], acc[sub][b][1]), 0u);
-        o[1] = pk_max_i16(cvt_pk_bf16(acc[sub][b][2], acc[sub][b][3]), 0u);
+        o[0] = pk_max_i16(cvt_pk_h16(acc[sub][b][0], acc[sub][b][1]), 0u);
+        o[1] = pk_max_i16(cvt_pk_h16(acc[sub][b][2], acc[sub][b][3]), 0u);
         *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
       }
     }
@@ -543,7 +543,7 @@ constexpr int H_W6 = 12, H_W7 = 18, H_W8 = 3;       // fragment counts
 constexpr int H_WTAIL_BYTES = (H_W6 + H_W7 + H_W8) * 1024;
 
 struct TailArgs {
-  const __bf16 *c5;
+  const h16_t *c5;
   int CZ, CY, CX;                // chunk-local coarse dims
   const unsigned char *wtail;    // L6 [2][6], L7 [3][6], L8 [3][1] fragments
   const float *shift6, *shift7;
@@ -554,15 +554,15 @@ struct TailArgs {
   int64_t VZ, VY, VX;            // valid fine extents (dim - 14)
 };
 
-__global__ __launch_bounds__(256) void vgg_tail_bf16(TailArgs a) {
+__global__ __launch_bounds__(256) void FPLK(vgg_tail)(TailArgs a) {
   unsigned char *wtail = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   for (int i = tid; i < H_WTAIL_BYTES / 16; i += 256)
     reinterpret_cast<u32x4 *>(wtail)[i] = reinterpret_cast<const u32x4 *>(a.wtail)[i];
-  const bf16x8 *w6 = reinterpret_cast<const bf16x8 *>(wtail);
-  const bf16x8 *w7 = w6 + H_W6 * 64;
-  const bf16x8 *w8 = w7 + H_W7 * 64;
+  const h16x8 *w6 = reinterpret_cast<const h16x8 *>(wtail);
+  const h16x8 *w7 = w6 + H_W6 * 64;
+  const h16x8 *w8 = w7 + H_W7 * 64;
   f32x4 sh6[6], sh7[6];
 #pragma unroll
   for (int b = 0; b < 6; ++b)
@@ -578,14 +578,14 @@ __global__ __launch_bounds__(256) void vgg_tail_bf16(TailArgs a) {
     const int cxb = (int)(grp % xg), cy = (int)((grp / xg) % a.CY), cz = (int)(grp / ((int64_t)xg * a.CY));
     const int cx = cxb * 16 + c;
     const int cxl = cx < a.CX ? cx : a.CX - 1;
-    const __bf16 *src = a.c5 + (((int64_t)cz * a.CY + cy) * a.CX + cxl) * CH + 4 * g;
+    const h16_t *src = a.c5 + (((int64_t)cz * a.CY + cy) * a.CX + cxl) * CH + 4 * g;
     // B fragments in accumulator order: k-slot (s,g,j) = channel 16(2s + (j>>2)) + 4g + (j&3)
     const u32x2 q0 = *reinterpret_cast<const u32x2 *>(src);
     const u32x2 q1 = *reinterpret_cast<const u32x2 *>(src + 16);
     const u32x2 q2 = *reinterpret_cast<const u32x2 *>(src + 32);
-    bf16x8 h[3];
-    h[0] = __builtin_bit_cast(bf16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
-    h[1] = __builtin_bit_cast(bf16x8, u32x4{q2[0], q2[1], 0u, 0u});
+    h16x8 h[3];
+    h[0] = __builtin_bit_cast(h16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
+    h[1] = __builtin_bit_cast(h16x8, u32x4{q2[0], q2[1], 0u, 0u});
     f32x4 a6[6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
@@ -671,11 +671,11 @@ bool is_vgg_like(const fpl_program *prog) {
 }
 
 int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
-  VggFastState *st = (VggFastState *)prog->fast_state;
+  VggFastState *st = (VggFastState *)prog->fast_state_h16[FPL_H16_SLOT];
   if (!st) {
     st = new VggFastState();
-    prog->fast_state = st;
-    prog->fast_state_free = vgg_state_free;
+    prog->fast_state_h16[FPL_H16_SLOT] = st;
+    prog->fast_state_h16_free[FPL_H16_SLOT] = vgg_state_free;
   }
   *out = st;
   if (st->version == prog->arena_version) return 0;
@@ -705,6 +705,12 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
     shifts.insert(shifts.end(), A + op.shift_off, A + op.shift_off + op.cout);
     while (shifts.size() % 4) shifts.push_back(0.f);
   }
+#ifdef FPL_F16
+  for (uint16_t h : all)
+    FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
+                "a folded weight exceeds the IEEE-half range (65504); use precision "
+                "bf16 or f32 for this network");
+#endif
   st->bias8 = A[prog->ops[9].shift_off];
   if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
   if (st->shifts) FPL_HIP(ctx, hipFree(st->shifts));
@@ -716,11 +722,11 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
                          hipMemcpyHostToDevice));
   FPL_HIP(ctx, hipMemcpy(st->shifts, shifts.data(), shifts.size() * sizeof(float),
                          hipMemcpyHostToDevice));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vgg_mid_pool_bf16<false>,
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool)<false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vgg_mid_pool_bf16<true>,
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool)<true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vgg_c5_bf16,
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_c5),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM));
   st->version = prog->arena_version;
   return 0;
@@ -728,15 +734,15 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
 
 }  // namespace
 
-bool fpl_fast_path_available(const fpl_program *prog, int precision,
+bool FPLK(fpl_fast_path_available)(const fpl_program *prog, int precision,
                              const int32_t offset[3], const int32_t out_sz[3]) {
-  if (precision != FPL_PREC_BF16 || !is_vgg_like(prog)) return false;
+  if (precision != FPL_THIS_PREC || !is_vgg_like(prog)) return false;
   for (int a = 0; a < 3; ++a)
     if (offset[a] != 7 || out_sz[a] % 4 != 0) return false;
   return true;
 }
 
-int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
+int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src,
                           int src_dtype, float mean, float sd,
                           const int64_t dims[3], const int32_t tile_in[3],
                           const int32_t offset[3], int precision,
@@ -744,7 +750,7 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                           const int32_t out_sz[3], int32_t zb, int32_t ze,
                           float *dst, bool *handled) {
   *handled = false;
-  if (!fpl_fast_path_available(prog, precision, offset, out_sz)) return 0;
+  if (!FPLK(fpl_fast_path_available)(prog, precision, offset, out_sz)) return 0;
   VggFastState *st;
   FPL_TRY(vgg_prepare(ctx, prog, &st));
   hipStream_t stream = ctx->stream;
@@ -784,25 +790,25 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
       // block rounding may reach past the rows this slab stages: they only
       // feed masked outputs, so they read as zero
       a.z_hi = std::min<int64_t>(SZ, 4 * (c0 + CZ) + 14);
-      a.w1 = (const bf16x8 *)(F + st->off_w[0]);
-      a.w2 = (const bf16x8 *)(F + st->off_w[1]);
+      a.w1 = (const h16x8 *)(F + st->off_w[0]);
+      a.w2 = (const h16x8 *)(F + st->off_w[1]);
       a.shift1 = S + st->off_s[0]; a.shift2 = S + st->off_s[1];
-      a.p1 = (__bf16 *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
+      a.p1 = (h16_t *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
       dim3 grid((unsigned)ceil_div64(P1X, S_PX), (unsigned)ceil_div64(P1Y, S_PY),
                 (unsigned)ceil_div64(P1Z, S_PZ));
-      TimedLaunch tl(ctx, "vgg_stem_pool_bf16");
+      TimedLaunch tl(ctx, "vgg_stem_pool_" FPL_PREC_STR);
       if (src_dtype == FPL_U8)
-        vgg_stem_pool_bf16<uint8_t><<<grid, 256, 0, stream>>>(a);
+        FPLK(vgg_stem_pool)<uint8_t><<<grid, 256, 0, stream>>>(a);
       else
-        vgg_stem_pool_bf16<float><<<grid, 256, 0, stream>>>(a);
+        FPLK(vgg_stem_pool)<float><<<grid, 256, 0, stream>>>(a);
     }
     {
       MidArgs a;
-      a.p1 = (const __bf16 *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
+      a.p1 = (const h16_t *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
       a.w3 = F + st->off_w[2];
-      a.w4 = (const bf16x8 *)(F + st->off_w[3]);
+      a.w4 = (const h16x8 *)(F + st->off_w[3]);
       a.shift3 = S + st->off_s[2]; a.shift4 = S + st->off_s[3];
-      a.p2 = (__bf16 *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
+      a.p2 = (h16_t *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
       dim3 grid((unsigned)ceil_div64(P2X, 8), (unsigned)ceil_div64(P2Y, 2),
                 (unsigned)ceil_div64(P2Z, 2));
       a.dbg = nullptr;
@@ -812,7 +818,7 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
         void *dbg;
         FPL_TRY(tmp.alloc(nwg * 32, &dbg));
         a.dbg = (unsigned long long *)dbg;
-        vgg_mid_pool_bf16<true><<<grid, 256, M_SMEM, stream>>>(a);
+        FPLK(vgg_mid_pool)<true><<<grid, 256, M_SMEM, stream>>>(a);
         std::vector<unsigned long long> h(nwg * 4);
         FPL_HIP(ctx, hipMemcpyAsync(h.data(), dbg, nwg * 32, hipMemcpyDeviceToHost, stream));
         FPL_HIP(ctx, hipStreamSynchronize(stream));
@@ -826,31 +832,31 @@ int fpl_fast_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
         fprintf(stderr, "[FPL_DIAG_MID] %zu WGs: mean cycles fill %.0f  kloop %.0f  epilogue %.0f  total %.0f\n",
                 nwg, fill / nwg, loop / nwg, epi / nwg, tot / nwg);
       } else {
-        TimedLaunch tl(ctx, "vgg_mid_pool_bf16");
-        vgg_mid_pool_bf16<false><<<grid, 256, M_SMEM, stream>>>(a);
+        TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
+        FPLK(vgg_mid_pool)<false><<<grid, 256, M_SMEM, stream>>>(a);
       }
     }
     {
       C5Args a;
-      a.p2 = (const __bf16 *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
+      a.p2 = (const h16_t *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
       a.w5 = F + st->off_w[4]; a.shift5 = S + st->off_s[4];
-      a.c5 = (__bf16 *)c5v; a.CZ = CZ; a.CY = CY; a.CX = CX;
+      a.c5 = (h16_t *)c5v; a.CZ = CZ; a.CY = CY; a.CX = CX;
       dim3 grid((unsigned)ceil_div64(CX, 16), (unsigned)ceil_div64(CY, 4),
                 (unsigned)ceil_div64(CZ, 4));
-      TimedLaunch tl(ctx, "vgg_c5_bf16");
-      vgg_c5_bf16<<<grid, 256, H_SMEM, stream>>>(a);
+      TimedLaunch tl(ctx, "vgg_c5_" FPL_PREC_STR);
+      FPLK(vgg_c5)<<<grid, 256, H_SMEM, stream>>>(a);
     }
     {
       TailArgs a;
-      a.c5 = (const __bf16 *)c5v; a.CZ = CZ; a.CY = CY; a.CX = CX;
+      a.c5 = (const h16_t *)c5v; a.CZ = CZ; a.CY = CY; a.CX = CX;
       a.wtail = F + st->off_w[5];      // L6, L7, L8 fragments are contiguous
       a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
       a.dst = dst; a.DY = SY; a.DX = SX; a.cz0 = c0;
       a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX;
       const int64_t groups = (int64_t)CZ * CY * ceil_div64(CX, 16);
       const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(groups, 4), (int64_t)ctx->n_cu * 16);
-      TimedLaunch tl(ctx, "vgg_tail_bf16");
-      vgg_tail_bf16<<<grid, 256, H_WTAIL_BYTES, stream>>>(a);
+      TimedLaunch tl(ctx, "vgg_tail_" FPL_PREC_STR);
+      FPLK(vgg_tail)<<<grid, 256, H_WTAIL_BYTES, stream>>>(a);
     }
     FPL_HIP(ctx, hipGetLastError());
   }

@@ -18,7 +18,8 @@ import numpy as np
 from . import _capi, fplutils, multi_gpu, runtime
 
 _PRECISIONS = {'f32': _capi.PREC_F32, 'fp32': _capi.PREC_F32,
-               'float32': _capi.PREC_F32, 'bf16': _capi.PREC_BF16}
+               'float32': _capi.PREC_F32, 'bf16': _capi.PREC_BF16,
+               'f16': _capi.PREC_F16, 'float16': _capi.PREC_F16}
 
 
 class InferNetwork:

@@ -30,14 +30,17 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 2
+#define FPL_ABI_VERSION 3
 
 typedef struct fpl_ctx fpl_ctx;
 typedef struct fpl_program fpl_program;
 
 enum fpl_mem { FPL_MEM_HOST = 0, FPL_MEM_DEVICE = 1 };
 enum fpl_dtype { FPL_U8 = 0, FPL_F32 = 1, FPL_F64 = 2 };
-enum fpl_precision { FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1 };
+/* arithmetic of the convolutions: fp32 (exact reference arithmetic), or 16-bit MFMA
+ * operands with fp32 accumulation - bfloat16 (8 significant bits) or IEEE half (11
+ * bits, range 65504: probabilities within ~1e-4 of fp32; same speed as bf16) */
+enum fpl_precision { FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1, FPL_PREC_F16 = 2 };
 
 /* fused layer-program ops, produced by LayerGraph.lower_inference()
  * (flypylib_amd/program.py); layer semantics = Keras layers instantiated in

@@ -175,28 +175,32 @@ def conv3d_valid_numpy(x, kernel):
 
 
 # ---- bf16 emulation of the fused MI355X kernels (csrc/vgg_fused.hip) -----------
-def _bf16_round(t):
-    """round-to-nearest-even to bfloat16, kept in float32"""
-    return t.to(torch.bfloat16).to(torch.float32)
+def _bf16_round(t, kind='bf16'):
+    """round-to-nearest-even to the 16-bit operand type of the fused kernels
+    (bfloat16, or IEEE half for kind='f16'), kept in float32"""
+    return t.to(torch.float16 if kind == 'f16' else torch.bfloat16).to(torch.float32)
 
 
-def vgg_like_forward_bf16emu(x, weights, upsample_stride=None):
+def vgg_like_forward_bf16emu(x, weights, upsample_stride=None, kind='bf16'):
     """vgg_like with the rounding points of the fused bf16 kernels: BN scale is
     folded into the kernel before rounding it to bf16, BN shift stays fp32,
     activations are rounded to bf16 after every ReLU, accumulation is fp32.
     x: (N,D,H,W,1) float32 already normalised."""
     w = _W(weights, torch.float32)
-    h = _bf16_round(_t(x, torch.float32).permute(0, 4, 1, 2, 3))
+
+    def _r(t):
+        return _bf16_round(t, kind)
+    h = _r(_t(x, torch.float32).permute(0, 4, 1, 2, 3))
 
     def block(h, pool):
         kern = w.take()
         g, b, m, v = w.take(4)
         s = g / torch.sqrt(v + BN_EPS)
-        kf = _bf16_round(kern * s.view(1, 1, 1, 1, -1))
+        kf = _r(kern * s.view(1, 1, 1, 1, -1))
         y = conv3d_valid(h, kf) + (b - m * s).view(1, -1, 1, 1, 1)
         if pool:
             y = maxpool2(y)
-        return _bf16_round(torch.relu(y))
+        return _r(torch.relu(y))
 
     h = block(h, False)
     h = block(h, True)
@@ -206,33 +210,36 @@ def vgg_like_forward_bf16emu(x, weights, upsample_stride=None):
     h = block(h, False)
     h = block(h, False)
     kern, bias = w.take(2)
-    h = torch.sigmoid(conv3d_valid(h, _bf16_round(kern)) + bias.view(1, -1, 1, 1, 1))
+    h = torch.sigmoid(conv3d_valid(h, _r(kern)) + bias.view(1, -1, 1, 1, 1))
     w.done()
     if upsample_stride is not None:
         h = upsample(h, upsample_stride)
     return h.permute(0, 2, 3, 4, 1).contiguous().numpy()
 
 
-def unet_like2_forward_bf16emu(x, weights):
+def unet_like2_forward_bf16emu(x, weights, kind='bf16'):
     """unet_like2 with the rounding points of the bf16 MFMA kernels
     (csrc/conv_mfma.hip): input and every post-ReLU activation rounded to bf16,
     BN scale folded into bf16 kernels, fp32 accumulation and shift."""
     w = _W(weights, torch.float32)
-    h = _bf16_round(_t(x, torch.float32).permute(0, 4, 1, 2, 3))
+
+    def _r(t):
+        return _bf16_round(t, kind)
+    h = _r(_t(x, torch.float32).permute(0, 4, 1, 2, 3))
 
     def block(h):
         kern = w.take()
         g, b, m, v = w.take(4)
         s = g / torch.sqrt(v + BN_EPS)
-        kf = _bf16_round(kern * s.view(1, 1, 1, 1, -1))
+        kf = _r(kern * s.view(1, 1, 1, 1, -1))
         y = conv3d_valid(h, kf) + (b - m * s).view(1, -1, 1, 1, 1)
-        return _bf16_round(torch.relu(y))
+        return _r(torch.relu(y))
 
     c1 = block(block(h))
     c2 = block(block(maxpool2(c1)))
     c3 = block(maxpool2(c2))
     c4 = block(block(torch.cat([upsample(c3, 2), c2], dim=1)))
     c5 = block(block(torch.cat([upsample(c4, 2), crop(c1, 6)], dim=1)))
-    out = torch.sigmoid(conv3d_valid(c5, _bf16_round(w.take())))
+    out = torch.sigmoid(conv3d_valid(c5, _r(w.take())))
     w.done()
     return out.permute(0, 2, 3, 4, 1).contiguous().numpy()

@@ -1,10 +1,12 @@
-"""GPU parity for the fused bf16 MFMA vgg_like path (csrc/vgg_fused.hip).
+"""GPU parity for the fused 16-bit MFMA vgg_like path (csrc/vgg_fused.hip), built
+for bfloat16 and for IEEE-half operands.
 
 Two references:
-  * the bf16 emulation oracle (same rounding points as the kernels): tight
-    tolerance - proves indexing, fragment maps, pooling, lattice and edges;
-  * the fp32 oracle: the bf16 path's precision cost, asserted at BF16_TOL (the
-    1e-3 north-star gate applies to the fp32 path, tests/test_gpu_cnn.py).
+  * the emulation oracle (same rounding points as the kernels, same 16-bit type):
+    tight tolerance - proves indexing, fragment maps, pooling, lattice and edges;
+  * the fp32 oracle: the precision cost.  bf16 is asserted at BF16_TOL; **f16 must
+    meet the north star's 1e-3 gate** (F16_TOL), as the fp32 paths do
+    (tests/test_gpu_cnn.py).
 """
 import numpy as np
 import pytest
@@ -13,8 +15,11 @@ from flypylib_amd import _capi, fplmodels, multi_gpu, synth
 from oracle import cnn_oracle, infer_oracle
 
 pytestmark = pytest.mark.gpu
-EMU_TOL = 1e-2       # worst voxel: bf16 one-ulp flips at rounding points, amplified
+EMU_TOL = {'bf16': 1e-2, 'f16': 2e-3}   # worst voxel: one-ulp flips at rounding points, amplified
 BF16_TOL = 5e-2      # bf16 vs fp32 probabilities, max abs
+F16_TOL = 1e-3       # f16 vs fp32 probabilities, max abs: the north-star gate
+PREC = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16}
+KINDS = ['bf16', 'f16']
 
 
 def _net(seed, tile=30):
@@ -23,10 +28,10 @@ def _net(seed, tile=30):
     return g
 
 
-def _refs(g, img, tile):
+def _refs(g, img, tile, kind='bf16'):
     def emu(batch):
         return cnn_oracle.vgg_like_forward_bf16emu(batch.astype(np.float32),
-                                                   g.weights, 4)
+                                                   g.weights, 4, kind=kind)
 
     def f32(batch):
         return cnn_oracle.vgg_like_forward(batch.astype(np.float32), g.weights, 4)
@@ -35,43 +40,47 @@ def _refs(g, img, tile):
     return a, b
 
 
+@pytest.mark.parametrize('kind', KINDS)
 @pytest.mark.parametrize('shape,tile', [
     ((50, 47, 41), 30), ((46, 46, 46), 30), ((31, 30, 64), 30),
     ((75, 33, 90), 30), ((104, 120, 110), 102), ((40, 135, 52), 46)])
-def test_fused_bf16_matches_emulation_and_fp32(ctx, shape, tile):
+def test_fused_bf16_matches_emulation_and_fp32(ctx, shape, tile, kind):
     g = _net(21, tile)
     prog = _capi.Program(ctx, g, (4, 4, 4))
     u8 = synth.em_volume_u8(9, shape)
     img = (u8.astype(np.float32) - np.float32(128)) / np.float32(33)
     got = prog.infer_volume(u8, (tile,) * 3, (7,) * 3, mean=128.0, std=33.0,
-                            precision=_capi.PREC_BF16)
-    emu, f32 = _refs(g, img, tile)
+                            precision=PREC[kind])
+    emu, f32 = _refs(g, img, tile, kind)
     assert got.shape == shape and got.dtype == np.float32
     assert not got[:7].any() and not got[-7:].any()
     assert not got[:, :7].any() and not got[:, :, -7:].any()
     d_emu = np.abs(got - emu)
     d_f32 = np.abs(got - f32)
-    assert d_emu.max() < EMU_TOL, 'vs bf16 emulation: max %g' % d_emu.max()
-    assert d_emu.mean() < 1e-4
+    assert d_emu.max() < EMU_TOL[kind], 'vs %s emulation: max %g' % (kind, d_emu.max())
+    assert d_emu.mean() < (1e-4 if kind == 'bf16' else 2e-5)
     assert np.mean(d_emu > 1e-3) < 1e-3       # 99.9 % of voxels within 1e-3
-    assert d_f32.max() < BF16_TOL, 'vs fp32 oracle: max %g' % d_f32.max()
+    tol = BF16_TOL if kind == 'bf16' else F16_TOL
+    assert d_f32.max() < tol, '%s vs fp32 oracle: max %g' % (kind, d_f32.max())
     assert f32[7:-7, 7:-7, 7:-7].std() > 1e-3
 
 
-def test_fused_bf16_float_input(ctx):
+@pytest.mark.parametrize('kind', KINDS)
+def test_fused_bf16_float_input(ctx, kind):
     g = _net(22)
     prog = _capi.Program(ctx, g, (4, 4, 4))
     img = synth.hash_uniform_f32(3, (44, 52, 39)) * np.float32(4) - np.float32(2)
-    got = prog.infer_volume(img, (30,) * 3, (7,) * 3, precision=_capi.PREC_BF16)
-    emu, _ = _refs(g, img, 30)
-    assert np.abs(got - emu).max() < EMU_TOL
+    got = prog.infer_volume(img, (30,) * 3, (7,) * 3, precision=PREC[kind])
+    emu, _ = _refs(g, img, 30, kind)
+    assert np.abs(got - emu).max() < EMU_TOL[kind]
 
 
-def test_fused_bf16_slabs_equal_whole(ctx):
+@pytest.mark.parametrize('kind', KINDS)
+def test_fused_bf16_slabs_equal_whole(ctx, kind):
     g = _net(23)
     prog = _capi.Program(ctx, g, (4, 4, 4))
     u8 = synth.em_volume_u8(4, (120, 40, 52))
-    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_BF16)
+    kw = dict(mean=128.0, std=33.0, precision=PREC[kind])
     whole = prog.infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
     n = multi_gpu.n_tile_rows(120, 30, 7)
     out = np.full_like(whole, np.nan)
@@ -82,12 +91,13 @@ def test_fused_bf16_slabs_equal_whole(ctx):
     assert np.array_equal(out, whole)
 
 
-def test_fused_bf16_is_tiling_independent(ctx):
+@pytest.mark.parametrize('kind', KINDS)
+def test_fused_bf16_is_tiling_independent(ctx, kind):
     """the coarse grid is anchored at the volume origin: any infer_sz = 4n+14
     gives bit-identical output (vgg_like is phase-safe)"""
     g30, g46 = _net(24, 30), _net(24, 46)
     u8 = synth.em_volume_u8(5, (60, 66, 58))
-    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_BF16)
+    kw = dict(mean=128.0, std=33.0, precision=PREC[kind])
     a = _capi.Program(ctx, g30, (4, 4, 4)).infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
     b = _capi.Program(ctx, g46, (4, 4, 4)).infer_volume(u8, (46,) * 3, (7,) * 3, **kw)
     assert np.array_equal(a, b)
@@ -104,3 +114,31 @@ def test_set_weights_repacks_fragments(ctx):
     b = prog.infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
     fresh = _capi.Program(ctx, g, (4, 4, 4)).infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
     assert not np.array_equal(a, b) and np.array_equal(b, fresh)
+
+
+def test_both_16bit_types_share_a_program(ctx):
+    """one program serves bf16 and f16 calls in any order (separate packed-weight
+    slots) and the two differ (they are different arithmetic)"""
+    g = _net(27)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(7, (46, 46, 46))
+    kw = dict(mean=128.0, std=33.0)
+    a = prog.infer_volume(u8, (30,) * 3, (7,) * 3, precision=_capi.PREC_BF16, **kw)
+    b = prog.infer_volume(u8, (30,) * 3, (7,) * 3, precision=_capi.PREC_F16, **kw)
+    a2 = prog.infer_volume(u8, (30,) * 3, (7,) * 3, precision=_capi.PREC_BF16, **kw)
+    assert np.array_equal(a, a2) and not np.array_equal(a, b)
+    assert np.abs(a - b).max() < 5e-2
+
+
+def test_f16_rejects_weights_beyond_the_half_range(ctx):
+    g = _net(28)
+    w = g.get_weights()
+    w[0] = w[0] * np.float32(1e7)
+    g.set_weights(w)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(7, (46, 46, 46))
+    with pytest.raises(_capi.FplHipError, match='half range'):
+        prog.infer_volume(u8, (30,) * 3, (7,) * 3, mean=128.0, std=33.0,
+                          precision=_capi.PREC_F16)
+    prog.infer_volume(u8, (30,) * 3, (7,) * 3, mean=128.0, std=33.0,
+                      precision=_capi.PREC_BF16)          # bf16 has the range
