@@ -63,6 +63,20 @@ def test_vgg_like_1024_cubed_bf16_properties(ctx):
         got = whole[sl][7:-7, 7:-7, 7:-7]
         d = np.abs(got - ref[7:-7, 7:-7, 7:-7])
         assert d.max() < 1e-2 and d.mean() < 1e-4 and np.mean(d > 1e-3) < 1e-3, (org, d.max())
+    # (e) the IEEE-half build of the same kernels meets the 1e-3 gate against the fp32
+    # oracle on those tiles
+    kw16 = dict(kw, precision=_capi.PREC_F16)
+    prog.infer_volume(src, (102,) * 3, (7,) * 3, dst=dst2, **kw16)
+    half = dst2.to_host()
+
+    def f32(batch):
+        return cnn_oracle.vgg_like_forward(batch.astype(np.float32), g.weights, 4)
+    for org in ((0, 0, 0), (440, 528, 352), (880, 880, 880)):
+        sl = tuple(slice(o, o + 102) for o in org)
+        img = (u8[sl].astype(np.float32) - np.float32(128)) / np.float32(33)
+        ref = infer_oracle.infer_lattice(img, (102,) * 3, (7,) * 3, f32)
+        d = np.abs(half[sl][7:-7, 7:-7, 7:-7] - ref[7:-7, 7:-7, 7:-7])
+        assert d.max() < 1e-3, (org, d.max())
     for b in (src, dst, dst2):
         b.free()
 
