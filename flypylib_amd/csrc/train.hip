@@ -80,6 +80,131 @@ __global__ void chan_reduce_partial(const float *__restrict__ a,
   }
 }
 
+// float4 form of the same reduction for C % 4 == 0: block = (C/4, R) threads, a thread
+// owns 4 channels and streams 16-B pieces, four rows in flight
+template <int MODE>
+__global__ void chan_reduce_partial4(const float *__restrict__ a,
+                                     const float *__restrict__ b,
+                                     const float *__restrict__ mean,
+                                     const float *__restrict__ invstd, int64_t M,
+                                     int C, double *__restrict__ part,
+                                     const float *__restrict__ y3 = nullptr) {
+  extern __shared__ double red[];
+  const int c4 = threadIdx.x, r = threadIdx.y, R = blockDim.y, C4 = C / 4;
+  const int64_t row0 = (int64_t)blockIdx.x * RED_ROWS;
+  const int64_t row1 = row0 + RED_ROWS < M ? row0 + RED_ROWS : M;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+  if (MODE == 1 || MODE == 3) {
+    mu = reinterpret_cast<const float4 *>(mean)[c4];
+    is = reinterpret_cast<const float4 *>(invstd)[c4];
+  }
+  const float4 *a4 = reinterpret_cast<const float4 *>(a);
+  const float4 *b4 = reinterpret_cast<const float4 *>(b);
+  const float4 *y4 = reinterpret_cast<const float4 *>(y3);
+  auto add = [&](const float4 &va, const float4 &vb, const float4 &vy) {
+    float v[4] = {va.x, va.y, va.z, va.w};
+    const float xb[4] = {vb.x, vb.y, vb.z, vb.w}, yy[4] = {vy.x, vy.y, vy.z, vy.w};
+    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (MODE == 3) v[q] = yy[q] > 0.f ? v[q] : 0.f;
+      if (MODE == 0) {
+        s0[q] += v[q]; s1[q] += (double)v[q] * v[q];
+      } else if (MODE == 1 || MODE == 3) {
+        const float xh = (xb[q] - m4[q]) * i4[q];
+        s0[q] += v[q]; s1[q] += (double)v[q] * xh;
+      } else {
+        s0[q] += v[q];
+      }
+    }
+  };
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int64_t m = row0 + r;
+  for (; m + 3 * R < row1; m += 4 * R) {
+    float4 va[4], vb[4], vy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t idx = (m + u * R) * C4 + c4;
+      va[u] = a4[idx];
+      vb[u] = (MODE == 1 || MODE == 3) ? b4[idx] : z4;
+      vy[u] = MODE == 3 ? y4[idx] : z4;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add(va[u], vb[u], vy[u]);
+  }
+  for (; m < row1; m += R) {
+    const int64_t idx = m * C4 + c4;
+    add(a4[idx], (MODE == 1 || MODE == 3) ? b4[idx] : z4, MODE == 3 ? y4[idx] : z4);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    red[(r * C + 4 * c4 + q) * 2 + 0] = s0[q];
+    red[(r * C + 4 * c4 + q) * 2 + 1] = s1[q];
+  }
+  __syncthreads();
+  // the first C threads of the block finish one channel each
+  const int t = threadIdx.y * blockDim.x + threadIdx.x;
+  if (t < C) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < R; ++k) {
+      t0 += red[(k * C + t) * 2 + 0];
+      t1 += red[(k * C + t) * 2 + 1];
+    }
+    part[((int64_t)blockIdx.x * 2 + 0) * C + t] = t0;
+    part[((int64_t)blockIdx.x * 2 + 1) * C + t] = t1;
+  }
+}
+
+// float4 forms of the BN (+ReLU) apply / backward passes (C % 4 == 0; n4 = n / 4)
+template <bool RELU>
+__global__ void bn_apply4(const float4 *__restrict__ x, const float4 *__restrict__ mean,
+                          const float4 *__restrict__ invstd, const float4 *__restrict__ gamma,
+                          const float4 *__restrict__ beta, float4 *__restrict__ y,
+                          int64_t n4, int C4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i % C4);
+  const float4 v = x[i], m = mean[c], s = invstd[c], g = gamma[c], b = beta[c];
+  float4 o;
+  o.x = (v.x - m.x) * s.x * g.x + b.x; o.y = (v.y - m.y) * s.y * g.y + b.y;
+  o.z = (v.z - m.z) * s.z * g.z + b.z; o.w = (v.w - m.w) * s.w * g.w + b.w;
+  if (RELU) {
+    o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+  }
+  y[i] = o;
+}
+
+template <bool RELU>
+__global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__restrict__ y,
+                             const float4 *__restrict__ x, const float4 *__restrict__ mean,
+                             const float4 *__restrict__ invstd,
+                             const float4 *__restrict__ gamma,
+                             const float4 *__restrict__ sum_g,
+                             const float4 *__restrict__ sum_g_xhat, float4 *__restrict__ dx,
+                             int64_t n4, int C4, float inv_m) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i % C4);
+  const float4 d = dy[i], xv = x[i], m = mean[c], s = invstd[c], g = gamma[c],
+               sg = sum_g[c], sx = sum_g_xhat[c];
+  float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (RELU) yv = y[i];
+  float4 o = dx[i];
+  const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w},
+              mm[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w},
+              gg[4] = {g.x, g.y, g.z, g.w}, s0[4] = {sg.x, sg.y, sg.z, sg.w},
+              s1[4] = {sx.x, sx.y, sx.z, sx.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+  float oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float gq = (!RELU || yy[q] > 0.f) ? dd[q] : 0.f;
+    const float xh = (xx[q] - mm[q]) * ss[q];
+    oo[q] += gg[q] * ss[q] * (gq - inv_m * s0[q] - xh * inv_m * s1[q]);
+  }
+  dx[i] = make_float4(oo[0], oo[1], oo[2], oo[3]);
+}
+
 // BN forward statistics from the partials: mean, invstd (biased var), and the
 // moving-average deltas into the gradient arena
 __global__ void bn_finish_stats(const double *__restrict__ part, int nb, int C,
@@ -776,12 +901,29 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         FPL_TRY(alloc_f(C, &bn_mean[li]));
         FPL_TRY(alloc_f(C, &bn_invstd[li]));
         TimedLaunch tl(ctx, "train_bn_fwd");
-        chan_reduce_partial<0><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
-            val[L.src0], nullptr, nullptr, nullptr, M, C, part);
+        // float4 kernels when the per-channel vectors are 16-B aligned in the arena
+        const bool v4 = C % 4 == 0 && (L.w_off[0] % 4) == 0 && (L.w_off[1] % 4) == 0;
+        const int R4 = v4 ? std::max(1, 256 / (C / 4)) : 0;
+        if (v4)
+          chan_reduce_partial4<0><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
+              val[L.src0], nullptr, nullptr, nullptr, M, C, part);
+        else
+          chan_reduce_partial<0><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
+              val[L.src0], nullptr, nullptr, nullptr, M, C, part);
         bn_finish_stats<<<(C + 63) / 64, 64, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
             t->w + L.w_off[2], t->w + L.w_off[3], bn_mean[li], bn_invstd[li],
             t->g + L.w_off[2], t->g + L.w_off[3]);
-        if (bn_fused[li])
+        if (v4) {
+          typedef const float4 *cf4;
+          if (bn_fused[li])
+            bn_apply4<true><<<g1(n / 4), 256, 0, st>>>((cf4)val[L.src0], (cf4)bn_mean[li],
+                (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)(t->w + L.w_off[1]),
+                (float4 *)val[t->layers[li + 1].dst], n / 4, C / 4);
+          else
+            bn_apply4<false><<<g1(n / 4), 256, 0, st>>>((cf4)val[L.src0], (cf4)bn_mean[li],
+                (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)(t->w + L.w_off[1]),
+                (float4 *)val[L.dst], n / 4, C / 4);
+        } else if (bn_fused[li])
           bn_relu_apply<<<g1(n), 256, 0, st>>>(val[L.src0], bn_mean[li], bn_invstd[li],
               t->w + L.w_off[0], t->w + L.w_off[1], val[t->layers[li + 1].dst], n, C);
         else
@@ -950,7 +1092,15 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         FPL_HIP(ctx, hipMemsetAsync(sdyx, 0, (size_t)C * 4, st));
         TimedLaunch tl(ctx, "train_bn_bwd");
         const float *yrelu = bn_fused[li] ? val[t->layers[li + 1].dst] : nullptr;
-        if (bn_fused[li])
+        const bool v4 = C % 4 == 0 && (L.w_off[0] % 4) == 0;
+        const int R4 = v4 ? std::max(1, 256 / (C / 4)) : 0;
+        if (v4 && bn_fused[li])
+          chan_reduce_partial4<3><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part, yrelu);
+        else if (v4)
+          chan_reduce_partial4<1><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
+        else if (bn_fused[li])
           chan_reduce_partial<3><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
               dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part, yrelu);
         else
@@ -960,7 +1110,17 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         // dbeta = sum dy, dgamma = sum dy*xhat
         accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
         accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
-        if (dx && bn_fused[li])
+        if (dx && v4) {
+          typedef const float4 *cf4;
+          if (bn_fused[li])
+            bn_backward4<true><<<g1(n / 4), 256, 0, st>>>((cf4)dy, (cf4)yrelu, (cf4)val[L.src0],
+                (cf4)bn_mean[li], (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)sdy,
+                (cf4)sdyx, (float4 *)dx, n / 4, C / 4, 1.f / (float)M);
+          else
+            bn_backward4<false><<<g1(n / 4), 256, 0, st>>>((cf4)dy, nullptr, (cf4)val[L.src0],
+                (cf4)bn_mean[li], (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)sdy,
+                (cf4)sdyx, (float4 *)dx, n / 4, C / 4, 1.f / (float)M);
+        } else if (dx && bn_fused[li])
           bn_relu_backward<<<g1(n), 256, 0, st>>>(dy, yrelu, val[L.src0], bn_mean[li],
               bn_invstd[li], t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M);
         else if (dx)
