@@ -175,7 +175,7 @@ __global__ void bn_apply4(const float4 *__restrict__ x, const float4 *__restrict
   y[i] = o;
 }
 
-template <bool RELU>
+template <bool RELU, bool ACC>
 __global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__restrict__ y,
                              const float4 *__restrict__ x, const float4 *__restrict__ mean,
                              const float4 *__restrict__ invstd,
@@ -190,7 +190,8 @@ __global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__rest
                sg = sum_g[c], sx = sum_g_xhat[c];
   float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
   if (RELU) yv = y[i];
-  float4 o = dx[i];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ACC) o = dx[i];                      // else this pass is the tensor's only writer
   const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w},
               mm[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w},
               gg[4] = {g.x, g.y, g.z, g.w}, s0[4] = {sg.x, sg.y, sg.z, sg.w},
@@ -262,13 +263,15 @@ __global__ void bn_backward(const float *__restrict__ dy, const float *__restric
                             const float *__restrict__ gamma,
                             const float *__restrict__ sum_dy,
                             const float *__restrict__ sum_dy_xhat,
-                            float *__restrict__ dx, int64_t n, int C, float inv_m) {
+                            float *__restrict__ dx, int64_t n, int C, float inv_m,
+                            int acc) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = (int)(i % C);
   const float xh = (x[i] - mean[c]) * invstd[c];
-  dx[i] += gamma[c] * invstd[c] *
-           (dy[i] - inv_m * sum_dy[c] - xh * inv_m * sum_dy_xhat[c]);
+  const float v = gamma[c] * invstd[c] *
+                  (dy[i] - inv_m * sum_dy[c] - xh * inv_m * sum_dy_xhat[c]);
+  dx[i] = acc ? dx[i] + v : v;
 }
 
 // BatchNorm + ReLU in one pass (the pair always appears together, fplmodels.py:67-71)
@@ -290,13 +293,15 @@ __global__ void bn_relu_backward(const float *__restrict__ dy, const float *__re
                                  const float *__restrict__ gamma,
                                  const float *__restrict__ sum_g,
                                  const float *__restrict__ sum_g_xhat,
-                                 float *__restrict__ dx, int64_t n, int C, float inv_m) {
+                                 float *__restrict__ dx, int64_t n, int C, float inv_m,
+                                 int acc) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = (int)(i % C);
   const float gg = y[i] > 0.f ? dy[i] : 0.f;
   const float xh = (x[i] - mean[c]) * invstd[c];
-  dx[i] += gamma[c] * invstd[c] * (gg - inv_m * sum_g[c] - xh * inv_m * sum_g_xhat[c]);
+  const float v = gamma[c] * invstd[c] * (gg - inv_m * sum_g[c] - xh * inv_m * sum_g_xhat[c]);
+  dx[i] = acc ? dx[i] + v : v;
 }
 
 __global__ void relu_fwd(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
@@ -987,11 +992,30 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
     if (t->layers[li].dst == t->out_tensor) head = &t->layers[li];
   FPL_REQUIRE(ctx, head && head->kind == FPL_L_CONV && head->act == FPL_ACT_SIGMOID,
               "fpl_trainer_step: the output must be a sigmoid conv head");
+  // A tensor whose only consumer's backward pass writes every element of its gradient
+  // (BatchNorm; an MFMA-path convolution) gets that gradient by assignment: no
+  // zero-fill and no read-modify-write.  Everything else accumulates into zeros.
+  std::vector<int> n_use(nt, 0), cons(nt, -1);
+  for (int li = 0; li < nl; ++li) {
+    const fpl_layer &L = t->layers[li];
+    if (relu_fused[li]) continue;                 // consumes the unallocated BN output
+    ++n_use[L.src0]; cons[L.src0] = li;
+    if (L.src1 > 0) { ++n_use[L.src1]; cons[L.src1] = -2; }
+  }
+  std::vector<char> assign(nt, 0);
+  for (int ti = 1; ti < nt; ++ti) {
+    if (n_use[ti] != 1 || cons[ti] < 0) continue;
+    const fpl_layer &L = t->layers[cons[ti]];
+    if (L.kind == FPL_L_BN) assign[ti] = 1;
+    if (L.kind == FPL_L_CONV && use_mfma_bwd && fpl_tm_supported(L.k, L.cin, L.cout) &&
+        fpl_tm_supported(L.k, L.cout, L.cin))
+      assign[ti] = 1;
+  }
   for (int ti = 1; ti < nt; ++ti) {
     if (!val[ti]) continue;
     const int64_t n = (int64_t)batch * shp[ti].elems();
     FPL_TRY(alloc_f(n, &grad[ti]));
-    FPL_HIP(ctx, hipMemsetAsync(grad[ti], 0, (size_t)n * 4, st));
+    if (!assign[ti]) FPL_HIP(ctx, hipMemsetAsync(grad[ti], 0, (size_t)n * 4, st));
   }
   {
     TimedLaunch tl(ctx, "train_loss");
@@ -1037,7 +1061,10 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
             finish_sums<<<(L.cout + 63) / 64, 64, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
                                                            nullptr, 1.f);
           }
-          if (dx) {
+          if (dx && assign[L.src0]) {
+            FPL_TRY(fpl_tm_conv_dgrad(ctx, dy, batch, o.d, o.h, o.w, o.c, L.k, L.cin,
+                                      t->w + L.w_off[0], t->zeros, dx));
+          } else if (dx) {
             const int64_t in_el = (int64_t)batch * a.elems();
             float *tmpdx;
             FPL_TRY(alloc_f(in_el, &tmpdx));
@@ -1110,22 +1137,22 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         // dbeta = sum dy, dgamma = sum dy*xhat
         accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
         accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
+        const int acc = dx && !assign[L.src0];
         if (dx && v4) {
           typedef const float4 *cf4;
-          if (bn_fused[li])
-            bn_backward4<true><<<g1(n / 4), 256, 0, st>>>((cf4)dy, (cf4)yrelu, (cf4)val[L.src0],
-                (cf4)bn_mean[li], (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)sdy,
-                (cf4)sdyx, (float4 *)dx, n / 4, C / 4, 1.f / (float)M);
-          else
-            bn_backward4<false><<<g1(n / 4), 256, 0, st>>>((cf4)dy, nullptr, (cf4)val[L.src0],
-                (cf4)bn_mean[li], (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)sdy,
-                (cf4)sdyx, (float4 *)dx, n / 4, C / 4, 1.f / (float)M);
+#define FPL_BNB4(RELU, ACC, YP)                                                            \
+  bn_backward4<RELU, ACC><<<g1(n / 4), 256, 0, st>>>((cf4)dy, (cf4)(YP), (cf4)val[L.src0],    \
+      (cf4)bn_mean[li], (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)sdy, (cf4)sdyx,     \
+      (float4 *)dx, n / 4, C / 4, 1.f / (float)M)
+          if (bn_fused[li]) { if (acc) FPL_BNB4(true, true, yrelu); else FPL_BNB4(true, false, yrelu); }
+          else { if (acc) FPL_BNB4(false, true, nullptr); else FPL_BNB4(false, false, nullptr); }
+#undef FPL_BNB4
         } else if (dx && bn_fused[li])
           bn_relu_backward<<<g1(n), 256, 0, st>>>(dy, yrelu, val[L.src0], bn_mean[li],
-              bn_invstd[li], t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M);
+              bn_invstd[li], t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M, acc);
         else if (dx)
           bn_backward<<<g1(n), 256, 0, st>>>(dy, val[L.src0], bn_mean[li], bn_invstd[li],
-              t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M);
+              t->w + L.w_off[0], sdy, sdyx, dx, n, C, 1.f / (float)M, acc);
         break;
       }
       case FPL_L_RELU:
