@@ -178,10 +178,39 @@ class FplNetwork:
         return self.infer_network.program.infer_volume(
             image, self.infer_sz, self.rf_offset, **kw)
 
-    def voxel_loss(self, image, lm_prefix, l0_thresh=None, l1_thresh=None):
-        raise NotImplementedError(
-            'voxel_loss (reference fplnetwork.py:191-220) is a SURVEY 8f '
-            'follow-on; it needs the h5 label/mask files')
+    def voxel_loss(self, image, lm_prefix, l0_thresh=None, l1_thresh=None,
+                   normalize=None):
+        """per-voxel log loss of the prediction on labelled, unmasked voxels
+        (reference :191-220): confident negatives (loss < 0.005) are dropped, losses
+        are clamped to the optional [lo, hi] thresholds.  `lm_prefix`: the reference's
+        '<prefix>labels.h5' / '<prefix>mask.h5' prefix (needs h5py) or a
+        (labels, mask) pair of arrays / .npy paths."""
+        from .fplobjdetect import _load_main
+        pred = self.infer(image, normalize=normalize)
+        if isinstance(lm_prefix, str):
+            ll = np.array(_load_main('%slabels.h5' % lm_prefix))
+            mm = np.array(_load_main('%smask.h5' % lm_prefix))
+        else:
+            ll, mm = (np.array(_load_main(a)) for a in lm_prefix)
+        context_rr = tuple(int(round(cc / 2)) for cc in self.rf_size)
+        for ax in range(3):
+            sl = [slice(None)] * 3
+            sl[ax] = slice(0, context_rr[ax]); mm[tuple(sl)] = 0
+            sl[ax] = slice(-context_rr[ax], None); mm[tuple(sl)] = 0
+        l0_loss = -1. * (mm == 1) * (ll == 0) * np.log(np.maximum(1 - pred, 1e-8))
+        conf_neg = (l0_loss < 0.005) * (mm == 1) * (ll == 0)
+        l0_loss[conf_neg] = 0
+        mm[conf_neg] = 0
+        if l0_thresh is not None:
+            l0_mask = (ll == 0) * (mm == 1)
+            l0_loss = np.maximum(l0_loss, l0_thresh[0] * l0_mask)
+            l0_loss = np.minimum(l0_loss, l0_thresh[1] * l0_mask)
+        l1_loss = -1. * (mm == 1) * (ll == 1) * np.log(np.maximum(pred, 1e-8))
+        if l1_thresh is not None:
+            l1_mask = (ll == 1) * (mm == 1)
+            l1_loss = np.maximum(l1_loss, l1_thresh[0] * l1_mask)
+            l1_loss = np.minimum(l1_loss, l1_thresh[1] * l1_mask)
+        return (l0_loss + l1_loss).astype('float32')
 
     # pickling: device handles never travel
     def __getstate__(self):

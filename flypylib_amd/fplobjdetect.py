@@ -122,6 +122,8 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
 def _load_main(src):
     if isinstance(src, np.ndarray):
         return src
+    if isinstance(src, str) and src.endswith('.npy'):
+        return np.load(src)
     try:
         import h5py
     except ImportError:
@@ -199,6 +201,123 @@ def gen_batches(train_data, context_sz, batch_sz, is_mask=False, rng=None):
                 a[ii, :, :, :, 0] = v
         yield data, labels
         vi = (vi + 1) % len(vols)
+
+
+def _volumes(train_data, half):
+    """(image, labels, mask[, weights]) arrays per training volume with the mask
+    cleared where a patch would not fit (reference :690-705); entries are
+    (image, labels_prefix[, weights]) h5 paths as in the reference (needs h5py) or
+    (image, labels, mask[, weights]) arrays / .npy paths"""
+    vols = []
+    for tr in train_data:
+        if len(tr) >= 3 and not isinstance(tr[1], str):
+            im, ll, mm = (np.array(_load_main(a)) for a in tr[:3])
+            ww = np.array(_load_main(tr[3])) if len(tr) > 3 else None
+        else:
+            im = np.array(_load_main(tr[0]))
+            ll = np.array(_load_main('%slabels.h5' % tr[1]))
+            mm = np.array(_load_main('%smask.h5' % tr[1]))
+            ww = np.array(_load_main(tr[2])) if len(tr) > 2 else None
+        for ax in range(3):
+            sl = [slice(None)] * 3
+            sl[ax] = slice(0, half[ax]); mm[tuple(sl)] = 0
+            sl[ax] = slice(-half[ax], None); mm[tuple(sl)] = 0
+        vols.append((im, ll, mm, ww))
+    return vols
+
+
+def gen_volume2(train_data, context_sz, batch_sz, ratio, noise_aug=[0, 0], rng=None):
+    """generator of training batches with dense 6^3 labels for the U-Nets (reference
+    fplobjdetect.py:660-822): `ratio` of each outer round of 100 batches is centred on
+    label-0 voxels, the rest on label-1 voxels, drawn from all volumes (optionally
+    with the per-voxel sampling weights of `write_sampling_weights` as a 3rd / 4th
+    entry), in a random order; labels of masked-out voxels are 2 (the masked losses
+    ignore them); intensity noise `noise_aug = [additive sd, multiplicative sd]`;
+    rot90 in axes (1,2), flip of axis 1, flip of axis 0.  Yields
+    (data (B,s,s,s,1) float32, labels (B,6,6,6,1) uint8)."""
+    rng = np.random if rng is None else rng
+    context_sz = fplutils.to3d(context_sz)
+    half = tuple(int(round(cc / 2)) for cc in context_sz)
+    vols = _volumes(train_data, half)
+    weighted = vols[0][3] is not None
+    # sample positions per class: (volume index, z, y, x[, weight])
+    pos = []
+    for cc in range(2):
+        cols = [[], [], [], [], []]
+        for vi, (im, ll, mm, ww) in enumerate(vols):
+            sel = (ll == cc) & (mm == 1)
+            if weighted:
+                sel &= ww > 0
+            idx = sel.nonzero()
+            cols[0].append(np.full(idx[0].shape, vi, np.int32))
+            for a in range(3):
+                cols[1 + a].append(idx[a].astype(np.int32))
+            if weighted:
+                cols[4].append(ww[idx].astype(np.float64))
+        cols = [np.concatenate(c) if c else None for c in cols]
+        if weighted:
+            cols[4] = cols[4] / np.sum(cols[4].astype('float32'))
+        pos.append(cols)
+    labelled = []
+    for im, ll, mm, ww in vols:
+        ll = ll.copy()
+        ll[mm == 0] = 2                           # ignored by the masked losses
+        labelled.append(ll)
+
+    out_rr = (3, 3, 3)                            # out_sz (6, 6, 6), reference :744-746
+    data = np.zeros((batch_sz,) + tuple(context_sz) + (1,), dtype='float32')
+    labels = np.zeros((batch_sz, 6, 6, 6, 1), dtype='uint8')
+    outer_batches = 100
+    outer_batch_sz = outer_batches * batch_sz
+    n_neg = int(round(ratio * outer_batch_sz))
+    n_pos = outer_batch_sz - n_neg
+    while True:
+        neg_idx = rng.choice(len(pos[0][0]), n_neg, True, pos[0][4] if weighted else None)
+        pos_idx = rng.choice(len(pos[1][0]), n_pos, True, pos[1][4] if weighted else None)
+        all_idx = rng.permutation(outer_batch_sz)
+        sample_idx = 0
+        for _ in range(outer_batches):
+            for ex in range(batch_sz):
+                k = all_idx[sample_idx]
+                sample_idx += 1
+                cc, k = (0, neg_idx[k]) if k < n_neg else (1, pos_idx[k - n_neg])
+                vi, z, y, x = (int(pos[cc][a][k]) for a in range(4))
+                im = vols[vi][0]
+                data[ex, :, :, :, 0] = (
+                    ((noise_aug[1] * rng.randn()) + 1.) *
+                    im[z - half[0]:z + half[0], y - half[1]:y + half[1],
+                       x - half[2]:x + half[2]]) + noise_aug[0] * rng.randn()
+                labels[ex, :, :, :, 0] = labelled[vi][
+                    z - out_rr[0]:z + out_rr[0], y - out_rr[1]:y + out_rr[1],
+                    x - out_rr[2]:x + out_rr[2]]
+            rot = np.floor(4 * rng.rand(batch_sz))
+            ref = np.floor(2 * rng.rand(batch_sz))
+            fpz = np.floor(2 * rng.rand(batch_sz))
+            for ii in range(batch_sz):
+                for a in (data, labels):
+                    v = a[ii, :, :, :, 0]
+                    if rot[ii]:
+                        v = np.rot90(v, int(rot[ii]), (1, 2))
+                    if ref[ii]:
+                        v = np.fliplr(v)
+                    if fpz[ii]:
+                        v = np.flipud(v)
+                    a[ii, :, :, :, 0] = v
+            yield data.copy(), labels.copy()
+
+
+def write_sampling_weights(train_data, network, fn_prefix, l0_thresh, l1_thresh):
+    """per-voxel loss of the current network as sampling weights for `gen_volume2`
+    (reference :824-839).  Weights are written as '<fn_prefix>%02d.npy' (the
+    reference writes .h5; h5py is not available here) and appended to each entry."""
+    train_data_aug = []
+    for idx, tr in enumerate(train_data):
+        loss = network.voxel_loss(tr[0], tr[1] if isinstance(tr[1], str) else tr[1:3],
+                                  l0_thresh, l1_thresh)
+        ww_fn = '%s%02d.npy' % (fn_prefix, idx)
+        np.save(ww_fn, loss)
+        train_data_aug.append(list(tr) + [ww_fn, ])
+    return train_data_aug
 
 
 # the substack pipeline of the reference's fplobjdetect (fplobjdetect.py:841-1216)
