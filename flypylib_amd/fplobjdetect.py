@@ -203,6 +203,98 @@ def gen_batches(train_data, context_sz, batch_sz, is_mask=False, rng=None):
         vi = (vi + 1) % len(vols)
 
 
+# ---- evaluation against ground-truth points (reference fplobjdetect.py:259-455) ------
+from collections import namedtuple   # noqa: E402
+
+PR_Result = namedtuple('PR_Result', 'num_tp tot_pred tot_gt pp rr match')
+
+
+def obj_match(dists, allow_mult=False):
+    """match predictions to ground truth: `dists` (N x M) = distance minus the match
+    threshold, negative entries are admissible pairs.  Minimises the summed (negative)
+    cost with every ground-truth point used at most once and, unless `allow_mult`,
+    every prediction at most once - the integer program the reference hands to pulp
+    (:259-321), solved here as the equivalent assignment problem.  -> N x M bool."""
+    from scipy.optimize import linear_sum_assignment
+    dists = np.asarray(dists, np.float64)
+    n_pred, n_gt = dists.shape
+    out = np.zeros((n_pred, n_gt), dtype=bool)
+    if n_pred == 0 or n_gt == 0:
+        return out
+    if allow_mult:                     # only the ground-truth side is constrained
+        best = np.argmin(dists, axis=0)
+        ok = dists[best, np.arange(n_gt)] < 0
+        out[best[ok], np.arange(n_gt)[ok]] = True
+        return out
+    rows, cols = linear_sum_assignment(np.minimum(dists, 0.0))   # leaving a pair out costs 0
+    ok = dists[rows, cols] < 0
+    out[rows[ok], cols[ok]] = True
+    return out
+
+
+def obj_pr(predict_locs, groundtruth_locs, dist_thresh, predict_lbls=None,
+           groundtruth_lbls=None, allow_mult=False):
+    """precision / recall of predicted vs ground-truth locations at a distance
+    threshold (reference :323-376)"""
+    if (predict_locs.shape[0] == 0) | (groundtruth_locs.shape[0] == 0):
+        tot_pred, tot_gt = predict_locs.shape[0], groundtruth_locs.shape[0]
+        return PR_Result(num_tp=0, tot_pred=tot_pred, tot_gt=tot_gt,
+                         pp=1 if tot_pred == 0 else 0, rr=1 if tot_gt == 0 else 0,
+                         match=None)
+    pred = predict_locs.reshape((-1, 1, 3))
+    gt = groundtruth_locs.reshape((1, -1, 3))
+    dists = np.sqrt(((pred - gt) ** 2).sum(axis=2))
+    dists -= dist_thresh
+    if predict_lbls is not None:
+        lbl_constraint = (predict_lbls.reshape((-1, 1)) !=
+                          groundtruth_lbls.reshape((1, -1))).astype('float32')
+        dists += (dist_thresh + 1.) * lbl_constraint
+    match = obj_match(dists, allow_mult=allow_mult)
+    num_tp = match.sum()
+    pd_mult = np.maximum(match.sum(axis=1) - 1, 0).sum()
+    tot_pred = match.shape[0] + pd_mult
+    return PR_Result(num_tp=num_tp, tot_pred=tot_pred, tot_gt=match.shape[1],
+                     pp=num_tp / match.shape[0], rr=num_tp / match.shape[1], match=match)
+
+
+def obj_pr_curve(predict, groundtruth, dist_thresh, thresholds, predict_lbls=None,
+                 groundtruth_lbls=None, allow_mult=False):
+    """precision / recall at each confidence threshold (reference :378-436); `predict`
+    / `groundtruth` are {'locs','conf'} dicts or json files"""
+    from . import fplsynapses
+    if isinstance(predict, str):
+        predict = fplsynapses.load_from_json(predict)
+    if isinstance(groundtruth, str):
+        groundtruth = fplsynapses.load_from_json(groundtruth)
+    thresholds = np.asarray(thresholds)
+    n_thd = thresholds.size
+    num_tp, tot_pred, tot_gt, pp, rr = (np.zeros((n_thd,)) for _ in range(5))
+    match = None
+    for ii in range(n_thd):
+        idx = predict['conf'] >= thresholds[ii]
+        mm = obj_pr(predict['locs'][idx, :], groundtruth['locs'], dist_thresh,
+                    predict_lbls[idx] if predict_lbls is not None else None,
+                    groundtruth_lbls, allow_mult=allow_mult)
+        num_tp[ii], tot_pred[ii], tot_gt[ii] = mm.num_tp, mm.tot_pred, mm.tot_gt
+        pp[ii], rr[ii] = mm.pp, mm.rr
+        if match is None:
+            match = mm.match
+    return PR_Result(num_tp=num_tp, tot_pred=tot_pred, tot_gt=tot_gt, pp=pp, rr=rr,
+                     match=match)
+
+
+def aggregate_pr(results):
+    """pool per-substack PR curves (reference :439-455)"""
+    dim = results[0].num_tp.shape
+    num_tp, tot_pred, tot_gt = np.zeros(dim), np.zeros(dim), np.zeros(dim)
+    for r in results:
+        num_tp += r.num_tp
+        tot_pred += r.tot_pred
+        tot_gt += r.tot_gt
+    return PR_Result(num_tp=num_tp, tot_pred=tot_pred, tot_gt=tot_gt,
+                     pp=num_tp / (tot_pred + 10e-8), rr=num_tp / (tot_gt + 10e-8), match=None)
+
+
 def _volumes(train_data, half):
     """(image, labels, mask[, weights]) arrays per training volume with the mask
     cleared where a patch would not fit (reference :690-705); entries are

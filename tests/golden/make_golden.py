@@ -208,7 +208,37 @@ def gen_fri_get_image():
     np.savez_compressed(os.path.join(HERE, 'fri_get_image.npz'), **out)
 
 
+# ---- fplsynapses JSON formats + the pulp-free branches of obj_pr -----------------------
+def synapse_points():
+    rs = np.random.RandomState(7)
+    return {'locs': np.floor(rs.rand(12, 3) * [60, 50, 40]), 'conf': rs.rand(12)}
+
+
+def gen_synapses():
+    import json
+    from flypylib import fplsynapses
+    tb = synapse_points()
+    out = {}
+    dvid = fplsynapses.tbars_to_json_format(tb, labels=np.arange(12) * 3)
+    rav = fplsynapses.tbars_to_json_format_raveler(tb)
+    out['dvid_json'] = np.array(json.dumps(dvid, sort_keys=True))
+    out['raveler_json'] = np.array(json.dumps(rav, sort_keys=True))
+    for name, text in (('dvid', json.dumps(dvid)), ('raveler', json.dumps(rav)),
+                       ('nested', json.dumps([dvid]))):
+        back = fplsynapses.load_from_json(text)
+        out[name + '/locs'], out[name + '/conf'] = back['locs'], back['conf']
+        cut = fplsynapses.load_from_json(text, (60, 50, 40), (10, 5, 8))
+        out[name + '/buf_locs'], out[name + '/buf_conf'] = cut['locs'], cut['conf']
+    # obj_pr without pulp: the empty-set branches
+    e = np.zeros((0, 3))
+    for name, (p, g) in (('no_pred', (e, tb['locs'])), ('no_gt', (tb['locs'], e)), ('none', (e, e))):
+        r = fplobjdetect.obj_pr(p, g, 5.0)
+        out['pr_' + name] = np.array([r.num_tp, r.tot_pred, r.tot_gt, r.pp, r.rr], np.float64)
+    np.savez_compressed(os.path.join(HERE, 'synapses.npz'), **out)
+
+
 if __name__ == '__main__':
+    gen_synapses()
     gen_fri_get_image()
     gen_set_filter()
     gen_voxel2obj()
