@@ -119,6 +119,13 @@ struct Conv3Args {
   const float *shstem;
   // optional fused MaxPooling3D(2) of the (ReLU) output: (n, OD/2, OH/2, OW/2, 16*MB)
   h16_t *pool_out;
+  // Edge strip (transposed view).  An output width that is not a multiple of 16
+  // wastes lanes in the last x block (OW = 82: 14 of 16).  The strip x in [xorg, OW)
+  // is then run with the block's axes swapped: lanes walk y, the four sub-steps walk
+  // x - the same kernel through a transposed offset table, a transposed block origin
+  // and weight fragments packed with the dy / dx taps swapped (`w` points at those).
+  int transposed, xorg;
+  int main_w;                    // untransposed launch: columns [0, main_w) only (0 = all)
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -183,7 +190,8 @@ __global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
     for (int i = tid; i < TABN; i += 256) {
       const int vox = i < TZ * TY * TX ? i : TZ * TY * TX - 1;
       const int tz = vox / (TY * TX), ty = (vox / TX) % TY, tx = vox % TX;
-      offtab[t * TABN + i] = (unsigned)(((((tz >> U) * H + (ty >> U)) * W + (tx >> U)) * C) * 2);
+      const int sy = a.transposed ? tx : ty, sx = a.transposed ? ty : tx;   // source y, x
+      offtab[t * TABN + i] = (unsigned)(((((tz >> U) * H + (sy >> U)) * W + (sx >> U)) * C) * 2);
     }
   }
   const int vox0 = (tid >> 5) * 8 + (tid & 7);
@@ -210,7 +218,8 @@ __global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
     }
     const Src s = a.src[cc];
     const int z0 = ((bz % a.zblocks) * 4 + s.crop) >> s.ups;
-    const int y0 = (by * 4 + s.crop) >> s.ups, x0 = (bx * 16 + s.crop) >> s.ups;
+    const int y0 = ((a.transposed ? bx * 16 : by * 4) + s.crop) >> s.ups;
+    const int x0 = ((a.transposed ? a.xorg + by * 4 : bx * 16) + s.crop) >> s.ups;
     const unsigned char *base = reinterpret_cast<const unsigned char *>(
         s.p + ((((int64_t)n * s.D + z0) * s.H + y0) * s.W + x0) * s.C + s.ch0);
     const unsigned *tab = offtab + s.tab * TABN + vox0;
@@ -360,10 +369,11 @@ __global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
       const int bx = (int)(blk % a.nbx), by = (int)((blk / a.nbx) % a.nby);
       const int bz = (int)(blk / ((int64_t)a.nbx * a.nby));
       const int n = bz / a.zblocks;
-      const int oz = (bz % a.zblocks) * 4 + wave, ox = bx * 16 + c;
+      const int oz = (bz % a.zblocks) * 4 + wave;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
-        const int oy = by * 4 + sub;
+        const int oy = a.transposed ? bx * 16 + c : by * 4 + sub;
+        const int ox = a.transposed ? a.xorg + by * 4 + sub : bx * 16 + c;
         if (oz < a.OD && oy < a.OH && ox < a.OW)
           store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB),
                               g, acc[sub], a.relu);
@@ -492,6 +502,7 @@ struct UnetState {
   unsigned char *frags = nullptr;
   float *shifts = nullptr;
   size_t off_w[12] = {0}, off_s[12] = {0};
+  size_t off_w7t = 0;            // conv 7 with the dy / dx taps swapped (edge strip)
   float bias_tail = 0.f;
 };
 
@@ -580,6 +591,24 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
         fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, 27, SLOT_SPATIAL, &fc, true);
         f.insert(f.end(), fc.begin(), fc.end());
       }
+      if (l == 7) {              // the transposed edge strip swaps the roles of dy and dx
+        std::vector<uint16_t> ft;
+        for (int cc = 0; cc < ncc; ++cc) {
+          for (int ks = 0; ks < 27; ++ks) {
+            const int dz = ks / 9, dx = (ks / 3) % 3, dy = ks % 3;
+            const int tap = dz * 9 + dx * 3 + dy;
+            for (int ch = 0; ch < CC; ++ch)
+              memcpy(&sub[((size_t)ks * CC + ch) * op.cout],
+                     A + op.w_off + ((size_t)tap * op.cin + cc * CC + ch) * op.cout,
+                     op.cout * sizeof(float));
+          }
+          std::vector<uint16_t> fc;
+          fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, 27, SLOT_SPATIAL, &fc, true);
+          ft.insert(ft.end(), fc.begin(), fc.end());
+        }
+        st->off_w7t = all.size() * sizeof(uint16_t);
+        all.insert(all.end(), ft.begin(), ft.end());
+      }
     } else if (l == 9) {
       fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, 1, 1, SLOT_CHAIN, &f);
     } else {
@@ -626,27 +655,32 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   a.ntab = 0;
   for (int i = 0; i < (STEM ? 0 : a.ncc); ++i) {
     Src &s = a.src[i];
-    FPL_REQUIRE(ctx, !(s.ups && s.crop), "FPLK(conv3): crop of an upsampled source");
-    FPL_REQUIRE(ctx, s.crop % 2 == 0, "FPLK(conv3): odd crop");
+    FPL_REQUIRE(ctx, !(s.ups && s.crop), "conv3: crop of an upsampled source");
+    FPL_REQUIRE(ctx, s.crop % 2 == 0, "conv3: odd crop");
     int t = 0;
     for (; t < a.ntab; ++t)
       if (a.tabH[t] == s.H && a.tabW[t] == s.W && a.tabC[t] == s.C && a.tabU[t] == s.ups) break;
     if (t == a.ntab) {
-      FPL_REQUIRE(ctx, a.ntab < MAXTAB, "FPLK(conv3): more than %d source geometries", MAXTAB);
+      FPL_REQUIRE(ctx, a.ntab < MAXTAB, "conv3: more than %d source geometries", MAXTAB);
       a.tabH[t] = s.H; a.tabW[t] = s.W; a.tabC[t] = s.C; a.tabU[t] = s.ups;
       ++a.ntab;
     }
     s.tab = t;
   }
   a.zblocks = (int)ceil_div64(a.OD, 4);
-  a.nbx = (int)ceil_div64(a.OW, 16); a.nby = (int)ceil_div64(a.OH, 4); a.nbz = n * a.zblocks;
+  if (a.transposed) {            // lanes walk y, sub-steps walk x in [xorg, OW)
+    a.nbx = (int)ceil_div64(a.OH, 16); a.nby = (int)ceil_div64(a.OW - a.xorg, 4);
+  } else {
+    a.nbx = (int)ceil_div64(a.main_w ? a.main_w : a.OW, 16); a.nby = (int)ceil_div64(a.OH, 4);
+  }
+  a.nbz = n * a.zblocks;
   const int64_t total = (int64_t)a.nbx * a.nby * a.nbz;
   // two workgroups per CU, rounded to a multiple of the 8 XCDs
   int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * 2, (total + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
   FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
-              "FPLK(conv3): pool output / template mismatch");
+              "conv3: pool output / template mismatch");
   FPLK(conv3)<MB, PF, STEM, POOL><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
@@ -702,6 +736,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.w = F + st->off_w[l]; a.shift = S + st->off_s[l]; a.relu = 1;
     a.out = outp; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
     a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr; a.pool_out = nullptr;
+    a.transposed = 0; a.xorg = 0; a.main_w = 0;
     return a;
   };
   {  // L0 + L1: conv3 1->32 computed into the tile of conv3 32->32
@@ -742,12 +777,23 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
   }
   conv1(FPLK(conv1)<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), 6, c4, "unet_conv1_64_64");
-  {  // L7: conv3 (up2(c4) 64 | crop6(c1) 32) -> 32
+  {  // L7: conv3 (up2(c4) 64 | crop6(c1) 32) -> 32.  Output width 82 = 5 x 16 + 2: the
+     // last two columns go through the transposed edge strip instead of a sixth block
+     // column that would use 2 of its 16 lanes
     Conv3Args a = conv3_args(7, c5a, d5a);
     a.ncc = 3;
     for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c4, d4a, 64, 32 * cc, 2, 0);
     a.src[2] = make_src(c1, d1, 32, 0, 1, 6);
+    const int rem = d5a % 16;
+    const bool strip = rem > 0 && rem <= 4 && d5a > 16 && st->off_w7t != 0;
+    if (strip) a.main_w = d5a - rem;
     FPL_TRY((launch_conv3<2>(ctx, a, n, "unet_conv3_96_32")));
+    if (strip) {
+      Conv3Args e = a;
+      e.main_w = 0; e.transposed = 1; e.xorg = d5a - rem;
+      e.w = F + st->off_w7t;
+      FPL_TRY((launch_conv3<2>(ctx, e, n, "unet_conv3_96_32_edge")));
+    }
   }
   {  // L8 + L9: conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
     Conv1Args a;
