@@ -15,9 +15,6 @@ ONE all-reduce of the flat gradient arena over RCCL (`torch.distributed`, backen
 BN batch statistics stay per GPU, as each tower normalises its own slice.
 """
 import csv
-import os
-
-import numpy as np
 
 from . import _capi, runtime
 
