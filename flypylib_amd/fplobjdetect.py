@@ -318,6 +318,88 @@ def _volumes(train_data, half):
     return vols
 
 
+def get_out_sz(in_sz):
+    """output size of a unet-style net for an input subvolume (reference :525-534)"""
+    import math
+    bottleneck_sz = int(math.floor(math.floor((in_sz - 2) / 2) - 2) / 2)
+    return (bottleneck_sz * 2 - 2) * 2 - 2
+
+
+def gen_volume(train_data, context_sz, batch_sz, ratio, rng=None):
+    """generator of training batches with dense 6^3 labels (reference
+    fplobjdetect.py:536-658; what scripts/fpl_cx1_0_unet_4ss_all.py:41-42 trains
+    unet_like2 with): example i of a batch comes from volume i mod n_volumes, centred
+    on a label-0 voxel with probability `ratio`, else on a label-1 voxel (label 0 if
+    the volume has no positives); masked-out voxels are labelled 2; rot90 in axes
+    (1,2), flip of axis 2, flip of axis 0."""
+    rng = np.random if rng is None else rng
+    context_sz = fplutils.to3d(context_sz)
+    half = tuple(int(round(cc / 2)) for cc in context_sz)
+    vols = []
+    for im, ll, mm, _ in _volumes(train_data, half):
+        centres = [((ll == cc) & (mm == 1)).nonzero() for cc in range(2)]
+        ll = ll.copy()
+        ll[mm == 0] = 2
+        vols.append((im, ll, centres))
+    data = np.zeros((batch_sz,) + tuple(context_sz) + (1,), dtype='float32')
+    labels = np.zeros((batch_sz, 6, 6, 6, 1), dtype='uint8')
+    train_idx = 0
+    while True:
+        for ex in range(batch_sz):
+            im, ll, centres = vols[train_idx]
+            cc = 0 if rng.uniform(0, 1) < ratio else 1
+            if len(centres[cc][0]) == 0:
+                cc = 0
+            k = rng.choice(len(centres[cc][0]), batch_sz, True)[ex]
+            z, y, x = (int(centres[cc][a][k]) for a in range(3))
+            data[ex, :, :, :, 0] = im[z - half[0]:z + half[0], y - half[1]:y + half[1],
+                                      x - half[2]:x + half[2]]
+            labels[ex, :, :, :, 0] = ll[z - 3:z + 3, y - 3:y + 3, x - 3:x + 3]
+            train_idx = (train_idx + 1) % len(vols)
+        rot = np.floor(4 * rng.rand(batch_sz))
+        ref = np.floor(2 * rng.rand(batch_sz))
+        fpz = np.floor(2 * rng.rand(batch_sz))
+        for ii in range(batch_sz):
+            for a in (data, labels):
+                v = a[ii, :, :, :, 0]
+                if rot[ii]:
+                    v = np.rot90(v, int(rot[ii]), (1, 2))
+                if ref[ii]:
+                    v = np.flip(v, 2)
+                if fpz[ii]:
+                    v = np.flip(v, 0)
+                a[ii, :, :, :, 0] = v
+        yield data, labels
+
+
+def evaluate_substacks(network, substacks, thds, obj_min_dist=27, smoothing_sigma=5,
+                       volume_offset=(0, 0, 0), buffer_sz=5, allow_mult=False,
+                       normalize=None):
+    """precision / recall curves of a network on labelled substacks (reference
+    :463-523): per substack [image, ground-truth json (, segmentation)] -> infer ->
+    voxel2obj -> obj_pr_curve against the json's T-bars (buffer applied to both), then
+    the aggregate.  The reference forks a post-processing worker per substack; here
+    inference and voxel2obj share the GPU, so substacks run in order."""
+    from . import fplsynapses
+    thds = np.asarray(thds)
+    results = []
+    for ss in substacks:
+        pred = network.infer(ss[0], normalize=normalize)
+        out = voxel2obj(pred, obj_min_dist, smoothing_sigma, volume_offset, buffer_sz)
+        gt = fplsynapses.load_from_json(ss[1], pred.shape, buffer_sz)
+        lbls_pd = lbls_gt = None
+        if len(ss) >= 3 and ss[2] is not None:
+            seg = np.asarray(_load_main(ss[2]))
+
+            def labels_at(tt):
+                ind = tt['locs'].astype(int)
+                return seg[ind[:, 2], ind[:, 1], ind[:, 0]]
+            lbls_pd, lbls_gt = labels_at(out), labels_at(gt)
+        results.append(obj_pr_curve(out, gt, obj_min_dist, thds, lbls_pd, lbls_gt,
+                                    allow_mult=allow_mult))
+    return aggregate_pr(results), results
+
+
 def gen_volume2(train_data, context_sz, batch_sz, ratio, noise_aug=[0, 0], rng=None):
     """generator of training batches with dense 6^3 labels for the U-Nets (reference
     fplobjdetect.py:660-822): `ratio` of each outer round of 100 batches is centred on

@@ -175,3 +175,34 @@ def test_full_roi_inference_resumes_and_bf16_synth_source(ctx, tmp_path):
     again = fplobjdetect.full_roi_inference(vol, None, roi, net, 0.2, wd2, norm, precision='bf16', **kw)
     assert np.array_equal(again['locs'][n0:], full['locs'][n0:])
     assert np.array_equal(again['conf'][n0:], full['conf'][n0:])
+
+
+@pytest.mark.gpu
+def test_evaluate_substacks_usage_contract(ctx, tmp_path):
+    """scripts/fpl_cx1_0_unet_4ss_all.py:60-66: evaluate_substacks(network, [[image,
+    json], ...], thresholds, obj_min_dist, smoothing_sigma).  Ground truth = the
+    network's own detections above a confidence cut, so precision / recall are known."""
+    from flypylib_amd import fplsynapses
+    net, vol, _ = _small_setup()
+    img = (vol.astype(np.float32) - 128) / 33
+    pred = net.infer(img)
+    det = fplobjdetect.voxel2obj(pred, 5, 1.5, (0, 0, 0), 5)
+    assert len(det['conf']) > 20
+    cut = float(np.median(det['conf']))
+    keep = det['conf'] >= cut
+    gt_json = str(tmp_path / 'gt.json')
+    fplsynapses.tbars_to_json_format({'locs': det['locs'][keep], 'conf': det['conf'][keep]}, gt_json)
+    thds = np.array([0.0, cut, 2.0])
+    agg, per = fplobjdetect.evaluate_substacks(net, [[img, gt_json], [img, gt_json]], thds,
+                                               obj_min_dist=5, smoothing_sigma=1.5, buffer_sz=5)
+    # the reference applies the ground-truth buffer with pred.shape (z,y,x) against
+    # (x,y,z) columns (fplobjdetect.py:470) - kept literally, so count what it keeps
+    n_gt = len(fplsynapses.load_from_json(gt_json, pred.shape, 5)['conf'])
+    n_keep = int(keep.sum())
+    assert 0 < n_gt <= n_keep
+    assert len(per) == 2 and per[0].tot_gt[0] == n_gt
+    # every ground-truth point is one of the detections: recall 1 at both thresholds
+    assert per[0].num_tp[0] == n_gt and per[0].tot_pred[0] == len(det['conf'])
+    assert per[0].num_tp[1] == n_gt and per[0].tot_pred[1] == n_keep
+    assert per[0].tot_pred[2] == 0 and per[0].pp[2] == 1 and per[0].rr[2] == 0
+    assert np.allclose(agg.num_tp, 2 * per[0].num_tp) and abs(agg.rr[0] - 1.0) < 1e-6

@@ -139,3 +139,28 @@ def test_voxel_loss_formula_and_sampling_weight_files(tmp_path):
     d, lab = next(fplobjdetect.gen_volume2([(im, l2, np.ones_like(l2), str(tmp_path / 'w2.npy'))],
                                            (24, 24, 24), 2, 0.5, rng=np.random.RandomState(0)))
     assert d.shape == (2, 24, 24, 24, 1) and (lab == 1).any() and lab.max() <= 2
+
+
+def test_gen_volume_cycles_volumes_and_respects_ratio():
+    shape = (40, 40, 40)
+    ims = [np.full(shape, float(v), np.float32) for v in (1, 2, 3)]
+    lls = []
+    for v in range(3):
+        ll = np.zeros(shape, np.uint8)
+        if v != 2:                          # volume 2 has no positives -> negatives only
+            ll[18:22, 18:22, 18:22] = 1
+        lls.append(ll)
+    mm = np.ones(shape, np.uint8)
+    gen = fplobjdetect.gen_volume([(ims[v], lls[v], mm) for v in range(3)], (24, 24, 24), 6,
+                                  0.25, rng=np.random.RandomState(2))
+    n_pos = {0: 0, 1: 0, 2: 0}
+    for _ in range(50):
+        data, labels = next(gen)
+        assert data.shape == (6, 24, 24, 24, 1) and labels.shape == (6, 6, 6, 6, 1)
+        for ex in range(6):
+            vol = int(data[ex, 0, 0, 0, 0]) - 1
+            assert vol == ex % 3                       # example i <- volume i mod 3
+            centre = labels[ex, 2:4, 2:4, 2:4, 0]      # the centre voxel survives flips here
+            n_pos[vol] += int(centre.max() == 1)
+    assert n_pos[2] == 0 and 55 < n_pos[0] < 95 and 55 < n_pos[1] < 95     # ~75 % of 100
+    assert fplobjdetect.get_out_sz(18) == 6 and fplobjdetect.get_out_sz(24) == 10   # unet_like sizes
