@@ -302,7 +302,8 @@ def _volumes(train_data, half):
     (image, labels, mask[, weights]) arrays / .npy paths"""
     vols = []
     for tr in train_data:
-        if len(tr) >= 3 and not isinstance(tr[1], str):
+        as_prefix = isinstance(tr[1], str) and not tr[1].endswith('.npy')
+        if len(tr) >= 3 and not as_prefix:
             im, ll, mm = (np.array(_load_main(a)) for a in tr[:3])
             ww = np.array(_load_main(tr[3])) if len(tr) > 3 else None
         else:

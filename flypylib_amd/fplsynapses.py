@@ -1,5 +1,6 @@
 """Synapse (T-bar) point lists as JSON - the data formats on the output side of the
-detection path (reference `flypylib/fplsynapses.py:11-111`).  The DVID push / ROI /
+detection path (reference `flypylib/fplsynapses.py:11-111`) - and the label / mask
+volumes training is fed from (`write_labels_mask`, :251-310).  The DVID push / ROI /
 annotation-editing helpers of the reference need `libdvid` and are not part of this
 package."""
 import json
@@ -73,3 +74,38 @@ def tbars_to_json_format_raveler(tbars_np, json_file=None):
         with open(json_file, 'w') as f_out:
             json.dump(tbars_json, f_out)
     return tbars_json
+
+
+def write_labels_mask(tbars, roi_mask, radius_use, radius_ign, buffer_size, prefix):
+    """training labels and mask around annotated T-bars (reference :251-310): label 1
+    within `radius_use` of a T-bar; the mask is cleared in the shell between
+    `radius_use` and `radius_ign` (neither positive nor negative) and within
+    `buffer_size` of the faces.  Written as '<prefix>_labels.npy' / '<prefix>_mask.npy'
+    (the reference writes .h5; h5py is not available here) and returned."""
+    radius_use_flt = fplutils.set_filter(radius_use)
+    if radius_ign is not None:
+        radius_ign_flt = 1 - fplutils.set_filter(radius_ign)
+    else:
+        radius_ign = 0
+    mask = np.copy(roi_mask)
+    labels = np.zeros(mask.shape, dtype='uint8')
+    for jj in range(tbars['locs'].shape[0]):
+        xx, yy, zz = (int(v) for v in tbars['locs'][jj, :3])
+        if radius_ign > 0:
+            box = (slice(zz - radius_ign, zz + radius_ign + 1),
+                   slice(yy - radius_ign, yy + radius_ign + 1),
+                   slice(xx - radius_ign, xx + radius_ign + 1))
+            mask[box] = np.logical_and(mask[box], radius_ign_flt)
+        box = (slice(zz - radius_use, zz + radius_use + 1),
+               slice(yy - radius_use, yy + radius_use + 1),
+               slice(xx - radius_use, xx + radius_use + 1))
+        mask[box] = np.logical_or(mask[box], radius_use_flt)
+        labels[box] = np.logical_or(labels[box], radius_use_flt)
+    for ax in range(3):
+        sl = [slice(None)] * 3
+        sl[ax] = slice(0, buffer_size); mask[tuple(sl)] = 0
+        sl[ax] = slice(-buffer_size, None); mask[tuple(sl)] = 0
+    if prefix is not None:
+        np.save('%s_labels.npy' % prefix, labels)
+        np.save('%s_mask.npy' % prefix, mask)
+    return labels, mask

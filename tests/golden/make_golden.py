@@ -234,6 +234,15 @@ def gen_synapses():
     for name, (p, g) in (('no_pred', (e, tb['locs'])), ('no_gt', (tb['locs'], e)), ('none', (e, e))):
         r = fplobjdetect.obj_pr(p, g, 5.0)
         out['pr_' + name] = np.array([r.num_tp, r.tot_pred, r.tot_gt, r.pp, r.rr], np.float64)
+    # write_labels_mask: the arrays it hands to (the inert stub of) h5py
+    import sys
+    h5 = sys.modules['h5py']
+    h5.File.reset_mock()
+    tb_lm = {'locs': np.array([[12, 14, 16], [20, 15, 13], [25, 25, 25]]), 'conf': np.ones(3)}
+    fplsynapses.write_labels_mask(tb_lm, np.ones((36, 38, 40), 'uint8'), 3, 6, 4, '/nonexistent/x')
+    sets = h5.File.return_value.__getitem__.return_value.__setitem__.call_args_list
+    assert len(sets) == 2
+    out['lm_labels'], out['lm_mask'] = np.asarray(sets[0][0][1]), np.asarray(sets[1][0][1])
     np.savez_compressed(os.path.join(HERE, 'synapses.npz'), **out)
 
 

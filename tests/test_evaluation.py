@@ -86,3 +86,14 @@ def test_obj_pr_curve_and_aggregate():
     assert lbl.num_tp == 2                                     # label mismatch blocks one pair
     agg = fplobjdetect.aggregate_pr([r, r])
     assert np.allclose(agg.num_tp, 2 * r.num_tp) and np.allclose(agg.pp[:2], r.pp[:2], atol=1e-6)
+
+
+def test_write_labels_mask_matches_the_reference(tmp_path):
+    tb = {'locs': np.array([[12, 14, 16], [20, 15, 13], [25, 25, 25]]), 'conf': np.ones(3)}
+    labels, mask = fplsynapses.write_labels_mask(tb, np.ones((36, 38, 40), 'uint8'), 3, 6, 4,
+                                                 str(tmp_path / 'x'))
+    assert np.array_equal(labels, GOLD['lm_labels']) and np.array_equal(mask, GOLD['lm_mask'])
+    assert labels.dtype == np.uint8 and labels[16, 14, 12] == 1 and mask[16, 14, 12] == 1
+    assert mask[16, 14, 17] == 0                      # in the ignore shell
+    assert np.array_equal(np.load(str(tmp_path / 'x_labels.npy')), labels)
+    assert np.array_equal(np.load(str(tmp_path / 'x_mask.npy')), mask)

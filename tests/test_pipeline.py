@@ -206,3 +206,27 @@ def test_evaluate_substacks_usage_contract(ctx, tmp_path):
     assert per[0].num_tp[1] == n_gt and per[0].tot_pred[1] == n_keep
     assert per[0].tot_pred[2] == 0 and per[0].pp[2] == 1 and per[0].rr[2] == 0
     assert np.allclose(agg.num_tp, 2 * per[0].num_tp) and abs(agg.rr[0] - 1.0) < 1e-6
+
+
+@pytest.mark.gpu
+def test_documented_example_flow_on_synthetic_data(ctx, tmp_path):
+    """the README's entry point of the reference (scripts/fpl_fib25_example.py) end to
+    end with flypylib_amd on synthetic blobs: write_labels_mask -> gen_volume2 ->
+    FplNetwork(unet_like2).train (masked focal loss) -> save -> evaluate_substacks.
+    The trained net must find the planted points of an UNSEEN region."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'example_flow', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'tools',
+                                     'example_flow.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(['--size', '96', '--steps', '120', '--epochs', '2', '--out', str(tmp_path)])
+    for name in ('train', 'test'):
+        agg = out[name]
+        best = int(np.argmax(agg.pp * agg.rr))
+        assert agg.tot_gt[0] == 125
+        assert agg.pp[best] > 0.9 and agg.rr[best] > 0.9, (name, agg.pp, agg.rr)
+    rows = open(str(tmp_path / 'log.csv')).read().strip().splitlines()
+    assert float(rows[2].split(',')[3]) < float(rows[1].split(',')[3])      # loss falls
+    assert (tmp_path / 'net.npz').exists() or (tmp_path / 'net').exists() or \
+        any(p.name.startswith('net') for p in tmp_path.iterdir())
