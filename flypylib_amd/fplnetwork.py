@@ -188,28 +188,30 @@ class FplNetwork:
         from .fplobjdetect import _load_main
         pred = self.infer(image, normalize=normalize)
         if isinstance(lm_prefix, str):
-            ll = np.array(_load_main('%slabels.h5' % lm_prefix))
-            mm = np.array(_load_main('%smask.h5' % lm_prefix))
+            labels = np.array(_load_main('%slabels.h5' % lm_prefix))
+            mask = np.array(_load_main('%smask.h5' % lm_prefix))
         else:
-            ll, mm = (np.array(_load_main(a)) for a in lm_prefix)
-        context_rr = tuple(int(round(cc / 2)) for cc in self.rf_size)
-        for ax in range(3):
+            labels, mask = (np.array(_load_main(a)) for a in lm_prefix)
+        # voxels closer to a face than half the receptive field cannot be sampled
+        for ax, cc in enumerate(self.rf_size):
+            edge = int(round(cc / 2))
             sl = [slice(None)] * 3
-            sl[ax] = slice(0, context_rr[ax]); mm[tuple(sl)] = 0
-            sl[ax] = slice(-context_rr[ax], None); mm[tuple(sl)] = 0
-        l0_loss = -1. * (mm == 1) * (ll == 0) * np.log(np.maximum(1 - pred, 1e-8))
-        conf_neg = (l0_loss < 0.005) * (mm == 1) * (ll == 0)
-        l0_loss[conf_neg] = 0
-        mm[conf_neg] = 0
-        if l0_thresh is not None:
-            l0_mask = (ll == 0) * (mm == 1)
-            l0_loss = np.maximum(l0_loss, l0_thresh[0] * l0_mask)
-            l0_loss = np.minimum(l0_loss, l0_thresh[1] * l0_mask)
-        l1_loss = -1. * (mm == 1) * (ll == 1) * np.log(np.maximum(pred, 1e-8))
-        if l1_thresh is not None:
-            l1_mask = (ll == 1) * (mm == 1)
-            l1_loss = np.maximum(l1_loss, l1_thresh[0] * l1_mask)
-            l1_loss = np.minimum(l1_loss, l1_thresh[1] * l1_mask)
+            sl[ax] = slice(0, edge); mask[tuple(sl)] = 0
+            sl[ax] = slice(-edge, None); mask[tuple(sl)] = 0
+
+        def clamp(loss, bounds, where):
+            if bounds is None:
+                return loss
+            return np.minimum(np.maximum(loss, bounds[0] * where), bounds[1] * where)
+
+        neg = (mask == 1) & (labels == 0)
+        l0_loss = -1. * neg * np.log(np.maximum(1 - pred, 1e-8))
+        confident = neg & (l0_loss < 0.005)          # already learnt: never sampled again
+        l0_loss[confident] = 0
+        mask[confident] = 0
+        l0_loss = clamp(l0_loss, l0_thresh, (labels == 0) * (mask == 1))
+        pos = (mask == 1) & (labels == 1)
+        l1_loss = clamp(-1. * pos * np.log(np.maximum(pred, 1e-8)), l1_thresh, pos)
         return (l0_loss + l1_loss).astype('float32')
 
     # pickling: device handles never travel

@@ -235,26 +235,22 @@ def obj_match(dists, allow_mult=False):
 def obj_pr(predict_locs, groundtruth_locs, dist_thresh, predict_lbls=None,
            groundtruth_lbls=None, allow_mult=False):
     """precision / recall of predicted vs ground-truth locations at a distance
-    threshold (reference :323-376)"""
-    if (predict_locs.shape[0] == 0) | (groundtruth_locs.shape[0] == 0):
-        tot_pred, tot_gt = predict_locs.shape[0], groundtruth_locs.shape[0]
-        return PR_Result(num_tp=0, tot_pred=tot_pred, tot_gt=tot_gt,
-                         pp=1 if tot_pred == 0 else 0, rr=1 if tot_gt == 0 else 0,
-                         match=None)
-    pred = predict_locs.reshape((-1, 1, 3))
-    gt = groundtruth_locs.reshape((1, -1, 3))
-    dists = np.sqrt(((pred - gt) ** 2).sum(axis=2))
-    dists -= dist_thresh
+    threshold (reference :323-376): pairs closer than `dist_thresh` (and, if labels are
+    given, with equal labels) are admissible, `obj_match` picks the matching"""
+    n_pred, n_gt = predict_locs.shape[0], groundtruth_locs.shape[0]
+    if n_pred == 0 or n_gt == 0:
+        return PR_Result(num_tp=0, tot_pred=n_pred, tot_gt=n_gt,
+                         pp=1 if n_pred == 0 else 0, rr=1 if n_gt == 0 else 0, match=None)
+    delta = predict_locs.reshape(n_pred, 1, 3) - groundtruth_locs.reshape(1, n_gt, 3)
+    cost = np.sqrt((delta ** 2).sum(axis=2)) - dist_thresh
     if predict_lbls is not None:
-        lbl_constraint = (predict_lbls.reshape((-1, 1)) !=
-                          groundtruth_lbls.reshape((1, -1))).astype('float32')
-        dists += (dist_thresh + 1.) * lbl_constraint
-    match = obj_match(dists, allow_mult=allow_mult)
+        differ = predict_lbls.reshape(-1, 1) != groundtruth_lbls.reshape(1, -1)
+        cost += (dist_thresh + 1.) * differ.astype('float32')
+    match = obj_match(cost, allow_mult=allow_mult)
     num_tp = match.sum()
-    pd_mult = np.maximum(match.sum(axis=1) - 1, 0).sum()
-    tot_pred = match.shape[0] + pd_mult
-    return PR_Result(num_tp=num_tp, tot_pred=tot_pred, tot_gt=match.shape[1],
-                     pp=num_tp / match.shape[0], rr=num_tp / match.shape[1], match=match)
+    extra = np.maximum(match.sum(axis=1) - 1, 0).sum()     # predictions matched twice
+    return PR_Result(num_tp=num_tp, tot_pred=n_pred + extra, tot_gt=n_gt,
+                     pp=num_tp / n_pred, rr=num_tp / n_gt, match=match)
 
 
 def obj_pr_curve(predict, groundtruth, dist_thresh, thresholds, predict_lbls=None,
@@ -266,31 +262,25 @@ def obj_pr_curve(predict, groundtruth, dist_thresh, thresholds, predict_lbls=Non
         predict = fplsynapses.load_from_json(predict)
     if isinstance(groundtruth, str):
         groundtruth = fplsynapses.load_from_json(groundtruth)
-    thresholds = np.asarray(thresholds)
-    n_thd = thresholds.size
-    num_tp, tot_pred, tot_gt, pp, rr = (np.zeros((n_thd,)) for _ in range(5))
-    match = None
-    for ii in range(n_thd):
-        idx = predict['conf'] >= thresholds[ii]
-        mm = obj_pr(predict['locs'][idx, :], groundtruth['locs'], dist_thresh,
-                    predict_lbls[idx] if predict_lbls is not None else None,
-                    groundtruth_lbls, allow_mult=allow_mult)
-        num_tp[ii], tot_pred[ii], tot_gt[ii] = mm.num_tp, mm.tot_pred, mm.tot_gt
-        pp[ii], rr[ii] = mm.pp, mm.rr
-        if match is None:
-            match = mm.match
-    return PR_Result(num_tp=num_tp, tot_pred=tot_pred, tot_gt=tot_gt, pp=pp, rr=rr,
-                     match=match)
+    points = []
+    for thd in np.asarray(thresholds).reshape(-1):
+        sel = predict['conf'] >= thd
+        points.append(obj_pr(predict['locs'][sel, :], groundtruth['locs'], dist_thresh,
+                             None if predict_lbls is None else predict_lbls[sel],
+                             groundtruth_lbls, allow_mult=allow_mult))
+
+    def column(name):
+        return np.array([getattr(pt, name) for pt in points], dtype=np.float64)
+    return PR_Result(num_tp=column('num_tp'), tot_pred=column('tot_pred'),
+                     tot_gt=column('tot_gt'), pp=column('pp'), rr=column('rr'),
+                     match=points[0].match if points else None)
 
 
 def aggregate_pr(results):
     """pool per-substack PR curves (reference :439-455)"""
-    dim = results[0].num_tp.shape
-    num_tp, tot_pred, tot_gt = np.zeros(dim), np.zeros(dim), np.zeros(dim)
-    for r in results:
-        num_tp += r.num_tp
-        tot_pred += r.tot_pred
-        tot_gt += r.tot_gt
+    num_tp = sum(r.num_tp for r in results) + np.zeros(results[0].num_tp.shape)
+    tot_pred = sum(r.tot_pred for r in results) + np.zeros(results[0].num_tp.shape)
+    tot_gt = sum(r.tot_gt for r in results) + np.zeros(results[0].num_tp.shape)
     return PR_Result(num_tp=num_tp, tot_pred=tot_pred, tot_gt=tot_gt,
                      pp=num_tp / (tot_pred + 10e-8), rr=num_tp / (tot_gt + 10e-8), match=None)
 

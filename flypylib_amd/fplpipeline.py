@@ -53,28 +53,22 @@ def roi_from_txt(filename):
 def gen_full_tab_roi(filename, store_name, repo_uuid=None,
                      crop=(None, None, None), n_splits=1, step_size=512):
     """write '<filename>_%02d.txt' ROI files covering the volume in `step_size`
-    substacks, split into `n_splits` files (reference :1172-1208; `store_name` is
-    a data source as in `full_roi_inference`, whose extents start at 0)"""
+    substacks (z outer, x inner), split into `n_splits` files of equal length
+    (reference :1172-1208; `store_name` is a data source as in `full_roi_inference`,
+    whose extents start at 0)"""
+    import itertools
     extents = _open_source(store_name).extent
-    crop = [list(c) if c is not None else [0, int(e)] for c, e in zip(crop, extents)]
-    file_idx = 0
-    f_out = open('%s_%02d.txt' % (filename, file_idx), 'w')
-    count_idx = 0
-    max_count = int(np.ceil((
-        np.ceil((crop[0][1] - crop[0][0]) / float(step_size)) *
-        np.ceil((crop[1][1] - crop[1][0]) / float(step_size)) *
-        np.ceil((crop[2][1] - crop[2][0]) / float(step_size))) / n_splits))
-    for zz in range(crop[0][0], crop[0][1], step_size):
-        for yy in range(crop[1][0], crop[1][1], step_size):
-            for xx in range(crop[2][0], crop[2][1], step_size):
-                f_out.write('%d,%d,%d,%d\n' % (step_size, zz, yy, xx))
-                count_idx += 1
-                if count_idx == max_count:
-                    count_idx = 0
-                    file_idx += 1
-                    f_out.close()
-                    f_out = open('%s_%02d.txt' % (filename, file_idx), 'w')
-    f_out.close()
+    lo_hi = [tuple(c) if c is not None else (0, int(e)) for c, e in zip(crop, extents)]
+    starts = [range(lo, hi, step_size) for lo, hi in lo_hi]
+    n_total = int(np.prod([np.ceil((hi - lo) / float(step_size)) for lo, hi in lo_hi]))
+    per_file = int(np.ceil(n_total / n_splits))
+    lines = ['%d,%d,%d,%d\n' % (step_size, z, y, x) for z, y, x in itertools.product(*starts)]
+    # the reference opens the next file as soon as one is full, so an exact split
+    # leaves one empty trailing file: kept, downstream globbing may count on it
+    n_files = len(lines) // per_file + 1
+    for idx in range(n_files):
+        with open('%s_%02d.txt' % (filename, idx), 'w') as f_out:
+            f_out.writelines(lines[idx * per_file:(idx + 1) * per_file])
 
 
 def fri_filename(working_dir, substack):
