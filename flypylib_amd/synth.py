@@ -117,3 +117,25 @@ def dropout_keep_mask(seed, layer, n, rate):
         h = _splitmix64(np.uint64(seed) ^ _splitmix64(key))
         u = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
         return u >= np.float32(rate)
+
+
+def voronoi_segmentation(seed, shape, n_sites, tiny=0):
+    """synthetic segmentation: Voronoi cells of `n_sites` hashed sites (labels are
+    large sparse uint64 ids, as DVID body ids are), plus `tiny` isolated 2^3 specks
+    with their own labels.  Deterministic in (seed, shape, n_sites, tiny)."""
+    rs = np.random.RandomState(seed)
+    sites = rs.rand(n_sites, 3) * np.asarray(shape)
+    ids = (rs.randint(1, 2 ** 31, n_sites).astype(np.uint64) << np.uint64(20)) | \
+        np.arange(n_sites, dtype=np.uint64)
+    z, y, x = np.meshgrid(*(np.arange(s) for s in shape), indexing='ij')
+    best = np.full(shape, np.inf)
+    lab = np.zeros(shape, np.uint64)
+    for k in range(n_sites):
+        d = (z - sites[k, 0]) ** 2 + (y - sites[k, 1]) ** 2 + (x - sites[k, 2]) ** 2
+        m = d < best
+        best[m] = d[m]
+        lab[m] = ids[k]
+    for k in range(tiny):
+        c = [rs.randint(1, s - 3) for s in shape]
+        lab[c[0]:c[0] + 2, c[1]:c[1] + 2, c[2]:c[2] + 2] = np.uint64(7000000 + k)
+    return lab

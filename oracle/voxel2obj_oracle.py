@@ -67,14 +67,19 @@ def smooth_and_clear(pred, r, sigma, use_scipy=True):
     return vol
 
 
-def greedy_nms(vol, thresh, r):
-    """V5 on a prepared volume: list of (x, y, z, value) in selection order"""
+def greedy_nms(vol, thresh, r, seg=None, seg_dilate=None, seg_force=None):
+    """V5 on a prepared volume: list of (x, y, z, value) in selection order.
+    With a (padded) segmentation (reference :190-224) a pick only suppresses voxels
+    of its r-ball that lie in its own segment - the segment's mask inside the
+    (2r+1)^3 cube, grown by `seg_dilate` iterations of scipy's binary_dilation -
+    plus, unconditionally, the ball of radius `seg_force`."""
     shape = vol.shape
     flat = vol.reshape(-1)
     live = np.flatnonzero(flat > thresh)          # raster order, ascending
     ax = np.arange(-r, r + 1)
-    keep_outside = (ax[:, None, None] ** 2 + ax[None, :, None] ** 2
-                    + ax[None, None, :] ** 2) > r * r
+    d2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2
+    keep_outside = d2 > r * r
+    keep_off_centre = d2 > seg_force * seg_force if seg_force else None
     alive = np.ones(shape, dtype=bool)
     alive_flat = alive.reshape(-1)
     picked = []
@@ -86,19 +91,36 @@ def greedy_nms(vol, thresh, r):
             break
         z, y, x = np.unravel_index(live[j], shape)
         picked.append((x, y, z, v))
-        alive[z - r:z + r + 1, y - r:y + r + 1, x - r:x + r + 1] &= keep_outside
+        box = (slice(z - r, z + r + 1), slice(y - r, y + r + 1), slice(x - r, x + r + 1))
+        keep = keep_outside
+        if seg is not None:
+            same = seg[box] == seg[z, y, x]
+            if seg_dilate is not None:
+                same = ndimage.binary_dilation(same, iterations=seg_dilate)
+            keep = np.logical_not(same) | keep_outside
+            if seg_force:
+                keep = keep & keep_off_centre
+        alive[box] &= keep
         live = live[alive_flat[live]]
     return picked
 
 
 def voxel2obj(pred, obj_min_dist, smoothing_sigma, volume_offset=(0, 0, 0),
-              buffer_sz=0, thd=0, use_scipy=True):
+              buffer_sz=0, thd=0, use_scipy=True, seg=None, seg_dilate=None,
+              seg_sz_thd=None, seg_force=None):
     r = int(obj_min_dist)
     buf = (buffer_sz,) * 3 if np.size(buffer_sz) == 1 else tuple(buffer_sz)
     shape = np.asarray(pred).shape
     vol = smooth_and_clear(pred, r, smoothing_sigma, use_scipy)
+    if seg is not None:
+        seg = np.pad(np.asarray(seg), r, 'constant')
+    if seg_sz_thd is not None:                    # reference :177-181 (padding counts as
+        ids, counts = np.unique(seg, return_counts=True)      # part of segment 0)
+        for sid, cnt in zip(ids, counts):
+            if cnt < seg_sz_thd:
+                vol[seg == sid] = 0
     thresh = np.maximum(np.percentile(vol, 97), thd)
-    picked = greedy_nms(vol, thresh, r)
+    picked = greedy_nms(vol, thresh, r, seg, seg_dilate, seg_force)
     pts = (np.asarray(picked, dtype=np.float64) if picked
            else np.zeros((0, 4)))
     pts[:, :3] -= r

@@ -96,6 +96,34 @@ def gen_voxel2obj():
     np.savez_compressed(os.path.join(HERE, 'voxel2obj.npz'), **out)
 
 
+# (name, pred kind, pred seed, shape, r, sigma, thd, buffer, seg seed, n_sites, tiny,
+#  seg_dilate, seg_sz_thd, seg_force)
+V2O_SEG_CASES = [
+    ('seg_plain', 'blobs', 41, (48, 52, 56), 7, 2.0, 0.05, 2, 3, 9, 0, None, None, None),
+    ('seg_dilate', 'blobs', 42, (48, 52, 56), 7, 2.0, 0.05, 0, 4, 12, 0, 2, None, None),
+    ('seg_force', 'uniform', 43, (40, 44, 48), 6, 1.5, 0.1, 3, 5, 20, 0, None, None, 2),
+    ('seg_small', 'blobs', 44, (56, 48, 52), 9, 2.0, 0.05, 0, 6, 8, 30, 1, 60, None),
+    ('seg_all', 'blobs', 45, (64, 60, 56), 9, 3.0, 0.05, (2, 3, 4), 7, 15, 20, 3, 40, 4),
+]
+
+
+def gen_voxel2obj_seg():
+    """the segmentation-aware branch of the reference's voxel2obj (:161-224)"""
+    out = {'names': np.array([c[0] for c in V2O_SEG_CASES])}
+    for (name, kind, pseed, shape, r, sigma, thd, buf, sseed, n_sites, tiny, dil, szt,
+         force) in V2O_SEG_CASES:
+        pred = make_pred(kind, pseed, shape)
+        seg = synth.voronoi_segmentation(sseed, shape, n_sites, tiny)
+        res = fplobjdetect.voxel2obj(pred.copy(), r, sigma, (0, 0, 0), buf, thd, seg=seg.copy(),
+                                     seg_dilate=dil, seg_sz_thd=szt, seg_force=force)
+        plain = fplobjdetect.voxel2obj(pred.copy(), r, sigma, (0, 0, 0), buf, thd)
+        out[name + '_locs'], out[name + '_conf'] = res['locs'], res['conf']
+        out[name + '_pred_sha'], out[name + '_seg_sha'] = np.array(sha(pred)), np.array(sha(seg))
+        print('%-12s %4d detections (%d without the segmentation)'
+              % (name, len(res['conf']), len(plain['conf'])))
+    np.savez_compressed(os.path.join(HERE, 'voxel2obj_seg.npz'), **out)
+
+
 class _FakeNet:
     """crop-identity stand-in for the Keras inference network"""
 
@@ -247,6 +275,7 @@ def gen_synapses():
 
 
 if __name__ == '__main__':
+    gen_voxel2obj_seg()
     gen_synapses()
     gen_fri_get_image()
     gen_set_filter()

@@ -60,3 +60,16 @@ def coarse4(x, off):
 
 
 FAKE_NETS = {'_crop_identity': crop_identity, '_coarse4': coarse4}
+
+
+# the segmentation-aware voxel2obj cases of tests/golden/voxel2obj_seg.npz
+# (name, pred kind, pred seed, shape, r, sigma, thd, buffer, seg seed, n_sites, tiny,
+#  seg_dilate, seg_sz_thd, seg_force) - as in tests/golden/make_golden.py
+V2O_SEG_CASES = [
+    ('seg_plain', 'blobs', 41, (48, 52, 56), 7, 2.0, 0.05, 2, 3, 9, 0, None, None, None),
+    ('seg_dilate', 'blobs', 42, (48, 52, 56), 7, 2.0, 0.05, 0, 4, 12, 0, 2, None, None),
+    ('seg_force', 'uniform', 43, (40, 44, 48), 6, 1.5, 0.1, 3, 5, 20, 0, None, None, 2),
+    ('seg_small', 'blobs', 44, (56, 48, 52), 9, 2.0, 0.05, 0, 6, 8, 30, 1, 60, None),
+    ('seg_all', 'blobs', 45, (64, 60, 56), 9, 3.0, 0.05, (2, 3, 4), 7, 15, 20, 3, 40, 4),
+]
+

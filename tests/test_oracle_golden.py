@@ -97,3 +97,23 @@ def test_synth_volume_is_origin_consistent():
     b = synth.em_volume_u8(7, (130, 70, 110))
     assert np.array_equal(b[64:104, 10:60, 30:100], a)
     assert a.dtype == np.uint8 and 100 < a.mean() < 150
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('case', helpers.V2O_SEG_CASES, ids=[c[0] for c in helpers.V2O_SEG_CASES])
+def test_segmentation_aware_voxel2obj_oracle_matches_reference(golden, case):
+    """the seg / seg_dilate / seg_sz_thd / seg_force branch (reference :161-224)"""
+    from flypylib_amd import synth
+    from oracle import voxel2obj_oracle
+    g = golden('voxel2obj_seg.npz')
+    name, kind, pseed, shape, r, sigma, thd, buf, sseed, n_sites, tiny, dil, szt, force = case
+    pred = helpers.make_pred(kind, pseed, shape)
+    seg = synth.voronoi_segmentation(sseed, shape, n_sites, tiny)
+    assert helpers.sha(pred) == str(g[name + '_pred_sha'])
+    assert helpers.sha(seg) == str(g[name + '_seg_sha'])
+    res = voxel2obj_oracle.voxel2obj(pred, r, sigma, (0, 0, 0), buf, thd, seg=seg,
+                                     seg_dilate=dil, seg_sz_thd=szt, seg_force=force)
+    assert np.array_equal(res['locs'], g[name + '_locs'])
+    assert np.array_equal(res['conf'], g[name + '_conf'])
