@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FplHipError(RuntimeError):
@@ -64,6 +64,9 @@ SIGNATURES = {
     'fpl_v2o_smooth': (C.c_int, [_vp, _vp, C.c_int, _pi64, _i32, _vp, _i32,
                                  _pi64, _i32, _vp]),
     'fpl_v2o_nms': (C.c_int, [_vp, _f64, _vp, _i64, _pi64, _pi32]),
+    'fpl_v2o_set_seg': (C.c_int, [_vp, _vp, _i32, C.c_int, _pi64, _i64]),
+    'fpl_v2o_select': (C.c_int, [_vp, _pi64, _i32, _vp]),
+    'fpl_v2o_nms_seg': (C.c_int, [_vp, C.c_double, _i32, _i32, _vp, _i64, _pi64, _pi32]),
     'fpl_v2o_copy_smoothed': (C.c_int, [_vp, _vp, C.c_int]),
     'fpl_trainer_create': (C.c_int, [_vp, C.POINTER(fpl_layer), _i32, _i32, _i32,
                                      _vp, _i64, _f32, _f32, _f32, _f32,
@@ -247,6 +250,33 @@ class Context:
         n, rounds = C.c_int64(), C.c_int32()
         self.check(self.lib.fpl_v2o_nms(self.h, float(thresh), _ptr(out),
                                         int(cap), C.byref(n), C.byref(rounds)))
+        return out[:n.value].copy(), rounds.value
+
+    def v2o_set_seg(self, seg, dims, sz_thd=None):
+        if isinstance(seg, np.ndarray):
+            if seg.dtype.itemsize not in (4, 8) or seg.dtype.kind not in 'iu':
+                seg = seg.astype(np.uint64)
+            seg = np.ascontiguousarray(seg)
+            nbytes = seg.dtype.itemsize
+        else:
+            nbytes = np.dtype(getattr(seg, 'dtype', np.uint64)).itemsize
+        self.check(self.lib.fpl_v2o_set_seg(self.h, _ptr(seg), nbytes, _mem_of(seg),
+                                            _arr(dims, C.c_int64),
+                                            -1 if sz_thd is None else int(sz_thd)))
+
+    def v2o_select(self, ranks):
+        ranks = np.ascontiguousarray(ranks, np.int64)
+        vals = np.zeros(max(ranks.size, 1), np.float32)
+        self.check(self.lib.fpl_v2o_select(self.h, ranks.ctypes.data_as(_pi64),
+                                           int(ranks.size), _ptr(vals)))
+        return vals[:ranks.size]
+
+    def v2o_nms_seg(self, thresh, seg_dilate, seg_force, cap=1 << 20):
+        out = np.zeros((cap, 4), np.float64)
+        n, rounds = C.c_int64(), C.c_int32()
+        self.check(self.lib.fpl_v2o_nms_seg(self.h, float(thresh), int(seg_dilate or 0),
+                                            int(seg_force or 0), _ptr(out), int(cap),
+                                            C.byref(n), C.byref(rounds)))
         return out[:n.value].copy(), rounds.value
 
     def v2o_smoothed(self, pdims):

@@ -30,6 +30,9 @@ struct PendingTiming {
 struct V2oState {
   float *smoothed = nullptr;   // padded dims
   size_t cap_bytes = 0;
+  unsigned long long *seg = nullptr;   // padded segmentation (fpl_v2o_set_seg) or null
+  size_t seg_cap_bytes = 0;
+  bool seg_valid = false;
   int64_t pdims[3] = {0, 0, 0};
   int32_t r = 0;
   bool valid = false;

@@ -471,6 +471,143 @@ __global__ __launch_bounds__(256) void clear_balls(
   }
 }
 
+// ---- segmentation-aware suppression (reference fplobjdetect.py:161-224) ---------------
+// zero-padded u64 copy of the (Z,Y,X) label volume
+template <typename T>
+__global__ void seg_pad(const T *__restrict__ src, int64_t D0, int64_t D1, int64_t D2, int r,
+                        unsigned long long *__restrict__ dst, int64_t P1, int64_t P2,
+                        int64_t n_pad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  const int64_t x = i % P2 - r, y = (i / P2) % P1 - r, z = i / (P2 * P1) - r;
+  unsigned long long v = 0;
+  if (z >= 0 && y >= 0 && x >= 0 && z < D0 && y < D1 && x < D2)
+    v = (unsigned long long)src[(z * D1 + y) * D2 + x];
+  dst[i] = v;
+}
+
+// voxel counts per label: open-addressing hash (slot key = label + 1, 0 = empty); a
+// thread folds runs of equal labels among its 16 consecutive voxels into one insert
+__device__ __forceinline__ uint64_t seg_hash(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+  return k ^ (k >> 33);
+}
+
+__global__ void seg_count(const unsigned long long *__restrict__ seg, int64_t n,
+                          unsigned long long *__restrict__ keys,
+                          unsigned int *__restrict__ counts, uint64_t mask,
+                          unsigned int *__restrict__ overflow) {
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i0 >= n) return;
+  const int64_t i1 = i0 + 16 < n ? i0 + 16 : n;
+  unsigned long long cur = seg[i0];
+  unsigned int run = 0;
+  for (int64_t i = i0; i <= i1; ++i) {
+    const bool end = i == i1;
+    const unsigned long long v = end ? 0 : seg[i];
+    if (!end && v == cur) { ++run; continue; }
+    uint64_t h = seg_hash(cur) & mask;
+    bool done = false;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+      const unsigned long long prev = atomicCAS(&keys[h], 0ull, cur + 1ull);
+      if (prev == 0ull || prev == cur + 1ull) { atomicAdd(&counts[h], run); done = true; break; }
+      h = (h + 1) & mask;
+    }
+    if (!done) atomicExch(overflow, 1u);
+    cur = v; run = 1;
+  }
+}
+
+// smoothed = 0 where the voxel's segment has fewer than sz_thd voxels
+__global__ void seg_zero_small(const unsigned long long *__restrict__ seg, int64_t n,
+                               const unsigned long long *__restrict__ keys,
+                               const unsigned int *__restrict__ counts, uint64_t mask,
+                               long long sz_thd, float *__restrict__ smoothed) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = seg[i];
+  uint64_t h = seg_hash(k) & mask;
+  while (keys[h] != k + 1ull) h = (h + 1) & mask;      // every label was inserted
+  if ((long long)counts[h] < sz_thd) smoothed[i] = 0.f;
+}
+
+// one workgroup per winner: the part of its r-ball that lies in its own segment (mask
+// of the (2r+1)^3 cube, grown `dilate` times by the 6-neighbour cross, zero beyond the
+// cube - scipy.ndimage.binary_dilation(iterations=dilate)) plus the ball of radius
+// `force` is cleared in the live volume.  A cube row (z,y) is one 64-bit mask
+// (2r+1 <= 64), built with a ballot; rows live in LDS.
+__global__ __launch_bounds__(256) void clear_balls_seg(
+    const unsigned long long *__restrict__ round_list,
+    const unsigned long long *__restrict__ counters, uint32_t *__restrict__ live,
+    int64_t L1, int64_t L2, int64_t P1, int64_t P2, int r,
+    unsigned long long *__restrict__ best, int64_t C1, int64_t C2,
+    const unsigned long long *__restrict__ seg, int dilate, int force) {
+  extern __shared__ unsigned long long rows_lds[];       // 2 x side*side
+  const int side = 2 * r + 1, nrows = side * side;
+  unsigned long long *ma = rows_lds, *mb = rows_lds + nrows;
+  const unsigned long long full = side == 64 ? ~0ull : ((1ull << side) - 1ull);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long nwin = counters[1];
+  for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
+    const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(round_list[wi] & 0xFFFFFFFFu);
+    const int64_t x = flat % P2, y = (flat / P2) % P1, z = flat / (P2 * P1);
+    const unsigned long long id = seg[flat];
+    __syncthreads();                       // previous winner done with the LDS rows
+    for (int row = wave; row < nrows; row += 4) {
+      const int dz = row / side - r, dy = row % side - r;
+      bool same = false;
+      if (lane < side)
+        same = seg[((z + dz) * P1 + (y + dy)) * P2 + x - r + lane] == id;
+      const unsigned long long m = __ballot(same);
+      if (lane == 0) ma[row] = m;
+    }
+    __syncthreads();
+    for (int it = 0; it < dilate; ++it) {
+      for (int row = threadIdx.x; row < nrows; row += 256) {
+        const int rz = row / side, ry = row % side;
+        unsigned long long m = ma[row];
+        m |= (m << 1) | (m >> 1);
+        if (rz > 0) m |= ma[row - side];
+        if (rz + 1 < side) m |= ma[row + side];
+        if (ry > 0) m |= ma[row - 1];
+        if (ry + 1 < side) m |= ma[row + 1];
+        mb[row] = m & full;
+      }
+      __syncthreads();
+      unsigned long long *t = ma; ma = mb; mb = t;
+    }
+    for (int row = wave; row < nrows; row += 4) {
+      const int dz = row / side - r, dy = row % side - r;
+      const int rem = r * r - dz * dz - dy * dy;
+      unsigned long long bits = 0;
+      if (rem >= 0) {
+        int hx = (int)sqrtf((float)rem);
+        while ((hx + 1) * (hx + 1) <= rem) ++hx;
+        while (hx * hx > rem) --hx;
+        const unsigned long long ball =
+            (2 * hx + 1 == 64 ? ~0ull : ((1ull << (2 * hx + 1)) - 1ull)) << (r - hx);
+        bits = ball & ma[row];
+      }
+      const int remf = force * force - dz * dz - dy * dy;
+      if (force > 0 && remf >= 0) {
+        int hf = (int)sqrtf((float)remf);
+        while ((hf + 1) * (hf + 1) <= remf) ++hf;
+        while (hf * hf > remf) --hf;
+        bits |= ((1ull << (2 * hf + 1)) - 1ull) << (r - hf);
+      }
+      if (lane < side && ((bits >> lane) & 1ull))
+        live[((z + dz) * L1 + (y + dy)) * L2 + x - r + lane] = 0;
+    }
+    const int64_t cz0 = (z - r) / CELL, cy0 = (y - r) / CELL, cx0 = (x - r) / CELL;
+    const int nz = (int)((z + r) / CELL - cz0 + 1), ny = (int)((y + r) / CELL - cy0 + 1),
+              nx = (int)((x + r) / CELL - cx0 + 1);
+    for (int i = threadIdx.x; i < nz * ny * nx; i += blockDim.x) {
+      const int64_t cz = cz0 + i / (ny * nx), cy = cy0 + (i / nx) % ny, cx = cx0 + i % nx;
+      best[(cz * C1 + cy) * C2 + cx] = CELL_DIRTY;
+    }
+  }
+}
+
 struct RankQuery {
   int64_t rank;       // remaining rank inside the current prefix
   uint32_t prefix;    // key bits fixed so far
@@ -478,102 +615,16 @@ struct RankQuery {
 
 }  // namespace
 
-extern "C" {
-
-int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
-                   const int64_t dims[3], int32_t r, const double *weights,
-                   int32_t wr, const int64_t *ranks, int32_t n_ranks,
-                   float *rank_values) {
-  if (!ctx || !pred || !dims || !weights)
-    return fpl_fail(ctx, "fpl_v2o_smooth: NULL argument");
-  FPL_REQUIRE(ctx, r >= 0 && wr >= 0, "fpl_v2o_smooth: negative radius");
-  FPL_HIP(ctx, hipSetDevice(ctx->device));
-  int64_t P[3];
-  for (int a = 0; a < 3; ++a) {
-    FPL_REQUIRE(ctx, dims[a] > 0, "fpl_v2o_smooth: dims[%d] = %lld", a,
-                (long long)dims[a]);
-    P[a] = dims[a] + 2 * (int64_t)r;
-  }
-  const int64_t n_pad = P[0] * P[1] * P[2];
-  FPL_REQUIRE(ctx, n_pad < ((int64_t)1 << 32) - 1,
-              "fpl_v2o_smooth: padded volume has %lld voxels; the NMS keys hold "
-              "32-bit flat indices - process it as substacks (as "
-              "fplobjdetect.full_roi_inference does)", (long long)n_pad);
-  for (int i = 0; i < n_ranks; ++i)
-    FPL_REQUIRE(ctx, ranks[i] >= 0 && ranks[i] < n_pad,
-                "fpl_v2o_smooth: rank %lld out of range", (long long)ranks[i]);
+// exact order statistics of S.smoothed: 3-level radix select (11 / 11 / 10 bits) on the
+// monotone float key.  Level 0 comes out of the x pass when `have_level0` (its
+// histogram is already in hist_dev); the elements of the selected level-0 bin are
+// then compacted (one filtered scan) and levels 1-2 run on that short list.
+// hist_dev: 2049 u64 ([2048] spare); scratch: n_pad floats.
+static int v2o_select(fpl_ctx *ctx, const V2oState &S, int64_t n_pad, const int64_t *ranks,
+                      int32_t n_ranks, float *rank_values, unsigned long long *hist_dev,
+                      float *scratch, bool windowed, DevTemp &tmp) {
   hipStream_t st = ctx->stream;
-  DevTemp tmp(ctx);
-  V2oState &S = ctx->v2o;
-  S.valid = false;
-  const size_t vol_bytes = (size_t)n_pad * sizeof(float);
-  if (S.cap_bytes < vol_bytes) {
-    if (S.smoothed) fpl_dev_release(ctx, S.smoothed);
-    S.smoothed = nullptr;
-    S.cap_bytes = 0;
-    void *p;
-    FPL_TRY(fpl_dev_alloc(ctx, vol_bytes, &p));
-    S.smoothed = (float *)p;
-    S.cap_bytes = vol_bytes;
-  }
-  const float *pred_dev = pred;
-  if (pred_mem == FPL_MEM_HOST) {
-    void *p;
-    const size_t nb = (size_t)(dims[0] * dims[1] * dims[2]) * sizeof(float);
-    FPL_TRY(tmp.alloc(nb, &p));
-    FPL_HIP(ctx, hipMemcpyAsync(p, pred, nb, hipMemcpyHostToDevice, st));
-    pred_dev = (const float *)p;
-  }
   void *p;
-  FPL_TRY(tmp.alloc(vol_bytes, &p));
-  float *scratch = (float *)p;
-  FPL_TRY(tmp.alloc((size_t)(wr + 1) * sizeof(double), &p));
-  double *w_dev = (double *)p;
-  // weights[0..2wr] symmetric; kernel wants w[j] by distance j
-  FPL_HIP(ctx, hipMemcpyAsync(w_dev, weights + wr, (size_t)(wr + 1) * sizeof(double),
-                              hipMemcpyHostToDevice, st));
-  PadView pv{pred_dev, dims[0], dims[1], dims[2], r};
-  const unsigned grid = (unsigned)ceil_div64(n_pad, 256);
-  // [0..2047] histogram, [2048] compaction counter
-  FPL_TRY(tmp.alloc(2049 * sizeof(unsigned long long), &p));
-  unsigned long long *hist_dev = (unsigned long long *)p;
-  FPL_HIP(ctx, hipMemsetAsync(hist_dev, 0, 2049 * sizeof(unsigned long long), st));
-  // register-window kernels for the kernel radii flypylib's sigmas produce
-  // (sigma 1.5, 2, 3, 5 at truncate 2.0); the plain kernel covers the rest
-  bool windowed = true;
-  switch (wr) {
-    case 3: launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
-    case 4: launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
-    case 6: launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
-    case 10: launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
-    default: windowed = false;
-  }
-  if (!windowed) {
-    {
-      TimedLaunch tl(ctx, "v2o_gauss_z");
-      gauss_pass<0><<<grid, 256, 0, st>>>(pv, nullptr, S.smoothed, P[0], P[1], P[2],
-                                          w_dev, wr, r);
-    }
-    {
-      TimedLaunch tl(ctx, "v2o_gauss_y");
-      gauss_pass<1><<<grid, 256, 0, st>>>(pv, S.smoothed, scratch, P[0], P[1], P[2],
-                                          w_dev, wr, r);
-    }
-    {
-      TimedLaunch tl(ctx, "v2o_gauss_x");
-      gauss_pass<2><<<grid, 256, 0, st>>>(pv, scratch, S.smoothed, P[0], P[1], P[2],
-                                          w_dev, wr, r);
-    }
-  }
-  FPL_HIP(ctx, hipGetLastError());
-  for (int a = 0; a < 3; ++a) S.pdims[a] = P[a];
-  S.r = r;
-
-  // exact order statistics: 3-level radix select (11 / 11 / 10 bits) on the monotone
-  // float key.  Level 0 comes out of the x pass; the elements of the selected
-  // level-0 bin are then compacted (one filtered scan) and levels 1-2 run on that
-  // short list.
-  if (n_ranks > 0) {
     FPL_REQUIRE(ctx, rank_values, "fpl_v2o_smooth: rank_values is NULL");
     std::vector<unsigned long long> hist(2048);
     std::vector<RankQuery> q(n_ranks);
@@ -651,7 +702,103 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
       const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
       memcpy(&rank_values[i], &u, 4);
     }
+  return 0;
+}
+
+extern "C" {
+
+int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
+                   const int64_t dims[3], int32_t r, const double *weights,
+                   int32_t wr, const int64_t *ranks, int32_t n_ranks,
+                   float *rank_values) {
+  if (!ctx || !pred || !dims || !weights)
+    return fpl_fail(ctx, "fpl_v2o_smooth: NULL argument");
+  FPL_REQUIRE(ctx, r >= 0 && wr >= 0, "fpl_v2o_smooth: negative radius");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  int64_t P[3];
+  for (int a = 0; a < 3; ++a) {
+    FPL_REQUIRE(ctx, dims[a] > 0, "fpl_v2o_smooth: dims[%d] = %lld", a,
+                (long long)dims[a]);
+    P[a] = dims[a] + 2 * (int64_t)r;
   }
+  const int64_t n_pad = P[0] * P[1] * P[2];
+  FPL_REQUIRE(ctx, n_pad < ((int64_t)1 << 32) - 1,
+              "fpl_v2o_smooth: padded volume has %lld voxels; the NMS keys hold "
+              "32-bit flat indices - process it as substacks (as "
+              "fplobjdetect.full_roi_inference does)", (long long)n_pad);
+  for (int i = 0; i < n_ranks; ++i)
+    FPL_REQUIRE(ctx, ranks[i] >= 0 && ranks[i] < n_pad,
+                "fpl_v2o_smooth: rank %lld out of range", (long long)ranks[i]);
+  hipStream_t st = ctx->stream;
+  DevTemp tmp(ctx);
+  V2oState &S = ctx->v2o;
+  S.valid = false;
+  S.seg_valid = false;            // a segmentation belongs to one smoothed volume
+  const size_t vol_bytes = (size_t)n_pad * sizeof(float);
+  if (S.cap_bytes < vol_bytes) {
+    if (S.smoothed) fpl_dev_release(ctx, S.smoothed);
+    S.smoothed = nullptr;
+    S.cap_bytes = 0;
+    void *p;
+    FPL_TRY(fpl_dev_alloc(ctx, vol_bytes, &p));
+    S.smoothed = (float *)p;
+    S.cap_bytes = vol_bytes;
+  }
+  const float *pred_dev = pred;
+  if (pred_mem == FPL_MEM_HOST) {
+    void *p;
+    const size_t nb = (size_t)(dims[0] * dims[1] * dims[2]) * sizeof(float);
+    FPL_TRY(tmp.alloc(nb, &p));
+    FPL_HIP(ctx, hipMemcpyAsync(p, pred, nb, hipMemcpyHostToDevice, st));
+    pred_dev = (const float *)p;
+  }
+  void *p;
+  FPL_TRY(tmp.alloc(vol_bytes, &p));
+  float *scratch = (float *)p;
+  FPL_TRY(tmp.alloc((size_t)(wr + 1) * sizeof(double), &p));
+  double *w_dev = (double *)p;
+  // weights[0..2wr] symmetric; kernel wants w[j] by distance j
+  FPL_HIP(ctx, hipMemcpyAsync(w_dev, weights + wr, (size_t)(wr + 1) * sizeof(double),
+                              hipMemcpyHostToDevice, st));
+  PadView pv{pred_dev, dims[0], dims[1], dims[2], r};
+  const unsigned grid = (unsigned)ceil_div64(n_pad, 256);
+  // [0..2047] histogram, [2048] compaction counter
+  FPL_TRY(tmp.alloc(2049 * sizeof(unsigned long long), &p));
+  unsigned long long *hist_dev = (unsigned long long *)p;
+  FPL_HIP(ctx, hipMemsetAsync(hist_dev, 0, 2049 * sizeof(unsigned long long), st));
+  // register-window kernels for the kernel radii flypylib's sigmas produce
+  // (sigma 1.5, 2, 3, 5 at truncate 2.0); the plain kernel covers the rest
+  bool windowed = true;
+  switch (wr) {
+    case 3: launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    case 4: launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    case 6: launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    case 10: launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    default: windowed = false;
+  }
+  if (!windowed) {
+    {
+      TimedLaunch tl(ctx, "v2o_gauss_z");
+      gauss_pass<0><<<grid, 256, 0, st>>>(pv, nullptr, S.smoothed, P[0], P[1], P[2],
+                                          w_dev, wr, r);
+    }
+    {
+      TimedLaunch tl(ctx, "v2o_gauss_y");
+      gauss_pass<1><<<grid, 256, 0, st>>>(pv, S.smoothed, scratch, P[0], P[1], P[2],
+                                          w_dev, wr, r);
+    }
+    {
+      TimedLaunch tl(ctx, "v2o_gauss_x");
+      gauss_pass<2><<<grid, 256, 0, st>>>(pv, scratch, S.smoothed, P[0], P[1], P[2],
+                                          w_dev, wr, r);
+    }
+  }
+  FPL_HIP(ctx, hipGetLastError());
+  for (int a = 0; a < 3; ++a) S.pdims[a] = P[a];
+  S.r = r;
+
+  if (n_ranks > 0)
+    FPL_TRY(v2o_select(ctx, S, n_pad, ranks, n_ranks, rank_values, hist_dev, scratch, windowed, tmp));
   FPL_HIP(ctx, hipStreamSynchronize(st));
   S.valid = true;
   return 0;
@@ -670,8 +817,9 @@ int fpl_v2o_copy_smoothed(fpl_ctx *ctx, float *dst, int dst_mem) {
   return 0;
 }
 
-int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
-                int64_t *n_out, int32_t *n_rounds) {
+static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
+                   int64_t *n_out, int32_t *n_rounds, bool use_seg, int seg_dilate,
+                   int seg_force) {
   if (!ctx || !out_zyxv || !n_out)
     return fpl_fail(ctx, "fpl_v2o_nms: NULL argument");
   FPL_REQUIRE(ctx, ctx->v2o.valid,
@@ -734,8 +882,14 @@ int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
     }
     {
       TimedLaunch tl(ctx, "v2o_clear_balls");
-      clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, L1, L2, P1, P2,
-                                        r, best, C1, C2);
+      if (use_seg) {
+        const size_t lds = (size_t)2 * (2 * r + 1) * (2 * r + 1) * sizeof(unsigned long long);
+        clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, L1, L2, P1, P2, r,
+                                                best, C1, C2, S.seg, seg_dilate, seg_force);
+      } else {
+        clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, L1, L2, P1, P2,
+                                          r, best, C1, C2);
+      }
     }
     FPL_HIP(ctx, hipGetLastError());
     FPL_HIP(ctx, hipMemcpyAsync(host_cnt, counters, 4 * 8, hipMemcpyDeviceToHost, st));
@@ -768,6 +922,127 @@ int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   }
   *n_out = n;
   if (n_rounds) *n_rounds = rounds;
+  return 0;
+}
+
+
+int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
+                int64_t *n_out, int32_t *n_rounds) {
+  return v2o_nms(ctx, thresh, out_zyxv, cap, n_out, n_rounds, false, 0, 0);
+}
+
+int fpl_v2o_nms_seg(fpl_ctx *ctx, double thresh, int32_t seg_dilate, int32_t seg_force,
+                    double *out_zyxv, int64_t cap, int64_t *n_out, int32_t *n_rounds) {
+  if (!ctx) return fpl_fail(nullptr, "fpl_v2o_nms_seg: ctx is NULL");
+  FPL_REQUIRE(ctx, ctx->v2o.valid && ctx->v2o.seg_valid,
+              "fpl_v2o_nms_seg: call fpl_v2o_smooth and fpl_v2o_set_seg first");
+  FPL_REQUIRE(ctx, 2 * ctx->v2o.r + 1 <= 64,
+              "fpl_v2o_nms_seg: obj_min_dist %d > 31 (a cube row must fit a 64-bit mask)",
+              ctx->v2o.r);
+  FPL_REQUIRE(ctx, seg_dilate >= 0 && seg_force >= 0 && seg_force <= ctx->v2o.r,
+              "fpl_v2o_nms_seg: seg_dilate %d / seg_force %d out of range", seg_dilate, seg_force);
+  static bool attr_set = false;
+  if (!attr_set) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)clear_balls_seg,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 63 * 63 * 8));
+    attr_set = true;
+  }
+  return v2o_nms(ctx, thresh, out_zyxv, cap, n_out, n_rounds, true, seg_dilate, seg_force);
+}
+
+int fpl_v2o_set_seg(fpl_ctx *ctx, const void *seg, int32_t seg_bytes, int seg_mem,
+                    const int64_t dims[3], int64_t sz_thd) {
+  if (!ctx || !seg || !dims) return fpl_fail(ctx, "fpl_v2o_set_seg: NULL argument");
+  V2oState &S = ctx->v2o;
+  FPL_REQUIRE(ctx, S.valid, "fpl_v2o_set_seg: call fpl_v2o_smooth first");
+  FPL_REQUIRE(ctx, seg_bytes == 4 || seg_bytes == 8, "fpl_v2o_set_seg: labels must be 4 or 8 bytes");
+  const int r = S.r;
+  for (int a = 0; a < 3; ++a)
+    FPL_REQUIRE(ctx, dims[a] + 2 * r == S.pdims[a],
+                "fpl_v2o_set_seg: segmentation dims differ from the prediction's");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevTemp tmp(ctx);
+  const int64_t n = dims[0] * dims[1] * dims[2];
+  const int64_t n_pad = S.pdims[0] * S.pdims[1] * S.pdims[2];
+  const void *src = seg;
+  if (seg_mem == FPL_MEM_HOST) {
+    void *p;
+    FPL_TRY(tmp.alloc((size_t)n * seg_bytes, &p));
+    FPL_HIP(ctx, hipMemcpyAsync(p, seg, (size_t)n * seg_bytes, hipMemcpyHostToDevice, st));
+    src = p;
+  }
+  const size_t need = (size_t)n_pad * sizeof(unsigned long long);
+  if (S.seg_cap_bytes < need) {
+    if (S.seg) fpl_dev_release(ctx, S.seg);
+    S.seg = nullptr; S.seg_cap_bytes = 0;
+    void *p;
+    FPL_TRY(fpl_dev_alloc(ctx, need, &p));
+    S.seg = (unsigned long long *)p; S.seg_cap_bytes = need;
+  }
+  const unsigned grid = (unsigned)ceil_div64(n_pad, 256);
+  {
+    TimedLaunch tl(ctx, "v2o_seg_pad");
+    if (seg_bytes == 8)
+      seg_pad<unsigned long long><<<grid, 256, 0, st>>>((const unsigned long long *)src, dims[0],
+          dims[1], dims[2], r, S.seg, S.pdims[1], S.pdims[2], n_pad);
+    else
+      seg_pad<uint32_t><<<grid, 256, 0, st>>>((const uint32_t *)src, dims[0], dims[1], dims[2],
+          r, S.seg, S.pdims[1], S.pdims[2], n_pad);
+  }
+  FPL_HIP(ctx, hipGetLastError());
+  if (sz_thd >= 0) {
+    // voxel count per label (the zero padding counts towards label 0, as in the
+    // reference, which pads before np.unique) and the zeroing of small segments
+    uint64_t cap = 1ull << 16;
+    while (cap < (uint64_t)n_pad / 4 && cap < (1ull << 25)) cap <<= 1;
+    void *p;
+    FPL_TRY(tmp.alloc(cap * sizeof(unsigned long long), &p));
+    unsigned long long *keys = (unsigned long long *)p;
+    FPL_TRY(tmp.alloc(cap * sizeof(unsigned int) + 16, &p));
+    unsigned int *counts = (unsigned int *)p;
+    unsigned int *overflow = counts + cap;
+    FPL_HIP(ctx, hipMemsetAsync(keys, 0, cap * sizeof(unsigned long long), st));
+    FPL_HIP(ctx, hipMemsetAsync(counts, 0, cap * sizeof(unsigned int) + 16, st));
+    {
+      TimedLaunch tl(ctx, "v2o_seg_count");
+      seg_count<<<(unsigned)ceil_div64(ceil_div64(n_pad, 16), 256), 256, 0, st>>>(
+          S.seg, n_pad, keys, counts, cap - 1, overflow);
+    }
+    unsigned int ovf = 0;
+    FPL_HIP(ctx, hipMemcpyAsync(&ovf, overflow, 4, hipMemcpyDeviceToHost, st));
+    FPL_HIP(ctx, hipStreamSynchronize(st));
+    FPL_REQUIRE(ctx, ovf == 0, "fpl_v2o_set_seg: more than %llu distinct labels",
+                (unsigned long long)cap);
+    {
+      TimedLaunch tl(ctx, "v2o_seg_zero_small");
+      seg_zero_small<<<grid, 256, 0, st>>>(S.seg, n_pad, keys, counts, cap - 1,
+                                           (long long)sz_thd, S.smoothed);
+    }
+    FPL_HIP(ctx, hipGetLastError());
+  }
+  FPL_HIP(ctx, hipStreamSynchronize(st));
+  S.seg_valid = true;
+  return 0;
+}
+
+int fpl_v2o_select(fpl_ctx *ctx, const int64_t *ranks, int32_t n_ranks, float *rank_values) {
+  if (!ctx || !ranks || !rank_values) return fpl_fail(ctx, "fpl_v2o_select: NULL argument");
+  const V2oState &S = ctx->v2o;
+  FPL_REQUIRE(ctx, S.valid, "fpl_v2o_select: call fpl_v2o_smooth first");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n_pad = S.pdims[0] * S.pdims[1] * S.pdims[2];
+  for (int i = 0; i < n_ranks; ++i)
+    FPL_REQUIRE(ctx, ranks[i] >= 0 && ranks[i] < n_pad, "fpl_v2o_select: rank %lld out of range",
+                (long long)ranks[i]);
+  DevTemp tmp(ctx);
+  void *p;
+  FPL_TRY(tmp.alloc(2049 * sizeof(unsigned long long), &p));
+  unsigned long long *hist_dev = (unsigned long long *)p;
+  FPL_TRY(tmp.alloc((size_t)n_pad * sizeof(float), &p));
+  if (n_ranks > 0)
+    FPL_TRY(v2o_select(ctx, S, n_pad, ranks, n_ranks, rank_values, hist_dev, (float *)p, false, tmp));
+  FPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 

@@ -61,12 +61,14 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     Smoothing + percentile(97)-or-`thd` threshold + greedy non-maxima suppression
     with minimum distance `obj_min_dist`; detections inside `buffer_sz` of the
     volume faces are dropped; `volume_offset` (x,y,z) is added.
+
+    With `seg` (integer labels of pred's shape; array, device array or .npy path) the
+    suppression is segmentation-aware (reference :161-165,177-181,190-224): a pick
+    suppresses only the voxels of its ball that lie in its own segment - its mask
+    within the (2r+1)^3 cube, grown by `seg_dilate` binary-dilation iterations - plus
+    the ball of radius `seg_force`; `seg_sz_thd` first zeroes the smoothed prediction
+    inside segments of fewer voxels (obj_min_dist <= 31 in this mode).
     """
-    if seg is not None or seg_dilate is not None or seg_sz_thd is not None \
-            or seg_force:
-        raise NotImplementedError(
-            'segmentation-aware suppression (reference fplobjdetect.py:161-165,'
-            '177-181,190-224) is a SURVEY 8f follow-on')
     buffer_sz = fplutils.to3d(buffer_sz)
     if isinstance(pred, str):
         try:
@@ -90,9 +92,21 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     n_pad = int(np.prod([s + 2 * r for s in pred_sz]))
     lo_rank, hi_rank, gamma = percentile_plan(n_pad, 97, np.float32)
     weights = gaussian_kernel1d(smoothing_sigma, truncate=2.0)
-    lo_v, hi_v = ctx.v2o_smooth(pred, pred_sz, r, weights, [lo_rank, hi_rank])
-    thresh = np.maximum(percentile_lerp(lo_v, hi_v, gamma), thd)
-    pts, rounds = ctx.v2o_nms(float(thresh))
+    if seg is None:
+        if seg_sz_thd is not None:
+            raise ValueError('seg_sz_thd needs a segmentation')
+        lo_v, hi_v = ctx.v2o_smooth(pred, pred_sz, r, weights, [lo_rank, hi_rank])
+        thresh = np.maximum(percentile_lerp(lo_v, hi_v, gamma), thd)
+        pts, rounds = ctx.v2o_nms(float(thresh))
+    else:
+        if isinstance(seg, str):
+            seg = _load_main(seg)
+        assert tuple(int(v) for v in seg.shape) == pred_sz, 'seg must have pred\'s shape'
+        ctx.v2o_smooth(pred, pred_sz, r, weights, [])
+        ctx.v2o_set_seg(seg, pred_sz, seg_sz_thd)           # pads; zeroes small segments
+        lo_v, hi_v = ctx.v2o_select([lo_rank, hi_rank])
+        thresh = np.maximum(percentile_lerp(lo_v, hi_v, gamma), thd)
+        pts, rounds = ctx.v2o_nms_seg(float(thresh), seg_dilate, seg_force)
 
     # pts rows: (z, y, x, value) in padded coordinates, emission order
     obj_pred = np.empty((pts.shape[0], 4), np.float64)

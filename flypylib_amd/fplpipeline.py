@@ -83,14 +83,14 @@ class _ArraySource:
         self.arr = arr
         self.extent = tuple(int(s) for s in arr.shape)
 
-    def cube_host(self, origin, size):
-        """uint8 (size,)*3 cube at `origin`, zeros outside the extents; None if the
-        box does not meet the volume (reference :1053-1070)"""
+    def cube_host(self, origin, size, dtype=np.uint8):
+        """(size,)*3 cube at `origin`, zeros outside the extents; None if the box does
+        not meet the volume (reference :1053-1070)"""
         lo = np.maximum(origin, 0)
         hi = np.minimum(np.asarray(origin) + size, self.extent)
         if np.any(lo > hi):
             return None
-        image = np.zeros((size,) * 3, np.uint8)
+        image = np.zeros((size,) * 3, dtype)
         image[lo[0] - origin[0]:hi[0] - origin[0],
               lo[1] - origin[1]:hi[1] - origin[1],
               lo[2] - origin[2]:hi[2] - origin[2]] = self.arr[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
@@ -227,8 +227,13 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
     an ROI text file (`roi_from_txt`) or a list of `szyx`; `precision` overrides the
     network's ('f32' / 'bf16').  Returns {'locs': (N,3) x/y/z, 'conf': (N,)} (all
     ranks return the merged result once every rank's substacks are on disk)."""
+    # the reference reads a 'segmentation' labelmap from a second DVID node
+    # (dvid_seg_info = [server, uuid]); here it is a label volume with the image's
+    # extents: array-like or 'npy://file'
+    seg_src = None
     if dvid_seg_info is not None:
-        raise NotImplementedError('segmentation-aware post-processing (SURVEY 8f-4)')
+        seg_src = _open_source(dvid_seg_info)
+        assert isinstance(seg_src, _ArraySource), 'the segmentation must be an array source'
     for d in (working_dir, '%s/norm' % working_dir):
         os.makedirs(d, exist_ok=True)
     norm_dir = '%s/norm' % working_dir
@@ -292,10 +297,15 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
             prog.infer_volume(cube, network.infer_sz, network.rf_offset,
                               mean=st['mn_use'], std=image_normalize[1],
                               precision=prec, dst=pred, dims=(image_sz,) * 3)
+            seg_kw = {}
+            if seg_src is not None:               # fri_postprocess, reference :1143-1150
+                seg_dt = seg_src.arr.dtype if seg_src.arr.dtype.itemsize in (4, 8) else np.uint64
+                seg_kw = dict(seg=seg_src.cube_host(origin, image_sz, seg_dt), seg_dilate=8,
+                              seg_sz_thd=5000, seg_force=10)
             out = fplobjdetect.voxel2obj(
                 pred, obj_min_dist, smoothing_sigma,
                 (ss.x - buffer_sz, ss.y - buffer_sz, ss.z - buffer_sz),
-                buffer_sz, thd, device=ctx.device)
+                buffer_sz, thd, device=ctx.device, **seg_kw)
         tmp_fn = fri_filename(working_dir, ss) + '.tmp%d' % rank
         with open(tmp_fn, 'wb') as f_out:
             pickle.dump(out, f_out)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 3
+#define FPL_ABI_VERSION 4
 
 typedef struct fpl_ctx fpl_ctx;
 typedef struct fpl_program fpl_program;
@@ -145,6 +145,21 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
  * Returns the number of detections in *n_out (<= cap, else error). */
 int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
                 int64_t *n_out, int32_t *n_rounds);
+/* Segmentation-aware suppression (the seg / seg_dilate / seg_sz_thd / seg_force
+ * arguments of voxel2obj, fplobjdetect.py:161-165,177-181,190-224).  Call order:
+ * fpl_v2o_smooth (n_ranks = 0) -> fpl_v2o_set_seg -> fpl_v2o_select -> fpl_v2o_nms_seg.
+ * set_seg: `seg` = labels (Z,Y,X) of the prediction's dims, 4 or 8 bytes each, zero
+ * padded like the prediction; with sz_thd >= 0 the smoothed voxels of segments of
+ * fewer than sz_thd voxels are zeroed.  select: exact order statistics of the
+ * (possibly edited) smoothed volume.  nms_seg: a pick suppresses only the part of its
+ * ball inside its own segment (the segment's mask in the (2r+1)^3 cube grown by
+ * seg_dilate iterations of the 6-neighbour dilation) plus the ball of radius
+ * seg_force (0 = none); obj_min_dist <= 31. */
+int fpl_v2o_set_seg(fpl_ctx *ctx, const void *seg, int32_t seg_bytes, int seg_mem,
+                    const int64_t dims[3], int64_t sz_thd);
+int fpl_v2o_select(fpl_ctx *ctx, const int64_t *ranks, int32_t n_ranks, float *rank_values);
+int fpl_v2o_nms_seg(fpl_ctx *ctx, double thresh, int32_t seg_dilate, int32_t seg_force,
+                    double *out_zyxv, int64_t cap, int64_t *n_out, int32_t *n_rounds);
 /* smoothed padded volume of the last fpl_v2o_smooth call (tests) */
 int fpl_v2o_copy_smoothed(fpl_ctx *ctx, float *dst, int dst_mem);
 

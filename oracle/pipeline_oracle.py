@@ -54,9 +54,23 @@ def norm_line(size, buffer_sz, z, y, x, image_normalize, rec):
         rec['im_raw_mn'], rec['im_raw_std'])
 
 
+def _seg_cube(seg, size, z, y, x, buffer_sz):
+    """what dvid_node.get_labels3D hands fri_postprocess (:1139-1142): the labels of
+    the substack + buffer box, zero outside the volume"""
+    image_sz = size + 2 * buffer_sz
+    org = [z - buffer_sz, y - buffer_sz, x - buffer_sz]
+    lo = np.maximum(org, 0)
+    hi = np.minimum(np.asarray(org) + image_sz, seg.shape)
+    cube = np.zeros((image_sz,) * 3, seg.dtype)
+    if np.all(hi > lo):
+        cube[lo[0] - org[0]:hi[0] - org[0], lo[1] - org[1]:hi[1] - org[1],
+             lo[2] - org[2]:hi[2] - org[2]] = seg[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+    return cube
+
+
 def full_roi_inference(volume, substacks, predict_fn, infer_sz, rf_offset, thd,
                        image_normalize, obj_min_dist=27, smoothing_sigma=5, buffer_sz=35,
-                       preds=None):
+                       preds=None, seg=None):
     """substacks: iterable of (size, z, y, x).  `predict_fn` as in
     infer_oracle.infer_lattice.  `preds` (optional dict) substitutes the prediction of
     a substack (e.g. the device's) so that the post-processing can be compared bit for
@@ -72,9 +86,13 @@ def full_roi_inference(volume, substacks, predict_fn, infer_sz, rf_offset, thd,
                 pred = preds[(size, z, y, x)]
             else:
                 pred = infer_oracle.infer_lattice(image, infer_sz, rf_offset, predict_fn)
+            seg_kw = {}
+            if seg is not None:
+                seg_kw = dict(seg=_seg_cube(seg, size, z, y, x, buffer_sz), seg_dilate=8,
+                              seg_sz_thd=5000, seg_force=10)
             out = voxel2obj_oracle.voxel2obj(
                 pred, obj_min_dist, smoothing_sigma,
-                (x - buffer_sz, y - buffer_sz, z - buffer_sz), buffer_sz, thd)
+                (x - buffer_sz, y - buffer_sz, z - buffer_sz), buffer_sz, thd, **seg_kw)
         per[(size, z, y, x)] = out
         locs.append(out['locs'])
         conf.append(out['conf'])

@@ -64,7 +64,38 @@ def test_negative_and_empty_inputs(ctx):
     ref = voxel2obj_oracle.voxel2obj(pred, 5, 2.0)
     got = fplobjdetect.voxel2obj(pred, 5, 2.0)
     assert got['locs'].shape == ref['locs'].shape == (0, 3)
-    with pytest.raises(NotImplementedError):
-        fplobjdetect.voxel2obj(pred, 5, 2.0, seg=np.zeros((30, 30, 30)))
+    # a segmentation of all-negative predictions changes nothing: still no points
+    got = fplobjdetect.voxel2obj(pred, 5, 2.0, seg=np.zeros((30, 30, 30), np.uint64), seg_dilate=2)
+    assert got['locs'].shape == (0, 3)
     with pytest.raises(TypeError):
         fplobjdetect.voxel2obj(pred.astype(np.float64), 5, 2.0)
+
+
+@pytest.mark.parametrize('case', helpers.V2O_SEG_CASES, ids=[c[0] for c in helpers.V2O_SEG_CASES])
+def test_segmentation_aware_golden_cases_bit_exact(ctx, golden, case):
+    """seg / seg_dilate / seg_sz_thd / seg_force (reference :161-224): the reference's
+    own point lists"""
+    g = golden('voxel2obj_seg.npz')
+    name, kind, pseed, shape, r, sigma, thd, buf, sseed, n_sites, tiny, dil, szt, force = case
+    pred = helpers.make_pred(kind, pseed, shape)
+    seg = synth.voronoi_segmentation(sseed, shape, n_sites, tiny)
+    res = fplobjdetect.voxel2obj(pred, r, sigma, (0, 0, 0), buf, thd, seg=seg, seg_dilate=dil,
+                                 seg_sz_thd=szt, seg_force=force)
+    assert np.array_equal(res['locs'], g[name + '_locs']), name
+    assert np.array_equal(res['conf'], g[name + '_conf']), name
+
+
+def test_segmentation_aware_matches_oracle_at_pipeline_parameters(ctx):
+    """fri_postprocess's call (reference :1143-1150): r 27, sigma 5, seg_dilate 8,
+    seg_sz_thd 5000, seg_force 10, uint32 labels"""
+    shape = (150, 140, 160)
+    pred = synth.blob_prob_volume(78, shape, period=32, radius=7.0)
+    seg = (synth.voronoi_segmentation(9, shape, 40, 25) % np.uint64(2 ** 31)).astype(np.uint32)
+    kw = dict(seg_dilate=8, seg_sz_thd=5000, seg_force=10)
+    ref = voxel2obj_oracle.voxel2obj(pred, 27, 5.0, (5, 6, 7), 10, 0.05, seg=seg, **kw)
+    got = fplobjdetect.voxel2obj(pred, 27, 5.0, (5, 6, 7), 10, 0.05, seg=seg, **kw)
+    plain = fplobjdetect.voxel2obj(pred, 27, 5.0, (5, 6, 7), 10, 0.05)
+    assert len(ref['conf']) > len(plain['conf']) > 10
+    assert np.array_equal(got['locs'], ref['locs']) and np.array_equal(got['conf'], ref['conf'])
+    with pytest.raises(ValueError):
+        fplobjdetect.voxel2obj(pred, 27, 5.0, seg_sz_thd=10)

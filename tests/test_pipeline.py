@@ -230,3 +230,29 @@ def test_documented_example_flow_on_synthetic_data(ctx, tmp_path):
     assert float(rows[2].split(',')[3]) < float(rows[1].split(',')[3])      # loss falls
     assert (tmp_path / 'net.npz').exists() or (tmp_path / 'net').exists() or \
         any(p.name.startswith('net') for p in tmp_path.iterdir())
+
+
+@pytest.mark.gpu
+def test_full_roi_inference_with_a_segmentation(ctx, tmp_path):
+    """dvid_seg_info: per substack the label cube goes to voxel2obj with
+    seg_dilate 8, seg_sz_thd 5000, seg_force 10 as in fri_postprocess (reference
+    :1139-1150); the oracle post-processes the device predictions identically"""
+    net, vol, roi = _small_setup()
+    seg = synth.voronoi_segmentation(3, vol.shape, 30, 10)
+    kw = dict(obj_min_dist=11, smoothing_sigma=2.0, buffer_sz=12)   # seg_force 10 needs r >= 10
+    norm = [128., 33.]
+    wd = str(tmp_path / 'seg')
+    got = fplobjdetect.full_roi_inference(vol, None, roi[:8], net, 0.2, wd, norm, precision='f32',
+                                          dvid_seg_info=seg, **kw)
+    plain = fplobjdetect.full_roi_inference(vol, None, roi[:8], net, 0.2, str(tmp_path / 'plain'),
+                                            norm, precision='f32', **kw)
+    from oracle import cnn_oracle
+    graph = net.train_single
+
+    def predict(batch):
+        return cnn_oracle.graph_forward(graph, batch.astype(np.float32), upsample_stride=net.rf_stride)
+    want, _ = pipeline_oracle.full_roi_inference(vol, roi[:8], predict, net.infer_sz, net.rf_offset,
+                                                 0.2, norm, seg=seg, **kw)
+    assert np.array_equal(got['locs'], want['locs'])
+    np.testing.assert_allclose(got['conf'], want['conf'], rtol=0, atol=2e-6)
+    assert len(got['conf']) != len(plain['conf'])
