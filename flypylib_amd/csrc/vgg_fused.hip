@@ -768,7 +768,9 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
   const int P2Y = CY + 2, P2X = CX + 2, P1Y = 2 * P2Y + 2, P1X = 2 * P2X + 2;
   // chunk of coarse rows bounded by a scratch budget (P1 dominates)
   const int64_t p1_row_bytes = (int64_t)P1Y * P1X * VOX_BYTES;
-  const int64_t budget = (int64_t)48 << 30;
+  // (FPL_VGG_SCRATCH_MB shrinks it so that tests can force several chunks)
+  const char *budget_env = getenv("FPL_VGG_SCRATCH_MB");
+  const int64_t budget = budget_env ? (int64_t)atoll(budget_env) << 20 : (int64_t)48 << 30;
   int64_t cz_chunk = std::max<int64_t>(4, (budget / p1_row_bytes - 6) / 2);
   cz_chunk = std::min<int64_t>(cz_chunk, cz_hi - cz_lo);
   cz_chunk = (cz_chunk + 3) / 4 * 4;

@@ -142,3 +142,19 @@ def test_f16_rejects_weights_beyond_the_half_range(ctx):
                           precision=_capi.PREC_F16)
     prog.infer_volume(u8, (30,) * 3, (7,) * 3, mean=128.0, std=33.0,
                       precision=_capi.PREC_BF16)          # bf16 has the range
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_z_chunked_scratch_equals_one_pass(ctx, kind, monkeypatch):
+    """volumes whose pool-1 activations exceed the scratch budget (48 GB: beyond
+    ~1600^3) are processed in chunks of coarse Z rows; with the budget forced down to
+    8 MB a 200-deep volume takes many chunks and must not change a bit"""
+    g = _net(29, 102)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(8, (200, 150, 140))
+    kw = dict(mean=128.0, std=33.0, precision=PREC[kind])
+    one = prog.infer_volume(u8, (102,) * 3, (7,) * 3, **kw)
+    monkeypatch.setenv('FPL_VGG_SCRATCH_MB', '8')
+    many = prog.infer_volume(u8, (102,) * 3, (7,) * 3, **kw)
+    assert np.array_equal(one, many)
+    assert one[7:-7, 7:-7, 7:-7].std() > 1e-3
