@@ -88,9 +88,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--size', type=int, default=1024,
                     help='volume edge per GPU (Z is size*gpus)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16', 'f32'],
-                    help='bf16 = the configuration BASELINE.json names; f16 = the same '
-                         'kernels on IEEE-half operands (same rate, meets the 1e-3 gate)')
+    ap.add_argument('--precision', default='f16', choices=['f16', 'bf16', 'f32'],
+                    help='16-bit MFMA operands with fp32 accumulation.  f16 (default): IEEE '
+                         'half, probabilities within 1e-3 of fp32 - the north-star parity '
+                         'gate; bf16: the operand type BASELINE.json configs[1] names, same '
+                         'kernels, ~2 %% faster, but only 8 significant bits (up to 4e-3 off); '
+                         'f32: exact reference arithmetic')
     ap.add_argument('--tile', type=int, default=102,
                     help='reference infer_sz (tile lattice pitch = tile-14)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -220,6 +223,14 @@ def main():
                                    'lattice %d^3 (pitch %d), u8 in / f32 out '
                                    'resident in HBM' % (Z, Y, X, tile, pitch),
                        'volume': [Z, Y, X], 'tile_in': tile,
+                       'operands': {'f16': 'IEEE half MFMA operands, fp32 accumulate: within '
+                                           '1e-3 of fp32 (the parity gate); --precision bf16 '
+                                           'runs the same kernels on bfloat16 (~2 % faster, '
+                                           'up to 4e-3 off)',
+                                    'bf16': 'bfloat16 MFMA operands, fp32 accumulate (as '
+                                            'configs[1] names; up to 4e-3 off fp32); '
+                                            '--precision f16 meets the 1e-3 gate',
+                                    'f32': 'fp32 MFMA, exact reference arithmetic'}[args.precision],
                        'parallelism': 'z-slab tile sharding x%d, no collective'
                                       % world,
                        'device': info['name']},
