@@ -126,6 +126,13 @@ struct Conv3Args {
   // and weight fragments packed with the dy / dx taps swapped (`w` points at those).
   int transposed, xorg;
   int main_w;                    // untransposed launch: columns [0, main_w) only (0 = all)
+  // volume-side output (FplTileIO, fast_paths.h).  HEAD: the epilogue chains conv1 32->32 (+shift, ReLU) and conv1 32->1 (+bias, sigmoid) in
+  // registers and stores the probability of every valid voxel into the prediction
+  // volume - no 32-channel tensor, no separate head kernel, no stitch pass.
+  FplTileIO io;
+  const h16x8 *w8, *w9;          // HEAD: 2 fragments (SLOT_SPATIAL), 1 fragment (SLOT_CHAIN)
+  const float *sh8;
+  float bias9;
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -153,9 +160,10 @@ struct Conv3Args {
 constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
 constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
-template <int MB, bool PF, bool STEM = false, bool POOL = false>
+template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false>
 __global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
+  static_assert(!HEAD || (MB == 2 && !POOL), "the head variant is conv3 ->32");
   static_assert(NRAW % 256 == 0, "raw tile pieces per thread");
   constexpr int RING = KC * MB * 1024;
   constexpr int ROW = TX * PITCH;
@@ -374,7 +382,27 @@ __global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
       for (int sub = 0; sub < 4; ++sub) {
         const int oy = a.transposed ? bx * 16 + c : by * 4 + sub;
         const int ox = a.transposed ? a.xorg + by * 4 + sub : bx * 16 + c;
-        if (oz < a.OD && oy < a.OH && ox < a.OW)
+        if (HEAD) {
+          // with interleaved rows lane (c,g) holds channels 8g..8g+7 of voxel c: the
+          // packed pair IS the K-step of conv1 32->32 in SLOT_SPATIAL order
+          const h16x8 h7 = pack_relu(acc[sub][0], acc[sub][1]);
+          f32x4 a8[2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            f32x4 sh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[r] = a.sh8[16 * b + 4 * g + r];
+            a8[b] = mfma16(a.w8[b * 64 + lane], h7, sh);
+          }
+          const f32x4 t9 = mfma16(a.w9[lane], pack_relu(a8[0], a8[1]), f32x4{0.f, 0.f, 0.f, 0.f});
+          const float logit = __shfl(t9[0], c) + a.bias9;     // lane (c, g=0) register 0
+          const FplTileDesc td = a.io.tiles[n];
+          if (g == 0 && oz < td.ext[0] - 2 * a.io.off && oy < td.ext[1] - 2 * a.io.off &&
+              ox < td.ext[2] - 2 * a.io.off && oz < a.OD && oy < a.OH && ox < a.OW)
+            a.io.dst[((int64_t)(td.start[0] + a.io.off + oz - a.io.dst_z_base) * a.io.Y +
+                      td.start[1] + a.io.off + oy) * a.io.X + td.start[2] + a.io.off + ox] =
+                1.f / (1.f + __expf(-logit));
+        } else if (oz < a.OD && oy < a.OH && ox < a.OW)
           store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB),
                               g, acc[sub], a.relu);
       }
@@ -639,7 +667,7 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
   return 0;
 }
 
-template <int MB, bool STEM = false, bool POOL = false>
+template <int MB, bool STEM = false, bool POOL = false, bool HEAD = false>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   constexpr bool PF = true;
   // STEM keeps the bf16 raw tile behind the (single) offset table
@@ -647,7 +675,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL>,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL, HEAD>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
   }
@@ -681,7 +709,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   TimedLaunch tl(ctx, name);
   FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
               "conv3: pool output / template mismatch");
-  FPLK(conv3)<MB, PF, STEM, POOL><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
+  FPLK(conv3)<MB, PF, STEM, POOL, HEAD><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
 
@@ -700,10 +728,11 @@ bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
 
 // in: (n, T,T,T) f32 normalised tiles on the device; out: (n, T-18, T-18, T-18) f32
 int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
-                          int T, float *out) {
+                          int T, float *out, const FplTileIO *io) {
   int ci[10];
   FPL_REQUIRE(ctx, is_unet_like2(prog, ci), "not a unet_like2 program");
   FPL_REQUIRE(ctx, T % 4 == 0 && T >= 24, "unet_like2 tile edge %d must be 0 mod 4", T);
+  FPL_REQUIRE(ctx, in && (io || out), "fpl_unet_forward: no input tiles / no output");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, ci, &st));
   DevTemp tmp(ctx);
@@ -737,6 +766,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.out = outp; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
     a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr; a.pool_out = nullptr;
     a.transposed = 0; a.xorg = 0; a.main_w = 0;
+    memset(&a.io, 0, sizeof(a.io)); a.w8 = a.w9 = nullptr; a.sh8 = nullptr; a.bias9 = 0.f;
     return a;
   };
   {  // L0 + L1: conv3 1->32 computed into the tile of conv3 32->32
@@ -787,21 +817,30 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     const int rem = d5a % 16;
     const bool strip = rem > 0 && rem <= 4 && d5a > 16 && st->off_w7t != 0;
     if (strip) a.main_w = d5a - rem;
-    FPL_TRY((launch_conv3<2>(ctx, a, n, "unet_conv3_96_32")));
+    if (io) {                    // conv1 32->32, conv1 32->1, sigmoid and the store into
+      a.io = *io;                // the prediction volume ride in the epilogue
+      a.w8 = (const h16x8 *)(F + st->off_w[8]); a.sh8 = S + st->off_s[8];
+      a.w9 = (const h16x8 *)(F + st->off_w[9]); a.bias9 = st->bias_tail;
+      a.out = nullptr;
+      FPL_TRY((launch_conv3<2, false, false, true>(ctx, a, n, "unet_conv3_96_32_head")));
+    } else {
+      FPL_TRY((launch_conv3<2>(ctx, a, n, "unet_conv3_96_32")));
+    }
     if (strip) {
       Conv3Args e = a;
       e.main_w = 0; e.transposed = 1; e.xorg = d5a - rem;
       e.w = F + st->off_w7t;
-      FPL_TRY((launch_conv3<2>(ctx, e, n, "unet_conv3_96_32_edge")));
+      if (io) FPL_TRY((launch_conv3<2, false, false, true>(ctx, e, n, "unet_conv3_96_32_head_edge")));
+      else FPL_TRY((launch_conv3<2>(ctx, e, n, "unet_conv3_96_32_edge")));
     }
   }
-  {  // L8 + L9: conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
+  if (!io) {  // L8 + L9: conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
     Conv1Args a;
     a.in = c5a; a.M = (int64_t)n * cube(d5a); a.w = F + st->off_w[8]; a.shift = S + st->off_s[8];
     a.out = nullptr; a.w_tail = (const h16x8 *)(F + st->off_w[9]); a.bias_tail = st->bias_tail;
     a.out_f32 = out;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
-    TimedLaunch tl(ctx, "unet_head_bf16");
+    TimedLaunch tl(ctx, "unet_head_" FPL_PREC_STR);
     FPLK(conv1)<32, 2, 1><<<grid, 256, 2 * 1024, stm>>>(a);
   }
   FPL_HIP(ctx, hipGetLastError());

@@ -4,6 +4,25 @@
 
 #include "program.h"
 
+// one tile of the reference lattice (flypylib/fplnetwork.py:146-160)
+struct FplTileDesc {
+  int32_t start[3];   // input window origin in the volume
+  int32_t ext[3];     // input window extent (<= tile_in; the rest of the tile is zero)
+};
+
+// optional volume-side output of a tile batch: when given, the last kernel writes the
+// valid outputs of every tile straight into the (Z,Y,X) prediction volume - no
+// per-tile output tensor, no stitch pass.  (Reading the tiles straight from the volume
+// in the first kernel was measured too: its scattered byte loads and per-voxel
+// normalisation cost more than the 2.6 ms gather pass they replace.)
+struct FplTileIO {
+  int64_t Y, X;               // volume pitches
+  const FplTileDesc *tiles;   // device array, one per tile of the batch
+  float *dst;                 // row `dst_z_base` of the prediction volume
+  int64_t dst_z_base;
+  int32_t off;                // rf_offset
+};
+
 // The fused 16-bit paths exist twice, built from the same sources (mfma_util.h):
 // *_bf16 (FPL_PREC_BF16) and *_f16 (FPL_PREC_F16).
 //
@@ -26,7 +45,7 @@
                                      const int32_t offset[3], const int32_t out_sz[3]); \
   bool fpl_unet_fast_available_##sfx(const fpl_program *prog, int precision);           \
   int fpl_unet_forward_##sfx(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,   \
-                             int T, float *out);
+                             int T, float *out, const FplTileIO *io);
 FPL_DECLARE_H16_PATHS(bf16)
 FPL_DECLARE_H16_PATHS(f16)
 

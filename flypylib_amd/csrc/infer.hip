@@ -10,10 +10,7 @@
 
 namespace {
 
-struct TileDesc {
-  int32_t start[3];   // input window origin in the volume
-  int32_t ext[3];     // input window extent (<= tile_in)
-};
+typedef FplTileDesc TileDesc;
 
 template <typename T>
 __global__ void gather_tiles(const T *__restrict__ src, int64_t Y, int64_t X,
@@ -328,10 +325,16 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
               tot);
         FPL_HIP(ctx, hipGetLastError());
       }
-      if (unet_bf16)
+      if (unet_bf16) {
+        // the fused unet path writes its outputs straight into the volume
+        FplTileIO io;
+        io.Y = Y; io.X = X; io.tiles = tiles_dev + t0; io.dst = dst_dev;
+        io.dst_z_base = dst_base; io.off = offset[0];
         FPL_TRY((precision == FPL_PREC_F16 ? fpl_unet_forward_f16 : fpl_unet_forward_bf16)(
-            ctx, prog, (const float *)in_batch, (int)nb, tile_in[0], (float *)out_batch));
-      else if (f32_mfma)
+            ctx, prog, (const float *)in_batch, (int)nb, tile_in[0], nullptr, &io));
+        continue;
+      }
+      if (f32_mfma)
         FPL_TRY(fpl_forward_mfma_f32(ctx, prog, (const float *)in_batch, (int)nb,
                                      tile_in[0], (float *)out_batch));
       else
