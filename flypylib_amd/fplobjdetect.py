@@ -54,7 +54,7 @@ def percentile_lerp(lo, hi, gamma):
 def voxel2obj(pred, obj_min_dist, smoothing_sigma,
               volume_offset=(0, 0, 0), buffer_sz=0, thd=0,
               seg=None, seg_dilate=None, seg_sz_thd=None, seg_force=None,
-              device=None, return_info=False):
+              device=None, return_info=False, _ctx=None):
     """convert voxel-wise predictions to object (point) predictions.
 
     pred: (Z,Y,X) float32 numpy array, or a float32 device tensor of that shape.
@@ -87,8 +87,8 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     pred_sz = tuple(int(s) for s in pred.shape)
     assert len(pred_sz) == 3, 'pred must be (Z,Y,X)'
 
-    ctx = runtime.get_context(runtime.default_device() if device is None
-                              else device)
+    ctx = _ctx or runtime.get_context(runtime.default_device() if device is None
+                                      else device)
     n_pad = int(np.prod([s + 2 * r for s in pred_sz]))
     lo_rank, hi_rank, gamma = percentile_plan(n_pad, 97, np.float32)
     weights = gaussian_kernel1d(smoothing_sigma, truncate=2.0)

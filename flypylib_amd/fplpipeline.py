@@ -257,11 +257,19 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
     prog = network.infer_network.program
     ctx = prog.ctx
     prec = fplobjdetect_precision(network, precision)
+    # two lanes on the GPU: this thread prepares and infers substack i+1 on the
+    # network's context while a second thread post-processes substack i on a context of
+    # its own (its own HIP stream and voxel2obj state); predictions are double-buffered
+    from . import runtime
+    import queue
+    ctx_post = runtime.get_context(ctx.device, lane=1)
     bufs = {}
 
     def buffers(size):
         if size not in bufs:
-            bufs[size] = (ctx.malloc((size,) * 3, np.uint8), ctx.malloc((size,) * 3, np.float32))
+            bufs[size] = (ctx.malloc((size,) * 3, np.uint8),
+                          [ctx.malloc((size,) * 3, np.float32) for _ in range(2)],
+                          [threading.Semaphore(1), threading.Semaphore(1)])
         return bufs[size]
 
     # host-side prefetch of the next cube (array sources); synthetic cubes are made
@@ -274,50 +282,83 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
             sz = ss.size + 2 * buffer_sz
             staged[i] = src.cube_host([ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz], sz)
 
-    stage(0)
-    n_done = 0
-    for i, ss in enumerate(mine):
-        th = threading.Thread(target=stage, args=(i + 1,))
-        th.start()
-        image_sz = ss.size + 2 * buffer_sz
-        origin = [ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz]
-        cube, pred = buffers(image_sz)
-        if isinstance(src, _ArraySource):
-            image = staged.pop(i)
-            have = image is not None
-            if have:
-                cube.from_host(image)
-        else:
-            have = src.cube_device(ctx, origin, image_sz, cube)
-        if not have:
-            out = {'locs': np.zeros((0, 3)), 'conf': np.zeros(0)}
-        else:
-            st = normalisation_from_histogram(ctx.histogram_u8(cube), image_normalize)
-            _write_norm(norm_dir, ss, buffer_sz, image_normalize, st)
-            prog.infer_volume(cube, network.infer_sz, network.rf_offset,
-                              mean=st['mn_use'], std=image_normalize[1],
-                              precision=prec, dst=pred, dims=(image_sz,) * 3)
-            seg_kw = {}
-            if seg_src is not None:               # fri_postprocess, reference :1143-1150
-                seg_dt = seg_src.arr.dtype if seg_src.arr.dtype.itemsize in (4, 8) else np.uint64
-                seg_kw = dict(seg=seg_src.cube_host(origin, image_sz, seg_dt), seg_dilate=8,
-                              seg_sz_thd=5000, seg_force=10)
-            out = fplobjdetect.voxel2obj(
-                pred, obj_min_dist, smoothing_sigma,
-                (ss.x - buffer_sz, ss.y - buffer_sz, ss.z - buffer_sz),
-                buffer_sz, thd, device=ctx.device, **seg_kw)
+    def write_result(ss, out):
         tmp_fn = fri_filename(working_dir, ss) + '.tmp%d' % rank
         with open(tmp_fn, 'wb') as f_out:
             pickle.dump(out, f_out)
         os.replace(tmp_fn, fri_filename(working_dir, ss))     # a resume never sees half a file
-        th.join()
-        n_done += 1
-        if rank == 0 and sys.stdout.isatty():
-            sys.stdout.write('\r%d' % n_done)
-            sys.stdout.flush()
-    for cube, pred in bufs.values():
+
+    work = queue.Queue()
+    failure = []
+
+    def post_process():
+        while True:
+            item = work.get()
+            if item is None:
+                return
+            ss, pred, free, seg_kw = item
+            try:
+                if not failure:
+                    out = fplobjdetect.voxel2obj(
+                        pred, obj_min_dist, smoothing_sigma,
+                        (ss.x - buffer_sz, ss.y - buffer_sz, ss.z - buffer_sz),
+                        buffer_sz, thd, _ctx=ctx_post, **seg_kw)
+                    write_result(ss, out)
+            except BaseException as e:           # surfaces in the main thread below
+                failure.append(e)
+            finally:
+                free.release()
+
+    poster = threading.Thread(target=post_process)
+    poster.start()
+    stage(0)
+    n_done = 0
+    try:
+        for i, ss in enumerate(mine):
+            if failure:
+                break
+            th = threading.Thread(target=stage, args=(i + 1,))
+            th.start()
+            image_sz = ss.size + 2 * buffer_sz
+            origin = [ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz]
+            cube, preds, sems = buffers(image_sz)
+            if isinstance(src, _ArraySource):
+                image = staged.pop(i)
+                have = image is not None
+                if have:
+                    cube.from_host(image)
+            else:
+                have = src.cube_device(ctx, origin, image_sz, cube)
+            if not have:
+                write_result(ss, {'locs': np.zeros((0, 3)), 'conf': np.zeros(0)})
+            else:
+                st = normalisation_from_histogram(ctx.histogram_u8(cube), image_normalize)
+                _write_norm(norm_dir, ss, buffer_sz, image_normalize, st)
+                sems[i % 2].acquire()             # its previous prediction is post-processed
+                prog.infer_volume(cube, network.infer_sz, network.rf_offset,
+                                  mean=st['mn_use'], std=image_normalize[1],
+                                  precision=prec, dst=preds[i % 2], dims=(image_sz,) * 3)
+                seg_kw = {}
+                if seg_src is not None:           # fri_postprocess, reference :1143-1150
+                    seg_dt = seg_src.arr.dtype if seg_src.arr.dtype.itemsize in (4, 8) \
+                        else np.uint64
+                    seg_kw = dict(seg=seg_src.cube_host(origin, image_sz, seg_dt), seg_dilate=8,
+                                  seg_sz_thd=5000, seg_force=10)
+                work.put((ss, preds[i % 2], sems[i % 2], seg_kw))
+            th.join()
+            n_done += 1
+            if rank == 0 and sys.stdout.isatty():
+                sys.stdout.write('\r%d' % n_done)
+                sys.stdout.flush()
+    finally:
+        work.put(None)
+        poster.join()
+    if failure:
+        raise failure[0]
+    for cube, preds, _ in bufs.values():
         cube.free()
-        pred.free()
+        for pbuf in preds:
+            pbuf.free()
     if timings is not None:
         timings['substacks'] = n_done
 

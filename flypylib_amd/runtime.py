@@ -13,8 +13,12 @@ from . import _capi
 _contexts = {}
 
 
-def get_context(device=0):
-    key = (os.getpid(), int(device))
+def get_context(device=0, lane=0):
+    """`lane` > 0 names additional contexts on the same device - each has its own HIP
+    stream and voxel2obj state, so e.g. the substack pipeline post-processes substack
+    i on lane 1 while lane 0 infers substack i+1 (a context serves one thread at a
+    time; device buffers are shared across the lanes of a device)."""
+    key = (os.getpid(), int(device), int(lane))
     ctx = _contexts.get(key)
     if ctx is None or ctx.h is None:
         ctx = _capi.Context(device)
