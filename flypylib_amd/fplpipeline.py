@@ -10,8 +10,11 @@ the resume point.  Here a substack never leaves the GPU between those steps:
                       ->  fpl_infer_volume(u8, mn_use, std) -> float32 prediction (HBM)
                       ->  fpl_v2o_smooth / fpl_v2o_nms  -> points (host, a few KB)
 
-and only the point list and the normalisation record go back to the host.  The
-next substack's cube is cut (or synthesised) while the current one computes.
+and only the point list and the normalisation record go back to the host.  Two
+lanes share the GPU: the calling thread cuts (or synthesises) and infers substack
+i+1 on the network's context while a second thread post-processes substack i on a
+context of its own (own HIP stream, double-buffered predictions); a third thread
+cuts the next host cube for array sources.
 File formats (ROI text, `<size>_<z>_<y>_<x>.p` pickles, `norm/*.txt`, `all.p`)
 are the reference's, so an interrupted run resumes and downstream tools read the
 results unchanged.
