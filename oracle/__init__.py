@@ -1,7 +1,9 @@
 """CPU oracle for the T-bar detection hot path.  TEST INFRASTRUCTURE ONLY.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
-import this package - as the checker, never as the thing measured or shipped.
+import this package - as the checker, never as the thing measured or shipped (the
+measurement / debug scripts under `tools/` use it the same way: to diff detections
+and to time the CPU side; they are not part of the product either).
 The product (`flypylib_amd/`) never imports it and fails loudly when its HIP
 library is missing.
 

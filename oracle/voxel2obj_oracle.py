@@ -1,5 +1,5 @@
-"""CPU restatement of `fplobjdetect.voxel2obj` (seg-free path),
-`/root/reference/flypylib/fplobjdetect.py:132-257`.  TEST INFRASTRUCTURE - see
+"""CPU restatement of `fplobjdetect.voxel2obj` including its segmentation-aware
+branch, `/root/reference/flypylib/fplobjdetect.py:132-257`.  TEST INFRASTRUCTURE - see
 oracle/__init__.py.  Pinned by tests/golden/voxel2obj_*.npz (point lists produced
 by the reference's own function in the build container).
 
