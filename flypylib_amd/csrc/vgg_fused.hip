@@ -29,7 +29,7 @@ namespace {
 
 constexpr int CH = 48;                 // channels of P1 / P2
 constexpr int VOX_BYTES = CH * 2;      // 96 B per voxel (bf16)
-constexpr int KSTEPS = 42;             // 27*48 = 1296 -> 41 K-steps of 32, padded
+constexpr int KSTEPS = 41;             // 27*48 = 1296 -> 40.5 K-steps of 32
 
 // -------------------------------------------------------------------------------
 // K1: stem.  WG = 4 waves; pooled block 4 x 8 x 32; wave task = 16 pooled x of one
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
 
 // -------------------------------------------------------------------------------
 // Shared 3x3x3 48->48 implicit-GEMM K loop (K2 and K3).  The activation tile
-// (TZ x TY x TX voxels x 96 B) is resident in LDS; the 126 KiB of weight
-// fragments stream through a 2-slot LDS ring by LDS-DMA, one barrier per slot.
+// (TZ x TY x TX voxels x 96 B) is resident in LDS; the 123 KiB of weight
+// fragments come from L2 into registers, per wave (see conv3_kloop).
 // Lane (c,g) reads, per K-step, the 16 B of its voxel (+tap) that hold k-slots
 // 8g..8g+7: flat k = 32s + 8g + j over (tap, channel) -> tap = k/48, ch = k%48.
 // -------------------------------------------------------------------------------
@@ -218,56 +218,18 @@ __device__ __forceinline__ unsigned kslot_offset(int s, int g) {
                     ch0 * 2);
 }
 
-// k-slot offset table [g][chunk][KQ]: entry q = offset of K-step KC*chunk + q;
-// q = KC looks ahead into the next chunk (clamped at the last step)
-template <int KC> struct KGeom {
-  static constexpr int NCH = KSTEPS / KC;            // ring slots per pass
-  static constexpr int KQ = KC + 1 <= 4 ? 4 : 8;     // table entries per chunk
-  static constexpr int RING = KC * 3 * 1024;         // bytes per ring slot
-  static constexpr int TAB_BYTES = 4 * NCH * KQ * 4;
-  static_assert(KSTEPS % KC == 0, "KSTEPS must be a multiple of the chunk");
-};
+// k-slot offset table [g][KTAB]: entry s = tile offset of K-step s for lane group g
+// (entries past the last step repeat it), read four at a time
+constexpr int KTAB = (KSTEPS + 4) / 4 * 4;
+constexpr int KTAB_BYTES = 4 * KTAB * 4;
 
-template <int KC, int TY, int TX>
+template <int TY, int TX>
 __device__ __forceinline__ unsigned kslot_entry(int idx) {
-  using G = KGeom<KC>;
-  const int g = idx / (G::NCH * G::KQ), ck = (idx / G::KQ) % G::NCH, q = idx % G::KQ;
-  int s = ck * KC + q;
+  const int g = idx / KTAB;
+  int s = idx % KTAB;
   s = s < KSTEPS ? s : KSTEPS - 1;
   return kslot_offset<TY, TX>(s, g);
 }
-
-// One ring slot = KC K-steps x 3 fragments, contiguous in global memory.  A slot
-// is staged through REGISTERS: the global loads of slot ck+WDEPTH are issued
-// while slot ck is being multiplied, so WDEPTH slots (x 2 workgroups per CU) are
-// in flight - an LDS-DMA ring with one slot of lookahead left the MFMAs waiting
-// ~1 us per slot for L2.
-constexpr int WDEPTH = 4;
-
-template <int KC> struct WStage {
-  static constexpr int PIECES = KGeom<KC>::RING / 16;      // 16-B pieces per slot
-  static constexpr int PER = (PIECES + 255) / 256;         // per thread
-  u32x4 r[PER];
-  // branch-free: threads past the end re-load / re-store the last piece (same
-  // bytes, benign) so the compiler keeps counted vmcnt waits instead of vmcnt(0)
-  __device__ __forceinline__ void load(const unsigned char *wglobal, int chunk, int tid) {
-    const unsigned char *srcp = wglobal + (size_t)chunk * KGeom<KC>::RING;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int piece = tid + 256 * k;
-      piece = piece < PIECES ? piece : PIECES - 1;
-      r[k] = *reinterpret_cast<const u32x4 *>(srcp + (size_t)piece * 16);
-    }
-  }
-  __device__ __forceinline__ void store(unsigned char *slot, int tid) const {
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int piece = tid + 256 * k;
-      piece = piece < PIECES ? piece : PIECES - 1;
-      *reinterpret_cast<u32x4 *>(slot + (size_t)piece * 16) = r[k];
-    }
-  }
-};
 
 // fill the activation tile by LDS-DMA: tile is TZ*TY rows of TX voxels (96 B)
 template <int TZ, int TY, int TX>
@@ -290,81 +252,61 @@ __device__ __forceinline__ void stage_tile(const h16_t *act, int AZ, int AY, int
   }
 }
 
-template <int NSUB, int KC, bool DIAG = false, typename SubOff>
+// The K loop.  Every wave takes the weight fragments (3 x 1 KiB per K-step, the
+// same for all waves) straight from global memory - L2 / L1 hits - into registers,
+// WQ K-steps ahead of their use: no LDS ring and no barrier inside the loop, so the
+// waves of a workgroup drift apart and keep the MFMA pipe fed.  (An LDS ring staged
+// through registers cost a barrier every KC steps and was 6% slower; the 4x L2
+// weight traffic, ~9 TB/s chip-wide, is well inside what L2 delivers.)
+constexpr int WQ = 4;
+
+template <int NSUB, bool DIAG = false, typename SubOff>
 __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
-                                            unsigned char *ring,
                                             const unsigned *kofftab,
                                             const unsigned char *wglobal,
                                             unsigned vbase, SubOff sub_off,
                                             f32x4 (&acc)[NSUB][3], int tid,
                                             unsigned long long *t_ready = nullptr) {
-  using G = KGeom<KC>;
   const int lane = tid & 63, g = lane >> 4;
-  // weight slots 0..WDEPTH-1 start their trip from L2 right away
-  WStage<KC> wst[WDEPTH];
+  const unsigned char *wl = wglobal + lane * 16;
+  h16x8 wq[WQ][3];
 #pragma unroll
-  for (int d = 0; d < WDEPTH; ++d)
-    if (d < G::NCH) wst[d].load(wglobal, d, tid);
-  wst[0].store(ring, tid);
-  if (WDEPTH < G::NCH) wst[0].load(wglobal, WDEPTH, tid);
-  __syncthreads();            // activation tile (LDS-DMA) + slot 0 + table visible
+  for (int d = 0; d < WQ; ++d)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * 3 + b) * 1024);
+  __syncthreads();            // activation tile (LDS-DMA) + table visible
   if (DIAG) *t_ready = __builtin_amdgcn_s_memtime();
   // activation fragments run one K-step ahead of the MFMAs
   h16x8 bcur[NSUB], bnxt[NSUB];
-  const unsigned *ktab = kofftab + g * (G::NCH * G::KQ);
-  {
-    const unsigned koff = ktab[0];
+  const unsigned *ktab = kofftab + g * KTAB;
+  u32x4 kv = *reinterpret_cast<const u32x4 *>(ktab);
+#pragma unroll
+  for (int sub = 0; sub < NSUB; ++sub)
+    bcur[sub] = *reinterpret_cast<const h16x8 *>(tile + vbase + kv[0] + sub_off(sub));
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    // prefetch K-step s+1 (the final prefetch re-reads the last step: harmless)
+    if ((s + 1) % 4 == 0) kv = *reinterpret_cast<const u32x4 *>(ktab + s + 1);
+    const unsigned koff = kv[(s + 1) % 4];
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
-      bcur[sub] = *reinterpret_cast<const h16x8 *>(tile + vbase + koff + sub_off(sub));
-  }
+      bnxt[sub] = *reinterpret_cast<const h16x8 *>(tile + vbase + koff + sub_off(sub));
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int ck = 0; ck < G::NCH; ++ck) {
-    // slot (ck+1)&1 was last read during chunk ck-1, which every wave has left
-    if (ck > 0) __syncthreads();
-    if (ck + 1 < G::NCH) {
-      wst[(ck + 1) % WDEPTH].store(ring + ((ck + 1) & 1) * G::RING, tid);
-      if (ck + 1 + WDEPTH < G::NCH)
-        wst[(ck + 1) % WDEPTH].load(wglobal, ck + 1 + WDEPTH, tid);
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        acc[sub][b] = mfma16(wq[s % WQ][b], bcur[sub], acc[sub][b]);
+    __builtin_amdgcn_s_setprio(0);
+    if (s + WQ < KSTEPS) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        wq[s % WQ][b] =
+            *reinterpret_cast<const h16x8 *>(wl + (size_t)((s + WQ) * 3 + b) * 1024);
     }
-    const unsigned char *wslot = ring + (ck & 1) * G::RING + lane * 16;
-    // k-slot offsets of steps 1..KC of this chunk (entry KC = next chunk's step 0)
-    unsigned kq[G::KQ];
 #pragma unroll
-    for (int q4 = 0; q4 < G::KQ / 4; ++q4) {
-      const u32x4 v = *reinterpret_cast<const u32x4 *>(ktab + ck * G::KQ + 4 * q4);
-      kq[4 * q4 + 0] = v[0]; kq[4 * q4 + 1] = v[1];
-      kq[4 * q4 + 2] = v[2]; kq[4 * q4 + 3] = v[3];
-    }
-    h16x8 wcur[3], wnxt[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-      wcur[b] = *reinterpret_cast<const h16x8 *>(wslot + b * 1024);
-#pragma unroll
-    for (int ks = 0; ks < KC; ++ks) {
-      // prefetch K-step s+1 (the final prefetch re-reads step KSTEPS-1: harmless)
-      const unsigned koff = kq[ks + 1];
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
-        bnxt[sub] = *reinterpret_cast<const h16x8 *>(tile + vbase + koff + sub_off(sub));
-      if (ks + 1 < KC) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          wnxt[b] = *reinterpret_cast<const h16x8 *>(wslot + ((ks + 1) * 3 + b) * 1024);
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wcur[b], bcur[sub], acc[sub][b]);
-      __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) bcur[sub] = bnxt[sub];
-      if (ks + 1 < KC) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) wcur[b] = wnxt[b];
-      }
-    }
+    for (int sub = 0; sub < NSUB; ++sub) bcur[sub] = bnxt[sub];
   }
 }
 
@@ -372,13 +314,12 @@ __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
 // K2: conv3 48->48 + conv1 48->48 + maxpool2.  WG = 4 waves, pre-pool block
 // 4 x 4 x 16 (pooled 2 x 2 x 8); wave = one pooled (pz,py) row; lanes = 16
 // consecutive pre-pool x; 4 sub-steps = the (dz,dy) pooling window positions, the
-// x pair is pooled across adjacent lanes at the very end.  80 KiB of LDS per WG
+// x pair is pooled across adjacent lanes at the very end.  63 KiB of LDS per WG
 // so two WGs share a CU: one fills its tile while the other computes.
 // -------------------------------------------------------------------------------
-constexpr int M_KC = 3;
 constexpr int M_TZ = 6, M_TY = 6, M_TX = 18;
 constexpr int M_TILE_BYTES = ((M_TZ * M_TY * M_TX * VOX_BYTES + 1023) / 1024) * 1024;
-constexpr int M_SMEM = M_TILE_BYTES + 2 * KGeom<M_KC>::RING + KGeom<M_KC>::TAB_BYTES;
+constexpr int M_SMEM = M_TILE_BYTES + KTAB_BYTES;
 static_assert(2 * M_SMEM <= 160 * 1024, "two mid workgroups must fit one CU");
 
 struct MidArgs {
@@ -396,15 +337,13 @@ template <bool DIAG>
 __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
   if (DIAG) t0 = __builtin_amdgcn_s_memtime();
-  using G = KGeom<M_KC>;
   unsigned char *tile = smem;
-  unsigned char *ring = smem + M_TILE_BYTES;
-  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES + 2 * G::RING);
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int px0 = blockIdx.x * 8, py0 = blockIdx.y * 2, pz0 = blockIdx.z * 2;
 
-  if (tid < 4 * G::NCH * G::KQ) kofftab[tid] = kslot_entry<M_KC, M_TY, M_TX>(tid);
+  if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
   stage_tile<M_TZ, M_TY, M_TX>(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0,
                                tile, wave, lane);
 
@@ -423,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
   auto sub_off = [](int sub) -> unsigned {
     return (unsigned)(((((sub >> 1) & 1) * M_TY + (sub & 1)) * M_TX) * VOX_BYTES);
   };
-  conv3_kloop<4, M_KC, DIAG>(tile, ring, kofftab, a.w3, vbase, sub_off, acc, tid, &t1);
+  conv3_kloop<4, DIAG>(tile, kofftab, a.w3, vbase, sub_off, acc, tid, &t1);
   if (DIAG) t2 = __builtin_amdgcn_s_memtime();
 
   // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions
@@ -475,10 +414,9 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
 // structure as K2 (two workgroups per CU) without the pool: block 4(z) x 4(y) x
 // 16(x), wave = z, sub-steps = the 4 y rows.
 // -------------------------------------------------------------------------------
-constexpr int H_KC = 3;
 constexpr int H_TZ = 6, H_TY = 6, H_TX = 18;
 constexpr int H_TILE_BYTES = ((H_TZ * H_TY * H_TX * VOX_BYTES + 1023) / 1024) * 1024;
-constexpr int H_SMEM = H_TILE_BYTES + 2 * KGeom<H_KC>::RING + KGeom<H_KC>::TAB_BYTES;
+constexpr int H_SMEM = H_TILE_BYTES + KTAB_BYTES;
 static_assert(2 * H_SMEM <= 160 * 1024, "two c5 workgroups must fit one CU");
 
 struct C5Args {
@@ -491,15 +429,13 @@ struct C5Args {
 };
 
 __global__ __launch_bounds__(256, 2) void FPLK(vgg_c5)(C5Args a) {
-  using G = KGeom<H_KC>;
   unsigned char *tile = smem;
-  unsigned char *ring = smem + H_TILE_BYTES;
-  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + H_TILE_BYTES + 2 * G::RING);
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + H_TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int cx0 = blockIdx.x * 16, cy0 = blockIdx.y * 4, cz0 = blockIdx.z * 4;
 
-  if (tid < 4 * G::NCH * G::KQ) kofftab[tid] = kslot_entry<H_KC, H_TY, H_TX>(tid);
+  if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<H_TY, H_TX>(tid);
   stage_tile<H_TZ, H_TY, H_TX>(a.p2, a.P2Z, a.P2Y, a.P2X, cz0, cy0, cx0, tile, wave, lane);
 
   const unsigned vbase = (unsigned)(((wave * H_TY) * H_TX + c) * VOX_BYTES);
@@ -513,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_c5)(C5Args a) {
     for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
   }
   auto sub_off = [](int sub) -> unsigned { return (unsigned)(sub * H_TX * VOX_BYTES); };
-  conv3_kloop<4, H_KC>(tile, ring, kofftab, a.w5, vbase, sub_off, acc, tid);
+  conv3_kloop<4>(tile, kofftab, a.w5, vbase, sub_off, acc, tid);
 
   const int cz = cz0 + wave, cx = cx0 + c;
 #pragma unroll
