@@ -14,7 +14,7 @@
 // conv3_bf16: 4 waves, output block 4 x 4 x 16, wave = z, sub-steps = y, lanes = x;
 // persistent over blocks; planar activation tile (6 x 6 x 18 voxels, one 32-channel
 // chunk at a time) in LDS; K order (chunk, dz, dx, dy) with y-row fragment reuse;
-// weight fragments stream through a 2-slot LDS ring staged through registers;
+// weight fragments go from L2 straight into registers, a few K-steps ahead;
 // <= 80 KiB LDS so two workgroups share a CU.  Details at the kernel.
 #include <algorithm>
 
@@ -41,9 +41,8 @@ constexpr int MAXTAB = 2;                 // distinct source geometries per laun
 constexpr int TABN = NT * 64;              // voxel-offset table entries (>= tile voxels)
 constexpr int TAB_BYTES = MAXTAB * TABN * 4;
 static_assert(NPIECE % 32 == 0, "tile pieces come in groups of 32");
-constexpr int NCH = 9;                    // ring chunks per channel chunk: (dz, dx)
-constexpr int KC = 3;                     // K-steps per ring chunk: dy
-constexpr int WDEPTH = 3;                 // weight chunks in flight in registers
+constexpr int NCH = 9;                    // row groups per channel chunk: (dz, dx)
+constexpr int KC = 3;                     // K-steps per row group: dy
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -77,29 +76,6 @@ __device__ __forceinline__ void store_il(h16_t *vox_out, int g, const f32x4 (&ac
     *reinterpret_cast<u32x4 *>(dst + 8 * h) = o;
   }
 }
-
-template <int RING> struct WReg {
-  static constexpr int PIECES = RING / 16;
-  static constexpr int PER = (PIECES + 255) / 256;
-  u32x4 r[PER];
-  __device__ __forceinline__ void load(const unsigned char *w, int64_t chunk, int tid) {
-    const unsigned char *srcp = w + chunk * RING;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int piece = tid + 256 * k;
-      piece = piece < PIECES ? piece : PIECES - 1;
-      r[k] = *reinterpret_cast<const u32x4 *>(srcp + (size_t)piece * 16);
-    }
-  }
-  __device__ __forceinline__ void store(unsigned char *slot, int tid) const {
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int piece = tid + 256 * k;
-      piece = piece < PIECES ? piece : PIECES - 1;
-      *reinterpret_cast<u32x4 *>(slot + (size_t)piece * 16) = r[k];
-    }
-  }
-};
 
 struct Conv3Args {
   Src src[6];
@@ -161,15 +137,15 @@ constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
 constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
 template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false>
-__global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
+__global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a) {
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
   static_assert(!HEAD || (MB == 2 && !POOL), "the head variant is conv3 ->32");
   static_assert(NRAW % 256 == 0, "raw tile pieces per thread");
-  constexpr int RING = KC * MB * 1024;
+  // K-steps of weight fragments in flight (27 % WQ == 0)
+  constexpr int WQ = 3;
   constexpr int ROW = TX * PITCH;
   unsigned char *tile = smem;
-  unsigned char *ring = smem + TILE_BYTES;
-  unsigned *offtab = reinterpret_cast<unsigned *>(smem + TILE_BYTES + 2 * RING);
+  unsigned *offtab = reinterpret_cast<unsigned *>(smem + TILE_BYTES);
   // STEM: [0, TABN) = raw-tile offset of tile voxel v; then the bf16 raw tile
   unsigned short *rawt = reinterpret_cast<unsigned short *>(offtab + TABN);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -290,20 +266,24 @@ __global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[4 * MB * g + 4 * b + r];
   f32x4 acc[4][MB];
-  const int total_chunks = a.ncc * NCH;
+  const int total_steps = a.ncc * NCH * KC;
   __syncthreads();                                  // offset tables visible
   // The tile loads go out BEFORE the weight loads, as in the steady state of the
   // loop below: vmcnt retires in order, and with this order the waits hipcc derives
   // for put() leave the youngest weight loads in flight instead of draining them.
   if (PF) fetch(blk, 0);
   __builtin_amdgcn_sched_barrier(0);                // keep that issue order
-  WReg<RING> wst[WDEPTH];
+  // Weight fragments (MB x 1 KiB per K-step, the same for every wave) come straight
+  // from L2 into registers, WQ K-steps ahead of their use and across tile / block
+  // boundaries: no LDS ring and no barrier inside the K loop.
+  const unsigned char *wl = a.w + lane * 16;
+  h16x8 wq[WQ][MB];
 #pragma unroll
-  for (int d = 0; d < WDEPTH; ++d) wst[d].load(a.w, d < total_chunks ? d : 0, tid);
-  wst[0].store(ring, tid);
-  wst[0].load(a.w, WDEPTH < total_chunks ? WDEPTH : 0, tid);
+  for (int d = 0; d < WQ; ++d)
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * MB + b) * 1024);
 
-  unsigned par = 0;                                 // ring slot of the current chunk
   for (;;) {
     for (int cc = 0; cc < a.ncc; ++cc) {
       if (cc == 0) {
@@ -322,52 +302,39 @@ __global__ __launch_bounds__(256, 2) void FPLK(conv3)(Conv3Args a) {
         fetch(nb, last_cc ? 0 : cc + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();            // tile (+ ring slot) visible
+      __syncthreads();            // tile visible
       h16x8 brow[2][6];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
         brow[0][r] = *reinterpret_cast<const h16x8 *>(tile + vbase + r * ROW);
 #pragma unroll
       for (int ck = 0; ck < NCH; ++ck) {
-        if (ck > 0) __syncthreads();
-        {
-          int nxt = cc * NCH + ck + 1 + WDEPTH;
-          nxt = nxt < total_chunks ? nxt : nxt - total_chunks;   // next block starts over
-          wst[(ck + 1) % WDEPTH].store(ring + (par ^ 1u) * RING, tid);
-          wst[(ck + 1) % WDEPTH].load(a.w, nxt, tid);
-        }
-        const unsigned char *wslot = ring + par * RING + lane * 16;
-        par ^= 1u;
-        h16x8 wcur[MB], wnxt[MB];
-#pragma unroll
-        for (int b = 0; b < MB; ++b)
-          wcur[b] = *reinterpret_cast<const h16x8 *>(wslot + b * 1024);
-        // next ring chunk's rows: (dz, dx) of chunk ck+1 (wraps to the tile origin;
-        // the wrapped read of the last chunk is unused)
+        // next row group: (dz, dx) of ck+1 (wraps to the tile origin; the wrapped
+        // read of the last group is unused)
         const int nk = ck + 1 < NCH ? ck + 1 : 0;
         const unsigned noff = (unsigned)(((nk / 3) * TY * TX + nk % 3) * PITCH);
 #pragma unroll
         for (int dy = 0; dy < KC; ++dy) {
+          const int st = ck * KC + dy;              // K-step inside the channel chunk
           // spread the six prefetch reads over the three K-steps
 #pragma unroll
           for (int r = 2 * dy; r < 2 * dy + 2; ++r)
             brow[(ck + 1) & 1][r] =
                 *reinterpret_cast<const h16x8 *>(tile + vbase + noff + r * ROW);
-          if (dy + 1 < KC) {
-#pragma unroll
-            for (int b = 0; b < MB; ++b)
-              wnxt[b] = *reinterpret_cast<const h16x8 *>(wslot + ((dy + 1) * MB + b) * 1024);
-          }
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
             for (int b = 0; b < MB; ++b)
-              acc[sub][b] = mfma16(wcur[b], brow[ck & 1][sub + dy], acc[sub][b]);
+              acc[sub][b] = mfma16(wq[st % WQ][b], brow[ck & 1][sub + dy], acc[sub][b]);
           __builtin_amdgcn_s_setprio(0);
-          if (dy + 1 < KC) {
+          {
+            int nxt = cc * (NCH * KC) + st + WQ;
+            nxt = nxt < total_steps ? nxt : nxt - total_steps;   // next block starts over
 #pragma unroll
-            for (int b = 0; b < MB; ++b) wcur[b] = wnxt[b];
+            for (int b = 0; b < MB; ++b)
+              wq[st % WQ][b] =
+                  *reinterpret_cast<const h16x8 *>(wl + ((size_t)nxt * MB + b) * 1024);
           }
         }
       }
@@ -671,7 +638,7 @@ template <int MB, bool STEM = false, bool POOL = false, bool HEAD = false>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   constexpr bool PF = true;
   // STEM keeps the bf16 raw tile behind the (single) offset table
-  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024 + (STEM ? TABN * 4 + NRAW * 2 : TAB_BYTES);
+  constexpr int SMEM = TILE_BYTES + (STEM ? TABN * 4 + NRAW * 2 : TAB_BYTES);
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   static bool attr_set = false;
   if (!attr_set) {
@@ -704,7 +671,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   a.nbz = n * a.zblocks;
   const int64_t total = (int64_t)a.nbx * a.nby * a.nbz;
   // two workgroups per CU, rounded to a multiple of the 8 XCDs
-  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * 2, (total + 7) / 8 * 8);
+  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * (MB == 2 ? 3 : 2), (total + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
   FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
