@@ -80,6 +80,12 @@ __global__ void chan_reduce_partial(const float *__restrict__ a,
   }
 }
 
+// BN affine output with a fixed rounding sequence: the forward pass and the ReLU mask
+// recomputed by the backward passes (instead of re-reading y) must agree bit for bit
+__device__ __forceinline__ float bn_affine(float v, float m, float s, float g, float b) {
+  return __fmaf_rn(__fmul_rn(__fsub_rn(v, m), s), g, b);
+}
+
 // float4 form of the same reduction for C % 4 == 0: block = (C/4, R) threads, a thread
 // owns 4 channels and streams 16-B pieces, four rows in flight
 template <int MODE>
@@ -88,27 +94,33 @@ __global__ void chan_reduce_partial4(const float *__restrict__ a,
                                      const float *__restrict__ mean,
                                      const float *__restrict__ invstd, int64_t M,
                                      int C, double *__restrict__ part,
-                                     const float *__restrict__ y3 = nullptr) {
+                                     const float *__restrict__ gamma = nullptr,
+                                     const float *__restrict__ beta = nullptr) {
+  // MODE 3 = MODE 1 behind a fused ReLU: dy counts where BN's output was positive
   extern __shared__ double red[];
   const int c4 = threadIdx.x, r = threadIdx.y, R = blockDim.y, C4 = C / 4;
   const int64_t row0 = (int64_t)blockIdx.x * RED_ROWS;
   const int64_t row1 = row0 + RED_ROWS < M ? row0 + RED_ROWS : M;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, ga = mu, be = mu;
   if (MODE == 1 || MODE == 3) {
     mu = reinterpret_cast<const float4 *>(mean)[c4];
     is = reinterpret_cast<const float4 *>(invstd)[c4];
   }
+  if (MODE == 3) {
+    ga = reinterpret_cast<const float4 *>(gamma)[c4];
+    be = reinterpret_cast<const float4 *>(beta)[c4];
+  }
   const float4 *a4 = reinterpret_cast<const float4 *>(a);
   const float4 *b4 = reinterpret_cast<const float4 *>(b);
-  const float4 *y4 = reinterpret_cast<const float4 *>(y3);
-  auto add = [&](const float4 &va, const float4 &vb, const float4 &vy) {
+  auto add = [&](const float4 &va, const float4 &vb) {
     float v[4] = {va.x, va.y, va.z, va.w};
-    const float xb[4] = {vb.x, vb.y, vb.z, vb.w}, yy[4] = {vy.x, vy.y, vy.z, vy.w};
+    const float xb[4] = {vb.x, vb.y, vb.z, vb.w};
     const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+    const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, e4[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (MODE == 3) v[q] = yy[q] > 0.f ? v[q] : 0.f;
+      if (MODE == 3) v[q] = bn_affine(xb[q], m4[q], i4[q], g4[q], e4[q]) > 0.f ? v[q] : 0.f;
       if (MODE == 0) {
         s0[q] += v[q]; s1[q] += (double)v[q] * v[q];
       } else if (MODE == 1 || MODE == 3) {
@@ -122,20 +134,19 @@ __global__ void chan_reduce_partial4(const float *__restrict__ a,
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int64_t m = row0 + r;
   for (; m + 3 * R < row1; m += 4 * R) {
-    float4 va[4], vb[4], vy[4];
+    float4 va[4], vb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t idx = (m + u * R) * C4 + c4;
       va[u] = a4[idx];
       vb[u] = (MODE == 1 || MODE == 3) ? b4[idx] : z4;
-      vy[u] = MODE == 3 ? y4[idx] : z4;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) add(va[u], vb[u], vy[u]);
+    for (int u = 0; u < 4; ++u) add(va[u], vb[u]);
   }
   for (; m < row1; m += R) {
     const int64_t idx = m * C4 + c4;
-    add(a4[idx], (MODE == 1 || MODE == 3) ? b4[idx] : z4, MODE == 3 ? y4[idx] : z4);
+    add(a4[idx], (MODE == 1 || MODE == 3) ? b4[idx] : z4);
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -167,8 +178,8 @@ __global__ void bn_apply4(const float4 *__restrict__ x, const float4 *__restrict
   const int c = (int)(i % C4);
   const float4 v = x[i], m = mean[c], s = invstd[c], g = gamma[c], b = beta[c];
   float4 o;
-  o.x = (v.x - m.x) * s.x * g.x + b.x; o.y = (v.y - m.y) * s.y * g.y + b.y;
-  o.z = (v.z - m.z) * s.z * g.z + b.z; o.w = (v.w - m.w) * s.w * g.w + b.w;
+  o.x = bn_affine(v.x, m.x, s.x, g.x, b.x); o.y = bn_affine(v.y, m.y, s.y, g.y, b.y);
+  o.z = bn_affine(v.z, m.z, s.z, g.z, b.z); o.w = bn_affine(v.w, m.w, s.w, g.w, b.w);
   if (RELU) {
     o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
   }
@@ -176,7 +187,7 @@ __global__ void bn_apply4(const float4 *__restrict__ x, const float4 *__restrict
 }
 
 template <bool RELU, bool ACC>
-__global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__restrict__ y,
+__global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__restrict__ beta,
                              const float4 *__restrict__ x, const float4 *__restrict__ mean,
                              const float4 *__restrict__ invstd,
                              const float4 *__restrict__ gamma,
@@ -188,18 +199,18 @@ __global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__rest
   const int c = (int)(i % C4);
   const float4 d = dy[i], xv = x[i], m = mean[c], s = invstd[c], g = gamma[c],
                sg = sum_g[c], sx = sum_g_xhat[c];
-  float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-  if (RELU) yv = y[i];
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (RELU) bv = beta[c];                  // the ReLU mask is recomputed from x
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ACC) o = dx[i];                      // else this pass is the tensor's only writer
   const float dd[4] = {d.x, d.y, d.z, d.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w},
               mm[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w},
               gg[4] = {g.x, g.y, g.z, g.w}, s0[4] = {sg.x, sg.y, sg.z, sg.w},
-              s1[4] = {sx.x, sx.y, sx.z, sx.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+              s1[4] = {sx.x, sx.y, sx.z, sx.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
   float oo[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float gq = (!RELU || yy[q] > 0.f) ? dd[q] : 0.f;
+    const float gq = (!RELU || bn_affine(xx[q], mm[q], ss[q], gg[q], bb[q]) > 0.f) ? dd[q] : 0.f;
     const float xh = (xx[q] - mm[q]) * ss[q];
     oo[q] += gg[q] * ss[q] * (gq - inv_m * s0[q] - xh * inv_m * s1[q]);
   }
@@ -1119,11 +1130,12 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         FPL_HIP(ctx, hipMemsetAsync(sdyx, 0, (size_t)C * 4, st));
         TimedLaunch tl(ctx, "train_bn_bwd");
         const float *yrelu = bn_fused[li] ? val[t->layers[li + 1].dst] : nullptr;
-        const bool v4 = C % 4 == 0 && (L.w_off[0] % 4) == 0;
+        const bool v4 = C % 4 == 0 && (L.w_off[0] % 4) == 0 && (L.w_off[1] % 4) == 0;
         const int R4 = v4 ? std::max(1, 256 / (C / 4)) : 0;
         if (v4 && bn_fused[li])
           chan_reduce_partial4<3><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
-              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part, yrelu);
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part, t->w + L.w_off[0],
+              t->w + L.w_off[1]);
         else if (v4)
           chan_reduce_partial4<1><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
               dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
@@ -1144,7 +1156,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   bn_backward4<RELU, ACC><<<g1(n / 4), 256, 0, st>>>((cf4)dy, (cf4)(YP), (cf4)val[L.src0],    \
       (cf4)bn_mean[li], (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)sdy, (cf4)sdyx,     \
       (float4 *)dx, n / 4, C / 4, 1.f / (float)M)
-          if (bn_fused[li]) { if (acc) FPL_BNB4(true, true, yrelu); else FPL_BNB4(true, false, yrelu); }
+          if (bn_fused[li]) { if (acc) FPL_BNB4(true, true, t->w + L.w_off[1]); else FPL_BNB4(true, false, t->w + L.w_off[1]); }
           else { if (acc) FPL_BNB4(false, true, nullptr); else FPL_BNB4(false, false, nullptr); }
 #undef FPL_BNB4
         } else if (dx && bn_fused[li])
