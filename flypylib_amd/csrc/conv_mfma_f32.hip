@@ -79,6 +79,24 @@ __device__ __forceinline__ float act_f(float v, int act) {
   return v;
 }
 
+// store the four consecutive output channels a lane holds for m-block b: one 16-B
+// store when the channel count allows it (a wave then writes whole 64-B pieces
+// instead of 256 scattered dwords)
+__device__ __forceinline__ void store_quad(float *dst, int co0, int cout, const f32x4 &v, int act) {
+  if ((cout & 3) == 0) {
+    if (co0 < cout) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = act_f(v[r], act);
+      *reinterpret_cast<f32x4 *>(dst + co0) = o;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (co0 + r < cout) dst[co0 + r] = act_f(v[r], act);
+  }
+}
+
 template <int MB>
 __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
   constexpr int RING = KC * MB * 1024;
@@ -194,11 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
       float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.cout;
 #pragma unroll
       for (int b = 0; b < MB; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = 16 * b + 4 * g + r;
-          if (co < a.cout) dst[co] = act_f(acc[sub][b][r], a.act);
-        }
+        store_quad(dst, 16 * b + 4 * g, a.cout, acc[sub][b], a.act);
     }
   }
 }
@@ -255,11 +269,7 @@ __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
       float *dst = a.out + m * a.cout;
 #pragma unroll
       for (int b = 0; b < MB; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = 16 * b + 4 * g + r;
-          if (co < a.cout) dst[co] = act_f(acc[b][r], a.act);
-        }
+        store_quad(dst, 16 * b + 4 * g, a.cout, acc[b], a.act);
     }
   }
 }
@@ -327,13 +337,7 @@ __global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = mfma4(w[q][b][j], bv[4 * q + j], acc);
-      if (ok) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = 16 * b + 4 * g + r;
-          if (co < a.cout) dst[co] = act_f(acc[r], a.act);
-        }
-      }
+      if (ok) store_quad(dst, 16 * b + 4 * g, a.cout, acc, a.act);
     }
   }
 }
