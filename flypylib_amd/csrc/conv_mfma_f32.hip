@@ -925,6 +925,76 @@ __global__ __launch_bounds__(256) void conv1_wgrad_f32(Wgrad1Args a) {
     }
 }
 
+// 48 -> 48 (vgg_like's 1x1 convs): persistent workgroups, a wave keeps the whole 48 x 48
+// gradient (9 accumulator tiles) and streams voxels.  Row c of A-block q is channel
+// 3c + q (and column c of B-block b is channel 3c + b), so a lane's operands for one
+// voxel are 12 contiguous bytes of x and of dy: every row is read once, coalesced.
+// Partials per workgroup, then a deterministic sum (no float atomics).
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+
+__global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict__ x,
+                                                         const float *__restrict__ dy,
+                                                         int64_t M, float *__restrict__ part) {
+  __shared__ float red[4][2304];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  f32x4 acc[3][3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[q][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t groups = (M + 15) / 16;
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += 2 * stride) {
+    f32x3 av[2][4], bv[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t m = (grp + u * stride) * 16 + 4 * g + j;   // k-slot (g, j) = voxel
+        const bool ok = m < M;
+        const int64_t mm = ok ? m : 0;
+        av[u][j] = *reinterpret_cast<const f32x3 *>(x + mm * 48 + 3 * c);
+        bv[u][j] = *reinterpret_cast<const f32x3 *>(dy + mm * 48 + 3 * c);
+        if (!ok) av[u][j] = f32x3{0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) acc[q][b] = mfma4(av[u][j][q], bv[u][j][b], acc[q][b]);
+  }
+  // D row 4g + r of block (q, b) is ci = 3 (4g + r) + q, column c is co = 3c + b
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        red[wave][(3 * (4 * g + r) + q) * 48 + 3 * c + b] = acc[q][b][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2304; i += 256)
+    part[(int64_t)blockIdx.x * 2304 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+// dw[i] += sum over the nblk partials: 64 consecutive i per workgroup, four rows of
+// partials in flight per wave, fixed order
+__global__ __launch_bounds__(256) void wgrad_partials_add(const float *__restrict__ part, int nblk,
+                                                          int n, float *__restrict__ dw) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < n)
+    for (int k = wave; k < nblk; k += 4) s += part[(int64_t)k * n + i];
+  sh[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && i < n) dw[i] += (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
 }  // namespace
 
 bool fpl_tm_supported(int k, int cin, int cout) {
@@ -1039,10 +1109,20 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
                       const float *dy, int k, int cout, float *dw) {
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
   const int ncc = (cin + 15) / 16, nco = (cout + 47) / 48;
+  DevTemp tmp(ctx);
   if (k == 1) {
     Wgrad1Args a;
     a.x = x; a.dy = dy; a.M = (int64_t)n * D * H * W_; a.cin = cin; a.cout = cout; a.dw = dw;
     a.ncc = ncc; a.nco = nco;
+    if (cin == 48 && cout == 48) {
+      const int nblk = (int)std::min<int64_t>((int64_t)ctx->n_cu * 2, ceil_div64(a.M, 128));
+      void *part;
+      FPL_TRY(tmp.alloc((size_t)nblk * 2304 * 4, &part));
+      TimedLaunch tl(ctx, "mfma_wgrad1_f32");
+      conv1_wgrad48_f32<<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part);
+      wgrad_partials_add<<<36, 256, 0, ctx->stream>>>((const float *)part, nblk, 2304, dw);
+      return 0;
+    }
     const int64_t vb = ceil_div64(a.M, 1024);
     TimedLaunch tl(ctx, "mfma_wgrad1_f32");
     conv1_wgrad_f32<<<(unsigned)(vb * ncc * nco), 256, 0, ctx->stream>>>(a);

@@ -217,6 +217,28 @@ __global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__rest
   dx[i] = make_float4(oo[0], oo[1], oo[2], oo[3]);
 }
 
+// sum of the nb partials of channel c, by one 256-thread block (fixed tree: the result
+// does not depend on scheduling); valid in thread 0
+__device__ __forceinline__ void block_sum_partials(const double *__restrict__ part, int nb,
+                                                   int C, int c, double &s0, double &s1) {
+  __shared__ double sh[2][256];
+  double a0 = 0.0, a1 = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    a0 += part[((int64_t)b * 2 + 0) * C + c];
+    a1 += part[((int64_t)b * 2 + 1) * C + c];
+  }
+  sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  s0 = sh[0][0]; s1 = sh[1][0];
+}
+
 // BN forward statistics from the partials: mean, invstd (biased var), and the
 // moving-average deltas into the gradient arena
 __global__ void bn_finish_stats(const double *__restrict__ part, int nb, int C,
@@ -226,13 +248,10 @@ __global__ void bn_finish_stats(const double *__restrict__ part, int nb, int C,
                                 float *__restrict__ mean, float *__restrict__ invstd,
                                 float *__restrict__ d_mov_mean,
                                 float *__restrict__ d_mov_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s0 += part[((int64_t)b * 2 + 0) * C + c];
-    s1 += part[((int64_t)b * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x;                     // one 256-thread block per channel
+  double s0, s1;
+  block_sum_partials(part, nb, C, c, s0, s1);
+  if (threadIdx.x != 0) return;
   const double mu = s0 / (double)M;
   double var = s1 / (double)M - mu * mu;
   var = var > 0.0 ? var : 0.0;
@@ -245,13 +264,10 @@ __global__ void bn_finish_stats(const double *__restrict__ part, int nb, int C,
 __global__ void finish_sums(const double *__restrict__ part, int nb, int C,
                             float *__restrict__ s0_out, float *__restrict__ s1_out,
                             float scale) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s0 += part[((int64_t)b * 2 + 0) * C + c];
-    s1 += part[((int64_t)b * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x;                     // one 256-thread block per channel
+  double s0, s1;
+  block_sum_partials(part, nb, C, c, s0, s1);
+  if (threadIdx.x != 0) return;
   if (s0_out) s0_out[c] += (float)(s0 * scale);
   if (s1_out) s1_out[c] += (float)(s1 * scale);
 }
@@ -358,6 +374,32 @@ __global__ void pool2_bwd(const float *__restrict__ dy, const uint8_t *__restric
   const int p = arg[i];
   dx[((((t * D + 2 * oz + (p >> 2)) * H + 2 * oy + ((p >> 1) & 1)) * (int64_t)W +
        2 * ox + (p & 1)) * C) + c] += dy[i];      // windows do not overlap
+}
+
+// Pool gradient when the 2x2x2 windows tile the input exactly (even D, H, W) and
+// C % 4 == 0: a thread owns four channels of one window and WRITES all eight positions
+// (dy at the arg-max, zero elsewhere) - dx needs no zero-fill and no read-modify-write.
+__global__ void pool2_bwd_assign4(const float4 *__restrict__ dy, const uint32_t *__restrict__ arg,
+                                  float4 *__restrict__ dx, int64_t n4, int D, int H, int W,
+                                  int C4, int od, int oh, int ow) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  int64_t t = i;
+  const int c = (int)(t % C4); t /= C4;
+  const int ox = (int)(t % ow); t /= ow;
+  const int oy = (int)(t % oh); t /= oh;
+  const int oz = (int)(t % od); t /= od;
+  const float4 g = dy[i];
+  const uint32_t a = arg[i];
+  const int a0 = a & 255, a1 = (a >> 8) & 255, a2 = (a >> 16) & 255, a3 = a >> 24;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    float4 o;
+    o.x = a0 == p ? g.x : 0.f; o.y = a1 == p ? g.y : 0.f;
+    o.z = a2 == p ? g.z : 0.f; o.w = a3 == p ? g.w : 0.f;
+    dx[((((t * D + 2 * oz + (p >> 2)) * H + 2 * oy + ((p >> 1) & 1)) * (int64_t)W +
+         2 * ox + (p & 1)) * C4) + c] = o;
+  }
 }
 
 __device__ __forceinline__ bool drop_keep(uint64_t seed, int layer, int64_t i,
@@ -926,7 +968,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         else
           chan_reduce_partial<0><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
               val[L.src0], nullptr, nullptr, nullptr, M, C, part);
-        bn_finish_stats<<<(C + 63) / 64, 64, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
+        bn_finish_stats<<<C, 256, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
             t->w + L.w_off[2], t->w + L.w_off[3], bn_mean[li], bn_invstd[li],
             t->g + L.w_off[2], t->g + L.w_off[3]);
         if (v4) {
@@ -1014,10 +1056,14 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
     if (L.src1 > 0) { ++n_use[L.src1]; cons[L.src1] = -2; }
   }
   std::vector<char> assign(nt, 0);
+  auto pool_tiles = [](const TShape &x) {
+    return x.d % 2 == 0 && x.h % 2 == 0 && x.w % 2 == 0 && x.c % 4 == 0;
+  };
   for (int ti = 1; ti < nt; ++ti) {
     if (n_use[ti] != 1 || cons[ti] < 0) continue;
     const fpl_layer &L = t->layers[cons[ti]];
     if (L.kind == FPL_L_BN) assign[ti] = 1;
+    if (L.kind == FPL_L_POOL && pool_tiles(shp[ti])) assign[ti] = 1;
     if (L.kind == FPL_L_CONV && use_mfma_bwd && fpl_tm_supported(L.k, L.cin, L.cout) &&
         fpl_tm_supported(L.k, L.cout, L.cin))
       assign[ti] = 1;
@@ -1069,7 +1115,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
             TimedLaunch tl(ctx, "train_bias_grad");
             chan_reduce_partial<2><<<nb, dim3(L.cout, R), (size_t)L.cout * R * 2 * sizeof(double), st>>>(
                 dy, nullptr, nullptr, nullptr, n_vox, L.cout, part);
-            finish_sums<<<(L.cout + 63) / 64, 64, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
+            finish_sums<<<L.cout, 256, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
                                                            nullptr, 1.f);
           }
           if (dx && assign[L.src0]) {
@@ -1100,7 +1146,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
           TimedLaunch tl(ctx, "train_bias_grad");
           chan_reduce_partial<2><<<nb, dim3(L.cout, R), (size_t)L.cout * R * 2 * sizeof(double), st>>>(
               dy, nullptr, nullptr, nullptr, n_vox, L.cout, part);
-          finish_sums<<<(L.cout + 63) / 64, 64, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
+          finish_sums<<<L.cout, 256, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
                                                          nullptr, 1.f);
         }
         if (dx) {
@@ -1145,7 +1191,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         else
           chan_reduce_partial<1><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
               dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
-        finish_sums<<<(C + 63) / 64, 64, 0, st>>>(part, nb, C, sdy, sdyx, 1.f);
+        finish_sums<<<C, 256, 0, st>>>(part, nb, C, sdy, sdyx, 1.f);
         // dbeta = sum dy, dgamma = sum dy*xhat
         accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
         accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
@@ -1176,7 +1222,11 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       case FPL_L_POOL:
         if (dx) {
           TimedLaunch tl(ctx, "train_pool");
-          pool2_bwd<<<g1(n), 256, 0, st>>>(dy, arg[li], dx, n, a.d, a.h, a.w, a.c, o.d, o.h, o.w);
+          if (assign[L.src0])
+            pool2_bwd_assign4<<<g1(n / 4), 256, 0, st>>>((const float4 *)dy, (const uint32_t *)arg[li],
+                (float4 *)dx, n / 4, a.d, a.h, a.w, a.c / 4, o.d, o.h, o.w);
+          else
+            pool2_bwd<<<g1(n), 256, 0, st>>>(dy, arg[li], dx, n, a.d, a.h, a.w, a.c, o.d, o.h, o.w);
         }
         break;
       case FPL_L_DROPOUT:
