@@ -1115,7 +1115,7 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
     a.x = x; a.dy = dy; a.M = (int64_t)n * D * H * W_; a.cin = cin; a.cout = cout; a.dw = dw;
     a.ncc = ncc; a.nco = nco;
     if (cin == 48 && cout == 48) {
-      const int nblk = (int)std::min<int64_t>((int64_t)ctx->n_cu * 2, ceil_div64(a.M, 128));
+      const int nblk = (int)std::min<int64_t>((int64_t)ctx->n_cu * 4, ceil_div64(a.M, 128));
       void *part;
       FPL_TRY(tmp.alloc((size_t)nblk * 2304 * 4, &part));
       TimedLaunch tl(ctx, "mfma_wgrad1_f32");

@@ -38,7 +38,11 @@ inline unsigned g1(int64_t n) { return (unsigned)ceil_div64(n, 256); }
 // ---- per-channel reductions over rows of an [M][C] tensor -----------------------
 // block = (C, R) threads; each block covers rows blockIdx.x*ROWS .. ; partial
 // sums in double -> part[block][2][C]
-constexpr int RED_ROWS = 4096;
+// rows per block: enough blocks to fill the chip on small tensors, <= 4096 rows on big
+static inline int red_rows(int64_t M) {
+  const int64_t r = (ceil_div64(M, 2048) + 63) / 64 * 64;
+  return (int)std::min<int64_t>(4096, std::max<int64_t>(256, r));
+}
 
 template <int MODE>   // 0: (x, x^2)   1: (dy, dy*xhat)   2: (dy, 0)
                       // 3: as 1 with dy gated by the ReLU output y3 > 0
@@ -46,12 +50,12 @@ __global__ void chan_reduce_partial(const float *__restrict__ a,
                                     const float *__restrict__ b,
                                     const float *__restrict__ mean,
                                     const float *__restrict__ invstd, int64_t M,
-                                    int C, double *__restrict__ part,
+                                    int C, int rows, double *__restrict__ part,
                                     const float *__restrict__ y3 = nullptr) {
   extern __shared__ double red[];
   const int c = threadIdx.x, r = threadIdx.y, R = blockDim.y;
-  const int64_t row0 = (int64_t)blockIdx.x * RED_ROWS;
-  const int64_t row1 = row0 + RED_ROWS < M ? row0 + RED_ROWS : M;
+  const int64_t row0 = (int64_t)blockIdx.x * rows;
+  const int64_t row1 = row0 + rows < M ? row0 + rows : M;
   double s0 = 0.0, s1 = 0.0;
   const float mu = (MODE == 1 || MODE == 3) ? mean[c] : 0.f,
               is = (MODE == 1 || MODE == 3) ? invstd[c] : 0.f;
@@ -93,14 +97,14 @@ __global__ void chan_reduce_partial4(const float *__restrict__ a,
                                      const float *__restrict__ b,
                                      const float *__restrict__ mean,
                                      const float *__restrict__ invstd, int64_t M,
-                                     int C, double *__restrict__ part,
+                                     int C, int rows, double *__restrict__ part,
                                      const float *__restrict__ gamma = nullptr,
                                      const float *__restrict__ beta = nullptr) {
   // MODE 3 = MODE 1 behind a fused ReLU: dy counts where BN's output was positive
   extern __shared__ double red[];
   const int c4 = threadIdx.x, r = threadIdx.y, R = blockDim.y, C4 = C / 4;
-  const int64_t row0 = (int64_t)blockIdx.x * RED_ROWS;
-  const int64_t row1 = row0 + RED_ROWS < M ? row0 + RED_ROWS : M;
+  const int64_t row0 = (int64_t)blockIdx.x * rows;
+  const int64_t row1 = row0 + rows < M ? row0 + rows : M;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu, ga = mu, be = mu;
   if (MODE == 1 || MODE == 3) {
@@ -896,7 +900,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   FPL_HIP(ctx, hipMemsetAsync(t->g, 0, (size_t)t->n_w * 4, st));
   void *partv;
   const int64_t max_rows = (int64_t)batch * shp[0].vox();
-  const int max_nb = (int)ceil_div64(max_rows, RED_ROWS);
+  const int max_nb = (int)std::max<int64_t>(ceil_div64(max_rows, 4096), 2048) + 1;
   FPL_TRY(tmp.alloc((size_t)max_nb * 2 * 256 * sizeof(double), &partv));
   double *part = (double *)partv;
   void *sumsv;
@@ -954,7 +958,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       case FPL_L_BN: {
         const int C = a.c;
         const int64_t M = (int64_t)batch * a.vox();
-        const int nb = (int)ceil_div64(M, RED_ROWS);
+        const int rr = red_rows(M), nb = (int)ceil_div64(M, rr);
         const int R = std::max(1, 256 / C);
         FPL_TRY(alloc_f(C, &bn_mean[li]));
         FPL_TRY(alloc_f(C, &bn_invstd[li]));
@@ -964,10 +968,10 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         const int R4 = v4 ? std::max(1, 256 / (C / 4)) : 0;
         if (v4)
           chan_reduce_partial4<0><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
-              val[L.src0], nullptr, nullptr, nullptr, M, C, part);
+              val[L.src0], nullptr, nullptr, nullptr, M, C, rr, part);
         else
           chan_reduce_partial<0><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
-              val[L.src0], nullptr, nullptr, nullptr, M, C, part);
+              val[L.src0], nullptr, nullptr, nullptr, M, C, rr, part);
         bn_finish_stats<<<C, 256, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
             t->w + L.w_off[2], t->w + L.w_off[3], bn_mean[li], bn_invstd[li],
             t->g + L.w_off[2], t->g + L.w_off[3]);
@@ -1110,11 +1114,11 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
           FPL_TRY(fpl_tm_conv_wgrad(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, dy, L.k,
                                     L.cout, t->g + L.w_off[0]));
           if (L.use_bias) {
-            const int nb = (int)ceil_div64(n_vox, RED_ROWS);
+            const int rr = red_rows(n_vox), nb = (int)ceil_div64(n_vox, rr);
             const int R = std::max(1, 256 / L.cout);
             TimedLaunch tl(ctx, "train_bias_grad");
             chan_reduce_partial<2><<<nb, dim3(L.cout, R), (size_t)L.cout * R * 2 * sizeof(double), st>>>(
-                dy, nullptr, nullptr, nullptr, n_vox, L.cout, part);
+                dy, nullptr, nullptr, nullptr, n_vox, L.cout, rr, part);
             finish_sums<<<L.cout, 256, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
                                                            nullptr, 1.f);
           }
@@ -1141,11 +1145,11 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
               a.w, a.c, o.d, o.h, o.w, o.c, L.k, cit, cot);
         }
         if (L.use_bias) {
-          const int nb = (int)ceil_div64(n_vox, RED_ROWS);
+          const int rr = red_rows(n_vox), nb = (int)ceil_div64(n_vox, rr);
           const int R = std::max(1, 256 / L.cout);
           TimedLaunch tl(ctx, "train_bias_grad");
           chan_reduce_partial<2><<<nb, dim3(L.cout, R), (size_t)L.cout * R * 2 * sizeof(double), st>>>(
-              dy, nullptr, nullptr, nullptr, n_vox, L.cout, part);
+              dy, nullptr, nullptr, nullptr, n_vox, L.cout, rr, part);
           finish_sums<<<L.cout, 256, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
                                                          nullptr, 1.f);
         }
@@ -1167,7 +1171,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       case FPL_L_BN: {
         const int C = a.c;
         const int64_t M = (int64_t)batch * a.vox();
-        const int nb = (int)ceil_div64(M, RED_ROWS);
+        const int rr = red_rows(M), nb = (int)ceil_div64(M, rr);
         const int R = std::max(1, 256 / C);
         float *sdy, *sdyx;
         FPL_TRY(alloc_f(C, &sdy));
@@ -1180,17 +1184,17 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         const int R4 = v4 ? std::max(1, 256 / (C / 4)) : 0;
         if (v4 && bn_fused[li])
           chan_reduce_partial4<3><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
-              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part, t->w + L.w_off[0],
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, rr, part, t->w + L.w_off[0],
               t->w + L.w_off[1]);
         else if (v4)
           chan_reduce_partial4<1><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
-              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, rr, part);
         else if (bn_fused[li])
           chan_reduce_partial<3><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
-              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part, yrelu);
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, rr, part, yrelu);
         else
           chan_reduce_partial<1><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
-              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, part);
+              dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, rr, part);
         finish_sums<<<C, 256, 0, st>>>(part, nb, C, sdy, sdyx, 1.f);
         // dbeta = sum dy, dgamma = sum dy*xhat
         accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
