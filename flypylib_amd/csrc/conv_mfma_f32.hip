@@ -701,7 +701,7 @@ __global__ void pack_stem_dev(const float *__restrict__ W, float *__restrict__ o
 
 // ---- weight gradient, 3x3x3: dW[tap][ci][co] += sum_m X[m + tap][ci] * dY[m][co].
 // One workgroup = one 4 x 4 x 16 block of output voxels x one 16-channel chunk of the
-// input x up to 48 output channels; the 27 taps are split over the 4 waves, each
+// input x up to 48 output channels; the 27 taps are split over the 8 waves, each
 // wave sweeps all 16 K-blocks (rows of 16 x) for its taps.  A = X^T (ci x voxel),
 // B = dY (voxel x co), k-slot (j,g) of a K-block = voxel 4g + j of the row.
 constexpr int WG_YP = 48 * 4;                 // dY tile pitch (bytes): 48 floats
@@ -712,7 +712,10 @@ struct WgradArgs {
   int zblocks, ncc, nco;                      // ci chunks of 16, co chunks of 48
 };
 
-__global__ __launch_bounds__(256) void conv3_wgrad_f32(WgradArgs a) {
+// Persistent: workgroup (chunk pair, p) walks the voxel blocks p, p + P, ... with its
+// accumulators in registers and adds them to dW once at the end.
+__global__ __launch_bounds__(512) void conv3_wgrad_f32(WgradArgs a, int64_t total_blocks,
+                                                      int nbx, int nby, int P) {
   unsigned char *xt = smem;                               // (6,6,18) x 96 B
   unsigned char *yt = smem + TILE_BYTES;                  // 256 voxels x 192 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -720,11 +723,20 @@ __global__ __launch_bounds__(256) void conv3_wgrad_f32(WgradArgs a) {
   int bx = blockIdx.x;
   const int coc = bx % a.nco; bx /= a.nco;
   const int cc = bx % a.ncc; bx /= a.ncc;
-  const int x0 = bx * 16, y0 = blockIdx.y * 4;
-  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * 4;
   const int co0 = coc * 48;
+  const int tap0 = wave < 3 ? 4 * wave : 12 + 3 * (wave - 3), ntap = wave < 3 ? 4 : 3;   // 8 waves
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t blk = bx; blk < total_blocks; blk += P) {
+  const int x0 = (int)(blk % nbx) * 16, y0 = (int)((blk / nbx) % nby) * 4;
+  const int64_t bz = blk / ((int64_t)nbx * nby);
+  const int n = (int)(bz / a.zblocks), z0 = (int)(bz % a.zblocks) * 4;
+  __syncthreads();                                 // previous block consumed
   // stage X chunk (16 channels) and dY (48 channels), zero outside
-  for (int p = tid; p < TZ * TY * TX * 4; p += 256) {
+  for (int p = tid; p < TZ * TY * TX * 4; p += 512) {
     const int vox = p >> 2, pc = p & 3;
     const int z = z0 + vox / (TY * TX), y = y0 + (vox / TX) % TY, x = x0 + vox % TX;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_f32(WgradArgs a) {
     }
     *reinterpret_cast<f32x4 *>(xt + (size_t)vox * PITCH + pc * 16) = v;
   }
-  for (int p = tid; p < 256 * 12; p += 256) {
+  for (int p = tid; p < 256 * 12; p += 512) {
     const int vox = p / 12, pc = p % 12;
     const int z = z0 + vox / 64, y = y0 + (vox / 16) % 4, x = x0 + vox % 16;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -753,12 +765,6 @@ __global__ __launch_bounds__(256) void conv3_wgrad_f32(WgradArgs a) {
     *reinterpret_cast<f32x4 *>(yt + (size_t)vox * WG_YP + pc * 16) = v;
   }
   __syncthreads();
-  const int tap0 = wave * 7, ntap = wave < 3 ? 7 : 6;
-  f32x4 acc[7][3];
-#pragma unroll
-  for (int t = 0; t < 7; ++t)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int row = 0; row < 16; ++row) {             // (z,y) rows of 16 x
     const int vz = row >> 2, vy = row & 3;
     float bv[3][4];
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_f32(WgradArgs a) {
         bv[b][j] = *reinterpret_cast<const float *>(
             yt + (size_t)((vz * 4 + vy) * 16 + 4 * g + j) * WG_YP + (16 * b + c) * 4);
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
+    for (int t = 0; t < 4; ++t) {
       if (t < ntap) {
         const int tap = tap0 + t;
         const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
@@ -785,8 +791,9 @@ __global__ __launch_bounds__(256) void conv3_wgrad_f32(WgradArgs a) {
       }
     }
   }
+  }
 #pragma unroll
-  for (int t = 0; t < 7; ++t) {
+  for (int t = 0; t < 4; ++t) {
     if (t < ntap) {
       const int tap = tap0 + t;
 #pragma unroll
@@ -1147,11 +1154,14 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set = true;
   }
-  dim3 grid((unsigned)(ceil_div64(ow, 16) * ncc * nco), (unsigned)ceil_div64(oh, 4),
-            (unsigned)(n * a.zblocks));
+  const int nbx = (int)ceil_div64(ow, 16), nby = (int)ceil_div64(oh, 4);
+  const int64_t total = (int64_t)nbx * nby * n * a.zblocks;
+  // one workgroup per CU (110 KiB of LDS), shared out over the (ci chunk, co chunk) pairs
+  const int per_cu = (160 * 1024) / SMEM;
+  const int P = (int)std::max<int64_t>(1, std::min<int64_t>(total, (int64_t)ctx->n_cu * per_cu / (ncc * nco)));
   char tname[64];
   snprintf(tname, sizeof(tname), "mfma_wgrad3_f32_%dto%d", cin, cout);
   TimedLaunch tl(ctx, tname);
-  conv3_wgrad_f32<<<grid, 256, SMEM, ctx->stream>>>(a);
+  conv3_wgrad_f32<<<(unsigned)(P * ncc * nco), 512, SMEM, ctx->stream>>>(a, total, nbx, nby, P);
   return 0;
 }
