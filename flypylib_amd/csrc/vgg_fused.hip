@@ -231,24 +231,40 @@ __device__ __forceinline__ unsigned kslot_entry(int idx) {
   return kslot_offset<TY, TX>(s, g);
 }
 
-// fill the activation tile by LDS-DMA: tile is TZ*TY rows of TX voxels (96 B)
+// fill the activation tile by LDS-DMA: tile is TZ*TY rows of TX voxels (96 B).
+// Piece idx = lane + 64 wave + 256 it is (row, 16-B column cw) of the tile; the
+// coordinates are divided out once and then advanced by constant steps, and the edge
+// clamp is a min against per-block bounds: ~10 VALU per piece (the flat index
+// arithmetic this replaces, with its divisions, made the fill VALU-bound).
 template <int TZ, int TY, int TX>
 __device__ __forceinline__ void stage_tile(const h16_t *act, int AZ, int AY, int AX,
                                            int z0, int y0, int x0,
                                            unsigned char *tile, int wave, int lane) {
-  constexpr int ROW_CHUNKS = TX * VOX_BYTES / 16;          // 16-B pieces per row
-  constexpr int TOTAL = TZ * TY * ROW_CHUNKS;
+  constexpr int RC = TX * VOX_BYTES / 16;                  // 16-B pieces per row
+  constexpr int TOTAL = TZ * TY * RC;
   constexpr int PIECES = (TOTAL + 63) / 64;
+  constexpr int DR = 256 / RC, DC = 256 % RC;              // advance per iteration
+  static_assert(DR + 1 < TY, "a step wraps at most one z row");
+  const int idx0 = wave * 64 + lane;
+  int row = idx0 / RC, cw = idx0 % RC;
+  int rz = row / TY, ry = row % TY;
+  // clamp: edge blocks only feed masked outputs
+  const int zmax = AZ - 1 - z0, ymax = AY - 1 - y0, xmax = AX - 1 - x0;
+  const unsigned SY = (unsigned)AX * VOX_BYTES, SZ = (unsigned)AY * SY;
+  const unsigned char *base = reinterpret_cast<const unsigned char *>(
+      act + (((int64_t)z0 * AY + y0) * AX + x0) * CH);
   for (int p = wave; p < PIECES; p += 4) {
-    int idx = p * 64 + lane;
-    idx = idx < TOTAL ? idx : TOTAL - 1;                   // tail lanes re-read
-    const int row = idx / ROW_CHUNKS, cw = idx % ROW_CHUNKS;
-    int z = z0 + row / TY, y = y0 + row % TY, x = x0 + cw / 6;
-    z = z < AZ ? z : AZ - 1;                               // clamp: edge blocks
-    y = y < AY ? y : AY - 1;                               // only feed masked
-    x = x < AX ? x : AX - 1;                               // outputs
-    const h16_t *gp = act + (((int64_t)z * AY + y) * AX + x) * CH + (cw % 6) * 8;
-    glds16(gp, tile + (size_t)p * 1024);
+    const bool past = rz >= TZ;                            // tail lanes re-read the last piece
+    const int rzc = past ? TZ - 1 : rz, ryc = past ? TY - 1 : ry, cwc = past ? RC - 1 : cw;
+    const int vx = cwc / 6, pc = cwc - 6 * vx;
+    const int zc = rzc < zmax ? rzc : zmax, yc = ryc < ymax ? ryc : ymax, xc = vx < xmax ? vx : xmax;
+    const unsigned off = (unsigned)zc * SZ + (unsigned)yc * SY + (unsigned)(xc * VOX_BYTES + pc * 16);
+    glds16(base + off, tile + (size_t)p * 1024);
+    cw += DC;
+    int dr = DR;
+    if (cw >= RC) { cw -= RC; ++dr; }
+    ry += dr;
+    if (ry >= TY) { ry -= TY; ++rz; }
   }
 }
 
@@ -256,7 +272,7 @@ __device__ __forceinline__ void stage_tile(const h16_t *act, int AZ, int AY, int
 // same for all waves) straight from global memory - L2 / L1 hits - into registers,
 // WQ K-steps ahead of their use: no LDS ring and no barrier inside the loop, so the
 // waves of a workgroup drift apart and keep the MFMA pipe fed.  (An LDS ring staged
-// through registers cost a barrier every KC steps and was 6% slower; the 4x L2
+// through registers cost a barrier every three steps and was 6% slower; the 4x L2
 // weight traffic, ~9 TB/s chip-wide, is well inside what L2 delivers.)
 constexpr int WQ = 4;
 
