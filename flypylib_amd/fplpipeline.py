@@ -251,6 +251,12 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
             num_processed += 1
             continue
         todo.append(szyx(rr.size, rr.z, rr.y, rr.x))
+    if dist is not None and world > 1:
+        # every rank must split the SAME list: a rank that starts late would otherwise
+        # see substacks the others have already written (control plane only)
+        box = [todo, num_processed]
+        dist.broadcast_object_list(box, src=0)
+        todo, num_processed = box
     mine = todo[rank::world]
     if rank == 0:
         print('already processed: %d' % num_processed)

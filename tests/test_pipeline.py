@@ -256,3 +256,67 @@ def test_full_roi_inference_with_a_segmentation(ctx, tmp_path):
     assert np.array_equal(got['locs'], want['locs'])
     np.testing.assert_allclose(got['conf'], want['conf'], rtol=0, atol=2e-6)
     assert len(got['conf']) != len(plain['conf'])
+
+
+def _roi_rank_worker(rank, world, port, wd, out_q):
+    """one rank of the substack-sharded pipeline (every rank on the one GPU of the box)"""
+    import traceback
+    try:
+        import torch.distributed as dist
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ['LOCAL_RANK'] = '0'
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        net, vol, roi = _small_setup()
+        out = fplobjdetect.full_roi_inference(vol, None, roi, net, 0.2, wd, [128., 33., 0.7],
+                                              obj_min_dist=5, smoothing_sigma=1.5, buffer_sz=10)
+        out_q.put((rank, 'ok', (np.asarray(out['locs']), np.asarray(out['conf']))))
+        dist.destroy_process_group()
+    except Exception:                                   # the parent reports it and ends the peers
+        out_q.put((rank, 'error', traceback.format_exc()))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_full_roi_inference_two_ranks_equals_one_process(ctx, tmp_path):
+    """substacks go round-robin over the ranks (todo[rank::world]), every rank writes its
+    substack pickles, rank 0 merges after a barrier: no data-path collective, and the
+    merged list is the single-process list (reference: one process walks the ROI,
+    fplobjdetect.py:1000-1090)"""
+    import multiprocessing as mp
+    import socket
+    net, vol, roi = _small_setup()
+    kw = dict(obj_min_dist=5, smoothing_sigma=1.5, buffer_sz=10)
+    one = fplobjdetect.full_roi_inference(vol, None, roi, net, 0.2, str(tmp_path / 'one'),
+                                          [128., 33., 0.7], **kw)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mctx = mp.get_context('spawn')
+    q = mctx.Queue()
+    wd = str(tmp_path / 'two')
+    procs = [mctx.Process(target=_roi_rank_worker, args=(r, 2, port, wd, q), daemon=True)
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(2):
+            rank, status, payload = q.get(timeout=240)
+            assert status == 'ok', 'rank %d failed:\n%s' % (rank, payload)
+            got[rank] = payload
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:                                 # a peer of a failed rank sits in a barrier
+            if p.is_alive():
+                p.terminate()
+    for rank in (0, 1):                                 # every rank returns the merged result
+        locs, conf = got[rank]
+        assert len(conf) == len(one['conf']) > 0
+        assert np.array_equal(locs, np.asarray(one['locs']))
+        assert np.array_equal(conf, np.asarray(one['conf']))
+    # each substack was written exactly once
+    done = [f for f in os.listdir(wd) if f.endswith('.p') and f != 'all.p']
+    assert len(done) == len(roi)
