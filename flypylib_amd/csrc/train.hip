@@ -221,6 +221,149 @@ __global__ void bn_backward4(const float4 *__restrict__ dy, const float4 *__rest
   dx[i] = make_float4(oo[0], oo[1], oo[2], oo[3]);
 }
 
+// ---- BN + ReLU + MaxPooling3D(2) as one layer (exactly tiling windows, C % 4 == 0).
+// Forward: a thread owns four channels of one pooling window, reads the eight BN
+// inputs, and writes the pooled ReLU output and the arg-max bytes; the full-resolution
+// ReLU output is never stored.  Backward: the gradient of that output is non-zero only
+// at the arg-max position (and only where the output was positive), so both BN passes
+// read x once plus the pooled gradient (1/8 of the size) and nothing else.
+struct PoolGeo { int D, H, W, od, oh, ow; };      // BN tensor dims, pooled dims
+
+__device__ __forceinline__ int64_t pool_base4(const PoolGeo &g, int64_t row, int C4) {
+  // row = pooled voxel (t, oz, oy, ox) -> float4 index of window position 0, channel 0
+  int64_t t = row;
+  const int ox = (int)(t % g.ow); t /= g.ow;
+  const int oy = (int)(t % g.oh); t /= g.oh;
+  const int oz = (int)(t % g.od); t /= g.od;
+  return ((((t * g.D + 2 * oz) * g.H + 2 * oy) * (int64_t)g.W + 2 * ox)) * C4;
+}
+__device__ __forceinline__ int64_t pool_pos4(const PoolGeo &g, int p, int C4) {
+  return ((int64_t)((p >> 2) * g.H + ((p >> 1) & 1)) * g.W + (p & 1)) * C4;
+}
+
+__global__ void bn_relu_pool4(const float4 *__restrict__ x, const float4 *__restrict__ mean,
+                              const float4 *__restrict__ invstd, const float4 *__restrict__ gamma,
+                              const float4 *__restrict__ beta, float4 *__restrict__ y,
+                              uint32_t *__restrict__ arg, int64_t n4, int C4, PoolGeo g) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i % C4);
+  const int64_t base = pool_base4(g, i / C4, C4) + c;
+  const float4 m = mean[c], s = invstd[c], ga = gamma[c], be = beta[c];
+  float4 v[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) v[p] = x[base + pool_pos4(g, p, C4)];
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  uint32_t am[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const float o[4] = {fmaxf(bn_affine(v[p].x, m.x, s.x, ga.x, be.x), 0.f),
+                        fmaxf(bn_affine(v[p].y, m.y, s.y, ga.y, be.y), 0.f),
+                        fmaxf(bn_affine(v[p].z, m.z, s.z, ga.z, be.z), 0.f),
+                        fmaxf(bn_affine(v[p].w, m.w, s.w, ga.w, be.w), 0.f)};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (o[q] > best[q]) { best[q] = o[q]; am[q] = (uint32_t)p; }   // first maximum wins
+  }
+  y[i] = make_float4(best[0], best[1], best[2], best[3]);
+  arg[i] = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+}
+
+// partial sums (sum g, sum g * xhat) of the masked gradient, rows = pooling windows
+__global__ void chan_reduce_pool4(const float4 *__restrict__ dyp, const uint32_t *__restrict__ arg,
+                                  const float4 *__restrict__ x, const float *__restrict__ mean,
+                                  const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                  const float *__restrict__ beta, int64_t Mp, int C, int rows,
+                                  double *__restrict__ part, PoolGeo g) {
+  extern __shared__ double red[];
+  const int c4 = threadIdx.x, r = threadIdx.y, R = blockDim.y, C4 = C / 4;
+  const int64_t row0 = (int64_t)blockIdx.x * rows;
+  const int64_t row1 = row0 + rows < Mp ? row0 + rows : Mp;
+  const float4 mu = reinterpret_cast<const float4 *>(mean)[c4];
+  const float4 is = reinterpret_cast<const float4 *>(invstd)[c4];
+  const float4 ga = reinterpret_cast<const float4 *>(gamma)[c4];
+  const float4 be = reinterpret_cast<const float4 *>(beta)[c4];
+  const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+  const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, e4[4] = {be.x, be.y, be.z, be.w};
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  for (int64_t m = row0 + r; m < row1; m += R) {
+    const int64_t base = pool_base4(g, m, C4) + c4;
+    float4 v[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) v[p] = x[base + pool_pos4(g, p, C4)];
+    const float4 d = dyp[m * C4 + c4];
+    const uint32_t a = arg[m * C4 + c4];
+    const float dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = (int)((a >> (8 * q)) & 255u);
+      float xv = 0.f;
+#pragma unroll
+      for (int pp = 0; pp < 8; ++pp) {
+        const float cand = q == 0 ? v[pp].x : q == 1 ? v[pp].y : q == 2 ? v[pp].z : v[pp].w;
+        xv = pp == p ? cand : xv;
+      }
+      const float gq = bn_affine(xv, m4[q], i4[q], g4[q], e4[q]) > 0.f ? dd[q] : 0.f;
+      const float xh = (xv - m4[q]) * i4[q];
+      s0[q] += gq; s1[q] += (double)gq * xh;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    red[(r * C + 4 * c4 + q) * 2 + 0] = s0[q];
+    red[(r * C + 4 * c4 + q) * 2 + 1] = s1[q];
+  }
+  __syncthreads();
+  const int t = threadIdx.y * blockDim.x + threadIdx.x;
+  if (t < C) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int k = 0; k < R; ++k) {
+      t0 += red[(k * C + t) * 2 + 0];
+      t1 += red[(k * C + t) * 2 + 1];
+    }
+    part[((int64_t)blockIdx.x * 2 + 0) * C + t] = t0;
+    part[((int64_t)blockIdx.x * 2 + 1) * C + t] = t1;
+  }
+}
+
+template <bool ACC>
+__global__ void bn_backward_pool4(const float4 *__restrict__ dyp, const uint32_t *__restrict__ arg,
+                                  const float4 *__restrict__ x, const float4 *__restrict__ mean,
+                                  const float4 *__restrict__ invstd, const float4 *__restrict__ gamma,
+                                  const float4 *__restrict__ beta, const float4 *__restrict__ sum_g,
+                                  const float4 *__restrict__ sum_g_xhat, float4 *__restrict__ dx,
+                                  int64_t n4, int C4, float inv_m, PoolGeo g) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i % C4);
+  const int64_t base = pool_base4(g, i / C4, C4) + c;
+  const float4 m = mean[c], s = invstd[c], ga = gamma[c], be = beta[c], sg = sum_g[c],
+               sx = sum_g_xhat[c], d = dyp[i];
+  const uint32_t a = arg[i];
+  const float mm[4] = {m.x, m.y, m.z, m.w}, ss[4] = {s.x, s.y, s.z, s.w},
+              gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w},
+              s0[4] = {sg.x, sg.y, sg.z, sg.w}, s1[4] = {sx.x, sx.y, sx.z, sx.w},
+              dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int64_t idx = base + pool_pos4(g, p, C4);
+    const float4 xv = x[idx];
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC) o = dx[idx];
+    float oo[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool hit = (int)((a >> (8 * q)) & 255u) == p &&
+                       bn_affine(xx[q], mm[q], ss[q], gg[q], bb[q]) > 0.f;
+      const float gq = hit ? dd[q] : 0.f;
+      const float xh = (xx[q] - mm[q]) * ss[q];
+      oo[q] += gg[q] * ss[q] * (gq - inv_m * s0[q] - xh * inv_m * s1[q]);
+    }
+    dx[idx] = make_float4(oo[0], oo[1], oo[2], oo[3]);
+  }
+}
+
 // sum of the nb partials of channel c, by one 256-thread block (fixed tree: the result
 // does not depend on scheduling); valid in thread 0
 __device__ __forceinline__ void block_sum_partials(const double *__restrict__ part, int nb,
@@ -922,14 +1065,32 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       bn_fused[li] = 1;
       relu_fused[li + 1] = 1;
     }
+  // ... and when that ReLU's only consumer is an exactly tiling 2x2x2 pool, the three run
+  // as one layer: the full-resolution ReLU output and its gradient never exist
+  std::vector<char> pool_fused(nl, 0), pool_skipped(nl, 0);
+  for (int li = 0; li + 2 < nl; ++li) {
+    if (!bn_fused[li]) continue;
+    const fpl_layer &B = t->layers[li], &R = t->layers[li + 1], &P = t->layers[li + 2];
+    const TShape x = shp[B.src0];
+    if (P.kind == FPL_L_POOL && P.src0 == R.dst && n_cons[R.dst] == 1 && R.dst != t->out_tensor &&
+        P.p[0] == 2 && P.p[1] == 2 && P.p[2] == 2 &&
+        x.d % 2 == 0 && x.h % 2 == 0 && x.w % 2 == 0 && x.c % 4 == 0 && x.c <= 256 &&
+        B.w_off[0] % 4 == 0 && B.w_off[1] % 4 == 0) {
+      pool_fused[li] = 1;
+      pool_skipped[li + 2] = 1;
+    }
+  }
 
   // ------------------------------ forward ------------------------------------
   for (int li = 0; li < nl; ++li) {
     const fpl_layer &L = t->layers[li];
     const TShape a = shp[L.src0], o = shp[L.dst];
     const int64_t n = (int64_t)batch * o.elems();
-    if (relu_fused[li]) continue;                 // produced by the BN before it
-    if (bn_fused[li]) {
+    if (relu_fused[li] || pool_skipped[li]) continue;   // produced by the BN before it
+    if (pool_fused[li]) {
+      const int pdst = t->layers[li + 2].dst;
+      FPL_TRY(alloc_f((int64_t)batch * shp[pdst].elems(), &val[pdst]));
+    } else if (bn_fused[li]) {
       FPL_TRY(alloc_f(n, &val[t->layers[li + 1].dst]));
     } else {
       FPL_TRY(alloc_f(n, &val[L.dst]));
@@ -975,7 +1136,19 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         bn_finish_stats<<<C, 256, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
             t->w + L.w_off[2], t->w + L.w_off[3], bn_mean[li], bn_invstd[li],
             t->g + L.w_off[2], t->g + L.w_off[3]);
-        if (v4) {
+        if (pool_fused[li]) {
+          typedef const float4 *cf4;
+          const int pl = li + 2, pdst = t->layers[pl].dst;
+          const TShape po = shp[pdst];
+          const int64_t np4 = (int64_t)batch * po.elems() / 4;
+          void *q;
+          FPL_TRY(tmp.alloc((size_t)np4 * 4, &q));
+          arg[pl] = (uint8_t *)q;
+          const PoolGeo geo = {a.d, a.h, a.w, po.d, po.h, po.w};
+          bn_relu_pool4<<<g1(np4), 256, 0, st>>>((cf4)val[L.src0], (cf4)bn_mean[li],
+              (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)(t->w + L.w_off[1]),
+              (float4 *)val[pdst], (uint32_t *)arg[pl], np4, C / 4, geo);
+        } else if (v4) {
           typedef const float4 *cf4;
           if (bn_fused[li])
             bn_apply4<true><<<g1(n / 4), 256, 0, st>>>((cf4)val[L.src0], (cf4)bn_mean[li],
@@ -1102,8 +1275,9 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
     const fpl_layer &L = t->layers[li];
     const TShape a = shp[L.src0], o = shp[L.dst];
     const int64_t n = (int64_t)batch * o.elems();
-    if (relu_fused[li]) continue;                 // handled with the BN before it
-    float *dy = bn_fused[li] ? grad[t->layers[li + 1].dst] : grad[L.dst];
+    if (relu_fused[li] || pool_skipped[li]) continue;   // handled with the BN before it
+    float *dy = pool_fused[li] ? grad[t->layers[li + 2].dst]
+                : bn_fused[li] ? grad[t->layers[li + 1].dst] : grad[L.dst];
     float *dx = L.src0 > 0 ? grad[L.src0] : nullptr;
     switch (L.kind) {
       case FPL_L_CONV: {
@@ -1182,6 +1356,31 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         const float *yrelu = bn_fused[li] ? val[t->layers[li + 1].dst] : nullptr;
         const bool v4 = C % 4 == 0 && (L.w_off[0] % 4) == 0 && (L.w_off[1] % 4) == 0;
         const int R4 = v4 ? std::max(1, 256 / (C / 4)) : 0;
+        if (pool_fused[li]) {
+          // dy is the POOLED gradient; rows = pooling windows
+          typedef const float4 *cf4;
+          const int pl = li + 2;
+          const TShape po = shp[t->layers[pl].dst];
+          const int64_t Mp = (int64_t)batch * po.vox();
+          const int rp = red_rows(Mp), nbp = (int)ceil_div64(Mp, rp);
+          const PoolGeo geo = {a.d, a.h, a.w, po.d, po.h, po.w};
+          chan_reduce_pool4<<<nbp, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
+              (cf4)dy, (const uint32_t *)arg[pl], (cf4)val[L.src0], bn_mean[li], bn_invstd[li],
+              t->w + L.w_off[0], t->w + L.w_off[1], Mp, C, rp, part, geo);
+          finish_sums<<<C, 256, 0, st>>>(part, nbp, C, sdy, sdyx, 1.f);
+          accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
+          accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
+          if (dx) {
+            const int64_t np4 = Mp * (C / 4);
+#define FPL_BNP4(ACC)                                                                         \
+  bn_backward_pool4<ACC><<<g1(np4), 256, 0, st>>>((cf4)dy, (const uint32_t *)arg[pl],          \
+      (cf4)val[L.src0], (cf4)bn_mean[li], (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]),        \
+      (cf4)(t->w + L.w_off[1]), (cf4)sdy, (cf4)sdyx, (float4 *)dx, np4, C / 4, 1.f / (float)M, geo)
+            if (assign[L.src0]) FPL_BNP4(false); else FPL_BNP4(true);
+#undef FPL_BNP4
+          }
+          break;
+        }
         if (v4 && bn_fused[li])
           chan_reduce_partial4<3><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
               dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, rr, part, t->w + L.w_off[0],

@@ -91,6 +91,36 @@ def test_vgg_like_step_dense_patch(ctx):
     _check_step(ctx, g, (3, 30, 30, 30, 1), labels, data_seed=1)
 
 
+def test_vgg_like_step_odd_pool_input(ctx):
+    """24^3 patches: the first pool sees 22^3 (exactly tiled: BN + ReLU + pool run as one
+    layer), the second 9^3 (floor pooling: the separate BN / ReLU / pool kernels)"""
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 6)
+    rng = np.random.default_rng(2)
+    labels = (rng.random((4, 2, 2, 2, 1)) > 0.6).astype(np.uint8)
+    _check_step(ctx, g, (4, 24, 24, 24, 1), labels, data_seed=2)
+
+
+def test_fused_and_separate_bn_relu_pool_agree(ctx, monkeypatch):
+    """the fused BN + ReLU + pool layer (forward and both backward passes) against the
+    separate kernels on the same step: same loss, same gradients to rounding"""
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 7)
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal((4, 30, 30, 30, 1)).astype(np.float32)
+    labels = (rng.random((4, 4, 4, 4, 1)) > 0.7).astype(np.uint8)
+    tr = _capi.Trainer(ctx, g)
+    loss_f, acc_f = tr.step(data, labels, seed=9)
+    grads_f = [x.copy() for x in tr.get_grads()]
+    monkeypatch.setenv('FPL_TRAIN_UNFUSED', '1')
+    tr2 = _capi.Trainer(ctx, g)
+    loss_u, acc_u = tr2.step(data, labels, seed=9)
+    grads_u = tr2.get_grads()
+    assert abs(loss_f - loss_u) < 1e-6 and acc_f == acc_u
+    for i, (a, b) in enumerate(zip(grads_f, grads_u)):
+        assert _rel(a, b) < 2e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
+
+
 def test_unet_like2_step(ctx):
     g = fplmodels.unet_like2()[0]
     synth.synthetic_weights(g, 5)
