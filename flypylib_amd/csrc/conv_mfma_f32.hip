@@ -97,6 +97,61 @@ __device__ __forceinline__ void store_quad(float *dst, int co0, int cout, const 
   }
 }
 
+// Per-channel (sum, sum of squares) of a kernel's OUTPUT, for the BatchNorm that follows
+// in training: every lane accumulates its own voxels in fp64, the 16 voxel lanes of a
+// channel are summed once at the end of the kernel, the four waves meet in LDS and the
+// workgroup writes one row of partials part[block][2][C] (the layout of train.hip's
+// channel reductions, finished there by bn_finish_stats).
+template <int MB>
+struct ChanStats {
+  double s0[MB][4], s1[MB][4];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s0[b][r] = 0.0; s1[b][r] = 0.0; }
+  }
+  __device__ __forceinline__ void add(int b, const f32x4 &v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s0[b][r] += v[r]; s1[b][r] += (double)v[r] * v[r]; }
+  }
+  // red: 4 * 2 * 16 * MB doubles of LDS
+  __device__ __forceinline__ void finish(double *red, double *part, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double a0 = s0[b][r], a1 = s1[b][r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          a0 += __shfl_xor(a0, off);
+          a1 += __shfl_xor(a1, off);
+        }
+        if (c == 0) {
+          red[(wave * 2 + 0) * 16 * MB + 16 * b + 4 * g + r] = a0;
+          red[(wave * 2 + 1) * 16 * MB + 16 * b + 4 * g + r] = a1;
+        }
+      }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < C) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        part[((int64_t)blockIdx.x * 2 + k) * C + t] =
+            (red[(0 * 2 + k) * 16 * MB + t] + red[(1 * 2 + k) * 16 * MB + t]) +
+            (red[(2 * 2 + k) * 16 * MB + t] + red[(3 * 2 + k) * 16 * MB + t]);
+    }
+  }
+};
+__device__ __forceinline__ f32x4 act4(const f32x4 &v, int act) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = act_f(v[r], act);
+  return o;
+}
+
 template <int MB>
 __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
   constexpr int RING = KC * MB * 1024;
@@ -224,10 +279,14 @@ struct Conv1F {
   const float *shift;
   int act;
   float *out; int cout;
+  double *stats;                           // STATS: part[grid][2][cout]
 };
 
-template <int MB>
+template <int MB, bool STATS>
 __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
+  __shared__ double red[STATS ? 4 * 2 * 16 * MB : 1];
+  ChanStats<STATS ? MB : 1> cs;
+  if (STATS) cs.clear();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int nkb = (a.cin + 15) / 16;
@@ -268,10 +327,14 @@ __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
     if (ok) {
       float *dst = a.out + m * a.cout;
 #pragma unroll
-      for (int b = 0; b < MB; ++b)
-        store_quad(dst, 16 * b + 4 * g, a.cout, acc[b], a.act);
+      for (int b = 0; b < MB; ++b) {
+        const f32x4 o = act4(acc[b], a.act);
+        store_quad(dst, 16 * b + 4 * g, a.cout, o, FPL_ACT_NONE);
+        if (STATS) cs.add(b, o);
+      }
     }
   }
+  if (STATS) cs.finish(red, a.stats, a.cout);
 }
 
 // ---- conv3 1 -> cout (fp32): 27 taps = 2 K-blocks (k-slot (j,g) of block q = tap
@@ -285,10 +348,14 @@ struct StemF {
   const float *shift;
   int act;
   float *out; int cout; int OD, OH, OW, zblocks;
+  double *stats;                 // STATS: part[blocks][2][cout], blocks in launch order
 };
 
-template <int MB>
+template <int MB, bool STATS>
 __global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
+  __shared__ double red[STATS ? 4 * 2 * 16 * MB : 1];
+  ChanStats<STATS ? MB : 1> cs;
+  if (STATS) cs.clear();
   __shared__ float tile[ST_TZ * ST_TY * ST_TX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -337,8 +404,20 @@ __global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = mfma4(w[q][b][j], bv[4 * q + j], acc);
-      if (ok) store_quad(dst, 16 * b + 4 * g, a.cout, acc, a.act);
+      if (ok) {
+        const f32x4 o = act4(acc, a.act);
+        store_quad(dst, 16 * b + 4 * g, a.cout, o, FPL_ACT_NONE);
+        if (STATS) cs.add(b, o);
+      }
     }
+  }
+  if (STATS) {
+    // partials row = linear block index
+    double *part = a.stats;
+    const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    __syncthreads();
+    // finish() indexes rows by blockIdx.x: shift the base instead
+    cs.finish(red, part + (blk - blockIdx.x) * 2 * a.cout, a.cout);
   }
 }
 
@@ -418,7 +497,8 @@ int launch_stem(fpl_ctx *ctx, StemF &a, int n) {
   a.zblocks = (int)ceil_div64(a.OD, ST_Z);
   dim3 grid((unsigned)ceil_div64(a.OW, ST_X), (unsigned)ceil_div64(a.OH, ST_Y), (unsigned)(n * a.zblocks));
   TimedLaunch tl(ctx, "mfma_stem_f32");
-  stem_cin1_f32<MB><<<grid, 256, 0, ctx->stream>>>(a);
+  if (a.stats) stem_cin1_f32<MB, true><<<grid, 256, 0, ctx->stream>>>(a);
+  else stem_cin1_f32<MB, false><<<grid, 256, 0, ctx->stream>>>(a);
   return 0;
 }
 
@@ -462,7 +542,8 @@ template <int MB>
 int launch1(fpl_ctx *ctx, Conv1F &a) {
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
   TimedLaunch tl(ctx, "mfma_conv1_f32");
-  conv1_f32<MB><<<grid, 256, 0, ctx->stream>>>(a);
+  if (a.stats) conv1_f32<MB, true><<<grid, 256, 0, ctx->stream>>>(a);
+  else conv1_f32<MB, false><<<grid, 256, 0, ctx->stream>>>(a);
   return 0;
 }
 
@@ -589,7 +670,7 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       Conv1F c;
       c.in = a.p; c.M = (int64_t)n * cube(a.D); c.cin = op.cin;
       c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
-      c.out = dst; c.cout = op.cout;
+      c.out = dst; c.cout = op.cout; c.stats = nullptr;
       const int mb = (op.cout + 15) / 16;
       switch (mb) {
         case 1: FPL_TRY(launch1<1>(ctx, c)); break;
@@ -605,7 +686,7 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       StemF c;
       c.in = a.p; c.D = c.H = c.W = a.D;
       c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
-      c.out = dst; c.cout = op.cout; c.OD = c.OH = c.OW = od;
+      c.out = dst; c.cout = op.cout; c.OD = c.OH = c.OW = od; c.stats = nullptr;
       const int mb = (op.cout + 15) / 16;
       switch (mb) {
         case 1: FPL_TRY(launch_stem<1>(ctx, c, n)); break;
@@ -1010,8 +1091,20 @@ bool fpl_tm_supported(int k, int cin, int cout) {
 }
 
 // y = act(conv(x, W) + bias); x (n,D,H,W,cin), W [k^3][cin][cout] on the device
+// rows of per-channel statistics partials fpl_tm_conv_fwd writes for this shape when
+// given a `stats` buffer (rows x 2 x cout doubles); 0 = that kernel has no fused statistics
+int64_t fpl_tm_conv_stats_rows(fpl_ctx *ctx, int n, int D, int H, int W_, int cin, int k, int cout) {
+  if (cout > 64) return 0;
+  const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
+  if (k == 3 && cin == 1)
+    return ceil_div64(ow, ST_X) * ceil_div64(oh, ST_Y) * n * ceil_div64(od, ST_Z);
+  if (k == 1) return std::min<int64_t>(ceil_div64((int64_t)n * D * H * W_, 64), (int64_t)ctx->n_cu * 8);
+  return 0;
+}
+
 int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int k,
-                    int cout, const float *Wd, const float *bias, int act, float *y) {
+                    int cout, const float *Wd, const float *bias, int act, float *y,
+                    double *stats) {
   DevTemp tmp(ctx);
   const int mb = (cout + 15) / 16;
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
@@ -1022,7 +1115,7 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
     pack_stem_dev<<<(unsigned)ceil_div64(tot, 256), 256, 0, ctx->stream>>>(Wd, (float *)fr, cout, mb, tot);
     StemF a;
     a.in = x; a.D = D; a.H = H; a.W = W_; a.w = (const float *)fr; a.shift = bias; a.act = act;
-    a.out = y; a.cout = cout; a.OD = od; a.OH = oh; a.OW = ow;
+    a.out = y; a.cout = cout; a.OD = od; a.OH = oh; a.OW = ow; a.stats = stats;
     switch (mb) {
       case 1: return launch_stem<1>(ctx, a, n);
       case 2: return launch_stem<2>(ctx, a, n);
@@ -1038,7 +1131,7 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
   if (k == 1) {
     Conv1F c;
     c.in = x; c.M = (int64_t)n * D * H * W_; c.cin = cin; c.w = (const float *)fr; c.shift = bias;
-    c.act = act; c.out = y; c.cout = cout;
+    c.act = act; c.out = y; c.cout = cout; c.stats = stats;
     switch (mb) {
       case 1: return launch1<1>(ctx, c);
       case 2: return launch1<2>(ctx, c);
@@ -1081,7 +1174,7 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
   if (k == 1) {
     Conv1F c;
     c.in = dy; c.M = (int64_t)n * od * oh * ow; c.cin = cout; c.w = (const float *)fr;
-    c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin;
+    c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin; c.stats = nullptr;
     switch (mb) {
       case 1: return launch1<1>(ctx, c);
       case 2: return launch1<2>(ctx, c);

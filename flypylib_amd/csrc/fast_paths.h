@@ -57,8 +57,12 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
 
 // fp32 MFMA convolutions for the training engine (conv_mfma_f32.hip)
 bool fpl_tm_supported(int k, int cin, int cout);
+// `stats` (optional): per-channel (sum, sum of squares) partials of y for a following
+// BatchNorm, fpl_tm_conv_stats_rows(...) rows x 2 x cout doubles (0 rows = not offered)
+int64_t fpl_tm_conv_stats_rows(fpl_ctx *ctx, int n, int D, int H, int W_, int cin, int k, int cout);
 int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int k,
-                    int cout, const float *Wd, const float *bias, int act, float *y);
+                    int cout, const float *Wd, const float *bias, int act, float *y,
+                    double *stats = nullptr);
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
                       int k, int cin, const float *Wd, const float *zeros, float *dx);
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,

@@ -1016,6 +1016,8 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   std::vector<float *> val(nt, nullptr), grad(nt, nullptr);
   std::vector<uint8_t *> arg(nl, nullptr);
   std::vector<float *> bn_mean(nl, nullptr), bn_invstd(nl, nullptr);
+  std::vector<double *> conv_stats(nt, nullptr);     // per tensor: statistics partials
+  std::vector<int> conv_stats_rows(nt, 0);
   auto alloc_f = [&](int64_t n, float **p) -> int {
     void *q;
     int rc = tmp.alloc((size_t)n * sizeof(float), &q);
@@ -1100,8 +1102,21 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         const int64_t n_vox = (int64_t)batch * o.vox();
         const float *bias = L.use_bias ? t->w + L.w_off[1] : t->zeros;
         if (use_mfma && fpl_tm_supported(L.k, L.cin, L.cout)) {
+          // a BatchNorm next in line gets its batch statistics from this kernel's epilogue
+          double *st_part = nullptr;
+          if (li + 1 < nl && t->layers[li + 1].kind == FPL_L_BN &&
+              t->layers[li + 1].src0 == L.dst && !getenv("FPL_TRAIN_UNFUSED")) {
+            const int64_t rows = fpl_tm_conv_stats_rows(ctx, batch, a.d, a.h, a.w, a.c, L.k, L.cout);
+            if (rows > 0 && rows < (1 << 30)) {
+              void *q;
+              FPL_TRY(tmp.alloc((size_t)rows * 2 * L.cout * sizeof(double), &q));
+              st_part = (double *)q;
+              conv_stats[L.dst] = st_part;
+              conv_stats_rows[L.dst] = (int)rows;
+            }
+          }
           FPL_TRY(fpl_tm_conv_fwd(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, L.k, L.cout,
-                                  t->w + L.w_off[0], bias, L.act, val[L.dst]));
+                                  t->w + L.w_off[0], bias, L.act, val[L.dst], st_part));
           break;
         }
         TimedLaunch tl(ctx, "train_conv_fwd");
@@ -1127,13 +1142,18 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         // float4 kernels when the per-channel vectors are 16-B aligned in the arena
         const bool v4 = C % 4 == 0 && (L.w_off[0] % 4) == 0 && (L.w_off[1] % 4) == 0;
         const int R4 = v4 ? std::max(1, 256 / (C / 4)) : 0;
-        if (v4)
+        const double *spart = part;
+        int snb = nb;
+        if (conv_stats[L.src0]) {                  // written by the producing convolution
+          spart = conv_stats[L.src0];
+          snb = conv_stats_rows[L.src0];
+        } else if (v4)
           chan_reduce_partial4<0><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
               val[L.src0], nullptr, nullptr, nullptr, M, C, rr, part);
         else
           chan_reduce_partial<0><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
               val[L.src0], nullptr, nullptr, nullptr, M, C, rr, part);
-        bn_finish_stats<<<C, 256, 0, st>>>(part, nb, C, M, 1e-3f, 0.99f,
+        bn_finish_stats<<<C, 256, 0, st>>>(spart, snb, C, M, 1e-3f, 0.99f,
             t->w + L.w_off[2], t->w + L.w_off[3], bn_mean[li], bn_invstd[li],
             t->g + L.w_off[2], t->g + L.w_off[3]);
         if (pool_fused[li]) {
