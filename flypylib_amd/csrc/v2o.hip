@@ -342,19 +342,28 @@ __global__ __launch_bounds__(256) void key_histogram(
     if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
 }
 
-// live-key volume on the cell-aligned grid (dims L0,L1,L2 = multiples of CELL)
+// live-key volume on the cell-aligned grid (dims L0,L1,L2 = multiples of CELL): a
+// thread writes one cell row (CELL = 4 consecutive x, one 16-B store); the grid is
+// (row pieces, y, z) so no index is divided out per voxel
 __global__ void build_live(const float *__restrict__ s, int64_t P0, int64_t P1,
                            int64_t P2, int64_t L1, int64_t L2, double thresh,
-                           uint32_t *__restrict__ live, int64_t n_live) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_live) return;
-  const int64_t x = i % L2, y = (i / L2) % L1, z = i / (L2 * L1);
-  uint32_t k = 0;
-  if (z < P0 && y < P1 && x < P2) {
-    const float v = s[(z * P1 + y) * P2 + x];
-    if ((double)v > thresh && v > 0.f) k = __float_as_uint(v);
+                           uint32_t *__restrict__ live) {
+  const int64_t x4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t y = (int64_t)blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
+  if (x4 * CELL >= L2 || y >= L1) return;
+  uint32_t k[CELL];
+  const bool row = z < P0 && y < P1;
+  const float *sp = s + (z * P1 + y) * P2 + x4 * CELL;
+#pragma unroll
+  for (int d = 0; d < CELL; ++d) {
+    k[d] = 0;
+    if (row && x4 * CELL + d < P2) {
+      const float v = sp[d];
+      if ((double)v > thresh && v > 0.f) k[d] = __float_as_uint(v);
+    }
   }
-  live[i] = k;
+  static_assert(CELL == 4, "one uint4 per cell row");
+  *reinterpret_cast<uint4 *>(live + (z * L1 + y) * L2 + x4 * CELL) = make_uint4(k[0], k[1], k[2], k[3]);
 }
 
 // best live key per 4x4x4 cell: (value bits << 32) | ~flat_index(padded volume).
@@ -856,8 +865,9 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   FPL_HIP(ctx, hipMemsetAsync(counters, 0, 4 * 8, st));
   {
     TimedLaunch tl(ctx, "v2o_build_live");
-    build_live<<<(unsigned)ceil_div64(n_live, 256), 256, 0, st>>>(
-        S.smoothed, P0, P1, P2, L1, L2, thresh, live, n_live);
+    FPL_REQUIRE(ctx, L1 < 65536 && L0 < 65536, "voxel2obj: volume too large for the live grid");
+    build_live<<<dim3((unsigned)ceil_div64(L2 / CELL, 64), (unsigned)ceil_div64(L1, 4), (unsigned)L0), dim3(64, 4), 0, st>>>(
+        S.smoothed, P0, P1, P2, L1, L2, thresh, live);
   }
   const unsigned cgrid = (unsigned)ceil_div64(n_cells, 256);
   unsigned long long host_cnt[4];
