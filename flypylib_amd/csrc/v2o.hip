@@ -371,16 +371,19 @@ __global__ void build_live(const float *__restrict__ s, int64_t P0, int64_t P1,
 // clear_balls) are re-scanned; the others keep their key.
 constexpr unsigned long long CELL_DIRTY = 1ull;    // no live key has value bits 0
 
-__global__ void cell_best(const uint32_t *__restrict__ live, int64_t L1,
+__global__ __launch_bounds__(256) void cell_best(const uint32_t *__restrict__ live, int64_t L1,
                           int64_t L2, int64_t P1, int64_t P2, int64_t C0,
                           int64_t C1, int64_t C2,
                           unsigned long long *__restrict__ best,
                           unsigned long long *__restrict__ counters, int first_round) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool in = c < C0 * C1 * C2;
-  unsigned long long b = 0;
-  if (in) {
-    b = first_round ? CELL_DIRTY : best[c];
+  // grid-stride over the cells; the live-cell count goes to counters[0] with ONE atomic
+  // per workgroup (one per wave on a single address cost 0.15 ms a round)
+  __shared__ unsigned wcount[4];
+  const int64_t n_cells = C0 * C1 * C2;
+  unsigned mine = 0;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long b = first_round ? CELL_DIRTY : best[c];
     if (b == CELL_DIRTY) {
       b = 0;
       const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
@@ -403,9 +406,16 @@ __global__ void cell_best(const uint32_t *__restrict__ live, int64_t L1,
         }
       best[c] = b;
     }
+    mine += b != 0;
   }
-  const unsigned long long m = __ballot(in && b != 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[0], (unsigned long long)__popcll(m));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (tot) atomicAdd(&counters[0], (unsigned long long)tot);
+  }
 }
 
 template <int AXIS>
@@ -468,14 +478,28 @@ __global__ __launch_bounds__(256) void clear_balls(
       uint32_t *rowp = live + ((z + dz) * L1 + (y + dy)) * L2 + x;
       for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0;
     }
-    // cells of the ball's bounding box lose their cached key (the r shell of the
-    // padded volume keeps every ball inside it)
+    // cached keys of the cells in the ball's bounding box (the r shell of the padded
+    // volume keeps every ball inside it): a cell wholly inside the ball has no live
+    // voxel left (key 0), a cell the ball does not reach keeps its key, only the cells
+    // the sphere cuts through are re-scanned next round
     const int64_t cz0 = (z - r) / CELL, cy0 = (y - r) / CELL, cx0 = (x - r) / CELL;
     const int nz = (int)((z + r) / CELL - cz0 + 1), ny = (int)((y + r) / CELL - cy0 + 1),
               nx = (int)((x + r) / CELL - cx0 + 1);
+    auto span2 = [](int64_t lo, int64_t centre, int &near2, int &far2) {
+      // squared distance range from `centre` to the integer interval [lo, lo + CELL - 1]
+      const int a = (int)(lo - centre), b = (int)(lo + CELL - 1 - centre);
+      const int n = a > 0 ? a : (b < 0 ? -b : 0);
+      const int f = -a > b ? -a : b;
+      near2 = n * n; far2 = f * f;
+    };
     for (int i = threadIdx.x; i < nz * ny * nx; i += blockDim.x) {
       const int64_t cz = cz0 + i / (ny * nx), cy = cy0 + (i / nx) % ny, cx = cx0 + i % nx;
-      best[(cz * C1 + cy) * C2 + cx] = CELL_DIRTY;
+      int nz2, fz2, ny2, fy2, nx2, fx2;
+      span2(cz * CELL, z, nz2, fz2);
+      span2(cy * CELL, y, ny2, fy2);
+      span2(cx * CELL, x, nx2, fx2);
+      if (nz2 + ny2 + nx2 > r * r) continue;                  // untouched
+      best[(cz * C1 + cy) * C2 + cx] = fz2 + fy2 + fx2 <= r * r ? 0ull : CELL_DIRTY;
     }
   }
 }
@@ -870,13 +894,14 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
         S.smoothed, P0, P1, P2, L1, L2, thresh, live);
   }
   const unsigned cgrid = (unsigned)ceil_div64(n_cells, 256);
+  const unsigned bgrid = std::min<unsigned>(cgrid, (unsigned)ctx->n_cu * 8);   // cell_best: grid-stride
   unsigned long long host_cnt[4];
   int rounds = 0;
   for (;;) {
     FPL_HIP(ctx, hipMemsetAsync(counters, 0, 2 * 8, st));   // live cells, round winners
     {
       TimedLaunch tl(ctx, "v2o_cell_best");
-      cell_best<<<cgrid, 256, 0, st>>>(live, L1, L2, P1, P2, C0, C1, C2, best,
+      cell_best<<<bgrid, 256, 0, st>>>(live, L1, L2, P1, P2, C0, C1, C2, best,
                                        counters, rounds == 0);
     }
     {
