@@ -421,7 +421,9 @@ __global__ __launch_bounds__(256) void cell_best(const uint32_t *__restrict__ li
 template <int AXIS>
 __global__ void window_max(const unsigned long long *__restrict__ in,
                            unsigned long long *__restrict__ out, int64_t C0,
-                           int64_t C1, int64_t C2, int hw) {
+                           int64_t C1, int64_t C2, int hw,
+                           const unsigned long long *__restrict__ counters) {
+  if (counters[0] == 0) return;        // no live cell left: the closing round is a no-op
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C0 * C1 * C2) return;
   const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
@@ -906,9 +908,9 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
     }
     {
       TimedLaunch tl(ctx, "v2o_window_max");
-      window_max<2><<<cgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw);
-      window_max<1><<<cgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw);
-      window_max<0><<<cgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw);
+      window_max<2><<<cgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw, counters);
+      window_max<1><<<cgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw, counters);
+      window_max<0><<<cgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw, counters);
     }
     {
       TimedLaunch tl(ctx, "v2o_pick_winners");
