@@ -341,7 +341,7 @@ static_assert(2 * M_SMEM <= 160 * 1024, "two mid workgroups must fit one CU");
 struct MidArgs {
   const h16_t *p1;
   int P1Z, P1Y, P1X;
-  const unsigned char *w3;       // 42 x 3 fragments
+  const unsigned char *w3;       // KSTEPS x 3 fragments
   const h16x8 *w4;              // [s][b][lane]
   const float *shift3, *shift4;
   h16_t *p2;
@@ -438,7 +438,7 @@ static_assert(2 * H_SMEM <= 160 * 1024, "two c5 workgroups must fit one CU");
 struct C5Args {
   const h16_t *p2;
   int P2Z, P2Y, P2X;
-  const unsigned char *w5;       // 42 x 3 fragments
+  const unsigned char *w5;       // KSTEPS x 3 fragments
   const float *shift5;
   h16_t *c5;
   int CZ, CY, CX;                // chunk-local coarse dims (= c5 dims)
