@@ -38,6 +38,14 @@ constexpr int KSTEPS = 41;             // 27*48 = 1296 -> 40.5 K-steps of 32
 // -------------------------------------------------------------------------------
 constexpr int S_PZ = 4, S_PY = 8, S_PX = 32;
 constexpr int S_TZ = 2 * S_PZ + 2, S_TY = 2 * S_PY + 2, S_TX = 2 * S_PX + 2;
+// Row pitch of the LDS tile in elements.  The gather reads of a half-wave (lane groups
+// g = 0,1 and g = 2,3) hit rows that are 2 rows, 1 row +- 1 plane and 1 plane apart:
+// with a pitch of 40 dwords and 18 rows per plane those are 16, 24 and 16 banks apart,
+// so the two 16-lane groups never share a bank (at the natural pitch of 33 dwords
+// three of the five reads were 2-way conflicted: 38 % of the LDS cycles).
+constexpr int S_TP = 80;
+static_assert(S_TP >= S_TX && (2 * (S_TP / 2)) % 64 >= 16 && (S_TY * (S_TP / 2)) % 64 == 16,
+              "stem tile pitch: bank spread of the gather");
 
 struct StemArgs {
   const void *src;
@@ -53,12 +61,12 @@ struct StemArgs {
 
 // element offset of tap row `row` = (tz,ty) inside the input tile
 __device__ __forceinline__ int stem_row_off(int row) {
-  return ((row / 3) * S_TY + row % 3) * S_TX;
+  return ((row / 3) * S_TY + row % 3) * S_TP;
 }
 
 template <typename SRC>
 __global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned short tile[S_TZ * S_TY * S_TX];
+  __shared__ __attribute__((aligned(16))) unsigned short tile[S_TZ * S_TY * S_TP];
   __shared__ unsigned short lut[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -103,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
           if (ok[k] && x0_ok) b0 = h16_bits(((float)v0[k] - a.mean) / a.sd);
           if (ok[k] && x1_ok) b1 = h16_bits(((float)v1[k] - a.mean) / a.sd);
         }
-        tile[row * S_TX + lane] = b0;
-        if (lane < 2) tile[row * S_TX + 64 + lane] = b1;
+        tile[row * S_TP + lane] = b0;
+        if (lane < 2) tile[row * S_TP + 64 + lane] = b1;
       }
     }
   }
@@ -120,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
                               : stem_row_off(6 + i) + (e == 0 ? 2 : 0));
 #pragma unroll
     for (int h = 0; h < 2; ++h)
-      offS[e][h] = g < 3 ? 2 * (stem_row_off(2 * g + h) + (e == 0 ? 2 : 1)) : 0;
+      // g = 3 (k-slots 30, 31: zero weights) mirrors g = 2: same address, no bank conflict
+      offS[e][h] = 2 * (stem_row_off(2 * (g < 3 ? g : 2) + h) + (e == 0 ? 2 : 1));
   }
   h16x8 w1[2][3], w2[2][3];
   f32x4 sh1[3], sh2[3];
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
   for (int task = wave; task < S_PZ * S_PY * 2; task += 4) {
     const int row = task >> 1, xh = task & 1;
     const int pzl = row / S_PY, pyl = row % S_PY;
-    const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TX + 2 * (16 * xh + c));
+    const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TP + 2 * (16 * xh + c));
     // max-pool in fp32, two window positions per v_max3_f32 (rounding to bf16 is
     // monotonic, so rounding the fp32 max equals the max of the rounded values);
     // the initial 0 is the ReLU
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
       f32x4 a2[2][3];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {                 // sub = 2 sp + e: x parity e
-        const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TX);
+        const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
         u32x4 raw;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
