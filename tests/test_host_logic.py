@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from flypylib_amd import _capi, fplmodels, multi_gpu, program
+from flypylib_amd import _capi, fplmodels, multi_gpu, program, synth
 from oracle import cnn_oracle, infer_oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -175,3 +175,46 @@ def test_oracle_graph_interpreter_agrees_with_handwritten_forwards():
     a = cnn_oracle.unet_like2_forward(x, g.weights)
     b = cnn_oracle.graph_forward(g, x)
     assert a.shape == (1, 10, 10, 10, 1) and np.allclose(a, b, atol=1e-6)
+
+
+def test_keras_h5_converter_walks_layers_in_get_weights_order(tmp_path):
+    """tools/keras_h5_to_npz.py on a stand-in for the h5py tree of a Keras file (h5py is
+    absent here): arrays come out in `layer_names` x `weight_names` order and load into
+    the vgg_like graph"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'keras_h5_to_npz', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'tools', 'keras_h5_to_npz.py'))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+
+    class Node(dict):
+        def __init__(self, items=(), attrs=None):
+            super().__init__(items)
+            self.attrs = attrs or {}
+
+    graph = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(graph, 5)
+    ws = graph.get_weights()
+    # one Keras layer per 1 (conv) / 4 (BN) / 2 (conv + bias) arrays, names as Keras writes them
+    layers, names, i, k = {}, [], 0, 0
+    while i < len(ws):
+        n = 4 if ws[i].ndim == 1 and i + 3 < len(ws) and all(w.ndim == 1 for w in ws[i:i + 4]) else \
+            (2 if ws[i].ndim == 5 and i + 1 < len(ws) and ws[i + 1].ndim == 1 and ws[i + 1].shape[0] == ws[i].shape[-1] == 1 else 1)
+        lname = 'layer_%d' % k
+        wn = ['%s/w%d:0' % (lname, j) for j in range(n)]
+        layers[lname] = Node({w: ws[i + j] for j, w in enumerate(wn)},
+                             {'weight_names': [w.encode() for w in wn]})
+        names.append(lname.encode())
+        i += n
+        k += 1
+    root = Node({'model_weights': Node(layers, {'layer_names': names})})
+    got = conv.keras_weight_list(root)
+    assert len(got) == len(ws) and all(np.array_equal(a, b) for (_, a), b in zip(got, ws))
+    conv.check_against(got, 'vgg_like')
+    np.savez(str(tmp_path / 'w.npz'), *[a for _, a in got])
+    g2 = fplmodels.vgg_like()[0]
+    g2.load(str(tmp_path / 'w.npz'))
+    assert all(np.array_equal(a, b) for a, b in zip(g2.get_weights(), ws))
+    with pytest.raises(SystemExit):
+        conv.check_against(got[:-1], 'vgg_like')
