@@ -15,6 +15,7 @@
 #include "../../include/fplhip.h"
 
 #define FPL_MAX_ERR 1024
+#define FPL_MAX_DEVICES 64
 
 struct KernelStat {
   double ms = 0.0;

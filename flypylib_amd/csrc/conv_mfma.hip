@@ -640,11 +640,13 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   // STEM keeps the bf16 raw tile behind the (single) offset table
   constexpr int SMEM = TILE_BYTES + (STEM ? TABN * 4 + NRAW * 2 : TAB_BYTES);
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function attributes belong to the current device: one flag per device (a process may
+  // drive several GPUs, one context each; setting it twice is harmless)
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL, HEAD>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_set = true;
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
   // offset tables: one per distinct source geometry
   a.ntab = 0;

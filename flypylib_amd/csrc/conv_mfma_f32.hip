@@ -525,11 +525,13 @@ struct View {
 template <int MB>
 int launch3(fpl_ctx *ctx, Conv3F &a, int n) {
   constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function attributes belong to the current device: one flag per device (a process may
+  // drive several GPUs, one context each; setting it twice is harmless)
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_f32<MB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_set = true;
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
   a.zblocks = (int)ceil_div64(a.OD, 4);
   dim3 grid((unsigned)ceil_div64(a.OW, 16), (unsigned)ceil_div64(a.OH, 4), (unsigned)(n * a.zblocks));
@@ -1241,11 +1243,13 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
     return 0;
   }
   constexpr int SMEM = TILE_BYTES + 256 * WG_YP;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function attributes belong to the current device: one flag per device (a process may
+  // drive several GPUs, one context each; setting it twice is harmless)
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_wgrad_f32,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_set = true;
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
   const int nbx = (int)ceil_div64(ow, 16), nby = (int)ceil_div64(oh, 4);
   const int64_t total = (int64_t)nbx * nby * n * a.zblocks;

@@ -978,11 +978,13 @@ int fpl_v2o_nms_seg(fpl_ctx *ctx, double thresh, int32_t seg_dilate, int32_t seg
               ctx->v2o.r);
   FPL_REQUIRE(ctx, seg_dilate >= 0 && seg_force >= 0 && seg_force <= ctx->v2o.r,
               "fpl_v2o_nms_seg: seg_dilate %d / seg_force %d out of range", seg_dilate, seg_force);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // function attributes belong to the current device: one flag per device (a process may
+  // drive several GPUs, one context each; setting it twice is harmless)
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)clear_balls_seg,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 63 * 63 * 8));
-    attr_set = true;
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
   return v2o_nms(ctx, thresh, out_zyxv, cap, n_out, n_rounds, true, seg_dilate, seg_force);
 }
