@@ -41,9 +41,9 @@ KERNEL_LAYERS = {
     'vgg_stem_pool_bf16': ('L1', 'L2'), 'vgg_stem_pool_f32': ('L1', 'L2'),
     'vgg_mid_pool_bf16': ('L3', 'L4'), 'vgg_mid_pool_f32': ('L3', 'L4'),
     'vgg_head_bf16': ('L5', 'L6', 'L7', 'L8'),
-    'vgg_c5_bf16': ('L5',), 'vgg_tail_bf16': ('L6', 'L7', 'L8'),
+    'vgg_c5_tail_bf16': ('L5', 'L6', 'L7', 'L8'),
     'vgg_stem_pool_f16': ('L1', 'L2'), 'vgg_mid_pool_f16': ('L3', 'L4'),
-    'vgg_c5_f16': ('L5',), 'vgg_tail_f16': ('L6', 'L7', 'L8'),
+    'vgg_c5_tail_f16': ('L5', 'L6', 'L7', 'L8'),
     'vgg_head_f32': ('L5', 'L6', 'L7', 'L8'),
 }
 PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense

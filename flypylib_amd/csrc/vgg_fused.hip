@@ -5,10 +5,9 @@
 //                       conv1 48->48 +BN+ReLU -> maxpool2            -> P1 (bf16)
 //   vgg_mid_pool_bf16   P1 -> conv3 48->48 +BN+ReLU -> conv1 48->48 +BN+ReLU ->
 //                       maxpool2                                     -> P2 (bf16)
-//   vgg_c5_bf16         P2 -> conv3 48->48 +BN+ReLU                  -> C5 (bf16)
-//   vgg_tail_bf16       C5 -> conv1 48->96 -> conv1 96->96 -> conv1 96->1 +bias ->
-//                       sigmoid -> x4 nearest upsample, stored straight into the
-//                       (Z,Y,X) f32 prediction volume
+//   vgg_c5_tail_bf16    P2 -> conv3 48->48 +BN+ReLU -> conv1 48->96 -> conv1 96->96 ->
+//                       conv1 96->1 +bias -> sigmoid -> x4 nearest upsample, stored
+//                       straight into the (Z,Y,X) f32 prediction volume
 //
 // The 100^3 x 48 full-resolution activations never leave registers; P1 (12 B per
 // output voxel) and P2 (1.5 B) are the only intermediates in HBM.  BN is folded:
@@ -435,25 +434,39 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
 }
 
 // -------------------------------------------------------------------------------
-// K3a: conv3 48->48 + BN + ReLU on P2 -> C5 (bf16, quarter resolution).  Same
-// structure as K2 (two workgroups per CU) without the pool: block 4(z) x 4(y) x
-// 16(x), wave = z, sub-steps = the 4 y rows.
+// K3: conv3 48->48 + BN + ReLU on P2 and the 1x1 head.  Same structure as K2 (two
+// workgroups per CU) without the pool: block 4(z) x 4(y) x 16(x), wave = z,
+// sub-steps = the 4 y rows.
 // -------------------------------------------------------------------------------
 constexpr int H_TZ = 6, H_TY = 6, H_TX = 18;
 constexpr int H_TILE_BYTES = ((H_TZ * H_TY * H_TX * VOX_BYTES + 1023) / 1024) * 1024;
 constexpr int H_SMEM = H_TILE_BYTES + KTAB_BYTES;
 static_assert(2 * H_SMEM <= 160 * 1024, "two c5 workgroups must fit one CU");
 
-struct C5Args {
+constexpr int H_W6 = 12, H_W7 = 18, H_W8 = 3;       // fragment counts of L6, L7, L8
+
+struct C5TailArgs {
   const h16_t *p2;
   int P2Z, P2Y, P2X;
   const unsigned char *w5;       // KSTEPS x 3 fragments
   const float *shift5;
-  h16_t *c5;
-  int CZ, CY, CX;                // chunk-local coarse dims (= c5 dims)
+  int CZ, CY, CX;                // chunk-local coarse dims
+  const unsigned char *wtail;    // L6 [2][6], L7 [3][6], L8 [3][1] fragments
+  const float *shift6, *shift7;
+  float bias8;
+  float *dst;                    // (Z,Y,X) prediction volume, row 0
+  int64_t DY, DX;                // its pitches
+  int64_t gz0;                   // global coarse z of chunk-local coarse row 0
+  int64_t VZ, VY, VX;            // valid fine extents (dim - 14)
 };
 
-__global__ __launch_bounds__(256, 2) void FPLK(vgg_c5)(C5Args a) {
+// conv3 48->48 +BN+ReLU on P2, then - in registers, on the wave's four sub-steps in
+// lockstep so that every weight fragment is loaded once per wave - conv1 48->96,
+// conv1 96->96, conv1 96->1 + bias, sigmoid, and the x4 nearest upsample stored
+// straight into the (Z,Y,X) f32 prediction volume.  The accumulators of one layer are
+// the B fragments of the next (k-slot (s,g,j) = channel 16(2s + (j>>2)) + 4g + (j&3)),
+// so nothing is exchanged between lanes until the logit (lane (c, g=0), register 0).
+__global__ __launch_bounds__(256, 2) void FPLK(vgg_c5_tail)(C5TailArgs a) {
   unsigned char *tile = smem;
   unsigned *kofftab = reinterpret_cast<unsigned *>(smem + H_TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -476,103 +489,75 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_c5)(C5Args a) {
   auto sub_off = [](int sub) -> unsigned { return (unsigned)(sub * H_TX * VOX_BYTES); };
   conv3_kloop<4>(tile, kofftab, a.w5, vbase, sub_off, acc, tid);
 
+  const unsigned char *wt = a.wtail + lane * 16;
+  auto wfrag = [&](int f) { return *reinterpret_cast<const h16x8 *>(wt + (size_t)f * 1024); };
+  // C5 = ReLU(acc) as B fragments
+  h16x8 h5[4][2];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    h5[sub][0] = pack_relu(acc[sub][0], acc[sub][1]);
+    h5[sub][1] = pack_relu_lo(acc[sub][2]);
+  }
+  h16x8 h6[4][3];
+  {
+    f32x4 a6[4][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      f32x4 sh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sh[r] = a.shift6[16 * b + 4 * g + r];
+      const h16x8 w0 = wfrag(0 * 6 + b), w1 = wfrag(1 * 6 + b);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+        a6[sub][b] = mfma16(w1, h5[sub][1], mfma16(w0, h5[sub][0], sh));
+    }
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) h6[sub][s] = pack_relu(a6[sub][2 * s], a6[sub][2 * s + 1]);
+  }
+  h16x8 h7[4][3];
+  {
+    f32x4 a7[4][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      f32x4 sh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sh[r] = a.shift7[16 * b + 4 * g + r];
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) a7[sub][b] = sh;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const h16x8 w = wfrag(H_W6 + s * 6 + b);
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) a7[sub][b] = mfma16(w, h6[sub][s], a7[sub][b]);
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) h7[sub][s] = pack_relu(a7[sub][2 * s], a7[sub][2 * s + 1]);
+  }
+  f32x4 a8[4];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) a8[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const h16x8 w = wfrag(H_W6 + H_W7 + s);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) a8[sub] = mfma16(w, h7[sub][s], a8[sub]);
+  }
+
   const int cz = cz0 + wave, cx = cx0 + c;
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
     const int cy = cy0 + sub;
-    if (cz < a.CZ && cy < a.CY && cx < a.CX) {
-      h16_t *dst = a.c5 + (((int64_t)cz * a.CY + cy) * a.CX + cx) * CH + 4 * g;
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        u32x2 o;
-        o[0] = pk_max_i16(cvt_pk_h16(acc[sub][b][0], acc[sub][b][1]), 0u);
-        o[1] = pk_max_i16(cvt_pk_h16(acc[sub][b][2], acc[sub][b][3]), 0u);
-        *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
-      }
-    }
-  }
-}
-
-// -------------------------------------------------------------------------------
-// K3b: conv1 48->96 -> conv1 96->96 -> conv1 96->1 + bias -> sigmoid -> x4 nearest
-// upsample, stored straight into the (Z,Y,X) f32 prediction volume.  A pure
-// register chain per group of 16 coarse voxels (B fragments come from C5 in
-// accumulator order: two 8-byte pieces per K-step); the 33 KiB of weight fragments
-// sit in LDS.  Dominated by the 4 B/voxel output store.
-// -------------------------------------------------------------------------------
-constexpr int H_W6 = 12, H_W7 = 18, H_W8 = 3;       // fragment counts
-constexpr int H_WTAIL_BYTES = (H_W6 + H_W7 + H_W8) * 1024;
-
-struct TailArgs {
-  const h16_t *c5;
-  int CZ, CY, CX;                // chunk-local coarse dims
-  const unsigned char *wtail;    // L6 [2][6], L7 [3][6], L8 [3][1] fragments
-  const float *shift6, *shift7;
-  float bias8;
-  float *dst;                    // (Z,Y,X) prediction volume, row 0
-  int64_t DY, DX;                // its pitches
-  int64_t cz0;                   // global coarse z of chunk-local coarse row 0
-  int64_t VZ, VY, VX;            // valid fine extents (dim - 14)
-};
-
-__global__ __launch_bounds__(256) void FPLK(vgg_tail)(TailArgs a) {
-  unsigned char *wtail = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  for (int i = tid; i < H_WTAIL_BYTES / 16; i += 256)
-    reinterpret_cast<u32x4 *>(wtail)[i] = reinterpret_cast<const u32x4 *>(a.wtail)[i];
-  const h16x8 *w6 = reinterpret_cast<const h16x8 *>(wtail);
-  const h16x8 *w7 = w6 + H_W6 * 64;
-  const h16x8 *w8 = w7 + H_W7 * 64;
-  f32x4 sh6[6], sh7[6];
-#pragma unroll
-  for (int b = 0; b < 6; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      sh6[b][r] = a.shift6[16 * b + 4 * g + r];
-      sh7[b][r] = a.shift7[16 * b + 4 * g + r];
-    }
-  __syncthreads();
-  const int xg = (a.CX + 15) / 16;
-  const int64_t groups = (int64_t)a.CZ * a.CY * xg;
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
-    const int cxb = (int)(grp % xg), cy = (int)((grp / xg) % a.CY), cz = (int)(grp / ((int64_t)xg * a.CY));
-    const int cx = cxb * 16 + c;
-    const int cxl = cx < a.CX ? cx : a.CX - 1;
-    const h16_t *src = a.c5 + (((int64_t)cz * a.CY + cy) * a.CX + cxl) * CH + 4 * g;
-    // B fragments in accumulator order: k-slot (s,g,j) = channel 16(2s + (j>>2)) + 4g + (j&3)
-    const u32x2 q0 = *reinterpret_cast<const u32x2 *>(src);
-    const u32x2 q1 = *reinterpret_cast<const u32x2 *>(src + 16);
-    const u32x2 q2 = *reinterpret_cast<const u32x2 *>(src + 32);
-    h16x8 h[3];
-    h[0] = __builtin_bit_cast(h16x8, u32x4{q0[0], q0[1], q1[0], q1[1]});
-    h[1] = __builtin_bit_cast(h16x8, u32x4{q2[0], q2[1], 0u, 0u});
-    f32x4 a6[6];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      a6[b] = mfma16(w6[(0 * 6 + b) * 64 + lane], h[0], sh6[b]);
-      a6[b] = mfma16(w6[(1 * 6 + b) * 64 + lane], h[1], a6[b]);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) h[s] = pack_relu(a6[2 * s], a6[2 * s + 1]);
-    f32x4 a7[6];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      a7[b] = sh7[b];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) a7[b] = mfma16(w7[(s * 6 + b) * 64 + lane], h[s], a7[b]);
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) h[s] = pack_relu(a7[2 * s], a7[2 * s + 1]);
-    f32x4 a8 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 3; ++s) a8 = mfma16(w8[s * 64 + lane], h[s], a8);
     // lane (c, g=0) register 0 holds the logit of coarse voxel c
-    const float logit = __shfl(a8[0], c) + a.bias8;
+    const float logit = __shfl(a8[sub][0], c) + a.bias8;
     const float p = 1.f / (1.f + __expf(-logit));
     // x4 upsample store: lane (c,g) writes 4 fine x of fine row (4cy+g), 4 z rows
-    if (cx < a.CX) {
-      const int64_t fz0 = 4 * (a.cz0 + cz), fy = 4 * (int64_t)cy + g, fx0 = 4 * (int64_t)cx;
+    if (cz < a.CZ && cy < a.CY && cx < a.CX) {
+      const int64_t fz0 = 4 * (a.gz0 + cz), fy = 4 * (int64_t)cy + g, fx0 = 4 * (int64_t)cx;
       if (fy < a.VY && fx0 < a.VX) {
         const int nx = (int)(a.VX - fx0 < 4 ? a.VX - fx0 : 4);
 #pragma unroll
@@ -687,7 +672,7 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool)<true>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_c5),
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_c5_tail),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM));
   st->version = prog->arena_version;
   return 0;
@@ -739,8 +724,6 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
   void *p1v, *p2v;
   FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 6) * p1_row_bytes, &p1v));
   FPL_TRY(tmp.alloc((size_t)(cz_chunk + 2) * P2Y * P2X * VOX_BYTES, &p2v));
-  void *c5v;
-  FPL_TRY(tmp.alloc((size_t)cz_chunk * CY * CX * VOX_BYTES + 64, &c5v));
   const unsigned char *F = st->frags;
   const float *S = st->shifts;
   for (int64_t c0 = cz_lo; c0 < cz_hi; c0 += cz_chunk) {
@@ -800,26 +783,18 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
       }
     }
     {
-      C5Args a;
+      C5TailArgs a;
       a.p2 = (const h16_t *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
       a.w5 = F + st->off_w[4]; a.shift5 = S + st->off_s[4];
-      a.c5 = (h16_t *)c5v; a.CZ = CZ; a.CY = CY; a.CX = CX;
-      dim3 grid((unsigned)ceil_div64(CX, 16), (unsigned)ceil_div64(CY, 4),
-                (unsigned)ceil_div64(CZ, 4));
-      TimedLaunch tl(ctx, "vgg_c5_" FPL_PREC_STR);
-      FPLK(vgg_c5)<<<grid, 256, H_SMEM, stream>>>(a);
-    }
-    {
-      TailArgs a;
-      a.c5 = (const h16_t *)c5v; a.CZ = CZ; a.CY = CY; a.CX = CX;
+      a.CZ = CZ; a.CY = CY; a.CX = CX;
       a.wtail = F + st->off_w[5];      // L6, L7, L8 fragments are contiguous
       a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
-      a.dst = dst; a.DY = SY; a.DX = SX; a.cz0 = c0;
+      a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
       a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX;
-      const int64_t groups = (int64_t)CZ * CY * ceil_div64(CX, 16);
-      const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(groups, 4), (int64_t)ctx->n_cu * 16);
-      TimedLaunch tl(ctx, "vgg_tail_" FPL_PREC_STR);
-      FPLK(vgg_tail)<<<grid, 256, H_WTAIL_BYTES, stream>>>(a);
+      dim3 grid((unsigned)ceil_div64(CX, 16), (unsigned)ceil_div64(CY, 4),
+                (unsigned)ceil_div64(CZ, 4));
+      TimedLaunch tl(ctx, "vgg_c5_tail_" FPL_PREC_STR);
+      FPLK(vgg_c5_tail)<<<grid, 256, H_SMEM, stream>>>(a);
     }
     FPL_HIP(ctx, hipGetLastError());
   }

@@ -67,7 +67,7 @@ def run_group(name, counters, out, bench_args, script='bench.py'):
 
 def short(name):
     for key in ('conv3_bf16', 'conv1_bf16', 'stem_cin1_bf16', 'pool2_bf16',
-                'vgg_c5', 'vgg_tail', 'gather_tiles', 'stitch_tiles'):
+                'vgg_c5_tail', 'gather_tiles', 'stitch_tiles'):
         if key in name:
             i = name.index(key)
             return name[i:].split('(')[0].replace('(anonymous namespace)::', '')
