@@ -334,6 +334,25 @@ __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
   }
 }
 
+// Block order of the 3x3x3 kernels.  Workgroups go round-robin over the 8 XCDs, each with
+// its own L2.  The 1-D grid is decoded with the z block's low three bits fastest, so an
+// XCD owns whole z slabs: the x and y neighbours of a block - whose input tiles overlap
+// and whose output rows share cache lines - meet in one L2.  (z neighbours never do, in
+// any order: they are thousands of workgroups apart.)
+struct BlockGrid { int nbx, nby, nbz; };
+inline unsigned block_grid_size(const BlockGrid &g) {
+  return (unsigned)((int64_t)g.nbx * g.nby * ((g.nbz + 7) / 8 * 8));
+}
+__device__ __forceinline__ bool block_coords(const BlockGrid &g, int &xb, int &yb, int &zb) {
+  unsigned q = blockIdx.x;
+  const int z8 = (int)(q & 7u);
+  q >>= 3;
+  xb = (int)(q % (unsigned)g.nbx); q /= (unsigned)g.nbx;
+  yb = (int)(q % (unsigned)g.nby);
+  zb = (int)(q / (unsigned)g.nby) * 8 + z8;
+  return zb < g.nbz;
+}
+
 // -------------------------------------------------------------------------------
 // K2: conv3 48->48 + conv1 48->48 + maxpool2.  WG = 4 waves, pre-pool block
 // 4 x 4 x 16 (pooled 2 x 2 x 8); wave = one pooled (pz,py) row; lanes = 16
@@ -355,6 +374,7 @@ struct MidArgs {
   h16_t *p2;
   int P2Z, P2Y, P2X;
   unsigned long long *dbg;       // diagnostic build only: 4 stamps per workgroup
+  BlockGrid bg;
 };
 
 template <bool DIAG>
@@ -365,7 +385,9 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
   unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int px0 = blockIdx.x * 8, py0 = blockIdx.y * 2, pz0 = blockIdx.z * 2;
+  int xb, yb, zb;
+  if (!block_coords(a.bg, xb, yb, zb)) return;
+  const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 2;
 
   if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
   stage_tile<M_TZ, M_TY, M_TX>(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0,
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
   }
   if (DIAG && tid == 0) {
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t wg = blockIdx.x;
     a.dbg[4 * wg + 0] = t0; a.dbg[4 * wg + 1] = t1;
     a.dbg[4 * wg + 2] = t2; a.dbg[4 * wg + 3] = t3;
   }
@@ -458,6 +480,7 @@ struct C5TailArgs {
   int64_t DY, DX;                // its pitches
   int64_t gz0;                   // global coarse z of chunk-local coarse row 0
   int64_t VZ, VY, VX;            // valid fine extents (dim - 14)
+  BlockGrid bg;
 };
 
 // conv3 48->48 +BN+ReLU on P2, then - in registers, on the wave's four sub-steps in
@@ -471,7 +494,9 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_c5_tail)(C5TailArgs a) {
   unsigned *kofftab = reinterpret_cast<unsigned *>(smem + H_TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int cx0 = blockIdx.x * 16, cy0 = blockIdx.y * 4, cz0 = blockIdx.z * 4;
+  int xb, yb, zb;
+  if (!block_coords(a.bg, xb, yb, zb)) return;
+  const int cx0 = xb * 16, cy0 = yb * 4, cz0 = zb * 4;
 
   if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<H_TY, H_TX>(tid);
   stage_tile<H_TZ, H_TY, H_TX>(a.p2, a.P2Z, a.P2Y, a.P2X, cz0, cy0, cx0, tile, wave, lane);
@@ -755,28 +780,32 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
       a.w4 = (const h16x8 *)(F + st->off_w[3]);
       a.shift3 = S + st->off_s[2]; a.shift4 = S + st->off_s[3];
       a.p2 = (h16_t *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
-      dim3 grid((unsigned)ceil_div64(P2X, 8), (unsigned)ceil_div64(P2Y, 2),
-                (unsigned)ceil_div64(P2Z, 2));
+      a.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 2)};
+      const unsigned grid = block_grid_size(a.bg);
       a.dbg = nullptr;
       if (getenv("FPL_DIAG_MID")) {
         // diagnostic build: per-workgroup s_memtime stamps (never timed/shipped)
-        const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+        const size_t nwg = grid;
         void *dbg;
         FPL_TRY(tmp.alloc(nwg * 32, &dbg));
         a.dbg = (unsigned long long *)dbg;
+        FPL_HIP(ctx, hipMemsetAsync(dbg, 0, nwg * 32, stream));   // padding blocks leave zeros
         FPLK(vgg_mid_pool)<true><<<grid, 256, M_SMEM, stream>>>(a);
         std::vector<unsigned long long> h(nwg * 4);
         FPL_HIP(ctx, hipMemcpyAsync(h.data(), dbg, nwg * 32, hipMemcpyDeviceToHost, stream));
         FPL_HIP(ctx, hipStreamSynchronize(stream));
         double fill = 0, loop = 0, epi = 0, tot = 0;
+        size_t real = 0;
         for (size_t i = 0; i < nwg; ++i) {
+          if (!h[4 * i + 3]) continue;
+          ++real;
           fill += (double)(h[4 * i + 1] - h[4 * i]);
           loop += (double)(h[4 * i + 2] - h[4 * i + 1]);
           epi += (double)(h[4 * i + 3] - h[4 * i + 2]);
           tot += (double)(h[4 * i + 3] - h[4 * i]);
         }
         fprintf(stderr, "[FPL_DIAG_MID] %zu WGs: mean cycles fill %.0f  kloop %.0f  epilogue %.0f  total %.0f\n",
-                nwg, fill / nwg, loop / nwg, epi / nwg, tot / nwg);
+                real, fill / real, loop / real, epi / real, tot / real);
       } else {
         TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
         FPLK(vgg_mid_pool)<false><<<grid, 256, M_SMEM, stream>>>(a);
@@ -791,10 +820,9 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
       a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
       a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
       a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX;
-      dim3 grid((unsigned)ceil_div64(CX, 16), (unsigned)ceil_div64(CY, 4),
-                (unsigned)ceil_div64(CZ, 4));
+      a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
       TimedLaunch tl(ctx, "vgg_c5_tail_" FPL_PREC_STR);
-      FPLK(vgg_c5_tail)<<<grid, 256, H_SMEM, stream>>>(a);
+      FPLK(vgg_c5_tail)<<<block_grid_size(a.bg), 256, H_SMEM, stream>>>(a);
     }
     FPL_HIP(ctx, hipGetLastError());
   }
