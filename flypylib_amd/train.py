@@ -16,6 +16,8 @@ BN batch statistics stay per GPU, as each tower normalises its own slice.
 """
 import csv
 
+import numpy as np
+
 from . import _capi, runtime
 
 _OPTIMIZERS = {'adam': dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)}
@@ -76,6 +78,51 @@ class _DeviceArena:
             'version': 2}
 
 
+class _Prefetch:
+    """Background consumer of the batch generator (what Keras' `fit_generator` does with
+    its enqueuer thread, `max_queue_size` batches ahead): the host-side patch sampling
+    and augmentation of batch i+1 overlap the GPU step of batch i - the step is a C call
+    that releases the GIL.  Order is preserved (one worker); batches are copied because
+    the reference-style generators reuse their output arrays."""
+
+    def __init__(self, generator, depth=2):
+        import queue
+        import threading
+        self._q = queue.Queue(depth)
+        self._stop = threading.Event()
+        self._full = queue.Full
+        self._t = threading.Thread(target=self._work, args=(generator,), daemon=True)
+        self._t.start()
+
+    def _put(self, item):
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except self._full:
+                pass
+        return False
+
+    def _work(self, generator):
+        try:
+            for item in generator:
+                if not self._put(tuple(np.array(a) for a in item)):
+                    return
+            self._put(StopIteration())
+        except BaseException as e:          # surfaces in the training thread
+            self._put(e)
+
+    def __next__(self):
+        item = self._q.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        self._stop.set()
+        self._t.join(5)
+
+
 def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
                   save_filepath, seed=0):
     graph = network.train_single
@@ -104,24 +151,28 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
         writer.writerow(['epoch'] + cols)
     step_no = 0
     history = []
-    for epoch in range(epochs):
-        tot = dict.fromkeys(cols, 0.0)
-        for _ in range(steps_per_epoch):
-            data, labels = next(generator)
-            trainer.step(data, labels, seed=seed + step_no)
-            trainer.apply(allreduce_grads(trainer))
-            m = trainer.metrics()
-            for k in cols:
-                tot[k] += m[k]
-            step_no += 1
-        graph.set_weights(trainer.get_weights())
-        row = (epoch,) + tuple(tot[k] / steps_per_epoch for k in cols)
-        history.append(row)
-        if writer:
-            writer.writerow(row)
-            f.flush()
-        if rank == 0 and save_filepath:
-            graph.save('%s_%03d' % (save_filepath, epoch))
+    batches = _Prefetch(generator)
+    try:
+        for epoch in range(epochs):
+            tot = dict.fromkeys(cols, 0.0)
+            for _ in range(steps_per_epoch):
+                data, labels = next(batches)
+                trainer.step(data, labels, seed=seed + step_no)
+                trainer.apply(allreduce_grads(trainer))
+                m = trainer.metrics()
+                for k in cols:
+                    tot[k] += m[k]
+                step_no += 1
+            graph.set_weights(trainer.get_weights())
+            row = (epoch,) + tuple(tot[k] / steps_per_epoch for k in cols)
+            history.append(row)
+            if writer:
+                writer.writerow(row)
+                f.flush()
+            if rank == 0 and save_filepath:
+                graph.save('%s_%03d' % (save_filepath, epoch))
+    finally:
+        batches.close()
     if writer:
         f.close()
     trainer.close()
