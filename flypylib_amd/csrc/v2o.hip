@@ -70,13 +70,14 @@ __global__ __launch_bounds__(256) void gauss_pass(
 
 // Register-window form of one pass: a thread produces OUT consecutive outputs along
 // AXIS from OUT + 2*WR loaded values (3.5 loads per output for WR = 10 instead of
-// 21); lanes run along x, so the loads of passes 0 and 1 are coalesced.  Same
+// 21; 2.25 with the 16 outputs of passes 0 and 1); lanes run along x, so the loads of
+// passes 0 and 1 are coalesced.  Same
 // arithmetic order as gauss_pass.
 template <int AXIS, int WR>
 __global__ __launch_bounds__(256) void gauss_pass_win(
     PadView pv, const float *__restrict__ in, float *__restrict__ out, int64_t P0,
     int64_t P1, int64_t P2, const double *__restrict__ w, int r) {
-  constexpr int OUT = AXIS == 2 ? 4 : 8;
+  constexpr int OUT = AXIS == 2 ? 4 : 16;
   constexpr int NW = OUT + 2 * WR;
   const int64_t PA = AXIS == 0 ? P0 : (AXIS == 1 ? P1 : P2);
   const int64_t nblk = (PA + OUT - 1) / OUT;
