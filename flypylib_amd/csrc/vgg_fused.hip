@@ -479,7 +479,8 @@ struct C5TailArgs {
   float *dst;                    // (Z,Y,X) prediction volume, row 0
   int64_t DY, DX;                // its pitches
   int64_t gz0;                   // global coarse z of chunk-local coarse row 0
-  int64_t VZ, VY, VX;            // valid fine extents (dim - 14)
+  int64_t VZ, VY, VX;            // valid fine extents (dim - 2 * off)
+  int off;                       // rf offset of the network: 7 (vgg_like), 10 (vgg_like2)
   BlockGrid bg;
 };
 
@@ -589,12 +590,172 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_c5_tail)(C5TailArgs a) {
         for (int dz = 0; dz < 4; ++dz) {
           const int64_t fz = fz0 + dz;
           if (fz >= a.VZ) break;
-          float *o = a.dst + ((fz + 7) * a.DY + fy + 7) * a.DX + fx0 + 7;
+          float *o = a.dst + ((fz + a.off) * a.DY + fy + a.off) * a.DX + fx0 + a.off;
           if (nx == 4) {
             *reinterpret_cast<f32x4_a4 *>(o) = f32x4_a4{p, p, p, p};
           } else {
             for (int i = 0; i < nx; ++i) o[i] = p;
           }
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------
+// vgg_like2 (flypylib/fplmodels.py:138-172): every second conv is 3x3x3, so the stack is
+//   [conv3 1->48, conv3 48->48, pool] [conv3 48->48, conv3 48->48, pool] conv3 48->48, head
+// and the 1x1 chaining of vgg_like does not apply.  One kernel template covers the four
+// 48->48 convolutions (the fifth is vgg_c5_tail): block 4 x 4 x 16 outputs, the K loop and
+// tile of K2 / K3, and
+//   STEM  the 6 x 6 x 18 x 48 input tile is not read but COMPUTED: conv3 1->48 + BN + ReLU
+//         of the raw 8 x 8 x 20 (normalised, zero past the volume end) input tile, 41
+//         groups of 16 tile voxels x 3 MFMAs (27 taps = one K-step) - the full-resolution
+//         48-channel tensor (96 B per voxel) never exists in HBM;
+//   POOL  ReLU + 2x2x2 max pool in the epilogue (wave = pooled (z,y) row as in K2),
+//         otherwise ReLU and a plain channels-last store (wave = z as in K3).
+// -------------------------------------------------------------------------------
+constexpr int V2_RZ = M_TZ + 2, V2_RY = M_TY + 2, V2_RX = M_TX + 2;     // raw tile 8 x 8 x 20
+constexpr int V2_NRAW = V2_RZ * V2_RY * V2_RX;
+static_assert(V2_NRAW % 256 == 0, "raw tile pieces per thread");
+constexpr int V2_SMEM = M_TILE_BYTES + KTAB_BYTES + V2_NRAW * 2 + 256 * 2;
+static_assert(2 * V2_SMEM <= 160 * 1024, "two vgg_like2 workgroups must fit one CU");
+
+struct V2Args {
+  // STEM: the raw volume
+  const void *src;
+  int64_t SZ, SY, SX;
+  float mean, sd;
+  int64_t gz0;                   // raw z of chunk-local conv row 0
+  const h16x8 *wstem;            // 3 fragments, k-slot (g,j) = tap 8g + j
+  const float *shstem;
+  // otherwise: a 48-channel tensor
+  const h16_t *in;
+  int IZ, IY, IX;
+  const unsigned char *w;        // KSTEPS x 3 fragments
+  const float *shift;
+  h16_t *out;
+  int OZ, OY, OX;                // output dims (pooled dims with POOL)
+  BlockGrid bg;
+};
+
+template <bool STEM, bool POOL, typename SRC>
+__global__ __launch_bounds__(256, 2) void FPLK(vgg2_conv3)(V2Args a) {
+  unsigned char *tile = smem;
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
+  unsigned short *rawt = reinterpret_cast<unsigned short *>(smem + M_TILE_BYTES + KTAB_BYTES);
+  unsigned short *lut = rawt + V2_NRAW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int xb, yb, zb;
+  if (!block_coords(a.bg, xb, yb, zb)) return;
+  // origin of the block's 4 x 4 x 16 conv outputs (= of its input tile)
+  const int x0 = xb * 16, y0 = yb * 4, z0 = zb * 4;
+
+  if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
+  if (STEM) {
+    const SRC *src = (const SRC *)a.src;
+    if (sizeof(SRC) == 1) {
+      lut[tid] = h16_bits(((float)tid - a.mean) / a.sd);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < V2_NRAW / 256; ++j) {
+      const int p = tid + 256 * j;
+      const int64_t z = a.gz0 + z0 + p / (V2_RY * V2_RX), y = y0 + (p / V2_RX) % V2_RY, x = x0 + p % V2_RX;
+      unsigned short b = 0;                              // zero past the volume end
+      if (z < a.SZ && y < a.SY && x < a.SX) {
+        const SRC v = src[(z * a.SY + y) * a.SX + x];
+        b = sizeof(SRC) == 1 ? lut[(int)v] : h16_bits(((float)v - a.mean) / a.sd);
+      }
+      rawt[p] = b;
+    }
+    int toff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 8 * g + j;
+      toff[j] = t < 27 ? ((t / 9) * V2_RY + (t / 3) % 3) * V2_RX + t % 3 : 0;
+    }
+    h16x8 w1[3];
+    f32x4 sh1[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      w1[b] = a.wstem[b * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sh1[b][r] = a.shstem[16 * b + 4 * g + r];
+    }
+    __syncthreads();                                    // raw tile visible
+    constexpr int NVOX = M_TZ * M_TY * M_TX, NGRP = (NVOX + 15) / 16;
+    for (int grp = wave; grp < NGRP; grp += 4) {
+      const int v = 16 * grp + c, vv = v < NVOX ? v : NVOX - 1;
+      const int tz = vv / (M_TY * M_TX), ty = (vv / M_TX) % M_TY, tx = vv % M_TX;
+      const int ro = (tz * V2_RY + ty) * V2_RX + tx;
+      u16x8 rw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rw[j] = rawt[ro + toff[j]];
+      const h16x8 bf = __builtin_bit_cast(h16x8, rw);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const f32x4 a1 = mfma16(w1[b], bf, sh1[b]);
+        u32x2 o;
+        o[0] = pk_max_i16(cvt_pk_h16(a1[0], a1[1]), 0u);
+        o[1] = pk_max_i16(cvt_pk_h16(a1[2], a1[3]), 0u);
+        if (v < NVOX) *reinterpret_cast<u32x2 *>(tile + v * VOX_BYTES + (16 * b + 4 * g) * 2) = o;
+      }
+    }
+  } else {
+    stage_tile<M_TZ, M_TY, M_TX>(a.in, a.IZ, a.IY, a.IX, z0, y0, x0, tile, wave, lane);
+  }
+
+  // POOL: wave = pooled (z,y) row, sub-steps = the (dz,dy) window; else wave = z, subs = y
+  const int pzl = wave >> 1, pyl = wave & 1;
+  const unsigned vbase = POOL ? (unsigned)((((2 * pzl) * M_TY + 2 * pyl) * M_TX + c) * VOX_BYTES)
+                              : (unsigned)(((wave * M_TY) * M_TX + c) * VOX_BYTES);
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    f32x4 sh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = a.shift[16 * b + 4 * g + r];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
+  }
+  auto sub_off = [](int sub) -> unsigned {
+    return POOL ? (unsigned)(((((sub >> 1) & 1) * M_TY + (sub & 1)) * M_TX) * VOX_BYTES)
+                : (unsigned)(sub * M_TX * VOX_BYTES);
+  };
+  conv3_kloop<4>(tile, kofftab, a.w, vbase, sub_off, acc, tid);
+
+  if (POOL) {
+    u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) pool_relu_h16(pooled[b], acc[sub][b]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {      // the x pair: lanes c and c^1
+      pooled[b][0] = pk_max_i16(pooled[b][0], (unsigned)__shfl_xor((int)pooled[b][0], 1));
+      pooled[b][1] = pk_max_i16(pooled[b][1], (unsigned)__shfl_xor((int)pooled[b][1], 1));
+    }
+    const int pz = zb * 2 + pzl, py = yb * 2 + pyl, px = xb * 8 + (c >> 1);
+    if ((c & 1) == 0 && pz < a.OZ && py < a.OY && px < a.OX) {
+      h16_t *dst = a.out + (((int64_t)pz * a.OY + py) * a.OX + px) * CH + 4 * g;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
+    }
+  } else {
+    const int oz = z0 + wave, ox = x0 + c;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int oy = y0 + sub;
+      if (oz < a.OZ && oy < a.OY && ox < a.OX) {
+        h16_t *dst = a.out + (((int64_t)oz * a.OY + oy) * a.OX + ox) * CH + 4 * g;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          u32x2 o;
+          o[0] = pk_max_i16(cvt_pk_h16(acc[sub][b][0], acc[sub][b][1]), 0u);
+          o[1] = pk_max_i16(cvt_pk_h16(acc[sub][b][2], acc[sub][b][3]), 0u);
+          *reinterpret_cast<u32x2 *>(dst + 16 * b) = o;
         }
       }
     }
@@ -641,6 +802,28 @@ bool is_vgg_like(const fpl_program *prog) {
   return prog->out_tensor == prog->ops[9].dst;
 }
 
+// vgg_like2: the second conv of each block is 3x3x3 too (flypylib/fplmodels.py:138-172)
+bool is_vgg_like2(const fpl_program *prog) {
+  static const int kinds[10] = {0, 0, 1, 0, 0, 1, 0, 0, 0, 0};
+  static const int ks[10] = {3, 3, 0, 3, 3, 0, 3, 1, 1, 1};
+  static const int cin[10] = {1, 48, 48, 48, 48, 48, 48, 48, 96, 96};
+  static const int cout[10] = {48, 48, 48, 48, 48, 48, 48, 96, 96, 1};
+  if (prog->ops.size() != 10) return false;
+  if (prog->stride[0] != 4 || prog->stride[1] != 4 || prog->stride[2] != 4) return false;
+  for (int i = 0; i < 10; ++i) {
+    const fpl_op &op = prog->ops[i];
+    if (op.kind != kinds[i]) return false;
+    if (op.src0 != (i == 0 ? 0 : prog->ops[i - 1].dst)) return false;
+    if (op.kind == FPL_OP_CONV) {
+      if (op.k != ks[i] || op.cin != cin[i] || op.cout != cout[i]) return false;
+      if (op.act != (i == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return false;
+    } else if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) {
+      return false;
+    }
+  }
+  return prog->out_tensor == prog->ops[9].dst;
+}
+
 int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
   VggFastState *st = (VggFastState *)prog->fast_state_h16[FPL_H16_SLOT];
   if (!st) {
@@ -650,11 +833,18 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
   }
   *out = st;
   if (st->version == prog->arena_version) return 0;
+  const bool v2 = is_vgg_like2(prog);
   static const int conv_ops[8] = {0, 1, 3, 4, 6, 7, 8, 9};
   static const int mblocks[8] = {3, 3, 3, 3, 3, 6, 6, 1};
-  static const int ksteps[8] = {1, 2, KSTEPS, 2, KSTEPS, 2, 3, 3};
-  static const FplSlotMap maps[8] = {SLOT_STEM, SLOT_CHAIN, SLOT_SPATIAL, SLOT_CHAIN,
-                                     SLOT_SPATIAL, SLOT_CHAIN, SLOT_CHAIN, SLOT_CHAIN};
+  static const int ksteps1[8] = {1, 2, KSTEPS, 2, KSTEPS, 2, 3, 3};
+  static const FplSlotMap maps1[8] = {SLOT_STEM, SLOT_CHAIN, SLOT_SPATIAL, SLOT_CHAIN,
+                                      SLOT_SPATIAL, SLOT_CHAIN, SLOT_CHAIN, SLOT_CHAIN};
+  // vgg_like2: L1 as one K-step of 27 taps (k-slot (g,j) = tap 8g + j), L2..L5 3x3x3
+  static const int ksteps2[8] = {1, KSTEPS, KSTEPS, KSTEPS, KSTEPS, 2, 3, 3};
+  static const FplSlotMap maps2[8] = {SLOT_SPATIAL, SLOT_SPATIAL, SLOT_SPATIAL, SLOT_SPATIAL,
+                                      SLOT_SPATIAL, SLOT_CHAIN, SLOT_CHAIN, SLOT_CHAIN};
+  const int *ksteps = v2 ? ksteps2 : ksteps1;
+  const FplSlotMap *maps = v2 ? maps2 : maps1;
   std::vector<uint16_t> all;
   std::vector<float> shifts;
   const float *A = prog->arena_host.data();
@@ -665,7 +855,7 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
     if (l == 7) {
       // sigmoid head: scale is 1 (no BN); keep it explicit anyway
     }
-    if (l == 0)
+    if (l == 0 && !v2)
       fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f);
     else
       fpl_pack_frags(A + op.w_off, scale.data(), op.k * op.k * op.k, op.cin, op.cout,
@@ -699,6 +889,16 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_c5_tail),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM));
+  if (v2) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg2_conv3)<true, true, uint8_t>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg2_conv3)<true, true, float>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg2_conv3)<false, false, uint8_t>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg2_conv3)<false, true, uint8_t>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
+  }
   st->version = prog->arena_version;
   return 0;
 }
@@ -707,11 +907,105 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
 
 bool FPLK(fpl_fast_path_available)(const fpl_program *prog, int precision,
                              const int32_t offset[3], const int32_t out_sz[3]) {
-  if (precision != FPL_THIS_PREC || !is_vgg_like(prog)) return false;
+  if (precision != FPL_THIS_PREC) return false;
+  const bool v1 = is_vgg_like(prog), v2 = !v1 && is_vgg_like2(prog);
+  if (!v1 && !v2) return false;
   for (int a = 0; a < 3; ++a)
-    if (offset[a] != 7 || out_sz[a] % 4 != 0) return false;
+    if (offset[a] != (v1 ? 7 : 10) || out_sz[a] % 4 != 0) return false;
   return true;
 }
+
+namespace {
+
+// vgg_like2 over the coarse rows of a slab: four launches per chunk
+//   H1 = pool(conv3(conv3(volume)))   vgg2_conv3<STEM, POOL>   (half resolution)
+//   L3 = conv3(H1)                    vgg2_conv3<>
+//   Q  = pool(conv3(L3))              vgg2_conv3<POOL>         (quarter resolution)
+//   prediction = head(conv3(Q))       vgg_c5_tail
+// With out = 80 = 4 * 20 every reference tile's input origin is a multiple of the stride,
+// so as for vgg_like the coarse grid is anchored at the volume origin: pred[10 + p] =
+// O[p / 4], O[i] seeing input [4i, 4i + 24), zero (normalised) past the volume end.
+int vgg2_infer(fpl_ctx *ctx, VggFastState *st, const void *src, int src_dtype, float mean, float sd,
+               const int64_t dims[3], const std::vector<int32_t> origins[3],
+               const int32_t out_sz[3], int32_t zb, int32_t ze, float *dst) {
+  hipStream_t stream = ctx->stream;
+  constexpr int OFF = 10;
+  const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];
+  const int64_t VZ = SZ - 2 * OFF, VY = SY - 2 * OFF, VX = SX - 2 * OFF;
+  if (VZ <= 0 || VY <= 0 || VX <= 0 || zb >= ze) return 0;
+  const int64_t fz_lo = (int64_t)origins[0][zb] - OFF;
+  const int64_t fz_hi = std::min<int64_t>((int64_t)origins[0][ze - 1] - OFF + out_sz[0], VZ);
+  const int64_t cz_lo = fz_lo / 4, cz_hi = ceil_div64(fz_hi, 4);
+  const int CY = (int)ceil_div64(VY, 4), CX = (int)ceil_div64(VX, 4);
+  const int QY = CY + 2, QX = CX + 2, T3Y = 2 * QY + 2, T3X = 2 * QX + 2, HY = T3Y + 2, HX = T3X + 2;
+  const int64_t h_row = (int64_t)HY * HX * VOX_BYTES, t_row = (int64_t)T3Y * T3X * VOX_BYTES;
+  const char *budget_env = getenv("FPL_VGG_SCRATCH_MB");
+  const int64_t budget = budget_env ? (int64_t)atoll(budget_env) << 20 : (int64_t)64 << 30;
+  // H1 has 2 (cz + 2) + 4 rows, L3 two fewer
+  int64_t cz_chunk = std::max<int64_t>(4, (budget / (h_row + t_row) - 8) / 2);
+  cz_chunk = std::min<int64_t>(cz_chunk, cz_hi - cz_lo);
+  cz_chunk = (cz_chunk + 3) / 4 * 4;
+  DevTemp tmp(ctx);
+  void *h1v, *l3v, *qv;
+  FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 8) * h_row, &h1v));
+  FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 6) * t_row, &l3v));
+  FPL_TRY(tmp.alloc((size_t)(cz_chunk + 2) * QY * QX * VOX_BYTES, &qv));
+  const unsigned char *F = st->frags;
+  const float *S = st->shifts;
+  for (int64_t c0 = cz_lo; c0 < cz_hi; c0 += cz_chunk) {
+    const int CZ = (int)std::min<int64_t>(cz_chunk, cz_hi - c0);
+    const int QZ = CZ + 2, T3Z = 2 * QZ + 2, HZ = T3Z + 2;
+    {
+      V2Args a = {};
+      a.src = src; a.SZ = SZ; a.SY = SY; a.SX = SX; a.mean = mean; a.sd = sd;
+      a.gz0 = 4 * c0;
+      a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
+      a.w = F + st->off_w[1]; a.shift = S + st->off_s[1];
+      a.out = (h16_t *)h1v; a.OZ = HZ; a.OY = HY; a.OX = HX;
+      a.bg = BlockGrid{(int)ceil_div64(HX, 8), (int)ceil_div64(HY, 2), (int)ceil_div64(HZ, 2)};
+      TimedLaunch tl(ctx, "vgg2_stem_conv3_pool_" FPL_PREC_STR);
+      if (src_dtype == FPL_U8)
+        FPLK(vgg2_conv3)<true, true, uint8_t><<<block_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+      else
+        FPLK(vgg2_conv3)<true, true, float><<<block_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+    }
+    {
+      V2Args a = {};
+      a.in = (const h16_t *)h1v; a.IZ = HZ; a.IY = HY; a.IX = HX;
+      a.w = F + st->off_w[2]; a.shift = S + st->off_s[2];
+      a.out = (h16_t *)l3v; a.OZ = T3Z; a.OY = T3Y; a.OX = T3X;
+      a.bg = BlockGrid{(int)ceil_div64(T3X, 16), (int)ceil_div64(T3Y, 4), (int)ceil_div64(T3Z, 4)};
+      TimedLaunch tl(ctx, "vgg2_conv3_" FPL_PREC_STR);
+      FPLK(vgg2_conv3)<false, false, uint8_t><<<block_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+    }
+    {
+      V2Args a = {};
+      a.in = (const h16_t *)l3v; a.IZ = T3Z; a.IY = T3Y; a.IX = T3X;
+      a.w = F + st->off_w[3]; a.shift = S + st->off_s[3];
+      a.out = (h16_t *)qv; a.OZ = QZ; a.OY = QY; a.OX = QX;
+      a.bg = BlockGrid{(int)ceil_div64(QX, 8), (int)ceil_div64(QY, 2), (int)ceil_div64(QZ, 2)};
+      TimedLaunch tl(ctx, "vgg2_conv3_pool_" FPL_PREC_STR);
+      FPLK(vgg2_conv3)<false, true, uint8_t><<<block_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+    }
+    {
+      C5TailArgs a;
+      a.p2 = (const h16_t *)qv; a.P2Z = QZ; a.P2Y = QY; a.P2X = QX;
+      a.w5 = F + st->off_w[4]; a.shift5 = S + st->off_s[4];
+      a.CZ = CZ; a.CY = CY; a.CX = CX;
+      a.wtail = F + st->off_w[5];
+      a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
+      a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
+      a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = OFF;
+      a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
+      TimedLaunch tl(ctx, "vgg_c5_tail_" FPL_PREC_STR);
+      FPLK(vgg_c5_tail)<<<block_grid_size(a.bg), 256, H_SMEM, stream>>>(a);
+    }
+    FPL_HIP(ctx, hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace
 
 int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src,
                           int src_dtype, float mean, float sd,
@@ -724,6 +1018,11 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
   if (!FPLK(fpl_fast_path_available)(prog, precision, offset, out_sz)) return 0;
   VggFastState *st;
   FPL_TRY(vgg_prepare(ctx, prog, &st));
+  if (is_vgg_like2(prog)) {
+    FPL_TRY(vgg2_infer(ctx, st, src, src_dtype, mean, sd, dims, origins, out_sz, zb, ze, dst));
+    *handled = true;
+    return 0;
+  }
   hipStream_t stream = ctx->stream;
   const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];
   const int64_t VZ = SZ - 14, VY = SY - 14, VX = SX - 14;
@@ -819,7 +1118,7 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
       a.wtail = F + st->off_w[5];      // L6, L7, L8 fragments are contiguous
       a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
       a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
-      a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX;
+      a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = 7;
       a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
       TimedLaunch tl(ctx, "vgg_c5_tail_" FPL_PREC_STR);
       FPLK(vgg_c5_tail)<<<block_grid_size(a.bg), 256, H_SMEM, stream>>>(a);
