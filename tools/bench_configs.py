@@ -32,6 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--what', default='unet,train,v2o,pipeline')
     ap.add_argument('--unet-size', type=int, default=264)
+    ap.add_argument('--vgg2-size', type=int, default=1024)
     ap.add_argument('--sub', type=int, default=582)
     ap.add_argument('--roi-size', type=int, default=1536)
     ap.add_argument('--out', default=None)
@@ -68,6 +69,34 @@ def main():
                 kernels={k: round(v['ms'], 2) for k, v in ctx.timing_get().items()})
             ctx.timing(False)
             print(json.dumps(res['unet_like2_' + pname]), flush=True)
+
+    if 'vgg2' in what:
+        # vgg_like2 (scripts/fpl_cx1_0_vgg_4ss.py): 5 x conv3, 159 867 FLOP per output voxel
+        g = fplmodels.vgg_like2(100)[0]
+        synth.synthetic_weights(g, 8)
+        prog = _capi.Program(ctx, g, (4, 4, 4))
+        n = a.vgg2_size
+        src = torch.empty((n, n, n), dtype=torch.uint8, device='cuda')
+        dst = torch.empty((n, n, n), dtype=torch.float32, device='cuda')
+        ctx.synth_volume_u8(4, (n, n, n), out=src)
+        flop = 2 * (27 * 48 + 27 * 48 * 48 + (2 * 27 * 48 * 48) / 8 + (27 * 48 * 48 + 48 * 96 + 96 * 96 + 96) / 64)
+        for pname, prec in (('f16', _capi.PREC_F16), ('bf16', _capi.PREC_BF16), ('f32', _capi.PREC_F32)):
+            if pname == 'f32' and n > 420:
+                continue
+            kw = dict(mean=128.0, std=33.0, precision=prec, dst=dst, dims=(n, n, n))
+            prog.infer_volume(src, (100,) * 3, (10,) * 3, **kw)
+            ctx.synchronize()
+            ctx.timing(True); ctx.timing_reset()
+            t0 = time.perf_counter()
+            prog.infer_volume(src, (100,) * 3, (10,) * 3, **kw)
+            ctx.synchronize()
+            dt = time.perf_counter() - t0
+            vox = (n - 20) ** 3
+            res['vgg_like2_' + pname] = dict(
+                volume=n, mvox_s=vox / dt / 1e6, seconds=dt, tflops_algorithmic=vox * flop / dt / 1e12,
+                kernels={k: round(v['ms'], 2) for k, v in ctx.timing_get().items()})
+            ctx.timing(False)
+            print(json.dumps(res['vgg_like2_' + pname]), flush=True)
 
     if 'train' in what:
         g = fplmodels.vgg_like()[0]
