@@ -47,6 +47,7 @@ struct Conv3F {
   int act;               // fpl_act
   float *out;            // (n, OD, OH, OW, cout)
   int cout;              // real output channels (<= 16*MB)
+  int opitch;            // channel pitch of `out` (>= cout; a slice of a wider tensor)
   int OD, OH, OW, zblocks;
 };
 
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
   for (int sub = 0; sub < 4; ++sub) {
     const int oy = y0 + sub;
     if (oz < a.OD && oy < a.OH && ox < a.OW) {
-      float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.cout;
+      float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.opitch;
 #pragma unroll
       for (int b = 0; b < MB; ++b)
         store_quad(dst, 16 * b + 4 * g, a.cout, acc[sub][b], a.act);
@@ -726,7 +727,7 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       // the packed fragments assume channel chunks of the concatenated tensor in
       // order, each source starting on a 16-channel boundary
       c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
-      c.out = dst; c.cout = op.cout; c.OD = c.OH = c.OW = od;
+      c.out = dst; c.cout = op.cout; c.opitch = op.cout; c.OD = c.OH = c.OW = od;
       const int mb = (op.cout + 15) / 16;
       switch (mb) {
         case 1: FPL_TRY(launch3<1>(ctx, c, n)); break;
@@ -753,7 +754,8 @@ namespace {
 // mode 1: input-gradient fragments: W'[tap'][cout][cin] with tap' the mirrored tap
 //         (dX = valid correlation of the (k-1)-padded dY with the flipped kernel)
 __global__ void pack_frags_dev(const float *__restrict__ W, float *__restrict__ out, int k3,
-                               int cin, int cout, int mb, int mode, int64_t total) {
+                               int cin, int cout, int mb, int mode, int64_t total,
+                               int co_off = 0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
@@ -762,7 +764,7 @@ __global__ void pack_frags_dev(const float *__restrict__ W, float *__restrict__ 
   const int tap = (int)(t % k3); const int cc = (int)(t / k3);
   const int g = lane >> 4;
   const int kin = mode == 0 ? cin : cout, kout = mode == 0 ? cout : cin;
-  const int ci = 16 * cc + 4 * g + j, co = 16 * b + (lane & 15);
+  const int ci = 16 * cc + 4 * g + j, co = co_off + 16 * b + (lane & 15);   // a slice of the outputs
   float v = 0.f;
   if (ci < kin && co < kout) {
     if (mode == 0) v = W[((int64_t)tap * cin + ci) * cout + co];
@@ -1092,6 +1094,14 @@ bool fpl_tm_supported(int k, int cin, int cout) {
   return k == 1 && cout <= 128;
 }
 
+// input + weight gradients of a conv the forward supports: the 3x3x3 input gradient
+// comes in 64-channel slices, so cin may be wide; its K (= cout) is <= 12 chunks
+bool fpl_tm_bwd_supported(int k, int cin, int cout) {
+  if (!fpl_tm_supported(k, cin, cout)) return false;
+  if (k == 3) return cout <= 12 * 16 && cin % 4 == 0 ? true : fpl_tm_supported(k, cout, cin);
+  return fpl_tm_supported(k, cout, cin);
+}
+
 // y = act(conv(x, W) + bias); x (n,D,H,W,cin), W [k^3][cin][cout] on the device
 // rows of per-channel statistics partials fpl_tm_conv_fwd writes for this shape when
 // given a `stats` buffer (rows x 2 x cout doubles); 0 = that kernel has no fused statistics
@@ -1151,7 +1161,7 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
     s.p = x; s.D = D; s.H = H; s.W = W_; s.C = cin; s.ch0 = 16 * q; s.up = 1; s.crop = 0; s.pad = 0;
     c.src[q] = s;
   }
-  c.w = (const float *)fr; c.shift = bias; c.act = act; c.out = y; c.cout = cout;
+  c.w = (const float *)fr; c.shift = bias; c.act = act; c.out = y; c.cout = cout; c.opitch = cout;
   c.OD = od; c.OH = oh; c.OW = ow;
   switch (mb) {
     case 1: return launch3<1>(ctx, c, n);
@@ -1167,13 +1177,13 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
                       int k, int cin, const float *Wd, const float *zeros, float *dx) {
   DevTemp tmp(ctx);
-  const int mb = (cin + 15) / 16;              // outputs of this "conv" = cin
   const int ncc = (cout + 15) / 16, k3 = k * k * k;
-  const int64_t tot = (int64_t)ncc * k3 * mb * 256;
-  void *fr;
-  FPL_TRY(tmp.alloc(tot * 4, &fr));
-  pack_frags_dev<<<(unsigned)ceil_div64(tot, 256), 256, 0, ctx->stream>>>(Wd, (float *)fr, k3, cin, cout, mb, 1, tot);
   if (k == 1) {
+    const int mb = (cin + 15) / 16;            // outputs of this "conv" = cin
+    const int64_t tot = (int64_t)ncc * k3 * mb * 256;
+    void *fr;
+    FPL_TRY(tmp.alloc(tot * 4, &fr));
+    pack_frags_dev<<<(unsigned)ceil_div64(tot, 256), 256, 0, ctx->stream>>>(Wd, (float *)fr, k3, cin, cout, mb, 1, tot);
     Conv1F c;
     c.in = dy; c.M = (int64_t)n * od * oh * ow; c.cin = cout; c.w = (const float *)fr;
     c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin; c.stats = nullptr;
@@ -1187,23 +1197,35 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
     }
     return fpl_fail(ctx, "conv1 dgrad with %d channels", cin);
   }
-  Conv3F c;
-  c.ncc = ncc;
-  for (int q = 0; q < ncc; ++q) {
-    SrcF s;
-    s.p = dy; s.D = od; s.H = oh; s.W = ow; s.C = cout; s.ch0 = 16 * q; s.up = 1; s.crop = 0;
-    s.pad = k - 1;
-    c.src[q] = s;
+  // 3x3x3: the kernel makes up to 64 channels per launch; a wider input gradient (unet's
+  // 192- and 96-channel concats) is produced in 64-channel slices of the same tensor
+  FPL_REQUIRE(ctx, ncc <= 12, "conv3 dgrad: %d > 192 output-gradient channels", cout);
+  for (int c0 = 0; c0 < cin; c0 += 64) {
+    const int cs = std::min(64, cin - c0), mb = (cs + 15) / 16;
+    const int64_t tot = (int64_t)ncc * k3 * mb * 256;
+    void *fr;
+    FPL_TRY(tmp.alloc(tot * 4, &fr));
+    pack_frags_dev<<<(unsigned)ceil_div64(tot, 256), 256, 0, ctx->stream>>>(Wd, (float *)fr, k3, cin, cout, mb, 1, tot, c0);
+    Conv3F c;
+    c.ncc = ncc;
+    for (int q = 0; q < ncc; ++q) {
+      SrcF s;
+      s.p = dy; s.D = od; s.H = oh; s.W = ow; s.C = cout; s.ch0 = 16 * q; s.up = 1; s.crop = 0;
+      s.pad = k - 1;
+      c.src[q] = s;
+    }
+    c.w = (const float *)fr; c.shift = zeros; c.act = FPL_ACT_NONE;
+    c.out = dx + c0; c.cout = cs; c.opitch = cin;
+    c.OD = od + k - 1; c.OH = oh + k - 1; c.OW = ow + k - 1;
+    switch (mb) {
+      case 1: FPL_TRY(launch3<1>(ctx, c, n)); break;
+      case 2: FPL_TRY(launch3<2>(ctx, c, n)); break;
+      case 3: FPL_TRY(launch3<3>(ctx, c, n)); break;
+      case 4: FPL_TRY(launch3<4>(ctx, c, n)); break;
+      default: return fpl_fail(ctx, "conv3 dgrad slice with %d channels", cs);
+    }
   }
-  c.w = (const float *)fr; c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin;
-  c.OD = od + k - 1; c.OH = oh + k - 1; c.OW = ow + k - 1;
-  switch (mb) {
-    case 1: return launch3<1>(ctx, c, n);
-    case 2: return launch3<2>(ctx, c, n);
-    case 3: return launch3<3>(ctx, c, n);
-    case 4: return launch3<4>(ctx, c, n);
-  }
-  return fpl_fail(ctx, "conv3 dgrad with %d channels", cin);
+  return 0;
 }
 
 // dw [k^3][cin][cout] += weight gradient (float atomics)

@@ -57,6 +57,7 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
 
 // fp32 MFMA convolutions for the training engine (conv_mfma_f32.hip)
 bool fpl_tm_supported(int k, int cin, int cout);
+bool fpl_tm_bwd_supported(int k, int cin, int cout);   // dgrad + wgrad of that conv
 // `stats` (optional): per-channel (sum, sum of squares) partials of y for a following
 // BatchNorm, fpl_tm_conv_stats_rows(...) rows x 2 x cout doubles (0 rows = not offered)
 int64_t fpl_tm_conv_stats_rows(fpl_ctx *ctx, int n, int D, int H, int W_, int cin, int k, int cout);

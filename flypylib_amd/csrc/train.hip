@@ -1261,8 +1261,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
     const fpl_layer &L = t->layers[cons[ti]];
     if (L.kind == FPL_L_BN) assign[ti] = 1;
     if (L.kind == FPL_L_POOL && pool_tiles(shp[ti])) assign[ti] = 1;
-    if (L.kind == FPL_L_CONV && use_mfma_bwd && fpl_tm_supported(L.k, L.cin, L.cout) &&
-        fpl_tm_supported(L.k, L.cout, L.cin))
+    if (L.kind == FPL_L_CONV && use_mfma_bwd && fpl_tm_bwd_supported(L.k, L.cin, L.cout))
       assign[ti] = 1;
   }
   for (int ti = 1; ti < nt; ++ti) {
@@ -1303,8 +1302,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
       case FPL_L_CONV: {
         const int64_t n_vox = (int64_t)batch * o.vox();
         const int taps = L.k * L.k * L.k;
-        if (use_mfma_bwd && fpl_tm_supported(L.k, L.cin, L.cout) &&
-            fpl_tm_supported(L.k, L.cout, L.cin)) {
+        if (use_mfma_bwd && fpl_tm_bwd_supported(L.k, L.cin, L.cout)) {
           FPL_TRY(fpl_tm_conv_wgrad(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, dy, L.k,
                                     L.cout, t->g + L.w_off[0]));
           if (L.use_bias) {

@@ -121,6 +121,30 @@ def main():
         ctx.timing(False)
         print(json.dumps(res['vgg_train_b32_64cubed_f32']), flush=True)
 
+    if 'train_unet' in what:
+        # unet_like2 as scripts/fpl_cx1_0_unet_4ss_all.py trains it: rf-sized 24^3 patches,
+        # batch 64 per GPU, masked focal loss
+        g = fplmodels.unet_like2()[0]
+        synth.synthetic_weights(g, 3)
+        tr = _capi.Trainer(ctx, g, loss='masked_focal_loss')
+        rng = np.random.default_rng(0)
+        data = rng.standard_normal((64, 24, 24, 24, 1)).astype(np.float32)
+        labels = rng.integers(0, 3, (64, 6, 6, 6, 1)).astype(np.uint8)
+        tr.step(data, labels, 0); tr.apply(1.0)
+        ctx.synchronize()
+        ctx.timing(True); ctx.timing_reset()
+        t0 = time.perf_counter()
+        steps = 5
+        for s in range(steps):
+            tr.step(data, labels, s + 1); tr.apply(1.0)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res['unet_train_b64_24cubed_f32'] = dict(
+            seconds_per_step=dt, steps_per_s=1 / dt, note='includes H2D of the batch',
+            kernels={k: round(v['ms'] / steps, 3) for k, v in ctx.timing_get().items()})
+        ctx.timing(False)
+        print(json.dumps(res['unet_train_b64_24cubed_f32']), flush=True)
+
     if 'v2o' in what or 'pipeline' in what:
         n = a.sub
         g = fplmodels.vgg_like(102)[0]
