@@ -422,6 +422,24 @@ __global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
   }
 }
 
+// out = act(a + b), either operand seen through a centre crop of a larger cubic tile
+// (resnet_like's shortcuts, flypylib/fplmodels.py:174-208); channels-last, C % 4 == 0 not
+// required
+__global__ void add_view_f32(const float *__restrict__ a, int aD, int acrop,
+                             const float *__restrict__ b, int bD, int bcrop,
+                             float *__restrict__ out, int64_t n_out, int od, int C, int act) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  int64_t t = i;
+  const int c = (int)(t % C); t /= C;
+  const int x = (int)(t % od); t /= od;
+  const int y = (int)(t % od); t /= od;
+  const int z = (int)(t % od); t /= od;
+  const float va = a[((((t * aD + z + acrop) * aD + y + acrop) * (int64_t)aD + x + acrop) * C) + c];
+  const float vb = b[((((t * bD + z + bcrop) * bD + y + bcrop) * (int64_t)bD + x + bcrop) * C) + c];
+  out[i] = act_f(va + vb, act);
+}
+
 __global__ void pool2_f32v(const float *__restrict__ x, float *__restrict__ y, int64_t n_out,
                            int D, int H, int W, int C, int od, int oh, int ow) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -552,7 +570,7 @@ int launch1(fpl_ctx *ctx, Conv1F &a) {
 
 }  // namespace
 
-// every op kind except ADD; conv3 needs cout <= 64 and <= 12 channel chunks
+// every op kind; conv3 needs cout <= 64 and <= 12 channel chunks
 bool fpl_mfma_f32_supported(const fpl_program *prog) {
   // tensors that exist only as an index remap (up / crop / concat): consumable by a
   // multi-channel conv3 (its tile loader applies the remap), nothing else
@@ -566,13 +584,14 @@ bool fpl_mfma_f32_supported(const fpl_program *prog) {
       is_view[op.dst] = 1;
     } else if (op.kind == FPL_OP_CONV && op.k == 3 && op.cin > 1) {
       if (v1) return false;
+    } else if (op.kind == FPL_OP_ADD) {
+      // operands may be cropped views (checked for up / concat at run time)
     } else if (v0 || v1) {
       return false;
     }
     if (prog->out_tensor == op.dst && is_view[op.dst]) return false;
   }
   for (auto &op : prog->ops) {
-    if (op.kind == FPL_OP_ADD) return false;
     if (op.kind == FPL_OP_POOL && (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2)) return false;
     if (op.kind == FPL_OP_UP && (op.p[0] != op.p[1] || op.p[1] != op.p[2] || (op.p[0] != 1 && op.p[0] != 2)))
       return false;
@@ -654,6 +673,7 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
     int od = 0, oc = 0;
     if (op.kind == FPL_OP_CONV) { od = a.dim - (op.k - 1); oc = op.cout; }
     if (op.kind == FPL_OP_POOL) { od = a.dim / 2; oc = a.C; }
+    if (op.kind == FPL_OP_ADD) { od = a.dim; oc = a.C; }
     FPL_REQUIRE(ctx, od > 0, "op %zu: tile %d is too small for this architecture", i, T);
     if (op.dst == prog->out_tensor) {
       dst = out;
@@ -663,7 +683,15 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       dst = (float *)q;
     }
     o.p = dst; o.D = od; o.C = oc; o.dim = od;
-    if (op.kind == FPL_OP_POOL) {
+    if (op.kind == FPL_OP_ADD) {
+      const View b = view[op.src1];
+      FPL_REQUIRE(ctx, a.p && b.p && a.up == 1 && b.up == 1 && a.dim == b.dim && a.C == b.C,
+                  "op %zu: add of incompatible tensors", i);
+      const int64_t no = (int64_t)n * cube(od) * oc;
+      TimedLaunch tl(ctx, "mfma_add_f32");
+      add_view_f32<<<(unsigned)ceil_div64(no, 256), 256, 0, stm>>>(a.p, a.D, a.crop, b.p, b.D, b.crop,
+                                                                   dst, no, od, oc, op.act);
+    } else if (op.kind == FPL_OP_POOL) {
       FPL_REQUIRE(ctx, a.p && a.up == 1 && a.crop == 0, "op %zu: pool of a view", i);
       const int64_t no = (int64_t)n * cube(od) * oc;
       TimedLaunch tl(ctx, "mfma_pool_f32");
