@@ -85,7 +85,8 @@ struct Conv3Args {
   const unsigned char *w;        // fragments [cc][dz][dx][dy][mb], 1 KiB each
   const float *shift;
   int relu;
-  h16_t *out;                   // (n, OD, OH, OW, 16*MB)
+  h16_t *out;                   // (n, OD, OH, OW, cpitch): channels [0, 16*MB) of each voxel
+  int cpitch;                    // channel pitch of `out` (0 = 16*MB; 128 when two launches fill the halves)
   int OD, OH, OW, zblocks;       // zblocks = ceil(OD/4)
   int nbx, nby, nbz;             // blocks: ceil(OW/16), ceil(OH/4), n * zblocks
   // STEM variant: the (single) source is conv3 1->32 + shift + ReLU of this raw
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
                       td.start[1] + a.io.off + oy) * a.io.X + td.start[2] + a.io.off + ox] =
                 1.f / (1.f + __expf(-logit));
         } else if (oz < a.OD && oy < a.OH && ox < a.OW)
-          store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (16 * MB),
+          store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.cpitch,
                               g, acc[sub], a.relu);
       }
     }
@@ -497,6 +498,7 @@ struct UnetState {
   unsigned char *frags = nullptr;
   float *shifts = nullptr;
   size_t off_w[12] = {0}, off_s[12] = {0};
+  size_t half_bytes[12] = {0};   // conv3 with 128 outputs: bytes of the first 64-channel half
   size_t off_w7t = 0;            // conv 7 with the dy / dx taps swapped (edge strip)
   float bias_tail = 0.f;
 };
@@ -508,49 +510,106 @@ void unet_state_free(fpl_ctx *, void *p) {
   delete s;
 }
 
-// lowered unet_like2: conv,conv,pool,conv,conv,pool,conv1,up,concat,conv,conv1,
-//                     crop,up,concat,conv,conv1,conv1(sigmoid)     (17 ops; the crop
-// may be emitted before or after the up - match by kind counts + conv sequence)
-const int U_K[10] = {3, 3, 3, 3, 1, 3, 1, 3, 1, 1};
-const int U_CIN[10] = {1, 32, 32, 64, 64, 192, 64, 96, 32, 32};
-const int U_COUT[10] = {32, 32, 64, 64, 128, 64, 64, 32, 32, 1};
+// The U-Net skeleton of fplmodels.py:258-407 (unet_like2, unet_like3, unet_like4):
+//   conv3 1->32, conv3 32->32, pool, conv3 32->64, conv3 64->64, pool, BOTTOM,
+//   up, [crop skip2], concat, conv3 192->64, conv1 64->64, up, crop skip1, concat,
+//   conv3 96->32, conv1 32->32, conv1 32->1 (sigmoid)
+// with BOTTOM = conv1 64->128 | conv3 64->128, conv1 128->128 | conv3 64->128, conv3 128->128
+// (the crop may be emitted before or after the up - matched by kind counts, conv order
+// and data flow).  Conv roles: 0,1 stage 1; 2,3 stage 2; then the bottom; then
+// up1 (conv3, conv1), up2 (conv3, conv1), head.
+struct UnetDesc {
+  int nconv = 0;
+  int conv[12];                  // op index per conv, in order
+  int nbottom = 0;               // 1 or 2
+  int crop2 = 0, crop1 = 0;      // crop of the stage-2 / stage-1 skip
+  int l_up1() const { return 4 + nbottom; }      // conv3 192->64
+  int l_up2() const { return 6 + nbottom; }      // conv3 96->32
+};
 
-bool is_unet_like2(const fpl_program *prog, int conv_idx[10]) {
-  int nc = 0, np = 0, nu = 0, ncat = 0, ncrop = 0;
+bool match_unet(const fpl_program *prog, UnetDesc *d) {
+  int np = 0, nu = 0, ncat = 0, ncrop = 0;
+  int crops[2] = {0, 0};
+  d->nconv = 0;
   for (size_t i = 0; i < prog->ops.size(); ++i) {
     const fpl_op &op = prog->ops[i];
     switch (op.kind) {
       case FPL_OP_CONV:
-        if (nc >= 10 || op.k != U_K[nc] || op.cin != U_CIN[nc] || op.cout != U_COUT[nc]) return false;
-        if (op.act != (nc == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return false;
-        conv_idx[nc++] = (int)i;
+        if (d->nconv >= 12) return false;
+        d->conv[d->nconv++] = (int)i;
         break;
       case FPL_OP_POOL: if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) return false; ++np; break;
       case FPL_OP_UP: if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) return false; ++nu; break;
       case FPL_OP_CONCAT: ++ncat; break;
       case FPL_OP_CROP:
-        for (int q = 0; q < 6; ++q) if (op.p[q] != 6) return false;
-        ++ncrop;
+        if (ncrop >= 2) return false;
+        for (int q = 1; q < 6; ++q) if (op.p[q] != op.p[0]) return false;
+        if (op.p[0] <= 0 || op.p[0] % 2) return false;
+        crops[ncrop++] = op.p[0];
         break;
       default: return false;
     }
   }
-  if (nc != 10 || np != 2 || nu != 2 || ncat != 2 || ncrop != 1) return false;
+  if (np != 2 || nu != 2 || ncat != 2 || ncrop < 1) return false;
   if (prog->stride[0] != 1 || prog->stride[1] != 1 || prog->stride[2] != 1) return false;
-  // dataflow: conv i (i>=1) reads conv i-1 except through pool / concat
+  d->nbottom = d->nconv - 9;
+  if (d->nbottom != 1 && d->nbottom != 2) return false;
+  auto C = [&](int l) -> const fpl_op & { return prog->ops[d->conv[l]]; };
+  auto is = [&](int l, int k, int cin, int cout) {
+    return C(l).k == k && C(l).cin == cin && C(l).cout == cout;
+  };
+  if (!is(0, 3, 1, 32) || !is(1, 3, 32, 32) || !is(2, 3, 32, 64) || !is(3, 3, 64, 64)) return false;
+  if (d->nbottom == 1) {
+    if (!is(4, 1, 64, 128)) return false;
+  } else {
+    if (!is(4, 3, 64, 128)) return false;
+    if (!is(5, 1, 128, 128) && !is(5, 3, 128, 128)) return false;
+  }
+  const int u1 = d->l_up1(), u2 = d->l_up2();
+  if (!is(u1, 3, 192, 64) || !is(u1 + 1, 1, 64, 64) || !is(u2, 3, 96, 32) || !is(u2 + 1, 1, 32, 32) ||
+      !is(u2 + 2, 1, 32, 1))
+    return false;
+  for (int l = 0; l < d->nconv; ++l)
+    if (C(l).act != (l == d->nconv - 1 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return false;
+  // crops: the stage-2 skip's (if any) is created first (fplmodels.py:283-291)
+  d->crop2 = ncrop == 2 ? crops[0] : 0;
+  d->crop1 = ncrop == 2 ? crops[1] : crops[0];
+  // data flow: conv 2 and the first bottom conv read pools, the two up convs read concats
   const auto &o = prog->ops;
   auto src_kind = [&](int tensor) -> int {
     for (auto &op : o) if (op.dst == tensor) return op.kind;
     return -1;
   };
-  if (src_kind(o[conv_idx[2]].src0) != FPL_OP_POOL || src_kind(o[conv_idx[4]].src0) != FPL_OP_POOL)
-    return false;
-  if (src_kind(o[conv_idx[5]].src0) != FPL_OP_CONCAT || src_kind(o[conv_idx[7]].src0) != FPL_OP_CONCAT)
-    return false;
-  return prog->out_tensor == o[conv_idx[9]].dst;
+  if (src_kind(C(2).src0) != FPL_OP_POOL || src_kind(C(4).src0) != FPL_OP_POOL) return false;
+  if (src_kind(C(u1).src0) != FPL_OP_CONCAT || src_kind(C(u2).src0) != FPL_OP_CONCAT) return false;
+  for (int l : {1, 3, u1 + 1, u2 + 1, u2 + 2})
+    if (C(l).src0 != C(l - 1).dst) return false;
+  if (d->nbottom == 2 && C(5).src0 != C(4).dst) return false;
+  return prog->out_tensor == C(d->nconv - 1).dst;
 }
 
-int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetState **out) {
+// conv3 fragments: per CC-channel chunk, K-step order (dz, dx, dy) (or (dz, dy, dx) for
+// the transposed edge strip); output channels [co0, co0 + ncout) as one M-block set
+void pack_conv3(const float *A, const fpl_op &op, int co0, int ncout, bool transposed,
+                std::vector<uint16_t> *f) {
+  const int ncc = op.cin / CC, mb = (ncout + 15) / 16;
+  std::vector<float> sub((size_t)27 * CC * ncout), scale(A + op.scale_off + co0, A + op.scale_off + co0 + ncout);
+  f->clear();
+  for (int cc = 0; cc < ncc; ++cc) {
+    for (int ks = 0; ks < 27; ++ks) {
+      const int dz = ks / 9, d1 = (ks / 3) % 3, d2 = ks % 3;     // d1 = dx, d2 = dy
+      const int tap = transposed ? dz * 9 + d1 * 3 + d2 : dz * 9 + d2 * 3 + d1;
+      for (int ch = 0; ch < CC; ++ch)
+        memcpy(&sub[((size_t)ks * CC + ch) * ncout],
+               A + op.w_off + ((size_t)tap * op.cin + cc * CC + ch) * op.cout + co0, ncout * sizeof(float));
+    }
+    std::vector<uint16_t> fc;
+    fpl_pack_frags(sub.data(), scale.data(), 27, CC, ncout, mb, 27, SLOT_SPATIAL, &fc, true);
+    f->insert(f->end(), fc.begin(), fc.end());
+  }
+}
+
+int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState **out) {
   UnetState *st = (UnetState *)prog->fast_state_h16[FPL_H16_SLOT];
   if (!st) {
     st = new UnetState();
@@ -562,53 +621,38 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
   std::vector<uint16_t> all;
   std::vector<float> shifts;
   const float *A = prog->arena_host.data();
-  for (int l = 0; l < 10; ++l) {
-    const fpl_op &op = prog->ops[conv_idx[l]];
+  const int l_up2 = d.l_up2(), l_last = d.nconv - 1;
+  st->off_w7t = 0;
+  for (int l = 0; l < d.nconv; ++l) {
+    const fpl_op &op = prog->ops[d.conv[l]];
     std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
     std::vector<uint16_t> f;
     const int mb = (op.cout + 15) / 16;
     if (l == 0) {
       fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, mb, 1, SLOT_STEM, &f, true);
+    } else if (op.k == 3 && op.cout > 64) {
+      // 128 output channels: two 64-channel launches, their fragment sets back to back
+      FPL_REQUIRE(ctx, op.cout == 128, "unet: conv3 with %d output channels", op.cout);
+      std::vector<uint16_t> h0, h1;
+      pack_conv3(A, op, 0, 64, false, &h0);
+      pack_conv3(A, op, 64, 64, false, &h1);
+      st->half_bytes[l] = h0.size() * sizeof(uint16_t);
+      f = h0;
+      f.insert(f.end(), h1.begin(), h1.end());
     } else if (op.k == 3) {
-      // per CC-channel chunk, K-step order (dz, dx, dy): rows [kstep][channel]
-      const int ncc = op.cin / CC;
-      std::vector<float> sub((size_t)27 * CC * op.cout);
-      for (int cc = 0; cc < ncc; ++cc) {
-        for (int ks = 0; ks < 27; ++ks) {
-          const int dz = ks / 9, dx = (ks / 3) % 3, dy = ks % 3;
-          const int tap = dz * 9 + dy * 3 + dx;
-          for (int ch = 0; ch < CC; ++ch)
-            memcpy(&sub[((size_t)ks * CC + ch) * op.cout],
-                   A + op.w_off + ((size_t)tap * op.cin + cc * CC + ch) * op.cout,
-                   op.cout * sizeof(float));
-        }
-        std::vector<uint16_t> fc;
-        fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, 27, SLOT_SPATIAL, &fc, true);
-        f.insert(f.end(), fc.begin(), fc.end());
-      }
-      if (l == 7) {              // the transposed edge strip swaps the roles of dy and dx
+      pack_conv3(A, op, 0, op.cout, false, &f);
+      if (l == l_up2) {          // the transposed edge strip swaps the roles of dy and dx
         std::vector<uint16_t> ft;
-        for (int cc = 0; cc < ncc; ++cc) {
-          for (int ks = 0; ks < 27; ++ks) {
-            const int dz = ks / 9, dx = (ks / 3) % 3, dy = ks % 3;
-            const int tap = dz * 9 + dx * 3 + dy;
-            for (int ch = 0; ch < CC; ++ch)
-              memcpy(&sub[((size_t)ks * CC + ch) * op.cout],
-                     A + op.w_off + ((size_t)tap * op.cin + cc * CC + ch) * op.cout,
-                     op.cout * sizeof(float));
-          }
-          std::vector<uint16_t> fc;
-          fpl_pack_frags(sub.data(), scale.data(), 27, CC, op.cout, mb, 27, SLOT_SPATIAL, &fc, true);
-          ft.insert(ft.end(), fc.begin(), fc.end());
-        }
+        pack_conv3(A, op, 0, op.cout, true, &ft);
         st->off_w7t = all.size() * sizeof(uint16_t);
         all.insert(all.end(), ft.begin(), ft.end());
       }
-    } else if (l == 9) {
+    } else if (l == l_last) {
       fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, 1, 1, SLOT_CHAIN, &f);
     } else {
-      // l == 8 feeds the register-chained tail: plain row order there
-      fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL, &f, l != 8);
+      // the conv1 before the head feeds the register-chained tail: plain row order there
+      fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL, &f,
+                     l != l_last - 1);
     }
     st->off_w[l] = all.size() * sizeof(uint16_t);
     all.insert(all.end(), f.begin(), f.end());
@@ -622,7 +666,7 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const int conv_idx[10], UnetSt
                 "a folded weight exceeds the IEEE-half range (65504); use precision "
                 "bf16 or f32 for this network");
 #endif
-  st->bias_tail = A[prog->ops[conv_idx[9]].shift_off];
+  st->bias_tail = A[prog->ops[d.conv[l_last]].shift_off];
   if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
   if (st->shifts) FPL_HIP(ctx, hipFree(st->shifts));
   st->frags = nullptr; st->shifts = nullptr;
@@ -648,6 +692,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
+  if (a.cpitch == 0) a.cpitch = 16 * MB;
   // offset tables: one per distinct source geometry
   a.ntab = 0;
   for (int i = 0; i < (STEM ? 0 : a.ncc); ++i) {
@@ -691,24 +736,29 @@ Src make_src(const h16_t *p, int dim, int C, int ch0, int up, int crop) {
 }  // namespace
 
 bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
-  int idx[10];
-  return precision == FPL_THIS_PREC && is_unet_like2(prog, idx);
+  UnetDesc d;
+  return precision == FPL_THIS_PREC && match_unet(prog, &d);
 }
 
-// in: (n, T,T,T) f32 normalised tiles on the device; out: (n, T-18, T-18, T-18) f32
+// in: (n, T,T,T) f32 normalised tiles on the device; out: (n, O,O,O) f32, O = T - 2 * rf_offset
+// (unet_like2: T - 18; unet_like3: T - 26; unet_like4: T - 34)
 int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
                           int T, float *out, const FplTileIO *io) {
-  int ci[10];
-  FPL_REQUIRE(ctx, is_unet_like2(prog, ci), "not a unet_like2 program");
-  FPL_REQUIRE(ctx, T % 4 == 0 && T >= 24, "unet_like2 tile edge %d must be 0 mod 4", T);
+  UnetDesc D;
+  FPL_REQUIRE(ctx, match_unet(prog, &D), "not a unet_like2 / unet_like3 / unet_like4 program");
   FPL_REQUIRE(ctx, in && (io || out), "fpl_unet_forward: no input tiles / no output");
   UnetState *st;
-  FPL_TRY(unet_prepare(ctx, prog, ci, &st));
+  FPL_TRY(unet_prepare(ctx, prog, D, &st));
   DevTemp tmp(ctx);
   const unsigned char *F = st->frags;
   const float *S = st->shifts;
+  const bool b3[2] = {prog->ops[D.conv[4]].k == 3, D.nbottom == 2 && prog->ops[D.conv[5]].k == 3};
   const int d1a = T - 2, d1 = T - 4, dp1 = d1 / 2, d2a = dp1 - 2, d2 = dp1 - 4, dp2 = d2 / 2;
-  const int d4a = 2 * dp2 - 2, d5a = 2 * d4a - 2;      // = T - 18
+  const int db0 = dp2 - (b3[0] ? 2 : 0), db = db0 - (b3[1] ? 2 : 0);      // bottom outputs
+  const int d4a = 2 * db - 2, d5a = 2 * d4a - 2;
+  FPL_REQUIRE(ctx, T % 4 == 0 && d1 % 2 == 0 && d2 % 2 == 0 && db > 0 && d2 - 2 * D.crop2 == 2 * db &&
+                       d1 - 2 * D.crop1 == 2 * d4a,
+              "U-Net tile edge %d does not fit this architecture (0 mod 4, skips must meet)", T);
   auto cube = [](int d) { return (int64_t)d * d * d; };
   // conv3 tiles read up to 5 planes + 5 rows + 17 voxels past a source's last voxel
   auto balloc = [&](int64_t elems, int dim, int C, h16_t **p) -> int {
@@ -718,13 +768,14 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     *p = (h16_t *)q;
     return rc;
   };
-  h16_t *c1, *p1, *c2a, *c2, *p2, *c3, *c4a, *c4, *c5a;
+  h16_t *c1, *p1, *c2a, *c2, *p2, *c3a = nullptr, *c3, *c4a, *c4, *c5a;
   FPL_TRY(balloc(n * cube(d1) * 32, d1, 32, &c1));
   FPL_TRY(balloc(n * cube(dp1) * 32, dp1, 32, &p1));
   FPL_TRY(balloc(n * cube(d2a) * 64, d2a, 64, &c2a));
   FPL_TRY(balloc(n * cube(d2) * 64, d2, 64, &c2));
   FPL_TRY(balloc(n * cube(dp2) * 64, dp2, 64, &p2));
-  FPL_TRY(balloc(n * cube(dp2) * 128, dp2, 128, &c3));
+  if (D.nbottom == 2) FPL_TRY(balloc(n * cube(db0) * 128, db0, 128, &c3a));
+  FPL_TRY(balloc(n * cube(db) * 128, db, 128, &c3));
   FPL_TRY(balloc(n * cube(d4a) * 64, d4a, 64, &c4a));
   FPL_TRY(balloc(n * cube(d4a) * 64, d4a, 64, &c4));
   FPL_TRY(balloc(n * cube(d5a) * 32, d5a, 32, &c5a));
@@ -732,13 +783,13 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   auto conv3_args = [&](int l, h16_t *outp, int od) {
     Conv3Args a;
     a.w = F + st->off_w[l]; a.shift = S + st->off_s[l]; a.relu = 1;
-    a.out = outp; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
+    a.out = outp; a.cpitch = 0; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
     a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr; a.pool_out = nullptr;
     a.transposed = 0; a.xorg = 0; a.main_w = 0;
     memset(&a.io, 0, sizeof(a.io)); a.w8 = a.w9 = nullptr; a.sh8 = nullptr; a.bias9 = 0.f;
     return a;
   };
-  {  // L0 + L1: conv3 1->32 computed into the tile of conv3 32->32
+  {  // conv3 1->32 computed into the tile of conv3 32->32
     Conv3Args a = conv3_args(1, c1, d1);
     a.ncc = 1; a.src[0] = make_src(nullptr, d1a, 32, 0, 1, 0);
     a.raw = in; a.T = T;
@@ -746,12 +797,12 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.pool_out = p1;                               // MaxPooling3D(2) in the epilogue
     FPL_TRY((launch_conv3<2, true, true>(ctx, a, n, "unet_stem_conv3_32_32_pool")));
   }
-  {  // L2: conv3 32->64
+  {  // conv3 32->64
     Conv3Args a = conv3_args(2, c2a, d2a);
     a.ncc = 1; a.src[0] = make_src(p1, dp1, 32, 0, 1, 0);
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_32_64")));
   }
-  {  // L3: conv3 64->64
+  {  // conv3 64->64
     Conv3Args a = conv3_args(3, c2, d2);
     a.ncc = 2;
     for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c2a, d2a, 64, 32 * cc, 1, 0);
@@ -767,29 +818,51 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     TimedLaunch tl(ctx, name);
     kern<<<grid, 256, smem_frags * 1024, stm>>>(a);
   };
-  conv1(FPLK(conv1)<64, 8, 0>, 16, p2, (int64_t)n * cube(dp2), 4, c3, "unet_conv1_64_128");
-  {  // L5: conv3 (up2(c3) 128 | c2 64) -> 64
-    Conv3Args a = conv3_args(5, c4a, d4a);
+  // conv3 -> 128 channels: two 64-channel launches into the halves of one tensor
+  auto conv3_to128 = [&](int l, const h16_t *x, int xd, int xc, h16_t *y, int yd, const char *name) -> int {
+    for (int h = 0; h < 2; ++h) {
+      Conv3Args a = conv3_args(l, y + 64 * h, yd);
+      a.w = F + st->off_w[l] + (h ? st->half_bytes[l] : 0);
+      a.shift = S + st->off_s[l] + 64 * h;
+      a.cpitch = 128;
+      a.ncc = xc / 32;
+      for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = make_src(x, xd, xc, 32 * cc, 1, 0);
+      FPL_TRY((launch_conv3<4>(ctx, a, n, name)));
+    }
+    return 0;
+  };
+  // ---- bottom
+  if (!b3[0]) {
+    conv1(FPLK(conv1)<64, 8, 0>, 16, p2, (int64_t)n * cube(dp2), 4, c3, "unet_conv1_64_128");
+  } else {
+    h16_t *y0 = D.nbottom == 2 ? c3a : c3;
+    FPL_TRY(conv3_to128(4, p2, dp2, 64, y0, db0, "unet_conv3_64_128"));
+    if (b3[1]) FPL_TRY(conv3_to128(5, c3a, db0, 128, c3, db, "unet_conv3_128_128"));
+    else conv1(FPLK(conv1)<128, 8, 0>, 32, c3a, (int64_t)n * cube(db0), 5, c3, "unet_conv1_128_128");
+  }
+  const int lu1 = D.l_up1(), lu2 = D.l_up2();
+  {  // conv3 (up2(c3) 128 | crop(c2) 64) -> 64
+    Conv3Args a = conv3_args(lu1, c4a, d4a);
     a.ncc = 6;
-    for (int cc = 0; cc < 4; ++cc) a.src[cc] = make_src(c3, dp2, 128, 32 * cc, 2, 0);
-    for (int cc = 0; cc < 2; ++cc) a.src[4 + cc] = make_src(c2, d2, 64, 32 * cc, 1, 0);
+    for (int cc = 0; cc < 4; ++cc) a.src[cc] = make_src(c3, db, 128, 32 * cc, 2, 0);
+    for (int cc = 0; cc < 2; ++cc) a.src[4 + cc] = make_src(c2, d2, 64, 32 * cc, 1, D.crop2);
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
   }
-  conv1(FPLK(conv1)<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), 6, c4, "unet_conv1_64_64");
-  {  // L7: conv3 (up2(c4) 64 | crop6(c1) 32) -> 32.  Output width 82 = 5 x 16 + 2: the
-     // last two columns go through the transposed edge strip instead of a sixth block
+  conv1(FPLK(conv1)<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), lu1 + 1, c4, "unet_conv1_64_64");
+  {  // conv3 (up2(c4) 64 | crop(c1) 32) -> 32.  unet_like2's output width 82 = 5 x 16 + 2:
+     // the last two columns go through the transposed edge strip instead of a sixth block
      // column that would use 2 of its 16 lanes
-    Conv3Args a = conv3_args(7, c5a, d5a);
+    Conv3Args a = conv3_args(lu2, c5a, d5a);
     a.ncc = 3;
     for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c4, d4a, 64, 32 * cc, 2, 0);
-    a.src[2] = make_src(c1, d1, 32, 0, 1, 6);
+    a.src[2] = make_src(c1, d1, 32, 0, 1, D.crop1);
     const int rem = d5a % 16;
     const bool strip = rem > 0 && rem <= 4 && d5a > 16 && st->off_w7t != 0;
     if (strip) a.main_w = d5a - rem;
     if (io) {                    // conv1 32->32, conv1 32->1, sigmoid and the store into
       a.io = *io;                // the prediction volume ride in the epilogue
-      a.w8 = (const h16x8 *)(F + st->off_w[8]); a.sh8 = S + st->off_s[8];
-      a.w9 = (const h16x8 *)(F + st->off_w[9]); a.bias9 = st->bias_tail;
+      a.w8 = (const h16x8 *)(F + st->off_w[lu2 + 1]); a.sh8 = S + st->off_s[lu2 + 1];
+      a.w9 = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias9 = st->bias_tail;
       a.out = nullptr;
       FPL_TRY((launch_conv3<2, false, false, true>(ctx, a, n, "unet_conv3_96_32_head")));
     } else {
@@ -803,10 +876,10 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
       else FPL_TRY((launch_conv3<2>(ctx, e, n, "unet_conv3_96_32_edge")));
     }
   }
-  if (!io) {  // L8 + L9: conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
+  if (!io) {  // conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
     Conv1Args a;
-    a.in = c5a; a.M = (int64_t)n * cube(d5a); a.w = F + st->off_w[8]; a.shift = S + st->off_s[8];
-    a.out = nullptr; a.w_tail = (const h16x8 *)(F + st->off_w[9]); a.bias_tail = st->bias_tail;
+    a.in = c5a; a.M = (int64_t)n * cube(d5a); a.w = F + st->off_w[lu2 + 1]; a.shift = S + st->off_s[lu2 + 1];
+    a.out = nullptr; a.w_tail = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias_tail = st->bias_tail;
     a.out_f32 = out;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, "unet_head_" FPL_PREC_STR);
