@@ -459,15 +459,17 @@ __global__ void pool2_f32v(const float *__restrict__ x, float *__restrict__ y, i
 
 // ---- host: fragment packing + generic executor --------------------------------------
 // conv3 fragments: [cc][tap][mb][lane][j] = W[tap][16cc + 4g + j][16mb + (lane&15)] * scale
+// output channels [co0, co0 + 16 * mb) of a conv with `cout` channels (slices of 64 for
+// wider convs)
 void pack_conv3_f32(const float *W, const float *scale, int cin, int cout, int mb,
-                    std::vector<float> *out) {
+                    std::vector<float> *out, int co0 = 0) {
   const int ncc = (cin + 15) / 16;
   out->assign((size_t)ncc * 27 * mb * 256, 0.f);
   for (int cc = 0; cc < ncc; ++cc)
     for (int tap = 0; tap < 27; ++tap)
       for (int b = 0; b < mb; ++b)
         for (int lane = 0; lane < 64; ++lane) {
-          const int co = 16 * b + (lane & 15), g = lane >> 4;
+          const int co = co0 + 16 * b + (lane & 15), g = lane >> 4;
           if (co >= cout) continue;
           for (int j = 0; j < 4; ++j) {
             const int ci = 16 * cc + 4 * g + j;
@@ -599,7 +601,7 @@ bool fpl_mfma_f32_supported(const fpl_program *prog) {
                                     op.p[3] == op.p[4] && op.p[4] == op.p[5]))
       return false;
     if (op.kind == FPL_OP_CONV) {
-      if (op.k == 3 && (op.cout > 64 || op.cin > 12 * 16)) return false;
+      if (op.k == 3 && (op.cout > 256 || op.cin > 12 * 16)) return false;
       if (op.k == 1 && op.cout > 128) return false;
     }
   }
@@ -626,7 +628,15 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       std::vector<float> f;
       const int mb = (op.cout + 15) / 16;
       if (op.k == 3 && op.cin == 1) pack_stem_f32(A + op.w_off, A + op.scale_off, op.cout, mb, &f);
-      else if (op.k == 3) pack_conv3_f32(A + op.w_off, A + op.scale_off, op.cin, op.cout, mb, &f);
+      else if (op.k == 3) {
+        // 64 output channels per launch: slices back to back
+        for (int c0 = 0; c0 < op.cout; c0 += 64) {
+          std::vector<float> fs;
+          pack_conv3_f32(A + op.w_off, A + op.scale_off, op.cin, op.cout,
+                         (std::min(64, op.cout - c0) + 15) / 16, &fs, c0);
+          f.insert(f.end(), fs.begin(), fs.end());
+        }
+      }
       else pack_conv1_f32(A + op.w_off, A + op.scale_off, op.cin, op.cout, mb, &f);
       st->off[i] = all.size();
       all.insert(all.end(), f.begin(), f.end());
@@ -754,15 +764,19 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       }
       // the packed fragments assume channel chunks of the concatenated tensor in
       // order, each source starting on a 16-channel boundary
-      c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
-      c.out = dst; c.cout = op.cout; c.opitch = op.cout; c.OD = c.OH = c.OW = od;
-      const int mb = (op.cout + 15) / 16;
-      switch (mb) {
-        case 1: FPL_TRY(launch3<1>(ctx, c, n)); break;
-        case 2: FPL_TRY(launch3<2>(ctx, c, n)); break;
-        case 3: FPL_TRY(launch3<3>(ctx, c, n)); break;
-        case 4: FPL_TRY(launch3<4>(ctx, c, n)); break;
-        default: return fpl_fail(ctx, "op %zu: conv3 with %d output channels", i, op.cout);
+      c.act = op.act; c.opitch = op.cout; c.OD = c.OH = c.OW = od;
+      size_t woff = st->off[i];
+      for (int c0 = 0; c0 < op.cout; c0 += 64) {      // 64 output channels per launch
+        const int cs = std::min(64, op.cout - c0), mb = (cs + 15) / 16;
+        c.w = st->frags + woff; c.shift = prog->arena_dev + op.shift_off + c0;
+        c.out = dst + c0; c.cout = cs;
+        woff += (size_t)c.ncc * 27 * mb * 256;
+        switch (mb) {
+          case 1: FPL_TRY(launch3<1>(ctx, c, n)); break;
+          case 2: FPL_TRY(launch3<2>(ctx, c, n)); break;
+          case 3: FPL_TRY(launch3<3>(ctx, c, n)); break;
+          case 4: FPL_TRY(launch3<4>(ctx, c, n)); break;
+        }
       }
     }
     FPL_HIP(ctx, hipGetLastError());
@@ -1118,7 +1132,9 @@ __global__ __launch_bounds__(256) void wgrad_partials_add(const float *__restric
 }  // namespace
 
 bool fpl_tm_supported(int k, int cin, int cout) {
-  if (k == 3) return cout <= 64 && cin <= 12 * 16;
+  // 3x3x3: 64 output channels per launch (wider ones in slices, which need 16-B aligned
+  // channel offsets), <= 12 input chunks of 16
+  if (k == 3) return (cout <= 64 || cout % 4 == 0) && cout <= 256 && cin <= 12 * 16;
   return k == 1 && cout <= 128;
 }
 
@@ -1182,22 +1198,29 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
     }
     return fpl_fail(ctx, "conv1 with %d channels", cout);
   }
-  Conv3F c;
-  c.ncc = ncc;
-  for (int q = 0; q < ncc; ++q) {
-    SrcF s;
-    s.p = x; s.D = D; s.H = H; s.W = W_; s.C = cin; s.ch0 = 16 * q; s.up = 1; s.crop = 0; s.pad = 0;
-    c.src[q] = s;
+  for (int c0 = 0; c0 < cout; c0 += 64) {          // 64 output channels per launch
+    const int cs = std::min(64, cout - c0), mbs = (cs + 15) / 16;
+    const int64_t tots = (int64_t)ncc * k3 * mbs * 256;
+    void *frs;
+    FPL_TRY(tmp.alloc(tots * 4, &frs));
+    pack_frags_dev<<<(unsigned)ceil_div64(tots, 256), 256, 0, ctx->stream>>>(Wd, (float *)frs, k3, cin, cout, mbs, 0, tots, c0);
+    Conv3F c;
+    c.ncc = ncc;
+    for (int q = 0; q < ncc; ++q) {
+      SrcF s;
+      s.p = x; s.D = D; s.H = H; s.W = W_; s.C = cin; s.ch0 = 16 * q; s.up = 1; s.crop = 0; s.pad = 0;
+      c.src[q] = s;
+    }
+    c.w = (const float *)frs; c.shift = bias + c0; c.act = act; c.out = y + c0; c.cout = cs; c.opitch = cout;
+    c.OD = od; c.OH = oh; c.OW = ow;
+    switch (mbs) {
+      case 1: FPL_TRY(launch3<1>(ctx, c, n)); break;
+      case 2: FPL_TRY(launch3<2>(ctx, c, n)); break;
+      case 3: FPL_TRY(launch3<3>(ctx, c, n)); break;
+      case 4: FPL_TRY(launch3<4>(ctx, c, n)); break;
+    }
   }
-  c.w = (const float *)fr; c.shift = bias; c.act = act; c.out = y; c.cout = cout; c.opitch = cout;
-  c.OD = od; c.OH = oh; c.OW = ow;
-  switch (mb) {
-    case 1: return launch3<1>(ctx, c, n);
-    case 2: return launch3<2>(ctx, c, n);
-    case 3: return launch3<3>(ctx, c, n);
-    case 4: return launch3<4>(ctx, c, n);
-  }
-  return fpl_fail(ctx, "conv3 with %d channels", cout);
+  return 0;
 }
 
 // dx (n,D,H,W,cin) = input gradient of the valid conv for dy (n,od,oh,ow,cout);
