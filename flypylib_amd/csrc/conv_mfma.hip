@@ -492,6 +492,127 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
   }
 }
 
+// ---- unet_like's first stage (fplmodels.py:210-256): conv3 1->32 +BN+ReLU, conv1 32->32
+// +BN+ReLU chained in registers (with interleaved rows the packed output of the first is
+// the K-step of the second), stored as c1 and max-pooled to p1.  Block 4 x 4 x 16 voxels,
+// wave = z, sub-steps = y, lanes = x; the raw 6 x 6 x 18 tile sits in LDS as 16-bit.
+struct StemC1Args {
+  const float *raw; int T;       // (n, T, T, T) f32 normalised tiles
+  const h16x8 *wstem;            // 2 fragments, k-slot (g,j) = tap 8g + j, interleaved rows
+  const float *shstem;
+  const h16x8 *w1;               // 2 fragments of conv1 32->32 (SLOT_SPATIAL, interleaved rows)
+  const float *sh1;
+  h16_t *c1, *p1;                // (n, D, D, D, 32), D = T - 2; (n, D/2, D/2, D/2, 32)
+  int D, zblocks, nbx, nby;
+};
+
+__global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
+  constexpr int RZ = 6, RY = 6, RX = 18;
+  __shared__ unsigned short rawt[RZ * RY * RX];
+  __shared__ u32x4 xch[2 * 2 * 64];                        // [wave pair][y half][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int bx = blockIdx.x % a.nbx, by = (blockIdx.x / a.nbx) % a.nby, bz = blockIdx.x / (a.nbx * a.nby);
+  const int n = bz / a.zblocks, z0 = (bz % a.zblocks) * 4, y0 = by * 4, x0 = bx * 16;
+  const float *base = a.raw + (int64_t)n * a.T * a.T * a.T;
+  for (int p = tid; p < RZ * RY * RX; p += 256) {
+    int z = z0 + p / (RY * RX), y = y0 + (p / RX) % RY, x = x0 + p % RX;
+    z = z < a.T ? z : a.T - 1;                             // clamped reads only feed masked
+    y = y < a.T ? y : a.T - 1;                             // outputs
+    x = x < a.T ? x : a.T - 1;
+    rawt[p] = h16_bits(base[((int64_t)z * a.T + y) * a.T + x]);
+  }
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t = 8 * g + j;
+    toff[j] = t < 27 ? ((t / 9) * RY + (t / 3) % 3) * RX + t % 3 : 0;
+  }
+  h16x8 ws[2], w1[2];
+  f32x4 shs[2], sh1[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    ws[b] = a.wstem[b * 64 + lane];
+    w1[b] = a.w1[b * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      shs[b][r] = a.shstem[8 * g + 4 * b + r];
+      sh1[b][r] = a.sh1[8 * g + 4 * b + r];
+    }
+  }
+  __syncthreads();
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const int ro = (wave * RY + sub) * RX + c;
+    u16x8 rw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rw[j] = rawt[ro + toff[j]];
+    const h16x8 bf = __builtin_bit_cast(h16x8, rw);
+    const h16x8 h0 = pack_relu(mfma16(ws[0], bf, shs[0]), mfma16(ws[1], bf, shs[1]));
+    acc[sub][0] = mfma16(w1[0], h0, sh1[0]);
+    acc[sub][1] = mfma16(w1[1], h0, sh1[1]);
+    const int oz = z0 + wave, oy = y0 + sub, ox = x0 + c;
+    if (oz < a.D && oy < a.D && ox < a.D)
+      store_il<2, true>(a.c1 + ((((int64_t)n * a.D + oz) * a.D + oy) * a.D + ox) * 32, g, acc[sub], 1);
+  }
+  // 2x2x2 max pool of the block, as the POOL epilogue of conv3
+  u32x4 pm[2];
+#pragma unroll
+  for (int yh = 0; yh < 2; ++yh)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = q >> 1, r0 = (q & 1) * 2;
+      const unsigned lo = pk_max_i16(cvt_pk_h16(acc[2 * yh][b][r0], acc[2 * yh][b][r0 + 1]), 0u);
+      const unsigned hi = pk_max_i16(cvt_pk_h16(acc[2 * yh + 1][b][r0], acc[2 * yh + 1][b][r0 + 1]), 0u);
+      unsigned m = pk_max_i16(lo, hi);
+      m = pk_max_i16(m, (unsigned)__shfl_xor((int)m, 1));
+      pm[yh][q] = m;
+    }
+  if (wave & 1) {
+    xch[((wave >> 1) * 2 + 0) * 64 + lane] = pm[0];
+    xch[((wave >> 1) * 2 + 1) * 64 + lane] = pm[1];
+  }
+  __syncthreads();
+  if (!(wave & 1) && !(c & 1)) {
+    const int PD = a.D / 2;
+    const int pz = (bz % a.zblocks) * 2 + (wave >> 1), px = bx * 8 + (c >> 1);
+#pragma unroll
+    for (int yh = 0; yh < 2; ++yh) {
+      const int py = by * 2 + yh;
+      if (pz < PD && py < PD && px < PD) {
+        const u32x4 o = xch[((wave >> 1) * 2 + yh) * 64 + lane];
+        u32x4 m;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = pk_max_i16(pm[yh][q], o[q]);
+        *reinterpret_cast<u32x4 *>(a.p1 + ((((int64_t)n * PD + pz) * PD + py) * PD + px) * 32 + 8 * g) = m;
+      }
+    }
+  }
+}
+
+// MaxPooling3D(2) of a non-negative (post-ReLU) 16-bit channels-last tensor: a thread takes
+// 8 channels (16 B) of one window; 16-bit order = int16 order for non-negative values
+__global__ void FPLK(pool2_h16)(const u32x4 *__restrict__ x, u32x4 *__restrict__ y, int64_t n_out,
+                                int D, int C8, int od) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  int64_t t = i;
+  const int c = (int)(t % C8); t /= C8;
+  const int ox = (int)(t % od); t /= od;
+  const int oy = (int)(t % od); t /= od;
+  const int oz = (int)(t % od); t /= od;
+  u32x4 m = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const u32x4 v = x[((((t * D + 2 * oz + (p >> 2)) * D + 2 * oy + ((p >> 1) & 1)) * (int64_t)D +
+                       2 * ox + (p & 1)) * C8) + c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = pk_max_i16(m[q], v[q]);
+  }
+  y[i] = m;
+}
+
 // ---- host: unet_like2 pattern + packed weights -------------------------------------
 struct UnetState {
   uint64_t version = ~0ull;
@@ -510,7 +631,8 @@ void unet_state_free(fpl_ctx *, void *p) {
   delete s;
 }
 
-// The U-Net skeleton of fplmodels.py:258-407 (unet_like2, unet_like3, unet_like4):
+// The U-Net skeleton of fplmodels.py:210-407 (unet_like, unet_like2, unet_like3, unet_like4;
+// unet_like's second conv of stages 1 and 2 is 1x1):
 //   conv3 1->32, conv3 32->32, pool, conv3 32->64, conv3 64->64, pool, BOTTOM,
 //   up, [crop skip2], concat, conv3 192->64, conv1 64->64, up, crop skip1, concat,
 //   conv3 96->32, conv1 32->32, conv1 32->1 (sigmoid)
@@ -523,6 +645,7 @@ struct UnetDesc {
   int conv[12];                  // op index per conv, in order
   int nbottom = 0;               // 1 or 2
   int crop2 = 0, crop1 = 0;      // crop of the stage-2 / stage-1 skip
+  bool first1 = false, second1 = false;   // unet_like: the second conv of stage 1 / 2 is 1x1
   int l_up1() const { return 4 + nbottom; }      // conv3 192->64
   int l_up2() const { return 6 + nbottom; }      // conv3 96->32
 };
@@ -558,7 +681,11 @@ bool match_unet(const fpl_program *prog, UnetDesc *d) {
   auto is = [&](int l, int k, int cin, int cout) {
     return C(l).k == k && C(l).cin == cin && C(l).cout == cout;
   };
-  if (!is(0, 3, 1, 32) || !is(1, 3, 32, 32) || !is(2, 3, 32, 64) || !is(3, 3, 64, 64)) return false;
+  if (!is(0, 3, 1, 32) || !is(2, 3, 32, 64)) return false;
+  d->first1 = is(1, 1, 32, 32);
+  d->second1 = is(3, 1, 64, 64);
+  if (!d->first1 && !is(1, 3, 32, 32)) return false;
+  if (!d->second1 && !is(3, 3, 64, 64)) return false;
   if (d->nbottom == 1) {
     if (!is(4, 1, 64, 128)) return false;
   } else {
@@ -745,7 +872,7 @@ bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
 int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
                           int T, float *out, const FplTileIO *io) {
   UnetDesc D;
-  FPL_REQUIRE(ctx, match_unet(prog, &D), "not a unet_like2 / unet_like3 / unet_like4 program");
+  FPL_REQUIRE(ctx, match_unet(prog, &D), "not a unet_like / unet_like2 / unet_like3 / unet_like4 program");
   FPL_REQUIRE(ctx, in && (io || out), "fpl_unet_forward: no input tiles / no output");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
@@ -753,12 +880,13 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   const unsigned char *F = st->frags;
   const float *S = st->shifts;
   const bool b3[2] = {prog->ops[D.conv[4]].k == 3, D.nbottom == 2 && prog->ops[D.conv[5]].k == 3};
-  const int d1a = T - 2, d1 = T - 4, dp1 = d1 / 2, d2a = dp1 - 2, d2 = dp1 - 4, dp2 = d2 / 2;
+  const int d1a = T - 2, d1 = D.first1 ? d1a : T - 4, dp1 = d1 / 2, d2a = dp1 - 2,
+            d2 = D.second1 ? d2a : dp1 - 4, dp2 = d2 / 2;
   const int db0 = dp2 - (b3[0] ? 2 : 0), db = db0 - (b3[1] ? 2 : 0);      // bottom outputs
   const int d4a = 2 * db - 2, d5a = 2 * d4a - 2;
-  FPL_REQUIRE(ctx, T % 4 == 0 && d1 % 2 == 0 && d2 % 2 == 0 && db > 0 && d2 - 2 * D.crop2 == 2 * db &&
-                       d1 - 2 * D.crop1 == 2 * d4a,
-              "U-Net tile edge %d does not fit this architecture (0 mod 4, skips must meet)", T);
+  FPL_REQUIRE(ctx, d1 > 0 && d1 % 2 == 0 && d2 > 0 && d2 % 2 == 0 && db > 0 &&
+                       d2 - 2 * D.crop2 == 2 * db && d1 - 2 * D.crop1 == 2 * d4a && d5a > 0,
+              "U-Net tile edge %d does not fit this architecture (pools need even sizes, skips must meet)", T);
   auto cube = [](int d) { return (int64_t)d * d * d; };
   // conv3 tiles read up to 5 planes + 5 rows + 17 voxels past a source's last voxel
   auto balloc = [&](int64_t elems, int dim, int C, h16_t **p) -> int {
@@ -789,7 +917,16 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     memset(&a.io, 0, sizeof(a.io)); a.w8 = a.w9 = nullptr; a.sh8 = nullptr; a.bias9 = 0.f;
     return a;
   };
-  {  // conv3 1->32 computed into the tile of conv3 32->32
+  if (D.first1) {  // unet_like: conv3 1->32 and conv1 32->32 chained, c1 + pooled p1
+    StemC1Args a;
+    a.raw = in; a.T = T;
+    a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
+    a.w1 = (const h16x8 *)(F + st->off_w[1]); a.sh1 = S + st->off_s[1];
+    a.c1 = c1; a.p1 = p1; a.D = d1;
+    a.zblocks = (int)ceil_div64(d1, 4); a.nbx = (int)ceil_div64(d1, 16); a.nby = (int)ceil_div64(d1, 4);
+    TimedLaunch tl(ctx, "unet_stem_conv1_32_32_pool");
+    FPLK(unet_stem_c1)<<<(unsigned)((int64_t)a.nbx * a.nby * n * a.zblocks), 256, 0, stm>>>(a);
+  } else {  // conv3 1->32 computed into the tile of conv3 32->32
     Conv3Args a = conv3_args(1, c1, d1);
     a.ncc = 1; a.src[0] = make_src(nullptr, d1a, 32, 0, 1, 0);
     a.raw = in; a.T = T;
@@ -802,7 +939,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.ncc = 1; a.src[0] = make_src(p1, dp1, 32, 0, 1, 0);
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_32_64")));
   }
-  {  // conv3 64->64
+  if (!D.second1) {  // conv3 64->64
     Conv3Args a = conv3_args(3, c2, d2);
     a.ncc = 2;
     for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c2a, d2a, 64, 32 * cc, 1, 0);
@@ -818,6 +955,12 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     TimedLaunch tl(ctx, name);
     kern<<<grid, 256, smem_frags * 1024, stm>>>(a);
   };
+  if (D.second1) {  // unet_like: conv1 64->64, then the pool as its own (HBM-bound) pass
+    conv1(FPLK(conv1)<64, 4, 0>, 8, c2a, (int64_t)n * cube(d2a), 3, c2, "unet_conv1_64_64");
+    const int64_t no = (int64_t)n * cube(dp2) * 8;
+    TimedLaunch tl(ctx, "unet_pool_64");
+    FPLK(pool2_h16)<<<(unsigned)ceil_div64(no, 256), 256, 0, stm>>>((const u32x4 *)c2, (u32x4 *)p2, no, d2, 8, dp2);
+  }
   // conv3 -> 128 channels: two 64-channel launches into the halves of one tensor
   auto conv3_to128 = [&](int l, const h16_t *x, int xd, int xc, h16_t *y, int yd, const char *name) -> int {
     for (int h = 0; h < 2; ++h) {
