@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
+COMM_ID_BYTES = 128
 
 
 class FplHipError(RuntimeError):
@@ -49,6 +50,7 @@ SIGNATURES = {
     'fpl_ctx_set_stream': (C.c_int, [_vp, _vp]),
     'fpl_ctx_synchronize': (C.c_int, [_vp]),
     'fpl_device_info': (C.c_int, [_vp, _pi32, _pi64, C.c_char_p, C.c_size_t]),
+    'fpl_device_pci_bus_id': (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     'fpl_malloc': (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     'fpl_free': (C.c_int, [_vp, _vp]),
     'fpl_memcpy': (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_size_t]),
@@ -81,6 +83,16 @@ SIGNATURES = {
     'fpl_trainer_get_weights': (C.c_int, [_vp, _vp, _i64]),
     'fpl_trainer_set_weights': (C.c_int, [_vp, _vp, _i64]),
     'fpl_trainer_get_grads': (C.c_int, [_vp, _vp, _i64]),
+    'fpl_trainer_set_grads': (C.c_int, [_vp, _vp, _i64]),
+    'fpl_last_path': (C.c_char_p, [_vp]),
+    'fpl_comm_unique_id': (C.c_int, [_vp]),
+    'fpl_comm_init': (C.c_int, [_vp, _i32, _i32, _vp]),
+    'fpl_comm_destroy': (C.c_int, [_vp]),
+    'fpl_comm_info': (C.c_int, [_vp, _pi32, _pi32, C.c_char_p, C.c_size_t]),
+    'fpl_comm_allreduce_sum_f32': (C.c_int, [_vp, _vp, _i64]),
+    'fpl_comm_broadcast_f32': (C.c_int, [_vp, _vp, _i64, _i32]),
+    'fpl_allreduce_grads': (C.c_int, [_vp]),
+    'fpl_trainer_broadcast_state': (C.c_int, [_vp, _i32]),
     'fpl_synth_volume_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _vp,
                                       C.c_int]),
     'fpl_synth_substack_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _pi64, _vp, C.c_int]),
@@ -139,6 +151,16 @@ def _arr(vals, ctype):
     return (ctype * len(vals))(*[int(v) for v in vals])
 
 
+def comm_unique_id():
+    """128-byte RCCL unique id (fpl_comm_unique_id): made by rank 0, carried to the
+    other ranks by the host, consumed by `Context.comm_init`"""
+    lib = load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    if lib.fpl_comm_unique_id(buf) != 0:
+        raise FplHipError(lib.fpl_last_error(None).decode())
+    return bytes(buf)
+
+
 class Context:
     """one GPU (fpl_ctx).  Create after fork(); use from one thread at a time."""
 
@@ -179,6 +201,39 @@ class Context:
                                             name, 256))
         return dict(n_cu=ncu.value, hbm_bytes=hbm.value,
                     name=name.value.decode())
+
+    def device_uuid(self):
+        """PCI bus id of this context's GPU"""
+        buf = C.create_string_buffer(64)
+        self.check(self.lib.fpl_device_pci_bus_id(self.h, buf, 64))
+        return buf.value.decode()
+
+    def last_path(self):
+        """executor the last infer_volume / forward of this context ran on"""
+        return self.lib.fpl_last_path(self.h).decode()
+
+    # ---- RCCL communicator of this GPU (data-parallel training)
+    def comm_init(self, rank, nranks, unique_id):
+        """collective: returns when all `nranks` ranks have joined"""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError('unique id must be %d bytes' % COMM_ID_BYTES)
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        self.check(self.lib.fpl_comm_init(self.h, int(rank), int(nranks), buf))
+
+    def comm_destroy(self):
+        self.check(self.lib.fpl_comm_destroy(self.h))
+
+    def comm_info(self):
+        rank, n = C.c_int32(), C.c_int32()
+        path = C.create_string_buffer(256)
+        self.check(self.lib.fpl_comm_info(self.h, C.byref(rank), C.byref(n), path, 256))
+        return dict(rank=rank.value, nranks=n.value, lib=path.value.decode())
+
+    def comm_allreduce_sum_f32(self, dev, n):
+        self.check(self.lib.fpl_comm_allreduce_sum_f32(self.h, _ptr(dev), int(n)))
+
+    def comm_broadcast_f32(self, dev, n, root=0):
+        self.check(self.lib.fpl_comm_broadcast_f32(self.h, _ptr(dev), int(n), int(root)))
 
     # ---- timing
     def timing(self, on=True):
@@ -529,3 +584,21 @@ class Trainer:
                                for w in weights])
         self.ctx.check(self.ctx.lib.fpl_trainer_set_weights(self.h, _ptr(flat),
                                                             flat.size))
+
+    # ---- data parallelism
+    def get_grads_flat(self):
+        flat = np.empty(self.n_w, np.float32)
+        self.ctx.check(self.ctx.lib.fpl_trainer_get_grads(self.h, _ptr(flat), self.n_w))
+        return flat
+
+    def set_grads_flat(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32).reshape(-1)
+        self.ctx.check(self.ctx.lib.fpl_trainer_set_grads(self.h, _ptr(flat), flat.size))
+
+    def allreduce_grads(self):
+        """ONE RCCL all-reduce (sum) of the gradient arena over the context's
+        communicator, stream-ordered before `apply`"""
+        self.ctx.check(self.ctx.lib.fpl_allreduce_grads(self.h))
+
+    def broadcast_state(self, root=0):
+        self.ctx.check(self.ctx.lib.fpl_trainer_broadcast_state(self.h, int(root)))

@@ -57,7 +57,14 @@ struct fpl_ctx {
   std::vector<PendingTiming> pending;
   std::vector<hipEvent_t> event_pool;
   V2oState v2o;
+  // RCCL communicator of this GPU (comm.hip); ncclComm_t kept opaque here
+  void *comm = nullptr;
+  int comm_rank = 0, comm_nranks = 1;
+  // executor chosen by the last fpl_infer_volume / fpl_program_forward (fpl_last_path)
+  char last_path[64] = {0};
 };
+
+void fpl_comm_release(fpl_ctx *ctx);                  // comm.hip
 
 extern thread_local char g_fpl_err[FPL_MAX_ERR];
 

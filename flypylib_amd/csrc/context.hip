@@ -55,6 +55,7 @@ int fpl_ctx_destroy(fpl_ctx *ctx) {
   if (!ctx) return 0;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  fpl_comm_release(ctx);
   for (auto &p : ctx->pending) {
     ctx->event_pool.push_back(p.start);
     ctx->event_pool.push_back(p.stop);
@@ -92,6 +93,12 @@ int fpl_device_info(fpl_ctx *ctx, int32_t *n_cu, int64_t *hbm_bytes, char *name,
   if (name && name_cap) {
     snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
   }
+  return 0;
+}
+
+int fpl_device_pci_bus_id(fpl_ctx *ctx, char *out, size_t cap) {
+  if (!ctx || !out || cap < 16) return fpl_fail(ctx, "fpl_device_pci_bus_id: bad argument");
+  FPL_HIP(ctx, hipDeviceGetPCIBusId(out, (int)cap, ctx->device));
   return 0;
 }
 

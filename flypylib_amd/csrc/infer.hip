@@ -12,6 +12,10 @@ namespace {
 
 typedef FplTileDesc TileDesc;
 
+inline void set_last_path(fpl_ctx *ctx, const char *name) {
+  snprintf(ctx->last_path, sizeof(ctx->last_path), "%s", name);
+}
+
 template <typename T>
 __global__ void gather_tiles(const T *__restrict__ src, int64_t Y, int64_t X,
                              const TileDesc *__restrict__ tiles, int I0, int I1,
@@ -134,10 +138,13 @@ int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
     net_out = (float *)p;
   }
   const bool cubic = in_dims[0] == in_dims[1] && in_dims[1] == in_dims[2];
-  if (cubic && fpl_mfma_f32_supported(prog) && !getenv("FPL_FORCE_PEROP"))
+  if (cubic && fpl_mfma_f32_supported(prog) && !getenv("FPL_FORCE_PEROP")) {
+    set_last_path(ctx, "mfma_f32");
     FPL_TRY(fpl_forward_mfma_f32(ctx, prog, in_dev, n, in_dims[0], net_out));
-  else
+  } else {
+    set_last_path(ctx, "perop_f32");
     FPL_TRY(fpl_forward_generic(ctx, prog, in_dev, n, in_dims, net_out));
+  }
   if (up) {
     TimedLaunch tl(ctx, "upsample_out");
     upsample_out<<<(unsigned)ceil_div64(out_elems, 256), 256, 0, ctx->stream>>>(
@@ -237,6 +244,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                                   (size_t)(wr_hi - wr_lo) * Y * X * sizeof(float), st));
     }
   }
+  set_last_path(ctx, "none");
   if (zb >= ze) {
     if (dst_mem == FPL_MEM_HOST && wr_hi > wr_lo)
       FPL_HIP(ctx, hipMemcpyAsync(dst + wr_lo * Y * X, dst_dev,
@@ -264,6 +272,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   FPL_TRY((precision == FPL_PREC_F16 ? fpl_fast_infer_volume_f16 : fpl_fast_infer_volume_bf16)(
       ctx, prog, src_dev - src_base * Y * X * esz, src_dtype, mean, sd, dims, tile_in,
       offset, precision, origins, out_sz, zb, ze, dst_dev - dst_base * Y * X, &handled));
+  if (handled) set_last_path(ctx, precision == FPL_PREC_F16 ? "vgg_fused_f16" : "vgg_fused_bf16");
   if (!handled) {
     const bool unet_bf16 = (fpl_unet_fast_available_bf16(prog, precision) ||
                             fpl_unet_fast_available_f16(prog, precision)) &&
@@ -274,6 +283,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || unet_bf16,
                 "fpl_infer_volume: no 16-bit MFMA kernels for this architecture yet; "
                 "use precision f32");
+    set_last_path(ctx, unet_bf16 ? (precision == FPL_PREC_F16 ? "unet_mfma_f16" : "unet_mfma_bf16")
+                       : f32_mfma ? "mfma_f32" : "perop_f32");
     // tile list in the reference's order (z outer, x inner)
     std::vector<TileDesc> tiles;
     for (int32_t iz = zb; iz < ze; ++iz)
@@ -358,5 +369,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   FPL_HIP(ctx, hipStreamSynchronize(st));
   return 0;
 }
+
+const char *fpl_last_path(fpl_ctx *ctx) { return ctx ? ctx->last_path : ""; }
 
 }  // extern "C"

@@ -977,6 +977,28 @@ int fpl_trainer_set_weights(fpl_trainer *t, const float *w, int64_t n) {
   return copy_arena(t, t->w, const_cast<float *>(w), n, false);
 }
 
+int fpl_trainer_set_grads(fpl_trainer *t, const float *g, int64_t n) {
+  if (!t || !g) return fpl_fail(nullptr, "fpl_trainer_set_grads: NULL");
+  return copy_arena(t, t->g, const_cast<float *>(g), n, false);
+}
+
+// one RCCL all-reduce (sum) of the flat gradient arena on the context's stream; the
+// Adam kernel of fpl_trainer_apply is ordered behind it on the same stream
+int fpl_allreduce_grads(fpl_trainer *t) {
+  if (!t) return fpl_fail(nullptr, "fpl_allreduce_grads: NULL");
+  return fpl_comm_allreduce_sum_f32(t->ctx, t->g, t->n_w);
+}
+
+// every rank starts from rank `root`'s weights and Adam state
+int fpl_trainer_broadcast_state(fpl_trainer *t, int32_t root) {
+  if (!t) return fpl_fail(nullptr, "fpl_trainer_broadcast_state: NULL");
+  FPL_TRY(fpl_comm_broadcast_f32(t->ctx, t->w, t->n_w, root));
+  FPL_TRY(fpl_comm_broadcast_f32(t->ctx, t->m, t->n_w, root));
+  FPL_TRY(fpl_comm_broadcast_f32(t->ctx, t->v, t->n_w, root));
+  FPL_HIP(t->ctx, hipStreamSynchronize(t->ctx->stream));
+  return 0;
+}
+
 int fpl_trainer_apply(fpl_trainer *t, float grad_scale) {
   if (!t) return fpl_fail(nullptr, "fpl_trainer_apply: NULL");
   fpl_ctx *ctx = t->ctx;

@@ -26,11 +26,11 @@ class InferNetwork:
     """what `FplNetwork.infer_network` holds: the fixed-size inference program
     (+ UpSampling3D(rf_stride)), resident on one GPU"""
 
-    def __init__(self, graph, stride, device):
+    def __init__(self, graph, stride, device, lane=0):
         self.graph = graph
         self.stride = stride
         self.device = device
-        self.program = _capi.Program(runtime.get_context(device), graph, stride)
+        self.program = _capi.Program(runtime.get_context(device, lane), graph, stride)
 
     @property
     def input_shape(self):
@@ -90,6 +90,7 @@ class FplNetwork:
         self.precision = precision
         self._device = runtime.default_device() if device is None else device
         self._parallel = None
+        self._parallel_devices = None
 
     # ---- persistence (reference :81-97; Keras .h5 replaced by .npz) -----------
     def save_network(self, filepath):
@@ -106,34 +107,51 @@ class FplNetwork:
              self._parallel) = keep
 
     # ---- inference network (reference :99-110) --------------------------------
-    def _build_infer(self, device):
+    def _build_infer(self, device, lane=0):
         graph, _, _, _ = self.model(self.infer_sz)
         graph.set_weights(self.train_single.get_weights())
-        return InferNetwork(graph, self.rf_stride, device)
+        return InferNetwork(graph, self.rf_stride, device, lane)
 
     def _set_infer(self):
-        self.infer_network = self._build_infer(self._device)
         if self._parallel is not None:
-            self.make_infer_parallel(self.n_gpu)
-
-    def make_infer_parallel(self, n_gpu):
-        """reference :130-134; tiles are sharded as Z slabs, one per GPU"""
-        if self.infer_network is None:
+            self.make_infer_parallel(self.n_gpu, self._parallel_devices)
+        else:
             self.infer_network = self._build_infer(self._device)
-        nets = [self.infer_network if d == self._device else
-                self._build_infer(d) for d in range(n_gpu)]
+
+    def make_infer_parallel(self, n_gpu, devices=None):
+        """reference :130-134 (which rebuilds the inference net, then wraps it); tile
+        rows are sharded as Z slabs, one per GPU, each written by its own host thread.
+        `devices` (not in the reference): the GPU of each slab, default 0..n_gpu-1; a
+        device named twice serves two slabs from two contexts (one-GPU rehearsal)."""
+        devices = list(range(n_gpu)) if devices is None else [int(d) for d in devices]
+        assert len(devices) == n_gpu, 'make_infer_parallel: one device per slab'
+        self.infer_network = self._build_infer(self._device)
+        nets, seen = [], {}
+        for d in devices:
+            lane = seen.get(d, 0)
+            seen[d] = lane + 1
+            # lanes 32+: contexts of their own, away from the pipeline's lanes 0/1
+            nets.append(self.infer_network if (d == self._device and lane == 0)
+                        else self._build_infer(d, 32 + lane if lane else 0))
         self._parallel_nets = nets
-        self._parallel = multi_gpu.make_parallel(
-            lambda d: nets[d].program, n_gpu)
+        self._parallel_devices = devices
+        self._parallel = multi_gpu.make_parallel(lambda i: nets[i].program, n_gpu)
         self.n_gpu = n_gpu
 
-    def make_train_parallel(self, n_gpu, batch_size, input_shape):
-        """reference :124-128.  Data-parallel training runs one process per GPU
-        (RCCL gradient all-reduce); see flypylib_amd/train.py"""
+    def make_train_parallel(self, n_gpu, batch_size, input_shape, devices=None):
+        """reference :124-128: `n_gpu` towers of `batch_size` examples each, the
+        generator yields batch_size * n_gpu per step (multi_gpu.py:21-25).  One
+        trainer + host thread per GPU in this process, gradients summed by one RCCL
+        all-reduce per step; under torchrun (one process per GPU) the ranks are the
+        towers.  See flypylib_amd/train.py.  `devices` (not in the reference): the GPU
+        of each tower, default 0..n_gpu-1."""
         from . import train
+        old = self.train_network
+        if isinstance(old, train.ParallelTrainNetwork):
+            old.close()
         self.train_network = train.make_parallel(
             self.train_single, n_gpu, batch_size,
-            list(fplutils.to3d(input_shape)) + [1])
+            list(fplutils.to3d(input_shape)) + [1], devices)
         self.train_network.compile(**self.compile_args)
 
     def train(self, generator, steps_per_epoch, epochs, log_file,
@@ -172,7 +190,7 @@ class FplNetwork:
             image = np.ascontiguousarray(image, dtype=np.float32)
         prec = _PRECISIONS[precision or self.precision]
         kw = dict(mean=mean, std=std, precision=prec)
-        if self._parallel is not None and self.n_gpu > 1:
+        if self._parallel is not None:
             return self._parallel.infer_volume(image, self.infer_sz,
                                                self.rf_offset, **kw)
         return self.infer_network.program.infer_volume(
@@ -218,6 +236,6 @@ class FplNetwork:
     def __getstate__(self):
         d = dict(self.__dict__)
         for k in ('train_single', 'train_network', 'infer_network', '_parallel',
-                  '_parallel_nets'):
+                  '_parallel_nets', '_trainer'):
             d[k] = None
         return d

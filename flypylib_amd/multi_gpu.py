@@ -58,7 +58,10 @@ class ParallelInfer:
         dims = image.shape
         parts = slab_partition(n_tile_rows(dims[0], tile_in[0], offset[0]),
                                self.n_gpu)
-        out = np.zeros(dims, np.float32)
+        out = np.empty(dims, np.float32)
+        if not all(hi > lo for lo, hi in (slab_rows(p, dims[0], tile_in[0], offset[0])
+                                          for p in parts)):
+            out[...] = 0                 # more GPUs than tile rows: idle ranks write nothing
         errs = []
 
         def work(rank):
@@ -67,9 +70,10 @@ class ParallelInfer:
                 lo, hi = slab_rows(zr, dims[0], tile_in[0], offset[0])
                 if hi <= lo:
                     return
-                part = self.programs[rank].infer_volume(
-                    image, tile_in, offset, z_range=zr, **kw)
-                out[lo:hi] = part[lo:hi]
+                # the library writes exactly the rows [lo, hi) of a host `dst`
+                # (its slab + the border shell at the volume's ends)
+                self.programs[rank].infer_volume(
+                    image, tile_in, offset, z_range=zr, dst=out, **kw)
             except Exception as e:       # surfaced after join
                 errs.append(e)
 

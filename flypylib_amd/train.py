@@ -7,29 +7,60 @@ callbacks: a CSV log (`CSVLogger`: epoch, acc, loss) and a per-epoch checkpoint
 '<save_filepath>_%03d' of the single-GPU weights (`multi_gpu_callback`,
 fplnetwork.py:9-17).
 
-Data parallelism (reference: in-graph towers slicing the batch,
-`flypylib/multi_gpu.py:20-61`): one process per GPU, every rank draws its own
-`batch_size` examples, gradients (and BN moving-average deltas) are summed with
-ONE all-reduce of the flat gradient arena over RCCL (`torch.distributed`, backend
-'nccl') and scaled by 1/world before the identical Adam update on every rank.
-BN batch statistics stay per GPU, as each tower normalises its own slice.
+Data parallelism.  The reference builds in-graph towers: the generator yields
+`batch_size * n_gpu` examples, tower i takes rows [i*batch_size, (i+1)*batch_size)
+(`flypylib/multi_gpu.py:21-25`), the loss is the mean over the concatenated outputs
+and the towers share their variables, so the applied gradient is the mean of the
+tower gradients; each tower normalises its own slice (BN batch statistics per tower).
+Here a tower is a `fpl_trainer` on its own GPU and the gradient mean is ONE sum
+all-reduce of the flat gradient arena over RCCL (`fpl_allreduce_grads`) followed by
+the identical Adam update scaled by 1/n on every tower.  BN moving averages: every
+tower's pending delta `(1 - momentum) * (batch_stat - moving)` rides in the same
+arena, so the applied delta is the mean over the towers.  Two launch styles:
+
+  * one process, `make_train_parallel(n_gpu, batch_size, input_shape)` as the
+    reference's scripts call it: one host thread + context + trainer per GPU
+    (`TowerGroup`); the threads join one RCCL communicator.
+  * one process per GPU (`torchrun`): an initialised `torch.distributed` process
+    group carries the RCCL unique id to every rank (`setup_rank_comm`) and the
+    library all-reduces over its own communicator.  After `make_train_parallel(world,
+    batch_size, ...)` rank r takes rows [r*batch_size, (r+1)*batch_size) of the
+    generator's batch (the reference's slicing; the generators of all ranks must then
+    yield the same batches, i.e. be seeded alike); without it every rank trains on the
+    whole batch its own generator yields.
+    Ranks that share a GPU (a rehearsal on a one-GPU box) cannot form an RCCL
+    communicator; they reduce through `torch.distributed` instead (host-staged for the
+    gloo backend).
 """
 import csv
+import os
+import queue
+import threading
 
 import numpy as np
 
 from . import _capi, runtime
 
 _OPTIMIZERS = {'adam': dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8)}
+_METRICS = ('loss', 'acc', 'masked_accuracy', 'lb0l1err', 'lb1l1err')
 
 
 class ParallelTrainNetwork:
-    """what `network.train_network` holds after make_train_parallel"""
+    """what `network.train_network` holds after `make_train_parallel`: the tower
+    layout (reference `multi_gpu.make_parallel(train_single, n_gpu, batch_size,
+    input_shape)`); `fit_generator` trains through it.  `devices` defaults to GPUs
+    0..n_gpu-1; naming a device twice puts two towers on it (rehearsal on one GPU)."""
 
-    def __init__(self, single, n_gpu, batch_size, input_shape):
-        self.single, self.n_gpu = single, n_gpu
-        self.batch_size, self.input_shape = batch_size, tuple(input_shape)
+    def __init__(self, single, n_gpu, batch_size, input_shape, devices=None):
+        self.single, self.n_gpu = single, int(n_gpu)
+        self.batch_size, self.input_shape = int(batch_size), tuple(input_shape)
+        self.devices = (list(range(self.n_gpu)) if devices is None
+                        else [int(d) for d in devices])
+        if len(self.devices) != self.n_gpu:
+            raise ValueError('make_parallel: %d devices for %d towers'
+                             % (len(self.devices), self.n_gpu))
         self.compile_args = None
+        self._towers = None
 
     def compile(self, **kw):
         self.compile_args = dict(kw)
@@ -37,9 +68,19 @@ class ParallelTrainNetwork:
     def get_weights(self):
         return self.single.get_weights()
 
+    def close(self):
+        if self._towers is not None:
+            self._towers.close()
+            self._towers = None
 
-def make_parallel(train_single, n_gpu, batch_size, input_shape):
-    return ParallelTrainNetwork(train_single, n_gpu, batch_size, input_shape)
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_towers'] = None
+        return d
+
+
+def make_parallel(train_single, n_gpu, batch_size, input_shape, devices=None):
+    return ParallelTrainNetwork(train_single, n_gpu, batch_size, input_shape, devices)
 
 
 def _dist():
@@ -52,21 +93,46 @@ def _dist():
     return None
 
 
-def allreduce_grads(trainer, force=False):
-    """sum the flat gradient arena over all ranks (RCCL over xGMI); returns the
-    scale to apply (1/world).  No-op without an initialised process group (or with
-    a single rank, unless `force`)."""
-    dist = _dist()
-    if dist is None or (dist.get_world_size() == 1 and not force):
-        return 1.0
-    import torch
-    ptr, n = trainer.grad_ptr()
-    # wrap the library-owned device arena without copying
-    arena = _DeviceArena(ptr, n)
-    t = torch.as_tensor(arena, device='cuda')
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    torch.cuda.current_stream().synchronize()
-    return 1.0 / dist.get_world_size()
+# ---- gradient reducers ------------------------------------------------------------
+class RcclReducer:
+    """the library's own communicator (fpl_comm_init): stream-ordered, no host sync"""
+    kind = 'rccl'
+
+    def __init__(self, nranks):
+        self.nranks = int(nranks)
+
+    def __call__(self, trainer):
+        trainer.allreduce_grads()
+        return 1.0 / self.nranks
+
+
+class TorchDistReducer:
+    """all-reduce through an initialised torch.distributed group: for ranks that
+    cannot form an RCCL communicator of their own (several ranks on one GPU).  With
+    the nccl backend the arena is reduced in place through a zero-copy device view;
+    any other backend stages it through host memory."""
+    kind = 'torch.distributed'
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.nranks = dist.get_world_size()
+
+    def __call__(self, trainer):
+        import torch
+        dist = self.dist
+        if dist.get_backend() == 'nccl':
+            dev = torch.device('cuda', trainer.ctx.device)
+            ptr, n = trainer.grad_ptr()
+            trainer.ctx.synchronize()        # the step ran on the context's stream
+            with torch.cuda.device(dev):
+                t = torch.as_tensor(_DeviceArena(ptr, n), device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                torch.cuda.current_stream(dev).synchronize()
+        else:
+            t = torch.from_numpy(trainer.get_grads_flat())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            trainer.set_grads_flat(t.numpy())
+        return 1.0 / self.nranks
 
 
 class _DeviceArena:
@@ -78,6 +144,182 @@ class _DeviceArena:
             'version': 2}
 
 
+class HostTowerReducer:
+    """sum over the towers of one process through host memory: for towers that share
+    a device, which RCCL refuses to put in one communicator"""
+    kind = 'host'
+
+    def __init__(self, n):
+        self.nranks = int(n)
+        self._barrier = threading.Barrier(self.nranks)
+        self._parts = [None] * self.nranks
+        self._sum = None
+
+    def __call__(self, trainer, rank):
+        self._parts[rank] = trainer.get_grads_flat()
+        if self._barrier.wait() == 0:
+            self._sum = np.sum(np.stack(self._parts), axis=0, dtype=np.float32)
+        self._barrier.wait()
+        trainer.set_grads_flat(self._sum)
+        self._barrier.wait()
+        return 1.0 / self.nranks
+
+    def abort(self):
+        self._barrier.abort()
+
+
+def allreduce_grads(trainer, force=False):
+    """sum the flat gradient arena over all ranks; returns the scale to apply
+    (1/world).  The context's own RCCL communicator when it has one, else the
+    torch.distributed group; a no-op without either (or with a single rank, unless
+    `force`)."""
+    info = trainer.ctx.comm_info()
+    if info['nranks'] > 1 or (force and info['nranks'] == 1):
+        return RcclReducer(info['nranks'])(trainer)
+    dist = _dist()
+    if dist is None or (dist.get_world_size() == 1 and not force):
+        return 1.0
+    return TorchDistReducer(dist)(trainer)
+
+
+def setup_rank_comm(ctx, dist=None):
+    """one process per GPU: rank 0 makes the RCCL unique id, the process group
+    carries it, every rank joins (fpl_comm_init).  Returns the reducer to use: the
+    library's communicator when every rank has a GPU of its own, else the
+    torch.distributed one."""
+    dist = dist or _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    info = ctx.comm_info()
+    if info['nranks'] == world and info['rank'] == rank:
+        return RcclReducer(world)
+    import socket
+    where = [None] * world
+    dist.all_gather_object(where, (socket.gethostname(), ctx.device_uuid()))
+    if len(set(where)) < world or os.environ.get('FPL_TRAIN_REDUCE') == 'torch':
+        return TorchDistReducer(dist)
+    box = [_capi.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if info['nranks']:
+        ctx.comm_destroy()
+    ctx.comm_init(rank, world, box[0])
+    return RcclReducer(world)
+
+
+# ---- towers of one process ----------------------------------------------------------
+class TowerGroup:
+    """`n` trainers, one host thread each, stepping in lockstep on slices of one
+    batch (the single-process form of make_train_parallel)"""
+
+    def __init__(self, graph, devices, loss, opt_args):
+        self.n = len(devices)
+        self.devices = list(devices)
+        shared = len(set(devices)) < self.n
+        self.ctxs, self.trainers = [], []
+        lanes = {}
+        for d in devices:
+            lane = lanes.get(d, 0)
+            lanes[d] = lane + 1
+            # towers that share a device need contexts of their own: lanes 16+
+            ctx = runtime.get_context(d, 16 + lane if shared else 0)
+            self.ctxs.append(ctx)
+            self.trainers.append(_capi.Trainer(ctx, graph, loss=loss, **opt_args))
+        self._jobs = [queue.Queue() for _ in range(self.n)]
+        self._done = queue.Queue()
+        self._host = HostTowerReducer(self.n) if (shared or os.environ.get(
+            'FPL_TRAIN_REDUCE') == 'host') and self.n > 1 else None
+        self.reduce_kind = 'host' if self._host else ('rccl' if self.n > 1 else 'none')
+        uid = _capi.comm_unique_id() if self.reduce_kind == 'rccl' else None
+        self._threads = [threading.Thread(target=self._work, args=(r, uid), daemon=True)
+                         for r in range(self.n)]
+        for t in self._threads:
+            t.start()
+        self._collect()                      # communicator formed (or failed)
+
+    def _work(self, rank, uid):
+        ctx, tr = self.ctxs[rank], self.trainers[rank]
+        try:
+            if uid is not None:
+                if ctx.comm_info()['nranks']:
+                    ctx.comm_destroy()
+                ctx.comm_init(rank, self.n, uid)
+            self._done.put((rank, None))
+        except BaseException as e:
+            self._done.put((rank, e))
+            return
+        while True:
+            job = self._jobs[rank].get()
+            if job is None:
+                return
+            kind, args = job
+            try:
+                if kind == 'step':
+                    data, labels, seed = args
+                    tr.step(data, labels, seed=seed)
+                    if self._host is not None:
+                        scale = self._host(tr, rank)
+                    elif self.n > 1:
+                        tr.allreduce_grads()
+                        scale = 1.0 / self.n
+                    else:
+                        scale = 1.0
+                    tr.apply(scale)
+                    self._done.put((rank, tr.metrics()))
+                elif kind == 'set_weights':
+                    tr.set_weights(args)
+                    self._done.put((rank, None))
+            except BaseException as e:
+                if self._host is not None:
+                    self._host.abort()
+                self._done.put((rank, e))
+
+    def _collect(self):
+        out = [None] * self.n
+        err = None
+        for _ in range(self.n):
+            rank, res = self._done.get()
+            if isinstance(res, BaseException):
+                err = err or res
+            out[rank] = res
+        if err is not None:
+            raise err
+        return out
+
+    def set_weights(self, weights):
+        for q in self._jobs:
+            q.put(('set_weights', weights))
+        self._collect()
+
+    def get_weights(self):
+        return self.trainers[0].get_weights()
+
+    def step(self, data, labels, batch_size, seed):
+        """tower i trains on rows [i*batch_size, (i+1)*batch_size); returns the
+        metrics of the whole batch (mean over the equally sized towers)"""
+        need = batch_size * self.n
+        if data.shape[0] != need:
+            raise ValueError(
+                'make_train_parallel(%d, %d, ...): the generator must yield batches of '
+                '%d examples (batch_size * n_gpu, as the reference towers slice them), '
+                'got %d' % (self.n, batch_size, need, data.shape[0]))
+        for r, q in enumerate(self._jobs):
+            sl = slice(r * batch_size, (r + 1) * batch_size)
+            q.put(('step', (data[sl], labels[sl], seed * self.n + r)))
+        ms = self._collect()
+        return {k: float(np.mean([m[k] for m in ms])) for k in ms[0]}
+
+    def close(self):
+        for q in self._jobs:
+            q.put(None)
+        for t in self._threads:
+            t.join()
+        for tr, ctx in zip(self.trainers, self.ctxs):
+            tr.close()
+            if self.reduce_kind == 'rccl' and ctx.comm_info()['nranks']:
+                ctx.comm_destroy()
+
+
 class _Prefetch:
     """Background consumer of the batch generator (what Keras' `fit_generator` does with
     its enqueuer thread, `max_queue_size` batches ahead): the host-side patch sampling
@@ -86,11 +328,8 @@ class _Prefetch:
     the reference-style generators reuse their output arrays."""
 
     def __init__(self, generator, depth=2):
-        import queue
-        import threading
         self._q = queue.Queue(depth)
         self._stop = threading.Event()
-        self._full = queue.Full
         self._t = threading.Thread(target=self._work, args=(generator,), daemon=True)
         self._t.start()
 
@@ -99,7 +338,7 @@ class _Prefetch:
             try:
                 self._q.put(item, timeout=0.1)
                 return True
-            except self._full:
+            except queue.Full:
                 pass
         return False
 
@@ -118,9 +357,32 @@ class _Prefetch:
             raise item
         return item
 
-    def close(self):
+    def close(self, timeout=60.0):
+        """stop the worker and wait for it: a generator still executing in the worker
+        would raise 'generator already executing' in the next train() call"""
         self._stop.set()
-        self._t.join(5)
+        self._t.join(timeout)
+        if self._t.is_alive():
+            raise RuntimeError('the batch generator did not return within %.0f s of '
+                               'the end of training' % timeout)
+
+
+def _single_trainer(network, graph, loss, opt, opt_args):
+    """one trainer per network, kept across train() calls like a compiled Keras
+    model keeps its optimizer: Adam moments and the step count persist"""
+    key = (network._device, loss, opt, len(graph.weights))
+    cached = getattr(network, '_trainer', None)
+    if cached is not None and cached[0] == key and cached[1].h is not None \
+            and cached[1].ctx.h is not None:
+        trainer = cached[1]
+        trainer.set_weights(graph.get_weights())
+        return trainer
+    if cached is not None:
+        cached[1].close()
+    ctx = runtime.get_context(network._device)
+    trainer = _capi.Trainer(ctx, graph, loss=loss, **opt_args)
+    network._trainer = (key, trainer)
+    return trainer
 
 
 def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
@@ -135,21 +397,51 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
     opt = args.get('optimizer', 'adam')
     if opt not in _OPTIMIZERS:
         raise NotImplementedError('optimizer %r' % (opt,))
-    ctx = runtime.get_context(network._device)
-    trainer = _capi.Trainer(ctx, graph, loss=loss, **_OPTIMIZERS[opt])
-    dist = _dist()
-    rank = dist.get_rank() if dist else 0
     cols = sorted(set(metric_names + ['loss']))
     for k in cols:
-        if k not in ('loss', 'acc', 'masked_accuracy', 'lb0l1err', 'lb1l1err'):
+        if k not in _METRICS:
             raise NotImplementedError('metric %r' % (k,))
+
+    dist = _dist()
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    par = network.train_network if isinstance(network.train_network,
+                                              ParallelTrainNetwork) else None
+    towers = trainer = reducer = None
+    if world > 1:
+        # one process per GPU
+        if par is not None and par.n_gpu != world:
+            raise ValueError('make_train_parallel(n_gpu=%d) under a process group of '
+                             '%d ranks: they must agree' % (par.n_gpu, world))
+        trainer = _single_trainer(network, graph, loss, opt, _OPTIMIZERS[opt])
+        reducer = setup_rank_comm(trainer.ctx, dist)
+        if reducer.kind == 'rccl':
+            trainer.broadcast_state(0)
+        else:
+            box = [graph.get_weights() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            trainer.set_weights(box[0])
+    elif par is not None and par.n_gpu > 1:
+        # one process, one tower per GPU
+        key = (tuple(par.devices), loss, opt, len(graph.weights))
+        if par._towers is None or par._towers_key != key:
+            par.close()
+            par._towers = TowerGroup(graph, par.devices, loss, _OPTIMIZERS[opt])
+            par._towers_key = key
+        towers = par._towers
+        towers.set_weights(graph.get_weights())
+    else:
+        trainer = _single_trainer(network, graph, loss, opt, _OPTIMIZERS[opt])
+    network.train_reduce_kind = (towers.reduce_kind if towers else
+                                 reducer.kind if reducer else 'none')
+
     writer = None
     if rank == 0 and log_file:
         f = open(log_file, 'w', newline='')
         writer = csv.writer(f)
         # CSVLogger: 'epoch' then the log keys in sorted order
         writer.writerow(['epoch'] + cols)
-    step_no = 0
+    step_no = getattr(network, '_train_steps_done', 0)
     history = []
     batches = _Prefetch(generator)
     try:
@@ -157,14 +449,36 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
             tot = dict.fromkeys(cols, 0.0)
             for _ in range(steps_per_epoch):
                 data, labels = next(batches)
-                trainer.step(data, labels, seed=seed + step_no)
-                trainer.apply(allreduce_grads(trainer))
-                m = trainer.metrics()
+                if towers is not None:
+                    m = towers.step(data, labels, par.batch_size, seed + step_no)
+                else:
+                    if world > 1 and par is not None:
+                        need = par.batch_size * world
+                        if data.shape[0] != need:
+                            raise ValueError(
+                                'make_train_parallel(%d, %d, ...): the generator must '
+                                'yield batches of %d examples, got %d'
+                                % (world, par.batch_size, need, data.shape[0]))
+                        sl = slice(rank * par.batch_size, (rank + 1) * par.batch_size)
+                        data, labels = data[sl], labels[sl]
+                    trainer.step(data, labels, seed=(seed + step_no) * world + rank)
+                    trainer.apply(reducer(trainer) if reducer else 1.0)
+                    m = trainer.metrics()
                 for k in cols:
                     tot[k] += m[k]
                 step_no += 1
-            graph.set_weights(trainer.get_weights())
-            row = (epoch,) + tuple(tot[k] / steps_per_epoch for k in cols)
+            weights = towers.get_weights() if towers else trainer.get_weights()
+            graph.set_weights(weights)
+            vals = [tot[k] / steps_per_epoch for k in cols]
+            if world > 1:
+                # the towers' mean, as Keras reports it for the concatenated batch
+                import torch
+                t = torch.tensor(vals, dtype=torch.float64)
+                if dist.get_backend() == 'nccl':
+                    t = t.to(torch.device('cuda', trainer.ctx.device))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                vals = [float(v) / world for v in t.cpu()]
+            row = (epoch,) + tuple(vals)
             history.append(row)
             if writer:
                 writer.writerow(row)
@@ -172,8 +486,8 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
             if rank == 0 and save_filepath:
                 graph.save('%s_%03d' % (save_filepath, epoch))
     finally:
+        network._train_steps_done = step_no
         batches.close()
-    if writer:
-        f.close()
-    trainer.close()
+        if writer:
+            f.close()
     return history

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 4
+#define FPL_ABI_VERSION 5
 
 typedef struct fpl_ctx fpl_ctx;
 typedef struct fpl_program fpl_program;
@@ -81,6 +81,9 @@ int fpl_ctx_set_stream(fpl_ctx *ctx, void *hip_stream);
 int fpl_ctx_synchronize(fpl_ctx *ctx);
 int fpl_device_info(fpl_ctx *ctx, int32_t *n_cu, int64_t *hbm_bytes,
                     char *name, size_t name_cap);
+/* PCI bus id ("0000:05:00.0") of the context's GPU: tells ranks that share a GPU
+ * from ranks that merely share a device index (per-process HIP_VISIBLE_DEVICES) */
+int fpl_device_pci_bus_id(fpl_ctx *ctx, char *out, size_t cap);
 
 /* ---- device buffers (thin; for callers without torch) ---------------------- */
 int fpl_malloc(fpl_ctx *ctx, size_t bytes, void **dev_ptr);
@@ -126,6 +129,14 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                      const int64_t dims[3], const int32_t tile_in[3],
                      const int32_t offset[3], int precision,
                      int32_t z_begin, int32_t z_end, float *dst, int dst_mem);
+
+/* name of the executor the last fpl_infer_volume / fpl_program_forward of this
+ * context ran on: "vgg_fused_f16" | "vgg_fused_bf16" | "unet_mfma_f16" |
+ * "unet_mfma_bf16" | "mfma_f32" | "perop_f32" | "none" (empty slab).  The 16-bit
+ * fused kernels are keyed on the architectures of flypylib/fplmodels.py; any other
+ * graph runs on the fp32 executors - this says which, instead of leaving the caller
+ * to infer it from the speed. */
+const char *fpl_last_path(fpl_ctx *ctx);
 
 /* ---- post-process ----------------------------------------------------------- */
 /* replaces: fplobjdetect.voxel2obj device stages (flypylib/fplobjdetect.py:
@@ -232,6 +243,36 @@ int fpl_trainer_get_weights(fpl_trainer *t, float *out, int64_t n_weights);
 int fpl_trainer_set_weights(fpl_trainer *t, const float *w, int64_t n_weights);
 /* tensors of the last step, for parity tests: grads (host copy of the arena) */
 int fpl_trainer_get_grads(fpl_trainer *t, float *out, int64_t n_weights);
+/* overwrite the gradient arena from the host (host-staged reductions: towers that
+ * share a device, or a process group without device collectives) */
+int fpl_trainer_set_grads(fpl_trainer *t, const float *g, int64_t n_weights);
+
+/* ---- data-parallel training: RCCL over xGMI ---------------------------------- */
+/* replaces: the implicit gradient sum over the in-graph towers that
+ * multi_gpu.make_parallel builds for FplNetwork.make_train_parallel
+ * (flypylib/multi_gpu.py:20-61, flypylib/fplnetwork.py:124-128).  One communicator
+ * per context (= per GPU); ranks are processes (torchrun, MPI, ...) or host threads
+ * of one process, one per GPU.  Rank 0 makes the id, the host carries its 128 bytes
+ * to the other ranks, every rank calls fpl_comm_init (collectively: it returns when
+ * all nranks have joined).  librccl is dlopen'ed on first use (FPL_RCCL_LIB
+ * overrides the search). */
+#define FPL_COMM_ID_BYTES 128
+int fpl_comm_unique_id(uint8_t out[FPL_COMM_ID_BYTES]);
+int fpl_comm_init(fpl_ctx *ctx, int32_t rank, int32_t nranks,
+                  const uint8_t unique_id[FPL_COMM_ID_BYTES]);
+int fpl_comm_destroy(fpl_ctx *ctx);
+/* nranks = 0 when the context has no communicator; lib_path = the librccl in use */
+int fpl_comm_info(fpl_ctx *ctx, int32_t *rank, int32_t *nranks, char *lib_path,
+                  size_t lib_path_cap);
+/* in-place sum over all ranks / copy from `root`, enqueued on the context's stream */
+int fpl_comm_allreduce_sum_f32(fpl_ctx *ctx, float *dev_ptr, int64_t n);
+int fpl_comm_broadcast_f32(fpl_ctx *ctx, float *dev_ptr, int64_t n, int32_t root);
+/* ONE all-reduce (sum) of the trainer's flat gradient arena (0.58 MB for vgg_like,
+ * the moving-average deltas ride in it) between fpl_trainer_step and
+ * fpl_trainer_apply(t, 1.0f / nranks); stream-ordered, no host synchronisation */
+int fpl_allreduce_grads(fpl_trainer *t);
+/* weights and Adam moments of every rank := rank `root`'s (start of training) */
+int fpl_trainer_broadcast_state(fpl_trainer *t, int32_t root);
 
 /* ---- synthetic data (bench / tests) -------------------- */
 /* EM-like uint8 volume from a counter-based hash; bit-identical to

@@ -1,0 +1,432 @@
+"""The multi-GPU entry points of the reference as EXECUTED code on the one GPU of the
+test box: `make_infer_parallel` (flypylib/fplnetwork.py:130-134) through
+`multi_gpu.ParallelInfer`, `make_train_parallel` (:124-128) through `train.TowerGroup`
+(towers of one process) and through ranks of a process group (what torchrun starts),
+and the RCCL communicator of the C ABI (`fpl_comm_init` / `fpl_allreduce_grads`).
+
+Two towers / ranks that share the one GPU cannot form an RCCL communicator (RCCL
+refuses a device twice), so those cases reduce through host memory - the slicing, the
+seeds, the sum, the 1/n Adam step and the BN moving-average rule are the same code.
+The 2-rank RCCL case runs when the box shows two GPUs and is skipped, loudly, when
+not."""
+import os
+import socket
+import traceback
+
+import numpy as np
+import pytest
+
+from flypylib_amd import FplNetwork, _capi, fplmodels, runtime, synth, train
+from flypylib_amd.program import LayerGraph
+
+pytestmark = pytest.mark.gpu
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _bn_free_model(in_sz=None):
+    """conv3 -> relu -> pool -> conv3 -> relu -> biased sigmoid head, no BatchNorm: the
+    gradient of a batch is the mean of the gradients of its halves"""
+    g = LayerGraph(in_sz)
+    x = g.relu(g.conv(g.input(), 8, 3, use_bias=True))
+    x = g.pool(x)
+    x = g.relu(g.conv(x, 8, 3, use_bias=True))
+    return g.finish(g.conv(x, 1, 1, use_bias=True, activation='sigmoid')), (8, 3, 2), 20, None
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _vgg_net(seed=3, infer=30):
+    net = FplNetwork(fplmodels.vgg_like)
+    net.infer_sz = (infer,) * 3
+    synth.synthetic_weights(net.train_single, seed)
+    net._set_infer()
+    return net
+
+
+# ---- make_infer_parallel -------------------------------------------------------------
+@pytest.mark.parametrize('precision', ['f32', 'f16'])
+def test_make_infer_parallel_one_gpu_equals_infer(ctx, precision):
+    """make_infer_parallel(1) goes through ParallelInfer (one slab, one thread) and is
+    bit-identical to infer()"""
+    net = _vgg_net()
+    u8 = synth.em_volume_u8(5, (75, 52, 47))
+    want = net.infer(u8, normalize=(128., 33.), precision=precision)
+    net.make_infer_parallel(1)
+    assert net._parallel is not None and net.n_gpu == 1
+    got = net.infer(u8, normalize=(128., 33.), precision=precision)
+    assert got.dtype == np.float32 and got.shape == u8.shape
+    assert np.array_equal(got, want)
+    assert want[10:-10, 10:-10, 10:-10].std() > 0
+
+
+@pytest.mark.parametrize('n', [2, 3, 5])
+def test_make_infer_parallel_slabs_on_one_gpu(ctx, n):
+    """n slabs (n host threads, n contexts) on device 0: every thread writes its own
+    rows of the shared output; idle slabs (more slabs than tile rows) write nothing"""
+    net = _vgg_net()
+    u8 = synth.em_volume_u8(6, (80, 41, 45))          # 4 tile rows of pitch 16
+    want = net.infer(u8, normalize=(128., 33.))
+    net.make_infer_parallel(n, devices=[0] * n)
+    got = net.infer(u8, normalize=(128., 33.))
+    assert np.array_equal(got, want)
+    # a retrained network rebuilds its towers (_set_infer keeps the parallel layout)
+    synth.synthetic_weights(net.train_single, 9)
+    net._set_infer()
+    assert net.n_gpu == n and len(net._parallel.programs) == n
+    got2 = net.infer(u8, normalize=(128., 33.))
+    net2 = _vgg_net(seed=9)
+    assert np.array_equal(got2, net2.infer(u8, normalize=(128., 33.)))
+    assert not np.array_equal(got2, got)
+
+
+def test_infer_reports_the_executor(ctx):
+    """fpl_last_path names the executor instead of leaving it to the timing names"""
+    net = _vgg_net()
+    u8 = synth.em_volume_u8(5, (46, 40, 38))
+    for prec, name in (('f32', 'mfma_f32'), ('f16', 'vgg_fused_f16'), ('bf16', 'vgg_fused_bf16')):
+        net.infer(u8, normalize=(128., 33.), precision=prec)
+        assert ctx.last_path() == name
+    unet = FplNetwork(fplmodels.unet_like2)
+    unet.infer_sz = (28,) * 3
+    synth.synthetic_weights(unet.train_single, 2)
+    unet._set_infer()
+    unet.infer(u8, normalize=(128., 33.), precision='f16')
+    assert ctx.last_path() == 'unet_mfma_f16'
+    # a width the fused kernels do not know runs on the fp32 MFMA executor - and says so
+    other = FplNetwork(fplmodels.baseline_model)
+    other.infer_sz = (30,) * 3
+    other._set_infer()
+    other.infer(u8, normalize=(128., 33.))
+    assert ctx.last_path() == 'mfma_f32'
+    with pytest.raises(_capi.FplHipError, match='no 16-bit MFMA kernels'):
+        other.infer(u8, normalize=(128., 33.), precision='f16')
+
+
+# ---- RCCL in the C ABI ----------------------------------------------------------------
+def test_comm_single_rank_allreduce_and_broadcast():
+    """fpl_comm_unique_id / fpl_comm_init / fpl_allreduce_grads with one rank: the sum
+    is the identity, the communicator lives and dies with the context"""
+    c = _capi.Context(0)
+    try:
+        assert c.comm_info()['nranks'] == 0
+        uid = _capi.comm_unique_id()
+        assert len(uid) == _capi.COMM_ID_BYTES and any(uid)
+        c.comm_init(0, 1, uid)
+        info = c.comm_info()
+        assert (info['rank'], info['nranks']) == (0, 1) and 'rccl' in info['lib']
+        with pytest.raises(_capi.FplHipError, match='already has a communicator'):
+            c.comm_init(0, 1, uid)
+        g = fplmodels.vgg_like()[0]
+        synth.synthetic_weights(g, 3)
+        tr = _capi.Trainer(c, g)
+        rng = np.random.default_rng(0)
+        data = rng.standard_normal((4, 18, 18, 18, 1)).astype(np.float32)
+        labels = (rng.random((4, 1, 1, 1, 1)) > 0.5).astype(np.uint8)
+        tr.step(data, labels, seed=1)
+        before = tr.get_grads_flat()
+        assert np.abs(before).max() > 0
+        tr.allreduce_grads()
+        assert train.allreduce_grads(tr, force=True) == 1.0
+        assert np.array_equal(tr.get_grads_flat(), before)
+        w = tr.get_weights()
+        tr.broadcast_state(0)
+        for a, b in zip(tr.get_weights(), w):
+            assert np.array_equal(a, b)
+        # set_grads round trip (the host-staged reducers' path)
+        tr.set_grads_flat(before * 2)
+        assert np.array_equal(tr.get_grads_flat(), before * 2)
+        tr.close()
+        c.comm_destroy()
+        assert c.comm_info()['nranks'] == 0
+        with pytest.raises(_capi.FplHipError, match='no communicator'):
+            c.comm_allreduce_sum_f32(0x1000, 4)
+    finally:
+        c.close()
+
+
+# ---- make_train_parallel: towers of one process ----------------------------------------
+def _batches(seed, n_steps, batch, size, out_size):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_steps):
+        data = rng.standard_normal((batch,) + (size,) * 3 + (1,)).astype(np.float32)
+        labels = (rng.random((batch,) + (out_size,) * 3 + (1,)) > 0.5).astype(np.uint8)
+        out.append((data, labels))
+    return out
+
+
+def _same_training(wa, wb, steps=1):
+    """two runs of the same training: equal up to the run-to-run noise of the
+    float-atomic weight gradients (Adam's early steps are lr * g / (|g| + 3e-7), so only
+    gradients at the noise level may move a weight by more than a rounding)"""
+    n_bad = n_all = 0
+    for a, b in zip(wa, wb):
+        n_bad += int(np.sum(np.abs(a - b) > 2e-6))
+        n_all += a.size
+        assert np.abs(a - b).max() <= 2.1e-3 * steps
+    assert n_bad < 1e-3 * n_all, (n_bad, n_all)
+
+
+def _gen(batches):
+    while True:
+        for b in batches:
+            yield b
+
+
+def test_two_towers_equal_one_step_on_the_concatenated_batch(ctx, tmp_path):
+    """BN-free graph: make_train_parallel(2, B) over batches of 2B == single-GPU training
+    on the same batches (mean of the tower gradients == gradient of the whole batch)"""
+    B, S = 6, 12
+    batches = _batches(1, 3, 2 * B, S, 3)
+    one = FplNetwork(_bn_free_model)
+    w0 = one.train_single.get_weights()
+    one.train(_gen(batches), 3, 1, str(tmp_path / 'one.csv'), None)
+    two = FplNetwork(_bn_free_model)
+    two.train_single.set_weights(w0)
+    two.make_train_parallel(2, B, S, devices=[0, 0])
+    two.train(_gen(batches), 3, 1, str(tmp_path / 'two.csv'), None)
+    assert two.train_reduce_kind == 'host'
+    moved = 0.0
+    for a, b, w in zip(one.train_single.get_weights(), two.train_single.get_weights(), w0):
+        moved = max(moved, float(np.abs(a - w).max()))
+        # Adam's first steps are sign-like: compare on the scale of the 3 * lr the weights move
+        assert np.abs(a - b).max() < 3e-5, np.abs(a - b).max()
+    assert moved > 1e-3
+    r1 = open(str(tmp_path / 'one.csv')).read().split('\n')
+    r2 = open(str(tmp_path / 'two.csv')).read().split('\n')
+    assert r1[0] == r2[0] == 'epoch,acc,loss'
+    l1, l2 = (float(r.split(',')[2]) for r in (r1[1], r2[1]))
+    assert abs(l1 - l2) < 1e-4 * max(1.0, abs(l1))
+    # wrong generator batch size: the reference's towers would fail on the slice too
+    with pytest.raises(ValueError, match='batch_size \\* n_gpu'):
+        two.train(_gen(_batches(1, 1, B, S, 3)), 1, 1, None, None)
+    two.train_network.close()
+
+
+def test_towers_follow_the_documented_bn_rule(ctx):
+    """vgg_like (BatchNorm, Dropout): after one tower step every tower holds
+    Adam(mean of the tower gradients) and moving statistics + mean of the towers' own
+    moving-average deltas (each tower normalises its own slice); dropout masks differ
+    per tower (seed * n + rank)"""
+    B = 4
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 7)
+    data, labels = _batches(2, 1, 2 * B, 18, 1)[0]
+    grp = train.TowerGroup(g, [0, 0], 'binary_crossentropy', train._OPTIMIZERS['adam'])
+    try:
+        assert grp.reduce_kind == 'host'
+        m = grp.step(data, labels, B, seed=11)
+        w_tow = [tr.get_weights() for tr in grp.trainers]
+    finally:
+        grp.close()
+    # the same from single trainers: tower r = rows [rB, (r+1)B), seed 11 * 2 + r
+    grads, mets = [], []
+    for r in range(2):
+        tr = _capi.Trainer(ctx, g)
+        tr.step(data[r * B:(r + 1) * B], labels[r * B:(r + 1) * B], seed=22 + r)
+        grads.append(tr.get_grads_flat())
+        mets.append(tr.metrics())
+        tr.close()
+    assert not np.array_equal(grads[0], grads[1])
+    ref = _capi.Trainer(ctx, g)
+    ref.set_grads_flat(grads[0] + grads[1])
+    ref.apply(0.5)
+    w_ref = ref.get_weights()
+    ref.close()
+    # the towers hold identical weights (same summed arena, same update) ...
+    for a, b in zip(*w_tow):
+        assert np.array_equal(a, b)
+    # ... equal to the reference update up to the run-to-run noise of the float-atomic
+    # weight gradients: Adam's first step is lr * g / (|g| + 3e-7), so only gradients
+    # at the noise level may differ by more than a rounding
+    _same_training(w_tow[0], w_ref)
+    for node in [n for n in g.nodes if n.kind == 'bn']:
+        for slot in node.weight_slots[2:]:          # moving mean / variance: no Adam
+            np.testing.assert_allclose(w_tow[0][slot], w_ref[slot], rtol=1e-6, atol=1e-7)
+    assert abs(m['loss'] - 0.5 * (mets[0]['loss'] + mets[1]['loss'])) < 1e-6
+    bn = [n for n in g.nodes if n.kind == 'bn'][0]
+    mm = bn.weight_slots[2]
+    assert not np.array_equal(w_ref[mm], g.weights[mm])
+
+
+def test_make_train_parallel_single_tower_uses_the_plain_path(ctx, tmp_path):
+    """n_gpu = 1 is the reference's degenerate tower: same result as no call at all"""
+    batches = _batches(3, 2, 4, 18, 1)
+    a = FplNetwork(fplmodels.vgg_like)
+    synth.synthetic_weights(a.train_single, 5)
+    w0 = a.train_single.get_weights()
+    a.train(_gen(batches), 2, 1, None, None)
+    b = FplNetwork(fplmodels.vgg_like)
+    b.train_single.set_weights(w0)
+    b.make_train_parallel(1, 4, 18)
+    b.train(_gen(batches), 2, 1, None, None)
+    assert b.train_reduce_kind == 'none'
+    _same_training(a.train_single.get_weights(), b.train_single.get_weights(), 2)
+
+
+def test_trainer_state_survives_train_calls(ctx):
+    """a compiled Keras model keeps its optimizer across fit_generator calls: two
+    train() calls of one step each == one call of two steps (Adam moments, step count
+    and the dropout seed sequence carry over)"""
+    batches = _batches(4, 2, 4, 18, 1)
+    a = FplNetwork(fplmodels.vgg_like)
+    synth.synthetic_weights(a.train_single, 5)
+    w0 = a.train_single.get_weights()
+    a.train(_gen(batches), 2, 1, None, None)
+    b = FplNetwork(fplmodels.vgg_like)
+    b.train_single.set_weights(w0)
+    b.train(_gen(batches[:1]), 1, 1, None, None)
+    b.train(_gen(batches[1:]), 1, 1, None, None)
+    _same_training(a.train_single.get_weights(), b.train_single.get_weights(), 2)
+    # a fresh optimizer for the second step would not: its bias correction restarts
+    c = FplNetwork(fplmodels.vgg_like)
+    c.train_single.set_weights(w0)
+    c.train(_gen(batches[:1]), 1, 1, None, None)
+    c._trainer[1].close()
+    c._trainer = None
+    c.train(_gen(batches[1:]), 1, 1, None, None)
+    with pytest.raises(AssertionError):
+        _same_training(a.train_single.get_weights(), c.train_single.get_weights(), 2)
+
+
+# ---- make_train_parallel: one process per rank -----------------------------------------
+def _rank_worker(rank, world, port, backend, devices, mode, out_q):
+    """one rank of data-parallel training, as torchrun would start it"""
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        os.environ['LOCAL_RANK'] = str(devices[rank])
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(devices[rank])
+            kw['device_id'] = torch.device('cuda', devices[rank])
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        B, S = 6, 12
+        batches = _batches(1, 3, world * B, S, 3)
+        if mode == 'fit':
+            net = FplNetwork(_bn_free_model)
+            if rank > 0:       # rank 0's weights must win (broadcast at the start)
+                net.train_single.set_weights([w + 1 for w in net.train_single.get_weights()])
+            net.make_train_parallel(world, B, S)
+            net.train(_gen(batches), 3, 1, None, None)
+            out_q.put((rank, 'ok', (net.train_reduce_kind, net.train_single.get_weights())))
+        else:
+            # the bare protocol: step -> train.allreduce_grads -> apply(scale)
+            g = _bn_free_model()[0]
+            tr = _capi.Trainer(runtime.get_context(devices[rank]), g)
+            if len(set(devices)) == world:
+                reducer = train.setup_rank_comm(tr.ctx, dist)
+                assert reducer.kind == 'rccl'
+            data, labels = batches[0]
+            sl = slice(rank * B, (rank + 1) * B)
+            tr.step(data[sl], labels[sl], seed=0)
+            own = tr.get_grads_flat()
+            scale = train.allreduce_grads(tr)
+            summed = tr.get_grads_flat()
+            tr.apply(scale)
+            out_q.put((rank, 'ok', (scale, own, summed, tr.get_weights())))
+        dist.destroy_process_group()
+    except Exception:
+        out_q.put((rank, 'error', traceback.format_exc()))
+
+
+def _run_ranks(world, backend, devices, mode):
+    import multiprocessing as mp
+    mctx = mp.get_context('spawn')
+    q = mctx.Queue()
+    port = _free_port()
+    procs = [mctx.Process(target=_rank_worker,
+                          args=(r, world, port, backend, devices, mode, q), daemon=True)
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            rank, status, payload = q.get(timeout=300)
+            assert status == 'ok', 'rank %d failed:\n%s' % (rank, payload)
+            got[rank] = payload
+        for p in procs:
+            p.join(60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return got
+
+
+def _check_protocol(ctx, got, world):
+    B, S = 6, 12
+    data, labels = _batches(1, 3, world * B, S, 3)[0]
+    g = _bn_free_model()[0]
+    whole = _capi.Trainer(ctx, g)
+    whole.step(data, labels, seed=0)
+    g_whole = whole.get_grads_flat()
+    whole.apply(1.0)
+    w_whole = whole.get_weights()
+    whole.close()
+    total = sum(got[r][1].astype(np.float64) for r in range(world))
+    for r in range(world):
+        scale, own, summed, w = got[r]
+        assert scale == 1.0 / world
+        np.testing.assert_allclose(summed, total, rtol=0, atol=1e-6 * np.abs(total).max())
+        assert np.array_equal(summed, got[0][2])          # every rank holds the same sum
+        np.testing.assert_allclose(summed * scale, g_whole, rtol=0,
+                                   atol=2e-5 * np.abs(g_whole).max())
+        for a, b, c in zip(w, got[0][3], w_whole):
+            assert np.array_equal(a, b)                   # ranks stay in lockstep
+            assert np.abs(a - c).max() < 2e-5             # == one step on the whole batch
+    assert not np.array_equal(got[0][1], got[1][1])       # the ranks saw different slices
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_allreduce_grads_and_apply_on_one_gpu(ctx):
+    """train.allreduce_grads + Trainer.apply(scale) with two REAL ranks (spawned
+    processes, gloo group, both on device 0): both ranks end with identical weights,
+    equal to a single-rank step on the concatenated batch"""
+    got = _run_ranks(2, 'gloo', [0, 0], 'protocol')
+    _check_protocol(ctx, got, 2)
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_fit_generator_on_one_gpu(ctx, tmp_path):
+    """FplNetwork.make_train_parallel(2, B) + train() under a 2-rank process group ==
+    the towers of one process == single-GPU training on the whole batches; rank 0's
+    initial weights are the ones trained"""
+    got = _run_ranks(2, 'gloo', [0, 0], 'fit')
+    assert got[0][0] == got[1][0] == 'torch.distributed'
+    for a, b in zip(got[0][1], got[1][1]):
+        assert np.array_equal(a, b)
+    B, S = 6, 12
+    batches = _batches(1, 3, 2 * B, S, 3)
+    one = FplNetwork(_bn_free_model)
+    one.train(_gen(batches), 3, 1, None, None)
+    for a, b in zip(got[0][1], one.train_single.get_weights()):
+        assert np.abs(a - b).max() < 3e-5
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_over_rccl_when_two_gpus_are_visible(ctx):
+    """the same protocol through fpl_comm_init / fpl_allreduce_grads (RCCL over xGMI)"""
+    if _n_devices() < 2:
+        pytest.skip('NOT RUN: the 2-rank RCCL all-reduce needs two GPUs, this box shows %d '
+                    '(RCCL refuses one device twice); the 1-rank communicator test and the '
+                    'host-staged 2-rank tests cover the rest of the path' % _n_devices())
+    got = _run_ranks(2, 'gloo', [0, 1], 'protocol')
+    _check_protocol(ctx, got, 2)
+    got = _run_ranks(2, 'nccl', [0, 1], 'fit')
+    assert got[0][0] == got[1][0] == 'rccl'
+    for a, b in zip(got[0][1], got[1][1]):
+        assert np.array_equal(a, b)
