@@ -49,9 +49,11 @@ KERNEL_LAYERS = {
 PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """CPU oracle (oracle/cnn_oracle.py, torch-CPU fp32 conv3d) on reference
-    tiles 102^3 -> 88^3, all host cores; bounded to ~seconds_budget"""
+def cpu_baseline(seconds_budget=8.0):
+    """CPU oracle (oracle/cnn_oracle.py, torch-CPU fp32 conv3d) on reference tiles
+    102^3 -> 88^3 of the 520^3 case (configs[0]): all host cores of the box's share for
+    ~seconds_budget, then ONE thread for two tiles (the figure BASELINE.md quotes a
+    single-process Keras-CPU run against).  Runs BEFORE the GPU legs."""
     import torch
     from flypylib_amd import fplmodels, synth
     from oracle import cnn_oracle
@@ -74,11 +76,145 @@ def cpu_baseline(seconds_budget=20.0):
         dt = time.perf_counter() - t0
         if dt > seconds_budget or n >= 64:
             break
+    torch.set_num_threads(1)
+    t1 = time.perf_counter()
+    n1 = 0
+    while n1 < 2 and (n1 == 0 or time.perf_counter() - t1 < 6.0):
+        cnn_oracle.vgg_like_forward(tile, g.weights, 4)
+        n1 += 1
+    dt1 = time.perf_counter() - t1
+    torch.set_num_threads(cores)
     return dict(value=n * 88 ** 3 / dt / 1e6, unit='Mvoxels/s',
-                cores=torch.get_num_threads(), kind='port',
-                sample='%d reference tiles 102^3->88^3 of the same synthetic '
-                       'volume, torch-CPU fp32 restatement of vgg_like '
-                       '(oracle/cnn_oracle.py), %.1f s' % (n, dt))
+                cores=cores, kind='port',
+                one_thread_value=n1 * 88 ** 3 / dt1 / 1e6,
+                sample='%d reference tiles 102^3->88^3 (the lattice of the 520^3 case: 216 '
+                       'such tiles) of the same synthetic volume, torch-CPU fp32 restatement '
+                       'of vgg_like (oracle/cnn_oracle.py, NOT Keras), %.1f s on %d threads; '
+                       '%d tiles in %.1f s on 1 thread' % (n, dt, cores, n1, dt1))
+
+
+UNET2_FLOP = 350720.0          # unet_like2, per valid output voxel
+TRAIN_C4_FLOP = 492e9          # vgg_like training step, 32 x 64^3 patches (3 x forward)
+HBM_PEAK_GBS = 8000.0
+
+
+def _infer_pass(ctx, prog, torch, size, tile, off, prec, steps, warmup, seed=20250101):
+    """`steps` timed passes of fpl_infer_volume over a resident size^3 uint8 volume;
+    returns (seconds per step, per-kernel HIP-event timings)"""
+    dims = (size,) * 3
+    src = torch.empty(dims, dtype=torch.uint8, device='cuda')
+    dst = torch.empty(dims, dtype=torch.float32, device='cuda')
+    ctx.synth_volume_u8(seed, dims, (0, 0, 0), out=src)
+    kw = dict(mean=128.0, std=33.0, precision=prec, dst=dst, dims=dims)
+    for _ in range(warmup):
+        prog.infer_volume(src, (tile,) * 3, (off,) * 3, **kw)
+    ctx.synchronize()
+    ctx.timing(True)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prog.infer_volume(src, (tile,) * 3, (off,) * 3, **kw)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern = {k: round(v['ms'] / steps, 4) for k, v in ctx.timing_get().items()}
+    ctx.timing(False)
+    del src, dst
+    return dt, kern, ctx.last_path()
+
+
+def secondary_legs(ctx, torch, prog, tile, off, size, steps):
+    """Driver-timed twins of the numbers DESIGN.md quotes beside the headline: the same
+    step in the other arithmetic types, the metric string's 520^3 size, and short legs
+    for configs[2] (unet_like2), configs[4]'s post-process (voxel2obj on one 582^3
+    substack) and configs[3] (one training step).  Each: ms, algorithmic work, the
+    fraction of the roofline that bounds it."""
+    from flypylib_amd import _capi, fplmodels, fplobjdetect, synth
+    legs = {}
+    k = max(1, min(steps, 5))
+
+    def vgg_leg(name, n, prec, pname, nsteps):
+        dt, kern, path = _infer_pass(ctx, prog, torch, n, tile, off, prec, nsteps, 1)
+        vox = (n - 2 * off) ** 3
+        tf = vox * VGG_FLOP_TOTAL / dt / 1e12
+        legs[name] = dict(workload='vgg_like inference %d^3 uint8, %s' % (n, pname),
+                          executor=path, ms=round(dt * 1e3, 3),
+                          mvox_s=round(vox / dt / 1e6, 1), bound='mfma',
+                          achieved_tflops=round(tf, 2), peak_tflops=PEAK_TFLOPS[pname],
+                          frac=round(tf / PEAK_TFLOPS[pname], 4), kernel_ms=kern)
+
+    vgg_leg('configs1_bf16', size, _capi.PREC_BF16, 'bf16', k)
+    vgg_leg('configs1_f32', size, _capi.PREC_F32, 'f32', 1)
+    vgg_leg('configs0_520_f16', 520, _capi.PREC_F16, 'f16', k)
+
+    # configs[2]: unet_like2 on the reference lattice (tile 100, pitch 82), 510^3 sample
+    g = fplmodels.unet_like2(100)[0]
+    synth.synthetic_weights(g, 7)
+    uprog = _capi.Program(ctx, g, (1, 1, 1))
+    n = 510
+    dt, kern, path = _infer_pass(ctx, uprog, torch, n, 100, 9, _capi.PREC_F16, 2, 1, seed=3)
+    vox = (n - 18) ** 3
+    tf = vox * UNET2_FLOP / dt / 1e12
+    legs['configs2_unet_like2_510_f16'] = dict(
+        workload='unet_like2 inference %d^3 uint8 (216 reference tiles 100^3), f16' % n,
+        executor=path, ms=round(dt * 1e3, 3), mvox_s=round(vox / dt / 1e6, 1), bound='mfma',
+        achieved_tflops=round(tf, 2), peak_tflops=2500.0, frac=round(tf / 2500.0, 4),
+        kernel_ms=kern)
+    uprog.close()
+
+    # configs[4] post-process: voxel2obj of one 512 + 2 x 35 substack (r 27, sigma 5)
+    n = 582
+    prob = torch.from_numpy(synth.blob_prob_volume(11, (n, n, n), period=64, radius=9.0)).cuda()
+    from flypylib_amd import runtime
+    vctx = runtime.get_context(ctx.device)           # the context voxel2obj runs on
+    fplobjdetect.voxel2obj(prob, 27, 5, (0, 0, 0), 35, 0.1)       # warm-up
+    vctx.timing(True)
+    vctx.timing_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fplobjdetect.voxel2obj(prob, 27, 5, (0, 0, 0), 35, 0.1)
+    dt = (time.perf_counter() - t0) / reps
+    kern = {kk: round(v['ms'] / reps, 4) for kk, v in vctx.timing_get().items()}
+    vctx.timing(False)
+    gbs = 12.0 * (n + 54) ** 3 / dt / 1e9
+    legs['configs4_voxel2obj_582'] = dict(
+        workload='voxel2obj on a 582^3 f32 probability volume resident in HBM, r 27, '
+                 'sigma 5, thd 0.1, buffer 35', ms=round(dt * 1e3, 3),
+        mvox_s=round(n ** 3 / dt / 1e6, 1), detections=int(len(out['conf'])), bound='hbm',
+        achieved_gbs=round(gbs, 1), peak_gbs=HBM_PEAK_GBS, frac=round(gbs / HBM_PEAK_GBS, 4),
+        algorithmic_bytes=12 * (n + 54) ** 3, kernel_ms=kern)
+    del prob
+
+    # configs[3]: one vgg_like training step, batch 32 of 64^3 patches, fp32
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 8)
+    tr = _capi.Trainer(ctx, g)
+    rng = np.random.default_rng(0)
+    data = rng.standard_normal((32, 64, 64, 64)).astype(np.float32)
+    labels = (rng.random((32, 12, 12, 12)) > 0.9).astype(np.uint8)
+    tr.step(data, labels, 0)
+    tr.apply(1.0)
+    ctx.synchronize()
+    ctx.timing(True)
+    ctx.timing_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for i in range(reps):
+        tr.step(data, labels, i + 1)
+        tr.apply(1.0)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kern = ctx.timing_get()
+    ctx.timing(False)
+    gpu_ms = sum(v['ms'] for v in kern.values()) / reps
+    tf = TRAIN_C4_FLOP / dt / 1e12
+    legs['configs3_train_vgg_b32_64'] = dict(
+        workload='vgg_like training step (fwd + bwd + Adam), 32 x 64^3 f32 patches from '
+                 'host memory, 1 GPU', ms=round(dt * 1e3, 3), steps_per_s=round(1 / dt, 2),
+        kernel_ms_sum=round(gpu_ms, 3), bound='mfma', achieved_tflops=round(tf, 2),
+        peak_tflops=PEAK_TFLOPS['f32'], frac=round(tf / PEAK_TFLOPS['f32'], 4))
+    tr.close()
+    return legs
 
 
 def main():
@@ -97,6 +233,8 @@ def main():
     ap.add_argument('--tile', type=int, default=102,
                     help='reference infer_sz (tile lattice pitch = tile-14)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-legs', action='store_true',
+                    help='skip the secondary legs (other precisions / sizes / configs)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend (gloo only to rehearse N>1 on one GPU)')
     args = ap.parse_args()
@@ -105,6 +243,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+
+    # the CPU leg first: the GPU legs then run back to back to the end of the process
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
 
     import torch
     import torch.distributed as dist
@@ -168,15 +311,18 @@ def main():
     dt = time.perf_counter() - t0
     timings = ctx.timing_get()
     ctx.timing(False)
+    executor = ctx.last_path()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64,
                          device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    del src, dst
 
-    # HBM bytes per launch of each kernel from the committed rocprofv3 --pmc pass
-    # (tools/profile_pmc.py; FETCH_SIZE doubled per the gfx950 correction) - only
-    # valid for the workload size it was collected on
+    # HBM bytes per launch of each kernel: NOT measured in this run - read from the
+    # latest committed rocprofv3 --pmc pass of the same command (tools/profile_pmc.py;
+    # FETCH_SIZE doubled per the gfx950 correction), valid only for the workload size and
+    # operand type it was collected on; `traffic_source` names the file
     traffic_by_kernel = {}
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_%d_%s.json'
@@ -203,10 +349,19 @@ def main():
                         peak=peak, unit='TFLOP/s',
                         frac=round(achieved / peak, 5),
                         traffic=traffic_by_kernel.get(name),
+                        traffic_source=(os.path.relpath(pmc_path, ROOT)
+                                        if name in traffic_by_kernel else None),
                         avg_launch_ms=round(avg_ms, 4), launches=tk['launches'],
                         algorithmic_flop_per_voxel=flop_per_vox,
                         kernel_ms_total={k: round(v['ms'], 3)
                                          for k, v in timings.items()})
+            # the whole step against the same peak
+            tf_step = VGG_FLOP_TOTAL * valid_local * args.steps / dt / 1e12
+            roof['whole_step'] = dict(achieved=round(tf_step, 2), frac=round(tf_step / peak, 4))
+
+    legs = None
+    if world == 1 and not args.no_legs:
+        legs = secondary_legs(ctx, torch, prog, tile, off, args.size, args.steps)
 
     if rank == 0:
         value = valid_global * args.steps / dt / 1e6
@@ -222,11 +377,12 @@ def main():
                                    'synthetic uint8 volume, reference tile '
                                    'lattice %d^3 (pitch %d), u8 in / f32 out '
                                    'resident in HBM' % (Z, Y, X, tile, pitch),
-                       'volume': [Z, Y, X], 'tile_in': tile,
+                       'volume': [Z, Y, X], 'tile_in': tile, 'executor': executor,
                        'operands': {'f16': 'IEEE half MFMA operands, fp32 accumulate: within '
-                                           '1e-3 of fp32 (the parity gate); --precision bf16 '
-                                           'runs the same kernels on bfloat16 (~2 % faster, '
-                                           'up to 4e-3 off)',
+                                           '1e-3 of fp32 (the parity gate); legs.configs1_bf16 '
+                                           'is the same step on bfloat16 (what configs[1] '
+                                           'names; up to 4e-3 off), legs.configs1_f32 on the '
+                                           'reference\'s own fp32',
                                     'bf16': 'bfloat16 MFMA operands, fp32 accumulate (as '
                                             'configs[1] names; up to 4e-3 off fp32); '
                                             '--precision f16 meets the 1e-3 gate',
@@ -236,8 +392,10 @@ def main():
                        'device': info['name']},
             'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        if legs is not None:
+            line['legs'] = legs
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
