@@ -252,6 +252,136 @@ __global__ __launch_bounds__(256) void gauss_x_lds(
       if (lh[b]) atomicAdd(&hist11[b], (unsigned long long)lh[b]);
 }
 
+// y and x passes fused through one LDS tile: a workgroup takes GYX_TY consecutive y
+// rows of one z plane over the WHOLE x extent.  Phase 1 (lanes along x, coalesced):
+// a thread slides the register window of gauss_pass_win<1> down its column and stores
+// the GYX_TY fp32-rounded y-pass outputs into the tile - with the row's reflected x
+// halo, which for a whole row is made of the row's own values.  Phase 2: the x pass of
+// gauss_x_lds on the tile rows (aligned 16-B LDS reads), margin zeroing, the 16-B
+// stores and the first radix level.  The y-pass volume never exists in HBM (one
+// 4 B/voxel write and one read less); arithmetic and rounding points are unchanged.
+// The 1-D grid is decoded so that the blocks an XCD receives (b, b + 8, ...) walk the
+// y tiles of consecutive planes: y neighbours share their 2*WR halo rows in that L2.
+constexpr int GYX_TY = 16;
+
+template <int WR>
+__global__ __launch_bounds__(256) void gauss_yx_fused(
+    const float *__restrict__ in, float *__restrict__ out, int64_t P0, int64_t P1,
+    int64_t P2, const double *__restrict__ w, int r, int lrow,
+    unsigned long long *__restrict__ hist11) {
+  constexpr int TY = GYX_TY;
+  constexpr int NWY = TY + 2 * WR;
+  constexpr int NWX = 4 + 2 * WR;
+  extern __shared__ __attribute__((aligned(16))) float yx_tile[];   // [TY][lrow]
+  __shared__ unsigned int lh[2048];
+  const int t = threadIdx.x;
+  for (int b = t; b < 2048; b += 256) lh[b] = 0u;
+  double wk[WR + 1];
+#pragma unroll
+  for (int j = 0; j <= WR; ++j) wk[j] = w[j];
+  const int64_t nty = (P1 + TY - 1) / TY;
+  const int64_t nwork = P0 * nty;
+  // XCD-contiguous work order (speed only): block b -> slot b / 8 of XCD b % 8
+  const int64_t per_xcd = (nwork + 7) / 8;
+  const int64_t wid = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (wid < nwork && (int64_t)(blockIdx.x >> 3) < per_xcd) {
+    const int64_t z = wid / nty, y0 = (wid % nty) * TY;
+    const bool interior = y0 - WR >= 0 && y0 + TY + WR <= P1;
+    const float *plane = in + z * P1 * P2;
+    // ---- phase 1: y pass, one column per thread and iteration
+    for (int64_t x = t; x < P2; x += 256) {
+      double win[NWY];
+      if (interior) {
+        const float *q = plane + (y0 - WR) * P2 + x;
+#pragma unroll
+        for (int i = 0; i < NWY; ++i) win[i] = (double)q[(int64_t)i * P2];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NWY; ++i)
+          win[i] = (double)plane[reflect_idx(y0 - WR + i, P1) * P2 + x];
+      }
+      // mirrored halo slots this column also fills ('reflect': -1 -> 0, P2 -> P2 - 1)
+      const int64_t ml = x < WR ? WR - 1 - x : -1;
+      const int64_t mr = x >= P2 - WR ? 2 * P2 - 1 - x + WR : -1;
+#pragma unroll
+      for (int o = 0; o < TY; ++o) {
+        double acc = __dmul_rn(win[WR + o], wk[0]);
+#pragma unroll
+        for (int j = WR; j >= 1; --j)
+          acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
+        const float v = (float)acc;
+        float *rowp = yx_tile + (size_t)o * lrow;
+        rowp[x + WR] = v;
+        if (ml >= 0) rowp[ml] = v;
+        if (mr >= 0) rowp[mr] = v;
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: x pass on the tile rows, 4 outputs per thread and iteration
+    const int nq = (int)((P2 + 3) / 4);
+    for (int u = t; u < TY * nq; u += 256) {
+      const int ty = u / nq;
+      const int64_t x0 = (int64_t)(u - ty * nq) * 4;
+      const int64_t y = y0 + ty;
+      if (y >= P1) continue;
+      const float *rowp = yx_tile + (size_t)ty * lrow + x0;
+      double win[NWX];
+#pragma unroll
+      for (int q = 0; q < (NWX + 3) / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(rowp + 4 * q);
+        if (4 * q + 0 < NWX) win[4 * q + 0] = (double)v.x;
+        if (4 * q + 1 < NWX) win[4 * q + 1] = (double)v.y;
+        if (4 * q + 2 < NWX) win[4 * q + 2] = (double)v.z;
+        if (4 * q + 3 < NWX) win[4 * q + 3] = (double)v.w;
+      }
+      const bool edge_zy = r > 0 && (z < r || y < r || z >= P0 - r || y >= P1 - r);
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double acc = __dmul_rn(win[WR + k], wk[0]);
+#pragma unroll
+        for (int j = WR; j >= 1; --j)
+          acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
+        const int64_t x = x0 + k;
+        o[k] = (edge_zy || (r > 0 && (x < r || x >= P2 - r))) ? 0.f : (float)acc;
+      }
+      const int64_t row = z * P1 + y;
+      float *dst = out + row * P2 + x0;
+      const int nv = (int)(P2 - x0 < 4 ? P2 - x0 : 4);
+      if (nv == 4 && ((row * P2 + x0) & 3) == 0) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < nv) dst[k] = o[k];
+      }
+      if (hist11) {
+        uint32_t kb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) kb[k] = float_key(o[k]) >> 21;
+        int run = 1;
+#pragma unroll
+        for (int k = 1; k <= 4; ++k) {
+          if (k < nv && kb[k] == kb[k - 1]) { ++run; continue; }
+          if (k <= nv) atomicAdd(&lh[kb[k - 1]], (unsigned)run);
+          run = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (hist11)
+    for (int b = t; b < 2048; b += 256)
+      if (lh[b]) atomicAdd(&hist11[b], (unsigned long long)lh[b]);
+}
+
+// LDS floats per tile row of gauss_yx_fused: the row, its two halos, rounded up to a
+// 16-B multiple plus 4 (the last thread's aligned window may read 3 floats past it)
+static inline int gyx_lrow(int64_t P2, int wr) { return (int)((P2 + 2 * wr + 3) / 4 * 4 + 4); }
+static inline bool gyx_fits(int64_t P2, int wr) {
+  return P2 >= 2 * wr && (size_t)GYX_TY * gyx_lrow(P2, wr) * sizeof(float) <= 56 * 1024;
+}
+
 // Compaction without global atomics: workgroup b scans elements [b*chunk, (b+1)*chunk)
 // and packs those whose key matches (key & mask) == want to the front of the same
 // range of `list` (as floats); counts[b] = how many.
@@ -302,16 +432,36 @@ __global__ __launch_bounds__(256) void key_histogram_chunks(
 }
 
 template <int WR>
-void launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t P[3],
-                      const double *w_dev, int r, unsigned long long *hist11) {
+int launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t P[3],
+                     const double *w_dev, int r, unsigned long long *hist11) {
   hipStream_t st = ctx->stream;
+  constexpr int OUT_ZY = 16;                 // outputs per thread of gauss_pass_win<0/1>
+  const bool fused = gyx_fits(P[2], WR) && !getenv("FPL_V2O_UNFUSED");
+  // fused: z pass -> b, y+x -> a;  separate passes: z -> a, y -> b, x -> a
   {
-    const int64_t n = ((P[0] + 7) / 8) * P[1] * P[2];
+    const int64_t n = ceil_div64(P[0], OUT_ZY) * P[1] * P[2];
     TimedLaunch tl(ctx, "v2o_gauss_z");
-    gauss_pass_win<0, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(pv, nullptr, a, P[0], P[1], P[2], w_dev, r);
+    gauss_pass_win<0, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(
+        pv, nullptr, fused ? b : a, P[0], P[1], P[2], w_dev, r);
+  }
+  if (fused) {
+    const int lrow = gyx_lrow(P[2], WR);
+    const size_t lds = (size_t)GYX_TY * lrow * sizeof(float);
+    static bool attr_set[FPL_MAX_DEVICES] = {false};
+    if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
+      FPL_HIP(ctx, hipFuncSetAttribute((const void *)gauss_yx_fused<WR>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 56 * 1024));
+      attr_set[ctx->device % FPL_MAX_DEVICES] = true;
+    }
+    const int64_t nwork = P[0] * ceil_div64(P[1], GYX_TY);
+    const int64_t nblk = ceil_div64(nwork, 8) * 8;
+    TimedLaunch tl(ctx, "v2o_gauss_yx");
+    gauss_yx_fused<WR><<<(unsigned)nblk, 256, lds, st>>>(b, a, P[0], P[1], P[2], w_dev, r, lrow,
+                                                         hist11);
+    return 0;
   }
   {
-    const int64_t n = P[0] * ((P[1] + 7) / 8) * P[2];
+    const int64_t n = P[0] * ceil_div64(P[1], OUT_ZY) * P[2];
     TimedLaunch tl(ctx, "v2o_gauss_y");
     gauss_pass_win<1, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(pv, a, b, P[0], P[1], P[2], w_dev, r);
   }
@@ -321,6 +471,7 @@ void launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_
     TimedLaunch tl(ctx, "v2o_gauss_x");
     gauss_x_lds<WR><<<(unsigned)nblk, 256, 0, st>>>(b, a, P[0], P[1], P[2], w_dev, r, hist11);
   }
+  return 0;
 }
 
 // histogram of `bits` key bits at `shift` over the elements whose key matches
@@ -343,37 +494,19 @@ __global__ __launch_bounds__(256) void key_histogram(
     if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
 }
 
-// live-key volume on the cell-aligned grid (dims L0,L1,L2 = multiples of CELL): a
-// thread writes one cell row (CELL = 4 consecutive x, one 16-B store); the grid is
-// (row pieces, y, z) so no index is divided out per voxel
-__global__ void build_live(const float *__restrict__ s, int64_t P0, int64_t P1,
-                           int64_t P2, int64_t L1, int64_t L2, double thresh,
-                           uint32_t *__restrict__ live) {
-  const int64_t x4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t y = (int64_t)blockIdx.y * blockDim.y + threadIdx.y, z = blockIdx.z;
-  if (x4 * CELL >= L2 || y >= L1) return;
-  uint32_t k[CELL];
-  const bool row = z < P0 && y < P1;
-  const float *sp = s + (z * P1 + y) * P2 + x4 * CELL;
-#pragma unroll
-  for (int d = 0; d < CELL; ++d) {
-    k[d] = 0;
-    if (row && x4 * CELL + d < P2) {
-      const float v = sp[d];
-      if ((double)v > thresh && v > 0.f) k[d] = __float_as_uint(v);
-    }
-  }
-  static_assert(CELL == 4, "one uint4 per cell row");
-  *reinterpret_cast<uint4 *>(live + (z * L1 + y) * L2 + x4 * CELL) = make_uint4(k[0], k[1], k[2], k[3]);
-}
-
+// The NMS works on the smoothed volume IN PLACE: a voxel is a live candidate while
+// (double)v > thresh && v > 0, and clear_balls suppresses by storing 0 (a separate
+// "live key" volume - one more 4 B/voxel write and read - is not needed; the smoothed
+// volume is consumed by the NMS).
+//
 // best live key per 4x4x4 cell: (value bits << 32) | ~flat_index(padded volume).
 // After the first round only the cells a cleared ball touched (marked CELL_DIRTY by
 // clear_balls) are re-scanned; the others keep their key.
 constexpr unsigned long long CELL_DIRTY = 1ull;    // no live key has value bits 0
 
-__global__ __launch_bounds__(256) void cell_best(const uint32_t *__restrict__ live, int64_t L1,
-                          int64_t L2, int64_t P1, int64_t P2, int64_t C0,
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void cell_best(const float *__restrict__ s, double thresh,
+                          int64_t P0, int64_t P1, int64_t P2, int64_t C0,
                           int64_t C1, int64_t C2,
                           unsigned long long *__restrict__ best,
                           unsigned long long *__restrict__ counters, int first_round) {
@@ -393,15 +526,22 @@ __global__ __launch_bounds__(256) void cell_best(const uint32_t *__restrict__ li
 #pragma unroll
         for (int dy = 0; dy < CELL; ++dy) {
           const int64_t z = cz * CELL + dz, y = cy * CELL + dy;
-          const uint4 q =
-              *reinterpret_cast<const uint4 *>(live + (z * L1 + y) * L2 + cx * CELL);
-          const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+          if (z >= P0 || y >= P1) continue;
+          const float *rowp = s + (z * P1 + y) * P2 + cx * CELL;
+          float v[4];
+          if (ALIGNED) {               // P2 % 4 == 0: the cell row is one aligned 16-B piece
+            const float4 q = *reinterpret_cast<const float4 *>(rowp);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+          } else {
+#pragma unroll
+            for (int dx = 0; dx < CELL; ++dx) v[dx] = cx * CELL + dx < P2 ? rowp[dx] : 0.f;
+          }
 #pragma unroll
           for (int dx = 0; dx < CELL; ++dx)
-            if (v[dx]) {
+            if ((double)v[dx] > thresh && v[dx] > 0.f) {
               const uint32_t flat = (uint32_t)((z * P1 + y) * P2 + cx * CELL + dx);
               const unsigned long long k =
-                  ((unsigned long long)v[dx] << 32) | (0xFFFFFFFFu - flat);
+                  ((unsigned long long)__float_as_uint(v[dx]) << 32) | (0xFFFFFFFFu - flat);
               b = k > b ? k : b;
             }
         }
@@ -462,8 +602,8 @@ __global__ void pick_winners(const unsigned long long *__restrict__ best,
 // one block per winner: clear the r-ball in the live volume
 __global__ __launch_bounds__(256) void clear_balls(
     const unsigned long long *__restrict__ round_list,
-    const unsigned long long *__restrict__ counters, uint32_t *__restrict__ live,
-    int64_t L1, int64_t L2, int64_t P1, int64_t P2, int r,
+    const unsigned long long *__restrict__ counters, float *__restrict__ live,
+    int64_t P1, int64_t P2, int r,
     unsigned long long *__restrict__ best, int64_t C1, int64_t C2) {
   const unsigned long long nwin = counters[1];
   for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
@@ -478,8 +618,8 @@ __global__ __launch_bounds__(256) void clear_balls(
       int hx = (int)sqrtf((float)rem);
       while ((hx + 1) * (hx + 1) <= rem) ++hx;
       while (hx * hx > rem) --hx;
-      uint32_t *rowp = live + ((z + dz) * L1 + (y + dy)) * L2 + x;
-      for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0;
+      float *rowp = live + ((z + dz) * P1 + (y + dy)) * P2 + x;
+      for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0.f;
     }
     // cached keys of the cells in the ball's bounding box (the r shell of the padded
     // volume keeps every ball inside it): a cell wholly inside the ball has no live
@@ -574,8 +714,8 @@ __global__ void seg_zero_small(const unsigned long long *__restrict__ seg, int64
 // (2r+1 <= 64), built with a ballot; rows live in LDS.
 __global__ __launch_bounds__(256) void clear_balls_seg(
     const unsigned long long *__restrict__ round_list,
-    const unsigned long long *__restrict__ counters, uint32_t *__restrict__ live,
-    int64_t L1, int64_t L2, int64_t P1, int64_t P2, int r,
+    const unsigned long long *__restrict__ counters, float *__restrict__ live,
+    int64_t P1, int64_t P2, int r,
     unsigned long long *__restrict__ best, int64_t C1, int64_t C2,
     const unsigned long long *__restrict__ seg, int dilate, int force) {
   extern __shared__ unsigned long long rows_lds[];       // 2 x side*side
@@ -632,7 +772,7 @@ __global__ __launch_bounds__(256) void clear_balls_seg(
         bits |= ((1ull << (2 * hf + 1)) - 1ull) << (r - hf);
       }
       if (lane < side && ((bits >> lane) & 1ull))
-        live[((z + dz) * L1 + (y + dy)) * L2 + x - r + lane] = 0;
+        live[((z + dz) * P1 + (y + dy)) * P2 + x - r + lane] = 0.f;
     }
     const int64_t cz0 = (z - r) / CELL, cy0 = (y - r) / CELL, cx0 = (x - r) / CELL;
     const int nz = (int)((z + r) / CELL - cz0 + 1), ny = (int)((y + r) / CELL - cy0 + 1),
@@ -806,10 +946,10 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
   // (sigma 1.5, 2, 3, 5 at truncate 2.0); the plain kernel covers the rest
   bool windowed = true;
   switch (wr) {
-    case 3: launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
-    case 4: launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
-    case 6: launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
-    case 10: launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev); break;
+    case 3: FPL_TRY(launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
+    case 4: FPL_TRY(launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
+    case 6: FPL_TRY(launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
+    case 10: FPL_TRY(launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
     default: windowed = false;
   }
   if (!windowed) {
@@ -862,21 +1002,20 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
               "fpl_v2o_nms: call fpl_v2o_smooth first");
   FPL_REQUIRE(ctx, cap > 0, "fpl_v2o_nms: cap must be positive");
   FPL_HIP(ctx, hipSetDevice(ctx->device));
-  const V2oState &S = ctx->v2o;
+  V2oState &S = ctx->v2o;
+  S.valid = false;                 // the NMS suppresses in place: the volume is consumed
   const int64_t P0 = S.pdims[0], P1 = S.pdims[1], P2 = S.pdims[2];
   const int r = S.r;
   hipStream_t st = ctx->stream;
   DevTemp tmp(ctx);
   const int64_t C0 = ceil_div64(P0, CELL), C1 = ceil_div64(P1, CELL),
                 C2 = ceil_div64(P2, CELL);
-  const int64_t L0 = C0 * CELL, L1 = C1 * CELL, L2 = C2 * CELL;
-  const int64_t n_live = L0 * L1 * L2, n_cells = C0 * C1 * C2;
+  const int64_t n_cells = C0 * C1 * C2;
+  float *live = S.smoothed;
   // window half-width in cells: cells [c-hw, c+hw] cover [4c-4hw, 4c+4hw+3]
   // which must contain [p-r, p+r] for every p in [4c, 4c+3]
   const int hw = (r + CELL - 1) / CELL;
   void *p;
-  FPL_TRY(tmp.alloc((size_t)n_live * sizeof(uint32_t), &p));
-  uint32_t *live = (uint32_t *)p;
   FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
   unsigned long long *best = (unsigned long long *)p;
   FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
@@ -890,12 +1029,6 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   FPL_TRY(tmp.alloc(4 * 8, &p));
   unsigned long long *counters = (unsigned long long *)p;
   FPL_HIP(ctx, hipMemsetAsync(counters, 0, 4 * 8, st));
-  {
-    TimedLaunch tl(ctx, "v2o_build_live");
-    FPL_REQUIRE(ctx, L1 < 65536 && L0 < 65536, "voxel2obj: volume too large for the live grid");
-    build_live<<<dim3((unsigned)ceil_div64(L2 / CELL, 64), (unsigned)ceil_div64(L1, 4), (unsigned)L0), dim3(64, 4), 0, st>>>(
-        S.smoothed, P0, P1, P2, L1, L2, thresh, live);
-  }
   const unsigned cgrid = (unsigned)ceil_div64(n_cells, 256);
   const unsigned bgrid = std::min<unsigned>(cgrid, (unsigned)ctx->n_cu * 8);   // cell_best: grid-stride
   unsigned long long host_cnt[4];
@@ -904,8 +1037,12 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
     FPL_HIP(ctx, hipMemsetAsync(counters, 0, 2 * 8, st));   // live cells, round winners
     {
       TimedLaunch tl(ctx, "v2o_cell_best");
-      cell_best<<<bgrid, 256, 0, st>>>(live, L1, L2, P1, P2, C0, C1, C2, best,
-                                       counters, rounds == 0);
+      if (P2 % CELL == 0)
+        cell_best<true><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
+                                               counters, rounds == 0);
+      else
+        cell_best<false><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
+                                                counters, rounds == 0);
     }
     {
       TimedLaunch tl(ctx, "v2o_window_max");
@@ -922,10 +1059,10 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
       TimedLaunch tl(ctx, "v2o_clear_balls");
       if (use_seg) {
         const size_t lds = (size_t)2 * (2 * r + 1) * (2 * r + 1) * sizeof(unsigned long long);
-        clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, L1, L2, P1, P2, r,
+        clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, P1, P2, r,
                                                 best, C1, C2, S.seg, seg_dilate, seg_force);
       } else {
-        clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, L1, L2, P1, P2,
+        clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, P1, P2,
                                           r, best, C1, C2);
       }
     }

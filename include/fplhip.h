@@ -153,7 +153,9 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
 /* Step 2: NMS over voxels with (double)value > thresh (and > 0) of the volume prepared
  * by step 1.  out_zyxv: rows (z, y, x in padded coordinates, value) as f64,
  * sorted by (value desc, flat index asc) = the reference's emission order.
- * Returns the number of detections in *n_out (<= cap, else error). */
+ * Returns the number of detections in *n_out (<= cap, else error).  The NMS
+ * suppresses in place: it CONSUMES the smoothed volume of step 1 (a second NMS needs a
+ * new fpl_v2o_smooth). */
 int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
                 int64_t *n_out, int32_t *n_rounds);
 /* Segmentation-aware suppression (the seg / seg_dilate / seg_sz_thd / seg_force

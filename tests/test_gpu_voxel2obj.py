@@ -15,13 +15,18 @@ def test_golden_cases_bit_exact(ctx, golden):
     n = 0
     for c in helpers.v2o_cases(g):
         pred = helpers.make_pred(c['kind'], c['seed'], c['shape'])
-        res, info = fplobjdetect.voxel2obj(pred, c['r'], c['sigma'], c['offset'],
-                                           c['buffer'], c['thd'],
-                                           return_info=True)
+        # the smoothed volume is read between the stages: the NMS consumes it
         pdims = tuple(s + 2 * c['r'] for s in c['shape'])
+        ctx.v2o_smooth(pred, c['shape'], c['r'],
+                       fplobjdetect.gaussian_kernel1d(c['sigma'], truncate=2.0), [])
         sm = ctx.v2o_smoothed(pdims)
         assert helpers.sha(sm) == c['smooth_sha'], \
             '%s: smoothed volume differs from scipy' % c['name']
+        res, info = fplobjdetect.voxel2obj(pred, c['r'], c['sigma'], c['offset'],
+                                           c['buffer'], c['thd'],
+                                           return_info=True)
+        with pytest.raises(Exception, match='no smoothed volume'):
+            ctx.v2o_smoothed(pdims)
         assert np.array_equal(res['locs'], c['locs']), c['name']
         assert np.array_equal(res['conf'], c['conf']), c['name']
         assert res['locs'].dtype == np.float64 and res['conf'].dtype == np.float64
