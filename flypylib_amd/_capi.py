@@ -65,6 +65,7 @@ SIGNATURES = {
                                    _vp, C.c_int]),
     'fpl_v2o_smooth': (C.c_int, [_vp, _vp, C.c_int, _pi64, _i32, _vp, _i32,
                                  _pi64, _i32, _vp]),
+    'fpl_v2o_set_floor': (C.c_int, [_vp, _f32]),
     'fpl_v2o_nms': (C.c_int, [_vp, _f64, _vp, _i64, _pi64, _pi32]),
     'fpl_v2o_set_seg': (C.c_int, [_vp, _vp, _i32, C.c_int, _pi64, _i64]),
     'fpl_v2o_select': (C.c_int, [_vp, _pi64, _i32, _vp]),
@@ -299,6 +300,10 @@ class Context:
             _ptr(weights), int(wr), ranks.ctypes.data_as(_pi64),
             int(ranks.size), _ptr(vals)))
         return vals[:ranks.size]
+
+    def v2o_set_floor(self, floor):
+        """the next NMS threshold will be >= floor (valid for one v2o_smooth)"""
+        self.check(self.lib.fpl_v2o_set_floor(self.h, float(floor)))
 
     def v2o_nms(self, thresh, cap=1 << 20):
         out = np.zeros((cap, 4), np.float64)

@@ -23,6 +23,8 @@ CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC',
             '-ffp-contract=on', '-Wall', '-Wno-unused-function',
             '-Wno-unused-but-set-variable', '-Wno-unused-variable',
             '-Wno-unused-value', '-Wno-unused-result']
+# throw-away timing experiments only (e.g. FPL_EXTRA_CXXFLAGS=-DFPL_EXP_NOMATH=1)
+CXXFLAGS += os.environ.get('FPL_EXTRA_CXXFLAGS', '').split()
 
 
 # translation units built a second time with -DFPL_F16 (IEEE-half operands instead of

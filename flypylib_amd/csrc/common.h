@@ -37,6 +37,13 @@ struct V2oState {
   int64_t pdims[3] = {0, 0, 0};
   int32_t r = 0;
   bool valid = false;
+  // per 4x4x4 cell: key of its largest positive voxel, taken by the fused y+x pass
+  // while the values are in registers (v2o.hip); stale once the volume is edited
+  unsigned long long *cellmax = nullptr;
+  size_t cellmax_cap_bytes = 0;
+  bool cellmax_valid = false;
+  float floor = 0.f;            // fpl_v2o_set_floor: the NMS threshold will be >= this
+  float cellmax_floor = 0.f;    // the floor the keys in `cellmax` were taken with
 };
 
 struct fpl_ctx {

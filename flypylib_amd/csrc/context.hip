@@ -63,6 +63,7 @@ int fpl_ctx_destroy(fpl_ctx *ctx) {
   for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
   if (ctx->v2o.smoothed) fpl_dev_release(ctx, ctx->v2o.smoothed);
   if (ctx->v2o.seg) fpl_dev_release(ctx, ctx->v2o.seg);
+  if (ctx->v2o.cellmax) fpl_dev_release(ctx, ctx->v2o.cellmax);
   fpl_dev_trim(ctx);
   for (auto &kv : ctx->live_blocks) hipFree(kv.first);
   hipStreamDestroy(ctx->own_stream);

@@ -32,6 +32,11 @@ __device__ __forceinline__ int64_t reflect_idx(int64_t i, int64_t n) {
   return i >= n ? p - 1 - i : i;
 }
 
+// single-bounce 'reflect' (-1 -> 0, n -> n - 1) for -n <= i < 2n
+__device__ __forceinline__ int reflect1(int i, int n) {
+  return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+}
+
 // virtual zero-padded view of the unpadded prediction
 struct PadView {
   const float *pred;
@@ -154,6 +159,10 @@ __global__ __launch_bounds__(256) void gauss_pass_win(
 // load per input instead of (4 + 2*WR) / 4 strided ones.  Arithmetic as gauss_pass;
 // the outer r shell is zeroed on store.
 constexpr int GX_ROWS = 8, GX_SEG = 128;
+// first radix level of the order statistics: the top L0_BITS key bits, histogrammed by
+// the last smoothing pass (10 bits = 4 KiB of LDS: three workgroups of the fused pass
+// per CU)
+constexpr int L0_BITS = 10, L0_SHIFT = 32 - L0_BITS, L0_BINS = 1 << L0_BITS;
 
 __device__ __forceinline__ uint32_t float_key(float f) {
   const uint32_t u = __float_as_uint(f);
@@ -164,15 +173,15 @@ template <int WR>
 __global__ __launch_bounds__(256) void gauss_x_lds(
     const float *__restrict__ in, float *__restrict__ out, int64_t P0, int64_t P1,
     int64_t P2, const double *__restrict__ w, int r,
-    unsigned long long *__restrict__ hist11) {
+    unsigned long long *__restrict__ hist0) {
   constexpr int NW = 4 + 2 * WR;
   constexpr int LROW = (GX_SEG + 2 * WR + 3) / 4 * 4 + 4;     // floats, 16-B multiple
   __shared__ __attribute__((aligned(16))) float tile[GX_ROWS][LROW];
-  // first level of the radix select (top 11 key bits of every smoothed voxel),
+  // first level of the radix select (top L0_BITS key bits of every smoothed voxel),
   // taken while the values are in registers: saves one scan of the volume
-  __shared__ unsigned int lh[2048];
+  __shared__ unsigned int lh[L0_BINS];
   const int t = threadIdx.x, rl = t >> 5, tx = t & 31;
-  for (int b = t; b < 2048; b += 256) lh[b] = 0u;
+  for (int b = t; b < L0_BINS; b += 256) lh[b] = 0u;
   double wk[WR + 1];
 #pragma unroll
   for (int j = 0; j <= WR; ++j) wk[j] = w[j];
@@ -223,11 +232,11 @@ __global__ __launch_bounds__(256) void gauss_x_lds(
       for (int k = 0; k < 4; ++k)
         if (x0 + k < P2) dst[k] = o[k];
     }
-    if (hist11) {
+    if (hist0) {
       // runs of equal bins (zeros of the shell, flat regions) cost one atomic
       uint32_t kb[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) kb[k] = float_key(o[k]) >> 21;
+      for (int k = 0; k < 4; ++k) kb[k] = float_key(o[k]) >> L0_SHIFT;
       const int nv = (int)(P2 - x0 < 4 ? P2 - x0 : 4);
       // a wave whose 256 values share one bin (shell zeros, smooth regions): one atomic
       const uint32_t first = __shfl(kb[0], 0);
@@ -247,9 +256,74 @@ __global__ __launch_bounds__(256) void gauss_x_lds(
     }
   }
   __syncthreads();
-  if (hist11)
-    for (int b = t; b < 2048; b += 256)
-      if (lh[b]) atomicAdd(&hist11[b], (unsigned long long)lh[b]);
+  if (hist0)
+    for (int b = t; b < L0_BINS; b += 256)
+      if (lh[b]) atomicAdd(&hist0[b], (unsigned long long)lh[b]);
+}
+
+// z pass, register-window form without per-thread index arithmetic: a workgroup is
+// blockDim.x consecutive x of one (y, block of GZ_OUT z) strip; a thread slides its
+// window down the (y, x) column of the UNPADDED prediction (zero outside it: the
+// virtual padding of fplobjdetect.py:152-159, reflected at the padded volume's ends as
+// scipy does).  The 1-D grid is decoded per workgroup (uniform) so that the blocks an
+// XCD receives (b, b + 8, ...) walk consecutive z blocks of one strip: the 2*WR halo
+// planes a block shares with its z neighbour are L2 hits instead of HBM re-reads.
+constexpr int GZ_OUT = 16;
+
+template <int WR>
+__global__ __launch_bounds__(512) void gauss_z_win(
+    PadView pv, float *__restrict__ out, int P0, int P1, int P2,
+    const double *__restrict__ w, int nxb, int nzb) {
+  constexpr int OUT = GZ_OUT, NW = OUT + 2 * WR;
+  const unsigned nwork = (unsigned)nxb * nzb * P1;
+  const unsigned per_xcd = (nwork + 7) / 8;
+  const unsigned slot = blockIdx.x >> 3;
+  const unsigned wid = (blockIdx.x & 7) * per_xcd + slot;
+  if (slot >= per_xcd || wid >= nwork) return;
+  const int zb = (int)(wid % (unsigned)nzb);
+  const unsigned rest = wid / (unsigned)nzb;
+  const int xb = (int)(rest % (unsigned)nxb), y = (int)(rest / (unsigned)nxb);
+  const int x = xb * (int)blockDim.x + (int)threadIdx.x;
+  if (x >= P2) return;
+  const int a0 = zb * OUT;
+  const int r = pv.r, D0 = (int)pv.D0, D1 = (int)pv.D1, D2 = (int)pv.D2;
+  const int yy = y - r, xx = x - r;
+  const bool col_ok = yy >= 0 && xx >= 0 && yy < D1 && xx < D2;
+  const int plane = D1 * D2;                       // < 2^31 / NW (checked by the host)
+  const float *col = pv.pred + (col_ok ? (int64_t)yy * D2 + xx : 0);
+  double win[NW];
+  const int z_lo = a0 - WR - r;                    // unpadded z of win[0]
+  const bool interior = a0 - WR >= 0 && a0 + OUT + WR <= P0;
+  if (!col_ok) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) win[i] = 0.0;
+  } else if (interior && z_lo >= 0 && z_lo + NW <= D0) {
+    const float *q = col + (int64_t)z_lo * plane;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) win[i] = (double)q[i * plane];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int zz = reflect1(a0 - WR + i, P0) - r;
+      win[i] = (zz >= 0 && zz < D0) ? (double)col[(int64_t)zz * plane] : 0.0;
+    }
+  }
+  double wk[WR + 1];
+#pragma unroll
+  for (int j = 0; j <= WR; ++j) wk[j] = w[j];
+  float *dst = out + ((int64_t)a0 * P1 + y) * P2 + x;
+  const int pplane = P1 * P2;
+#pragma unroll
+  for (int o = 0; o < OUT; ++o) {
+    double acc = __dmul_rn(win[WR + o], wk[0]);
+#pragma unroll
+    for (int j = WR; j >= 1; --j)
+      acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
+#ifdef FPL_EXP_NOMATH
+    acc = win[WR + o] + win[o] + win[o + 2 * WR];
+#endif
+    if (a0 + o < P0) dst[o * pplane] = (float)acc;
+  }
 }
 
 // y and x passes fused through one LDS tile: a workgroup takes GYX_TY consecutive y
@@ -265,66 +339,93 @@ __global__ __launch_bounds__(256) void gauss_x_lds(
 constexpr int GYX_TY = 16;
 
 template <int WR>
-__global__ __launch_bounds__(256) void gauss_yx_fused(
-    const float *__restrict__ in, float *__restrict__ out, int64_t P0, int64_t P1,
-    int64_t P2, const double *__restrict__ w, int r, int lrow,
-    unsigned long long *__restrict__ hist11) {
+__global__ __launch_bounds__(512) void gauss_yx_fused(
+    const float *__restrict__ in, float *__restrict__ out, int P0, int P1, int P2,
+    const double *__restrict__ w, int r, int lrow,
+    unsigned long long *__restrict__ hist0, unsigned long long *__restrict__ cellmax,
+    int C1, int C2, float floor_v) {
   constexpr int TY = GYX_TY;
   constexpr int NWY = TY + 2 * WR;
-  constexpr int NWX = 4 + 2 * WR;
-  extern __shared__ __attribute__((aligned(16))) float yx_tile[];   // [TY][lrow]
-  __shared__ unsigned int lh[2048];
-  const int t = threadIdx.x;
-  for (int b = t; b < 2048; b += 256) lh[b] = 0u;
+  constexpr int XO = 8;                        // x outputs per thread and iteration
+  constexpr int NWX = XO + 2 * WR;
+  extern __shared__ __attribute__((aligned(16))) float yx_tile[];   // [TY][lrow], then
+  // the keys of the workgroup's (TY / CELL) x C2 cells (8 B each)
+  unsigned long long *ck = reinterpret_cast<unsigned long long *>(yx_tile + TY * lrow);
+  __shared__ unsigned int lh[L0_BINS];
+  const int t = threadIdx.x, bd = blockDim.x;
+  for (int b = t; b < L0_BINS; b += bd) lh[b] = 0u;
+  for (int b = t; b < (TY / CELL) * C2; b += bd) ck[b] = 0ull;
   double wk[WR + 1];
 #pragma unroll
   for (int j = 0; j <= WR; ++j) wk[j] = w[j];
-  const int64_t nty = (P1 + TY - 1) / TY;
-  const int64_t nwork = P0 * nty;
+  const int nty = (P1 + TY - 1) / TY;
+  const int nwork = ((P0 + CELL - 1) / CELL) * nty;
   // XCD-contiguous work order (speed only): block b -> slot b / 8 of XCD b % 8
-  const int64_t per_xcd = (nwork + 7) / 8;
-  const int64_t wid = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (wid < nwork && (int64_t)(blockIdx.x >> 3) < per_xcd) {
-    const int64_t z = wid / nty, y0 = (wid % nty) * TY;
-    const bool interior = y0 - WR >= 0 && y0 + TY + WR <= P1;
-    const float *plane = in + z * P1 * P2;
+  const int per_xcd = (nwork + 7) / 8;
+  const int wid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (wid >= nwork || (int)(blockIdx.x >> 3) >= per_xcd) return;   // whole workgroup
+  const int zg = wid / nty, y0 = (wid - zg * nty) * TY;
+  // byte offsets of the window's rows inside a plane (uniform; reflected at the ends):
+  // soffset operands of the buffer loads - one shared 32-bit voffset per thread, no
+  // per-row 64-bit addresses
+  int roff[NWY];
+#pragma unroll
+  for (int i = 0; i < NWY; ++i) roff[i] = reflect1(y0 - WR + i, P1) * P2 * 4;
+  // a workgroup walks the CELL planes of its z group: the cell keys stay in LDS.
+  // (Running the window loads one column / plane ahead of the arithmetic was measured:
+  // 147 VGPRs, two workgroups per CU, 1.9 ms against 1.2 ms - not kept.)
+  for (int zi = 0; zi < CELL; ++zi) {
+    const int z = zg * CELL + zi;
+    if (z >= P0) break;
+    const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(in + (int64_t)z * P1 * P2), 0, P1 * P2 * 4, 0x00020000);
+    __syncthreads();              // the tile of the previous plane is consumed
     // ---- phase 1: y pass, one column per thread and iteration
-    for (int64_t x = t; x < P2; x += 256) {
+    for (int x = t; x < P2; x += bd) {
+      // all NWY loads in flight before the first conversion (left to itself the
+      // scheduler serialises load -> wait -> convert to save registers: 1.6 ms)
+      int raw[NWY];
+#pragma unroll
+      for (int i = 0; i < NWY; ++i)
+        raw[i] = __builtin_amdgcn_raw_buffer_load_b32(plane, x * 4, roff[i], 0);
+      __builtin_amdgcn_sched_barrier(0);
       double win[NWY];
-      if (interior) {
-        const float *q = plane + (y0 - WR) * P2 + x;
 #pragma unroll
-        for (int i = 0; i < NWY; ++i) win[i] = (double)q[(int64_t)i * P2];
-      } else {
-#pragma unroll
-        for (int i = 0; i < NWY; ++i)
-          win[i] = (double)plane[reflect_idx(y0 - WR + i, P1) * P2 + x];
-      }
-      // mirrored halo slots this column also fills ('reflect': -1 -> 0, P2 -> P2 - 1)
-      const int64_t ml = x < WR ? WR - 1 - x : -1;
-      const int64_t mr = x >= P2 - WR ? 2 * P2 - 1 - x + WR : -1;
+      for (int i = 0; i < NWY; ++i) win[i] = (double)__builtin_bit_cast(float, raw[i]);
+      float *colp = yx_tile + x + WR;
 #pragma unroll
       for (int o = 0; o < TY; ++o) {
         double acc = __dmul_rn(win[WR + o], wk[0]);
 #pragma unroll
         for (int j = WR; j >= 1; --j)
           acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
-        const float v = (float)acc;
-        float *rowp = yx_tile + (size_t)o * lrow;
-        rowp[x + WR] = v;
-        if (ml >= 0) rowp[ml] = v;
-        if (mr >= 0) rowp[mr] = v;
+#ifdef FPL_EXP_NOMATH
+        acc = win[WR + o] + win[o] + win[o + 2 * WR];
+#endif
+        colp[o * lrow] = (float)acc;
       }
     }
     __syncthreads();
-    // ---- phase 2: x pass on the tile rows, 4 outputs per thread and iteration
-    const int nq = (int)((P2 + 3) / 4);
-    for (int u = t; u < TY * nq; u += 256) {
-      const int ty = u / nq;
-      const int64_t x0 = (int64_t)(u - ty * nq) * 4;
-      const int64_t y = y0 + ty;
-      if (y >= P1) continue;
-      const float *rowp = yx_tile + (size_t)ty * lrow + x0;
+    // the rows' reflected x halos ('reflect': -1 -> 0, P2 -> P2 - 1) are the rows' own
+    // values: 2 * WR copies per row
+    for (int u = t; u < TY * 2 * WR; u += bd) {
+      const int row = u / (2 * WR), k = u - row * (2 * WR);
+      float *rowp = yx_tile + row * lrow;
+      if (k < WR) rowp[WR - 1 - k] = rowp[WR + k];
+      else rowp[WR + P2 + (k - WR)] = rowp[WR + P2 - 1 - (k - WR)];
+    }
+    __syncthreads();
+    // ---- phase 2: x pass on the tile rows, XO outputs per thread and iteration; the
+    // (row, piece) of unit t + bd * k advances without a division
+    const int nq = (P2 + XO - 1) / XO;
+    const int step_ty = bd / nq, step_xq = bd - step_ty * nq;
+    int ty = t / nq, xq = t - ty * nq;
+    for (; ty < TY; ty += step_ty, xq += step_xq) {
+      if (xq >= nq) { xq -= nq; ++ty; if (ty >= TY) break; }
+      const int y = y0 + ty;
+      if (y >= P1) break;
+      const int x0 = xq * XO;
+      const float *rowp = yx_tile + ty * lrow + x0;
       double win[NWX];
 #pragma unroll
       for (int q = 0; q < (NWX + 3) / 4; ++q) {
@@ -335,33 +436,60 @@ __global__ __launch_bounds__(256) void gauss_yx_fused(
         if (4 * q + 3 < NWX) win[4 * q + 3] = (double)v.w;
       }
       const bool edge_zy = r > 0 && (z < r || y < r || z >= P0 - r || y >= P1 - r);
-      float o[4];
+      float o[XO];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < XO; ++k) {
         double acc = __dmul_rn(win[WR + k], wk[0]);
 #pragma unroll
         for (int j = WR; j >= 1; --j)
           acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
-        const int64_t x = x0 + k;
+        const int x = x0 + k;
+#ifdef FPL_EXP_NOMATH
+        acc = win[WR + k] + win[k] + win[k + 2 * WR];
+#endif
         o[k] = (edge_zy || (r > 0 && (x < r || x >= P2 - r))) ? 0.f : (float)acc;
       }
-      const int64_t row = z * P1 + y;
-      float *dst = out + row * P2 + x0;
-      const int nv = (int)(P2 - x0 < 4 ? P2 - x0 : 4);
-      if (nv == 4 && ((row * P2 + x0) & 3) == 0) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      const int64_t flat = ((int64_t)z * P1 + y) * P2 + x0;
+      float *dst = out + flat;
+      const int nv = P2 - x0 < XO ? P2 - x0 : XO;
+      if (nv == XO && (flat & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k < XO; k += 4)
+          *reinterpret_cast<float4 *>(dst + k) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < XO; ++k)
           if (k < nv) dst[k] = o[k];
       }
-      if (hist11) {
-        uint32_t kb[4];
+      if (cellmax) {
+        // key of the largest value above the floor (>= 0) of each CELL-run:
+        // (bits << 32) | ~flat, so that equal values order by ascending flat index
+        // (cell_best's key).  With a floor most waves skip the LDS atomics altogether.
+        static_assert(XO % CELL == 0, "whole cells per piece");
 #pragma unroll
-        for (int k = 0; k < 4; ++k) kb[k] = float_key(o[k]) >> 21;
+        for (int c = 0; c < XO / CELL; ++c) {
+          unsigned long long best = 0ull;
+#pragma unroll
+          for (int d = 0; d < CELL; ++d) {
+            const int k = c * CELL + d;
+            if (k < nv && o[k] > floor_v) {
+              const unsigned long long key =
+                  ((unsigned long long)__float_as_uint(o[k]) << 32) |
+                  (0xFFFFFFFFu - (uint32_t)(flat + k));
+              best = key > best ? key : best;
+            }
+          }
+          if (best) atomicMax(&ck[(ty / CELL) * C2 + x0 / CELL + c], best);
+        }
+      }
+      if (hist0) {
+        // runs of equal bins (the shell's zeros, smooth regions) cost one LDS atomic
+        uint32_t kb[XO];
+#pragma unroll
+        for (int k = 0; k < XO; ++k) kb[k] = float_key(o[k]) >> L0_SHIFT;
         int run = 1;
 #pragma unroll
-        for (int k = 1; k <= 4; ++k) {
+        for (int k = 1; k <= XO; ++k) {
           if (k < nv && kb[k] == kb[k - 1]) { ++run; continue; }
           if (k <= nv) atomicAdd(&lh[kb[k - 1]], (unsigned)run);
           run = 1;
@@ -370,16 +498,41 @@ __global__ __launch_bounds__(256) void gauss_yx_fused(
     }
   }
   __syncthreads();
-  if (hist11)
-    for (int b = t; b < 2048; b += 256)
-      if (lh[b]) atomicAdd(&hist11[b], (unsigned long long)lh[b]);
+  if (cellmax)
+    for (int b = t; b < (TY / CELL) * C2; b += bd) {
+      const int yg = b / C2, xc = b - yg * C2;
+      const int cy = y0 / CELL + yg;
+      if (cy < C1) cellmax[((int64_t)zg * C1 + cy) * C2 + xc] = ck[b];
+    }
+  if (hist0)
+    for (int b = t; b < L0_BINS; b += bd)
+      if (lh[b]) atomicAdd(&hist0[b], (unsigned long long)lh[b]);
 }
 
 // LDS floats per tile row of gauss_yx_fused: the row, its two halos, rounded up to a
 // 16-B multiple plus 4 (the last thread's aligned window may read 3 floats past it)
-static inline int gyx_lrow(int64_t P2, int wr) { return (int)((P2 + 2 * wr + 3) / 4 * 4 + 4); }
-static inline bool gyx_fits(int64_t P2, int wr) {
-  return P2 >= 2 * wr && (size_t)GYX_TY * gyx_lrow(P2, wr) * sizeof(float) <= 56 * 1024;
+static inline int gyx_lrow(int64_t P2, int wr) {
+  return (int)((ceil_div64(P2, 8) * 8 + 2 * wr + 3) / 4 * 4 + 4);
+}
+// workgroup size (a multiple of 64 in [256, 512]) that wastes the fewest lanes on `n`
+// columns / pieces per pass
+static inline int best_block(int64_t n) {
+  int best = 256;
+  double waste = 1e9;
+  for (int bd = 256; bd <= 512; bd += 64) {
+    const double wst = (double)(ceil_div64(n, bd) * bd) / (double)n;
+    if (wst < waste - 1e-9) { waste = wst; best = bd; }
+  }
+  return best;
+}
+static inline size_t gyx_lds_bytes(int64_t P2, int wr) {
+  return (size_t)GYX_TY * gyx_lrow(P2, wr) * sizeof(float) +
+         (size_t)(GYX_TY / CELL) * ceil_div64(P2, CELL) * sizeof(unsigned long long);
+}
+static inline bool gyx_fits(const int64_t P[3], int wr) {
+  // single-bounce reflections, 32-bit in-plane offsets, tile + cell keys within 60 KiB
+  return P[1] * P[2] * 4 < ((int64_t)1 << 31) && P[2] >= 2 * wr && P[1] >= GYX_TY + 2 * wr && P[0] * ceil_div64(P[1], GYX_TY) < (1 << 28) &&
+         gyx_lds_bytes(P[2], wr) <= 60 * 1024;
 }
 
 // Compaction without global atomics: workgroup b scans elements [b*chunk, (b+1)*chunk)
@@ -392,21 +545,36 @@ __global__ __launch_bounds__(256) void compact_prefix(
   if (threadIdx.x == 0) cnt = 0u;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int64_t lo = (int64_t)blockIdx.x * chunk;
+  const int64_t lo = (int64_t)blockIdx.x * chunk;       // chunk: a multiple of 256 floats
   const int64_t hi = lo + chunk < n ? lo + chunk : n;
   float *dst = list + lo;
-  for (int64_t i0 = lo; i0 < hi; i0 += 256) {
-    const int64_t i = i0 + threadIdx.x;
-    const float f = i < hi ? v[i] : 0.f;
-    const bool hit = i < hi && (float_key(f) & mask) == want;
-    const unsigned long long m = __ballot(hit);
-    if (m == 0ull) continue;
-    unsigned int base = 0;
-    if (lane == 0) base = atomicAdd(&cnt, (unsigned)__popcll(m));
-    base = __shfl(base, 0);
-    // a hit is written at or before its own position of the range (in-place safe
-    // even if list aliased v, which it does not)
-    if (hit) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = f;
+  // 16-B loads (v is 256-B aligned and lo a multiple of 256 floats); the order of the
+  // hits inside the chunk does not matter: the list is only histogrammed
+  for (int64_t i0 = lo; i0 < hi; i0 += 1024) {
+    const int64_t i = i0 + 4 * (int64_t)threadIdx.x;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i + 4 <= hi) {
+      const float4 q = *reinterpret_cast<const float4 *>(v + i);
+      f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (i + c < hi) f[c] = v[i + c];
+    }
+    bool hit[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hit[c] = i + c < hi && (float_key(f[c]) & mask) == want;
+    if (__ballot(hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned long long m = __ballot(hit[c]);
+      if (m == 0ull) continue;
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(&cnt, (unsigned)__popcll(m));
+      base = __shfl(base, 0);
+      // at most as many hits as elements scanned so far: stays inside the chunk
+      if (hit[c]) dst[base + __popcll(m & ((1ull << lane) - 1ull))] = f[c];
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) counts[blockIdx.x] = cnt;
@@ -433,12 +601,25 @@ __global__ __launch_bounds__(256) void key_histogram_chunks(
 
 template <int WR>
 int launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t P[3],
-                     const double *w_dev, int r, unsigned long long *hist11) {
+                     const double *w_dev, int r, unsigned long long *hist0,
+                     unsigned long long *cellmax, float floor_v, bool *cellmax_done) {
+  *cellmax_done = false;
   hipStream_t st = ctx->stream;
   constexpr int OUT_ZY = 16;                 // outputs per thread of gauss_pass_win<0/1>
-  const bool fused = gyx_fits(P[2], WR) && !getenv("FPL_V2O_UNFUSED");
+  const bool fused = gyx_fits(P, WR) && !getenv("FPL_V2O_UNFUSED");
   // fused: z pass -> b, y+x -> a;  separate passes: z -> a, y -> b, x -> a
-  {
+  // 32-bit in-column / in-plane offsets of gauss_z_win
+  const bool small = (GZ_OUT + 2 * WR) * pv.D1 * pv.D2 < ((int64_t)1 << 31) &&
+                     P[1] * P[2] * GZ_OUT < ((int64_t)1 << 31) && P[0] >= 2 * WR;
+  if (small && !getenv("FPL_V2O_UNFUSED")) {
+    const int bd = best_block(P[2]);
+    const int64_t nxb = ceil_div64(P[2], bd), nzb = ceil_div64(P[0], GZ_OUT);
+    const int64_t nwork = nxb * nzb * P[1];
+    FPL_REQUIRE(ctx, nwork < ((int64_t)1 << 31), "voxel2obj: volume too large");
+    TimedLaunch tl(ctx, "v2o_gauss_z");
+    gauss_z_win<WR><<<(unsigned)(ceil_div64(nwork, 8) * 8), bd, 0, st>>>(
+        pv, fused ? b : a, (int)P[0], (int)P[1], (int)P[2], w_dev, (int)nxb, (int)nzb);
+  } else {
     const int64_t n = ceil_div64(P[0], OUT_ZY) * P[1] * P[2];
     TimedLaunch tl(ctx, "v2o_gauss_z");
     gauss_pass_win<0, WR><<<(unsigned)ceil_div64(n, 256), 256, 0, st>>>(
@@ -446,18 +627,23 @@ int launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t
   }
   if (fused) {
     const int lrow = gyx_lrow(P[2], WR);
-    const size_t lds = (size_t)GYX_TY * lrow * sizeof(float);
+    const size_t lds = gyx_lds_bytes(P[2], WR);
     static bool attr_set[FPL_MAX_DEVICES] = {false};
     if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
       FPL_HIP(ctx, hipFuncSetAttribute((const void *)gauss_yx_fused<WR>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 56 * 1024));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024));
       attr_set[ctx->device % FPL_MAX_DEVICES] = true;
     }
-    const int64_t nwork = P[0] * ceil_div64(P[1], GYX_TY);
+    const int64_t nwork = ceil_div64(P[0], CELL) * ceil_div64(P[1], GYX_TY);
     const int64_t nblk = ceil_div64(nwork, 8) * 8;
+    // phase 1 walks P2 columns, phase 2 16 * ceil(P2 / 8) pieces: size the workgroup
+    // for the columns (the pieces are ~2x as many and split evenly enough)
+    const int bd = best_block(P[2]);
     TimedLaunch tl(ctx, "v2o_gauss_yx");
-    gauss_yx_fused<WR><<<(unsigned)nblk, 256, lds, st>>>(b, a, P[0], P[1], P[2], w_dev, r, lrow,
-                                                         hist11);
+    gauss_yx_fused<WR><<<(unsigned)nblk, bd, lds, st>>>(
+        b, a, (int)P[0], (int)P[1], (int)P[2], w_dev, r, lrow, hist0, cellmax,
+        (int)ceil_div64(P[1], CELL), (int)ceil_div64(P[2], CELL), floor_v);
+    *cellmax_done = cellmax != nullptr;
     return 0;
   }
   {
@@ -469,7 +655,7 @@ int launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t
     const int64_t ntiles = ceil_div64(P[0] * P[1], GX_ROWS) * ceil_div64(P[2], GX_SEG);
     const int64_t nblk = std::min<int64_t>(ntiles, (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, "v2o_gauss_x");
-    gauss_x_lds<WR><<<(unsigned)nblk, 256, 0, st>>>(b, a, P[0], P[1], P[2], w_dev, r, hist11);
+    gauss_x_lds<WR><<<(unsigned)nblk, 256, 0, st>>>(b, a, P[0], P[1], P[2], w_dev, r, hist0);
   }
   return 0;
 }
@@ -546,6 +732,32 @@ __global__ __launch_bounds__(256) void cell_best(const float *__restrict__ s, do
             }
         }
       best[c] = b;
+    }
+    mine += b != 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (tot) atomicAdd(&counters[0], (unsigned long long)tot);
+  }
+}
+
+// round 0 from the keys the fused y+x pass took (per cell: its largest positive voxel):
+// a cell is live iff that voxel passes the threshold
+__global__ __launch_bounds__(256) void cell_threshold(unsigned long long *__restrict__ best,
+                                                      int64_t n_cells, double thresh,
+                                                      unsigned long long *__restrict__ counters) {
+  __shared__ unsigned wcount[4];
+  unsigned mine = 0;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long b = best[c];
+    if (b && !((double)__uint_as_float((uint32_t)(b >> 32)) > thresh)) {
+      b = 0;
+      best[c] = 0;
     }
     mine += b != 0;
   }
@@ -791,11 +1003,11 @@ struct RankQuery {
 
 }  // namespace
 
-// exact order statistics of S.smoothed: 3-level radix select (11 / 11 / 10 bits) on the
+// exact order statistics of S.smoothed: 3-level radix select (10 / 11 / 11 bits) on the
 // monotone float key.  Level 0 comes out of the x pass when `have_level0` (its
 // histogram is already in hist_dev); the elements of the selected level-0 bin are
 // then compacted (one filtered scan) and levels 1-2 run on that short list.
-// hist_dev: 2049 u64 ([2048] spare); scratch: n_pad floats.
+// hist_dev: 2049 u64 (level 0 uses the first L0_BINS); scratch: n_pad floats.
 static int v2o_select(fpl_ctx *ctx, const V2oState &S, int64_t n_pad, const int64_t *ranks,
                       int32_t n_ranks, float *rank_values, unsigned long long *hist_dev,
                       float *scratch, bool windowed, DevTemp &tmp) {
@@ -805,7 +1017,7 @@ static int v2o_select(fpl_ctx *ctx, const V2oState &S, int64_t n_pad, const int6
     std::vector<unsigned long long> hist(2048);
     std::vector<RankQuery> q(n_ranks);
     for (int i = 0; i < n_ranks; ++i) q[i] = RankQuery{ranks[i], 0u};
-    const int shifts[3] = {21, 10, 0}, nbits[3] = {11, 11, 10};
+    const int shifts[3] = {L0_SHIFT, 11, 0}, nbits[3] = {L0_BITS, 11, 11};
     auto hgrid_for = [&](int64_t n) {
       return (unsigned)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(n, 256 * 8),
                                                               (int64_t)ctx->n_cu * 16));
@@ -863,7 +1075,7 @@ static int v2o_select(fpl_ctx *ctx, const V2oState &S, int64_t n_pad, const int6
     std::vector<int> all(n_ranks);
     for (int i = 0; i < n_ranks; ++i) all[i] = i;
     FPL_TRY(resolve(0, 0u, all, windowed, false));
-    const uint32_t mask0 = 0x7FFu << 21, mask1 = mask0 | (0x7FFu << 10);
+    const uint32_t mask0 = (uint32_t)(L0_BINS - 1) << L0_SHIFT, mask1 = mask0 | (0x7FFu << 11);
     for (auto &grp : groups_of(all)) {
       {
         TimedLaunch tl(ctx, "v2o_compact_bin");
@@ -944,12 +1156,31 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
   FPL_HIP(ctx, hipMemsetAsync(hist_dev, 0, 2049 * sizeof(unsigned long long), st));
   // register-window kernels for the kernel radii flypylib's sigmas produce
   // (sigma 1.5, 2, 3, 5 at truncate 2.0); the plain kernel covers the rest
+  // per-cell keys for the NMS, filled by the fused pass
+  S.cellmax_valid = false;
+  {
+    const size_t need = (size_t)(ceil_div64(P[0], CELL) * ceil_div64(P[1], CELL) *
+                                 ceil_div64(P[2], CELL)) * sizeof(unsigned long long);
+    if (S.cellmax_cap_bytes < need) {
+      if (S.cellmax) fpl_dev_release(ctx, S.cellmax);
+      S.cellmax = nullptr;
+      S.cellmax_cap_bytes = 0;
+      void *q;
+      FPL_TRY(fpl_dev_alloc(ctx, need, &q));
+      S.cellmax = (unsigned long long *)q;
+      S.cellmax_cap_bytes = need;
+    }
+  }
+  bool cm_done = false;
+  const float floor_v = S.floor > 0.f ? S.floor : 0.f;
+  S.floor = 0.f;                         // a floor holds for one smoothing
+  S.cellmax_floor = floor_v;
   bool windowed = true;
   switch (wr) {
-    case 3: FPL_TRY(launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
-    case 4: FPL_TRY(launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
-    case 6: FPL_TRY(launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
-    case 10: FPL_TRY(launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev)); break;
+    case 3: FPL_TRY(launch_gauss_win<3>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev, S.cellmax, floor_v, &cm_done)); break;
+    case 4: FPL_TRY(launch_gauss_win<4>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev, S.cellmax, floor_v, &cm_done)); break;
+    case 6: FPL_TRY(launch_gauss_win<6>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev, S.cellmax, floor_v, &cm_done)); break;
+    case 10: FPL_TRY(launch_gauss_win<10>(ctx, pv, S.smoothed, scratch, P, w_dev, r, hist_dev, S.cellmax, floor_v, &cm_done)); break;
     default: windowed = false;
   }
   if (!windowed) {
@@ -972,11 +1203,19 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
   FPL_HIP(ctx, hipGetLastError());
   for (int a = 0; a < 3; ++a) S.pdims[a] = P[a];
   S.r = r;
+  S.cellmax_valid = cm_done;
 
   if (n_ranks > 0)
     FPL_TRY(v2o_select(ctx, S, n_pad, ranks, n_ranks, rank_values, hist_dev, scratch, windowed, tmp));
   FPL_HIP(ctx, hipStreamSynchronize(st));
   S.valid = true;
+  return 0;
+}
+
+int fpl_v2o_set_floor(fpl_ctx *ctx, float floor) {
+  if (!ctx) return fpl_fail(nullptr, "fpl_v2o_set_floor: ctx is NULL");
+  FPL_REQUIRE(ctx, floor == floor, "fpl_v2o_set_floor: NaN");
+  ctx->v2o.floor = floor;
   return 0;
 }
 
@@ -1016,8 +1255,16 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   // which must contain [p-r, p+r] for every p in [4c, 4c+3]
   const int hw = (r + CELL - 1) / CELL;
   void *p;
-  FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
-  unsigned long long *best = (unsigned long long *)p;
+  // cell keys: the ones the fused smoothing pass left (consumed here), else a scan
+  // (keys taken above a floor are complete only for thresholds >= that floor)
+  const bool have_keys = S.cellmax_valid && S.cellmax != nullptr &&
+                         thresh >= (double)S.cellmax_floor;
+  S.cellmax_valid = false;
+  unsigned long long *best = S.cellmax;
+  if (!have_keys) {
+    FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
+    best = (unsigned long long *)p;
+  }
   FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
   unsigned long long *wa = (unsigned long long *)p;
   FPL_TRY(tmp.alloc((size_t)n_cells * 8, &p));
@@ -1037,7 +1284,9 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
     FPL_HIP(ctx, hipMemsetAsync(counters, 0, 2 * 8, st));   // live cells, round winners
     {
       TimedLaunch tl(ctx, "v2o_cell_best");
-      if (P2 % CELL == 0)
+      if (rounds == 0 && have_keys)
+        cell_threshold<<<bgrid, 256, 0, st>>>(best, n_cells, thresh, counters);
+      else if (P2 % CELL == 0)
         cell_best<true><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
                                                counters, rounds == 0);
       else
@@ -1169,6 +1418,7 @@ int fpl_v2o_set_seg(fpl_ctx *ctx, const void *seg, int32_t seg_bytes, int seg_me
   }
   FPL_HIP(ctx, hipGetLastError());
   if (sz_thd >= 0) {
+    S.cellmax_valid = false;      // the volume is edited below: the fused cell keys are stale
     // voxel count per label (the zero padding counts towards label 0, as in the
     // reference, which pads before np.unique) and the zeroing of small segments
     uint64_t cap = 1ull << 16;

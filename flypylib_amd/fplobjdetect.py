@@ -95,6 +95,13 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     if seg is None:
         if seg_sz_thd is not None:
             raise ValueError('seg_sz_thd needs a segmentation')
+        if thd > 0:
+            # thresh = max(percentile, thd) >= thd; as float32 rounded DOWN so that the
+            # promise holds whatever thd's own precision
+            floor = np.float32(thd)
+            if float(floor) > float(thd):
+                floor = np.nextafter(floor, np.float32(-np.inf))
+            ctx.v2o_set_floor(floor)
         lo_v, hi_v = ctx.v2o_smooth(pred, pred_sz, r, weights, [lo_rank, hi_rank])
         thresh = np.maximum(percentile_lerp(lo_v, hi_v, gamma), thd)
         pts, rounds = ctx.v2o_nms(float(thresh))

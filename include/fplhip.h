@@ -150,6 +150,12 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
                    const int64_t dims[3], int32_t r, const double *weights,
                    int32_t wr, const int64_t *ranks, int32_t n_ranks,
                    float *rank_values);
+/* Optional hint before step 1: the threshold of the following NMS will be >= `floor`
+ * (voxel2obj's is max(percentile, thd) >= thd, fplobjdetect.py:183-185).  The smoothing
+ * pass then keeps per-cell candidate keys only above it and the NMS starts from them
+ * instead of scanning the volume; a smaller threshold than promised is still handled
+ * (by the scan).  Holds for one fpl_v2o_smooth. */
+int fpl_v2o_set_floor(fpl_ctx *ctx, float floor);
 /* Step 2: NMS over voxels with (double)value > thresh (and > 0) of the volume prepared
  * by step 1.  out_zyxv: rows (z, y, x in padded coordinates, value) as f64,
  * sorted by (value desc, flat index asc) = the reference's emission order.

@@ -66,17 +66,19 @@ def run_group(name, counters, out, bench_args, script='bench.py'):
 
 
 def short(name):
-    for key in ('conv3_bf16', 'conv1_bf16', 'stem_cin1_bf16', 'pool2_bf16',
-                'vgg_c5_tail', 'gather_tiles', 'stitch_tiles'):
-        if key in name:
-            i = name.index(key)
-            return name[i:].split('(')[0].replace('(anonymous namespace)::', '')
-    for key in ('vgg_stem_pool', 'vgg_mid_pool', 'vgg_head', 'generic_conv',
-                'synth_u8', 'v2o_', 'gauss_pass', 'fillBuffer'):
-        if key in name:
-            i = name.index(key)
-            return name[i:].split('(')[0].split('<')[0]
-    return name[:60]
+    """kernel name without namespace, return type and argument list (template
+    arguments kept: they tell the variants of one kernel apart)"""
+    n = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    depth, out = 0, []
+    for ch in n:
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            break
+        out.append(ch)
+    return ''.join(out).strip()[:80]
 
 
 def main():
@@ -86,18 +88,21 @@ def main():
     ap.add_argument('--precision', default='bf16')
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--groups', default=','.join(GROUPS))
-    ap.add_argument('--target', default='bench', choices=['bench', 'unet'],
+    ap.add_argument('--target', default='bench', choices=['bench', 'unet', 'v2o'],
                     help="bench = bench.py (vgg_like); unet = tools/bench_configs.py "
-                         "--what unet --unet-size SIZE")
+                         "--what unet --unet-size SIZE; v2o = tools/bench_v2o.py --sub SIZE")
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)
     os.makedirs(a.out, exist_ok=True)
     bench_args = ['--size', str(a.size), '--precision', a.precision, '--steps',
-                  str(a.steps), '--warmup', '1', '--no-cpu-baseline']
+                  str(a.steps), '--warmup', '1', '--no-cpu-baseline', '--no-legs']
     script = 'bench.py'
     if a.target == 'unet':
         script = os.path.join('tools', 'bench_configs.py')
         bench_args = ['--what', 'unet', '--unet-size', str(a.size)]
+    if a.target == 'v2o':
+        script = os.path.join('tools', 'bench_v2o.py')
+        bench_args = ['--sub', str(a.size), '--reps', str(a.steps)]
     summary = defaultdict(dict)
     for gname in a.groups.split(','):
         acc = run_group(gname, GROUPS[gname], a.out, bench_args, script)
