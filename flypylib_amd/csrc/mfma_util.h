@@ -80,6 +80,53 @@ __device__ __forceinline__ h16x8 pack_relu(const f32x4 &lo, const f32x4 &hi) {
   return __builtin_bit_cast(h16x8, v);
 }
 
+#ifdef FPL_F16
+// ReLU + conversion in ONE instruction for activations known to lie below 1
+// (v_cvt_pk_f16_f32 ... clamp: the compiler folds the [0, 1] clamp of the packed halves
+// into the conversion's output modifier).  The caller guarantees the upper bound by
+// scaling the producing layer by a power of two (exact) and the consuming layer's
+// weights by its inverse - see vgg_prepare.  No bfloat16 form: that conversion has no
+// clamp modifier.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_relu01(float a, float b) {
+  f32x2 f = {a, b};
+  f16x2_t h = __builtin_convertvector(f, f16x2_t);
+  const f16x2_t z = {(_Float16)0.f, (_Float16)0.f}, o = {(_Float16)1.f, (_Float16)1.f};
+  h = __builtin_elementwise_min(__builtin_elementwise_max(h, z), o);
+  return __builtin_bit_cast(unsigned, h);
+}
+#else
+__device__ __forceinline__ unsigned cvt_pk_relu01(float a, float b) {
+  return pk_max_i16(cvt_pk_h16(a, b), 0u);
+}
+#endif
+
+// pack_relu / pack_relu_lo with the one-instruction form (inputs < 1 by construction)
+template <bool CLAMP01>
+__device__ __forceinline__ h16x8 pack_relu_t(const f32x4 &lo, const f32x4 &hi) {
+  u32x4 v;
+  if (CLAMP01) {
+    v[0] = cvt_pk_relu01(lo[0], lo[1]); v[1] = cvt_pk_relu01(lo[2], lo[3]);
+    v[2] = cvt_pk_relu01(hi[0], hi[1]); v[3] = cvt_pk_relu01(hi[2], hi[3]);
+  } else {
+    v[0] = pk_max_i16(cvt_pk_h16(lo[0], lo[1]), 0u); v[1] = pk_max_i16(cvt_pk_h16(lo[2], lo[3]), 0u);
+    v[2] = pk_max_i16(cvt_pk_h16(hi[0], hi[1]), 0u); v[3] = pk_max_i16(cvt_pk_h16(hi[2], hi[3]), 0u);
+  }
+  return __builtin_bit_cast(h16x8, v);
+}
+template <bool CLAMP01>
+__device__ __forceinline__ h16x8 pack_relu_lo_t(const f32x4 &lo) {
+  u32x4 v;
+  if (CLAMP01) {
+    v[0] = cvt_pk_relu01(lo[0], lo[1]); v[1] = cvt_pk_relu01(lo[2], lo[3]);
+  } else {
+    v[0] = pk_max_i16(cvt_pk_h16(lo[0], lo[1]), 0u); v[1] = pk_max_i16(cvt_pk_h16(lo[2], lo[3]), 0u);
+  }
+  v[2] = 0u;
+  v[3] = 0u;
+  return __builtin_bit_cast(h16x8, v);
+}
+
 // same with the upper block missing (48 channels = 3 blocks): zeros
 __device__ __forceinline__ h16x8 pack_relu_lo(const f32x4 &lo) {
   u32x4 v;

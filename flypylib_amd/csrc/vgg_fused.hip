@@ -19,6 +19,7 @@
 // pred[7+p] = O[p/4] with O[i] seeing input [4i, 4i+18), zero (normalised) past
 // the volume end - independent of the tiling.  The kernels compute O directly.
 #include <algorithm>
+#include <cmath>
 
 #include "fast_paths.h"
 #include "mfma_util.h"
@@ -35,6 +36,9 @@ constexpr int KSTEPS = 41;             // 27*48 = 1296 -> 40.5 K-steps of 32
 // (pz,py) row; 8 sub-steps walk the 2x2x2 pooling window so the pool is an
 // element-wise max over accumulators (no cross-lane traffic).
 // -------------------------------------------------------------------------------
+#ifndef STEM_WPS
+#define STEM_WPS 2
+#endif
 constexpr int S_PZ = 4, S_PY = 8, S_PX = 32;
 constexpr int S_TZ = 2 * S_PZ + 2, S_TY = 2 * S_PY + 2, S_TX = 2 * S_PX + 2;
 // Row pitch of the LDS tile in elements.  The gather reads of a half-wave (lane groups
@@ -56,6 +60,8 @@ struct StemArgs {
   const float *shift1, *shift2;
   h16_t *p1;
   int P1Z, P1Y, P1X;       // chunk-local dims
+  int nbx, nby, nbz;       // blocks of S_PX x S_PY x S_PZ pooled voxels
+  float in_scale;          // power of two applied to the normalised input (1 = none)
 };
 
 // element offset of tap row `row` = (tz,ty) inside the input tile
@@ -63,58 +69,146 @@ __device__ __forceinline__ int stem_row_off(int row) {
   return ((row / 3) * S_TY + row % 3) * S_TP;
 }
 
+// The kernel is persistent (two workgroups per CU walk the blocks q, q + grid, ...) and
+// software-pipelined: while a wave computes the 16 tasks of block i from tile[cur] it
+// also loads, normalises and stores its 45 rows of block i+1's input tile into
+// tile[cur ^ 1], three rows per task, the global loads one task ahead of their use.
+// Measured on the one-block-per-workgroup form: the fill (3.2 ms at 1024^3) and the
+// MFMA phase (6.0 ms) simply added up - the two workgroups of a CU start together and
+// stay in lockstep, so "one fills while the other computes" never happened.  Spread over
+// the task loop the fill is ~1 LDS read + 1 LDS write + 3 VALU per 9 MFMAs.
+constexpr int S_ROWS = S_TZ * S_TY;            // 180 tile rows of 66 voxels
+constexpr int S_WROWS = S_ROWS / 4;            // 45 per wave
+constexpr int S_TASKS = S_PZ * S_PY * 2 / 4;   // 16 tasks per wave and block
+constexpr int S_RPT = 3;                       // rows per task iteration
+static_assert(S_ROWS % 4 == 0 && S_RPT * (S_TASKS - 1) == S_WROWS && S_WROWS <= 64,
+              "stem fill schedule");
+
+// The fill code is branch-free (clamped addresses, selects, whole-wave stores): a
+// conditional load or store is a basic-block boundary, and the task body must stay one
+// block for the MFMAs to be scheduled across the fill instructions.
 template <typename SRC>
-__global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned short tile[S_TZ * S_TY * S_TP];
+struct StemRows {
+  SRC v[S_RPT];
+  bool ok[S_RPT];          // row inside the volume (uniform)
+};
+
+struct StemBlock {
+  int px0, py0, pz0;       // pooled origin
+  int64_t gz0, gy0, gx0;   // origin of its input tile in the volume
+  unsigned xc;             // this lane's column 0..63 of the tile, clamped into the volume
+  bool x_ok;
+};
+
+__device__ __forceinline__ StemBlock stem_block(const StemArgs &a, int q, int lane) {
+  StemBlock b;
+  const int xb = q % a.nbx, t = q / a.nbx;
+  const int yb = t % a.nby, zb = t / a.nby;
+  b.px0 = xb * S_PX; b.py0 = yb * S_PY; b.pz0 = zb * S_PZ;
+  b.gz0 = 2 * (a.p1z0 + b.pz0); b.gy0 = 2 * (int64_t)b.py0; b.gx0 = 2 * (int64_t)b.px0;
+  const int64_t x = b.gx0 + lane;
+  b.x_ok = x < a.SX;
+  b.xc = (unsigned)(b.x_ok ? x : a.SX - 1);
+  return b;
+}
+
+// uniform row pointer (clamped into the volume) + whether the row exists
+template <typename SRC>
+__device__ __forceinline__ const SRC *stem_row_ptr(const StemArgs &a, const StemBlock &b, int row,
+                                                   bool &ok) {
+  const int64_t z = b.gz0 + row / S_TY, y = b.gy0 + row % S_TY;
+  ok = z < a.z_hi && y < a.SY;
+  const int64_t zc = z < a.z_hi ? z : a.z_hi - 1, yc = y < a.SY ? y : a.SY - 1;
+  return (const SRC *)a.src + (zc * a.SY + yc) * a.SX;
+}
+
+// issue the loads of columns 0..63 of tile rows [row0, row0 + S_RPT)
+template <typename SRC>
+__device__ __forceinline__ void stem_load_rows(const StemArgs &a, const StemBlock &b, int row0,
+                                               StemRows<SRC> &r) {
+#pragma unroll
+  for (int k = 0; k < S_RPT; ++k) {
+    const int row = __builtin_amdgcn_readfirstlane(row0 + k);
+    bool ok;
+    const SRC *rp = stem_row_ptr<SRC>(a, b, row, ok);
+    r.ok[k] = ok;
+    r.v[k] = rp[b.xc];
+  }
+}
+
+// normalise (v - mean) / sd, round to 16 bits; zero past the volume end.  For u8
+// sources the 256 possible values go through a per-WG lookup table: the divide +
+// convert happen once per value, not once per voxel.
+template <typename SRC>
+__device__ __forceinline__ unsigned short stem_norm(const StemArgs &a, const unsigned short *lut,
+                                                    SRC v, bool ok) {
+  unsigned short t;
+  if (sizeof(SRC) == 1) t = lut[(unsigned)v & 255u];
+  else t = h16_bits(((float)v - a.mean) / a.sd * a.in_scale);
+  return ok ? t : (unsigned short)0;
+}
+
+// conversion (LDS reads of the table) and store are separate steps so that the caller
+// can put MFMA work between them
+struct StemBits { unsigned short b[S_RPT]; };
+
+template <typename SRC>
+__device__ __forceinline__ void stem_convert_rows(const StemArgs &a, const StemBlock &b,
+                                                  const unsigned short *lut,
+                                                  const StemRows<SRC> &r, StemBits &o) {
+#pragma unroll
+  for (int k = 0; k < S_RPT; ++k) o.b[k] = stem_norm<SRC>(a, lut, r.v[k], r.ok[k] && b.x_ok);
+}
+
+__device__ __forceinline__ void stem_write_rows(unsigned short *tile, int row0, int lane,
+                                                const StemBits &o) {
+#pragma unroll
+  for (int k = 0; k < S_RPT; ++k) tile[(row0 + k) * S_TP + lane] = o.b[k];
+}
+
+// columns 64 and 65 of the wave's 45 rows: lane l < 45 takes row wrow0 + l, once per block
+template <typename SRC>
+struct StemEdge { SRC v[2]; bool ok[2]; };
+
+template <typename SRC>
+__device__ __forceinline__ void stem_load_edge(const StemArgs &a, const StemBlock &b, int wrow0,
+                                               int lane, StemEdge<SRC> &e) {
+  const int row = wrow0 + (lane < S_WROWS ? lane : S_WROWS - 1);
+  const int64_t z = b.gz0 + row / S_TY, y = b.gy0 + row % S_TY;
+  const bool rok = z < a.z_hi && y < a.SY;
+  const int64_t zc = z < a.z_hi ? z : a.z_hi - 1, yc = y < a.SY ? y : a.SY - 1;
+  const SRC *rp = (const SRC *)a.src + (zc * a.SY + yc) * a.SX;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t x = b.gx0 + 64 + j;
+    e.ok[j] = rok && x < a.SX;
+    e.v[j] = rp[x < a.SX ? x : a.SX - 1];
+  }
+}
+
+template <typename SRC>
+__device__ __forceinline__ void stem_store_edge(const StemArgs &a, unsigned short *tile,
+                                                const unsigned short *lut, int wrow0, int lane,
+                                                const StemEdge<SRC> &e) {
+  // lanes >= 45 repeat row 44's two stores (same address, same value)
+  const int row = wrow0 + (lane < S_WROWS ? lane : S_WROWS - 1);
+  const unsigned lo = stem_norm<SRC>(a, lut, e.v[0], e.ok[0]);
+  const unsigned hi = stem_norm<SRC>(a, lut, e.v[1], e.ok[1]);
+  *reinterpret_cast<unsigned *>(&tile[row * S_TP + 64]) = lo | (hi << 16);
+}
+
+// CLAMP01: conv3's activations are scaled below 1 (StemArgs w1 / shift1 / w2 are the
+// scaled set, vgg_prepare), so ReLU + conversion is one instruction per pair
+template <typename SRC, bool CLAMP01>
+__global__ __launch_bounds__(256, STEM_WPS) void FPLK(vgg_stem_pool)(StemArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short tiles[2][S_TZ * S_TY * S_TP];
   __shared__ unsigned short lut[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int px0 = blockIdx.x * S_PX, py0 = blockIdx.y * S_PY, pz0 = blockIdx.z * S_PZ;
-
-  // ---- input tile: normalise, round to bf16; zero past the volume end.  For u8
-  // sources the 256 possible values go through a per-WG lookup table, so the
-  // divide + convert happen once per value, not once per voxel.  One tile row
-  // (66 x) per wave iteration: the row address is wave-uniform (scalar math), a
-  // lane only adds its x.
-  {
-    const SRC *src = (const SRC *)a.src;
-    const int64_t gz0 = 2 * (a.p1z0 + pz0), gy0 = 2 * (int64_t)py0, gx0 = 2 * (int64_t)px0;
-    if (sizeof(SRC) == 1) {
-      lut[tid] = h16_bits(((float)tid - a.mean) / a.sd);
-      __syncthreads();
-    }
-    constexpr int ROWS = S_TZ * S_TY;            // 180 rows of 66
-    constexpr int RB = 9;                        // rows in flight per wave
-    const bool x0_ok = gx0 + lane < a.SX, x1_ok = lane < 2 && gx0 + 64 + lane < a.SX;
-    for (int r0 = wave * RB; r0 < ROWS; r0 += 4 * RB) {
-      SRC v0[RB], v1[RB];
-      bool ok[RB];
-#pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        const int row = __builtin_amdgcn_readfirstlane(r0 + k);
-        const int64_t z = gz0 + row / S_TY, y = gy0 + row % S_TY;
-        ok[k] = row < ROWS && z < a.z_hi && y < a.SY;
-        const SRC *rp = src + (z * a.SY + y) * a.SX + gx0;
-        v0[k] = (ok[k] && x0_ok) ? rp[lane] : (SRC)0;
-        v1[k] = (ok[k] && x1_ok) ? rp[64 + lane] : (SRC)0;
-      }
-#pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        const int row = r0 + k;
-        if (row >= ROWS) break;
-        unsigned short b0 = 0, b1 = 0;
-        if (sizeof(SRC) == 1) {
-          if (ok[k] && x0_ok) b0 = lut[(int)v0[k]];
-          if (ok[k] && x1_ok) b1 = lut[(int)v1[k]];
-        } else {
-          if (ok[k] && x0_ok) b0 = h16_bits(((float)v0[k] - a.mean) / a.sd);
-          if (ok[k] && x1_ok) b1 = h16_bits(((float)v1[k] - a.mean) / a.sd);
-        }
-        tile[row * S_TP + lane] = b0;
-        if (lane < 2) tile[row * S_TP + 64 + lane] = b1;
-      }
-    }
-  }
+  const int nblocks = a.nbx * a.nby * a.nbz;
+  int q = blockIdx.x;
+  if (q >= nblocks) return;
+  if (sizeof(SRC) == 1) lut[tid] = h16_bits(((float)tid - a.mean) / a.sd * a.in_scale);
 
   // ---- per-lane constants: byte offsets of the 3 pair reads and 2 single reads
   // for sub-step parity e = dx (k-slot layout: pack_weights.h::fpl_stem_slot_tap)
@@ -144,60 +238,122 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_stem_pool)(StemArgs a) {
       sh2[b][r] = a.shift2[16 * b + 4 * g + r];
     }
   }
-  __syncthreads();
-  const unsigned char *tb = reinterpret_cast<const unsigned char *>(tile);
+  __syncthreads();                      // lut
 
-  for (int task = wave; task < S_PZ * S_PY * 2; task += 4) {
-    const int row = task >> 1, xh = task & 1;
-    const int pzl = row / S_PY, pyl = row % S_PY;
-    const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TP + 2 * (16 * xh + c));
-    // max-pool in fp32, two window positions per v_max3_f32 (rounding to bf16 is
-    // monotonic, so rounding the fp32 max equals the max of the rounded values);
-    // the initial 0 is the ReLU
-    f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  // ---- the first block's tile: plain fill, once per workgroup
+  const int wrow0 = wave * S_WROWS, wrow1 = wrow0 + S_WROWS;
+  StemBlock blk = stem_block(a, q, lane);
+  for (int r0 = wrow0; r0 < wrow1; r0 += S_RPT) {
+    StemRows<SRC> rr;
+    StemBits hb;
+    stem_load_rows<SRC>(a, blk, r0, rr);
+    stem_convert_rows<SRC>(a, blk, lut, rr, hb);
+    stem_write_rows(tiles[0], r0, lane, hb);
+  }
+  {
+    StemEdge<SRC> ee;
+    stem_load_edge<SRC>(a, blk, wrow0, lane, ee);
+    stem_store_edge<SRC>(a, tiles[0], lut, wrow0, lane, ee);
+  }
+  __syncthreads();
+
+  // fill pipeline state: rr = rows of group 0 of the next block, ee = its edge columns;
+  // a block index past the end is clamped to the last block of this workgroup - its
+  // fill then lands, unused, in the idle buffer (no branches in the task loop)
+  const int G = (int)gridDim.x;
+  auto clampq = [&](int qq, int qlast) { return qq < nblocks ? qq : qlast; };
+  StemRows<SRC> rr;
+  StemEdge<SRC> ee;
+  {
+    const StemBlock n0 = stem_block(a, clampq(q + G, q), lane);
+    stem_load_rows<SRC>(a, n0, wrow0, rr);
+    stem_load_edge<SRC>(a, n0, wrow0, lane, ee);
+  }
+  int cur = 0;
+  for (;;) {
+    const int qn = q + G;
+    const bool has_next = qn < nblocks;                 // uniform
+    const StemBlock nxt = stem_block(a, has_next ? qn : q, lane);
+    const StemBlock nx2 = stem_block(a, clampq(qn + G, has_next ? qn : q), lane);
+    const unsigned char *tb = reinterpret_cast<const unsigned char *>(tiles[cur]);
+    unsigned short *tnext = tiles[cur ^ 1];
+#pragma unroll 1
+    for (int ti = 0; ti < S_TASKS; ++ti) {
+      // next block's tile, 16 groups of 3 rows (the 16th repeats row 44): group ti was
+      // loaded one task ago; it is converted here (table reads) and written after the
+      // first half of this task's MFMAs, where the loads of group ti + 1 - or, in the
+      // last task, of group 0 of the block after next - are issued
+      StemBits hb;
+      stem_convert_rows<SRC>(a, nxt, lut, rr, hb);
+      const int grow = wrow0 + (S_RPT * ti < S_WROWS ? S_RPT * ti : S_WROWS - S_RPT);
+      const bool last = ti + 1 == S_TASKS;
+      StemBlock lb = nxt;
+      if (last) lb = nx2;
+      int lrow = wrow0 + S_RPT * (ti + 1);
+      lrow = last ? wrow0 : (lrow < wrow1 ? lrow : wrow1 - S_RPT);
+      const int task = wave + 4 * ti;
+      const int row = task >> 1, xh = task & 1;
+      const int pzl = row / S_PY, pyl = row % S_PY;
+      const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TP + 2 * (16 * xh + c));
+      // max-pool in fp32, two window positions per v_max3_f32 (rounding to bf16 is
+      // monotonic, so rounding the fp32 max equals the max of the rounded values);
+      // the initial 0 is the ReLU
+      f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int sp = 0; sp < 4; ++sp) {
-      f32x4 a2[2][3];
+      for (int sp = 0; sp < 4; ++sp) {
+        f32x4 a2[2][3];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {                 // sub = 2 sp + e: x parity e
-        const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
-        u32x4 raw;
+        for (int e = 0; e < 2; ++e) {                 // sub = 2 sp + e: x parity e
+          const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
+          u32x4 raw;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-          raw[i] = *reinterpret_cast<const unsigned *>(tb + base + so + offP[e][i]);
-        const unsigned s0 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][0]);
-        const unsigned s1 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][1]);
-        raw[3] = s0 | (s1 << 16);
-        const h16x8 bfrag = __builtin_bit_cast(h16x8, raw);
-        f32x4 a1[3];
+          for (int i = 0; i < 3; ++i)
+            raw[i] = *reinterpret_cast<const unsigned *>(tb + base + so + offP[e][i]);
+          const unsigned s0 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][0]);
+          const unsigned s1 = *reinterpret_cast<const unsigned short *>(tb + base + so + offS[e][1]);
+          raw[3] = s0 | (s1 << 16);
+          const h16x8 bfrag = __builtin_bit_cast(h16x8, raw);
+          f32x4 a1[3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[e][b], bfrag, sh1[b]);
-        const h16x8 h0 = pack_relu(a1[0], a1[1]);
-        const h16x8 h1 = pack_relu_lo(a1[2]);
+          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[e][b], bfrag, sh1[b]);
+          const h16x8 h0 = pack_relu_t<CLAMP01>(a1[0], a1[1]);
+          const h16x8 h1 = pack_relu_lo_t<CLAMP01>(a1[2]);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          a2[e][b] = mfma16(w2[0][b], h0, sh2[b]);
-          a2[e][b] = mfma16(w2[1][b], h1, a2[e][b]);
+          for (int b = 0; b < 3; ++b) {
+            a2[e][b] = mfma16(w2[0][b], h0, sh2[b]);
+            a2[e][b] = mfma16(w2[1][b], h1, a2[e][b]);
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
+        if (sp == 1) {
+          stem_write_rows(tnext, grow, lane, hb);
+          stem_load_rows<SRC>(a, lb, lrow, rr);
         }
       }
+      u32x2 pooled[3];
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
+      for (int b = 0; b < 3; ++b) {
+        pooled[b][0] = cvt_pk_h16(poolf[b][0], poolf[b][1]);
+        pooled[b][1] = cvt_pk_h16(poolf[b][2], poolf[b][3]);
+      }
+      const int pz = blk.pz0 + pzl, py = blk.py0 + pyl, px = blk.px0 + 16 * xh + c;
+      if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
+        h16_t *dst = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * CH + 4 * g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
+        for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
+      }
     }
-    u32x2 pooled[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      pooled[b][0] = cvt_pk_h16(poolf[b][0], poolf[b][1]);
-      pooled[b][1] = cvt_pk_h16(poolf[b][2], poolf[b][3]);
-    }
-    const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + 16 * xh + c;
-    if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
-      h16_t *dst = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * CH + 4 * g;
-#pragma unroll
-      for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
-    }
+    if (!has_next) break;
+    stem_store_edge<SRC>(a, tnext, lut, wrow0, lane, ee);
+    stem_load_edge<SRC>(a, nx2, wrow0, lane, ee);
+    __syncthreads();        // tile[cur] consumed by every wave, tile[cur ^ 1] complete
+    q = qn;
+    blk = nxt;
+    cur ^= 1;
   }
 }
 
@@ -772,7 +928,18 @@ struct VggFastState {
   size_t off_w[8] = {0};              // byte offsets of L1..L8 fragments
   size_t off_s[8] = {0};              // float offsets of shift1..shift8
   float bias8 = 0.f;
+  // vgg_like, IEEE-half build: a second set of L1 / L2 fragments and shift1 with L1's
+  // output channel c scaled by 2^-e[c] and L2's input channel c by 2^e[c], e[c] the
+  // smallest exponent with  sum_taps |w| * STEM_XMAX + |shift| <= 2^e  - for inputs
+  // |x| <= STEM_XMAX conv3's activations then lie below 1 and ReLU + conversion is ONE
+  // v_cvt_pk_f16_f32 ... clamp (mfma_util.h).  Powers of two throughout: L2's sums are
+  // the unscaled ones (half subnormals of the activations aside)
+  bool have_scaled = false;
+  size_t off_w1s = 0, off_w2s = 0, off_s1s = 0;
+  float stem_in_scale = 1.f;
 };
+
+constexpr float STEM_XMAX = 8.f;   // |(v - mean) / sd| bound the scaled set is built for
 
 void vgg_state_free(fpl_ctx *ctx, void *p) {
   VggFastState *s = (VggFastState *)p;
@@ -866,7 +1033,58 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
     shifts.insert(shifts.end(), A + op.shift_off, A + op.shift_off + op.cout);
     while (shifts.size() % 4) shifts.push_back(0.f);
   }
+  st->have_scaled = false;
 #ifdef FPL_F16
+  if (!v2) {
+    const fpl_op &o1 = prog->ops[conv_ops[0]], &o2 = prog->ops[conv_ops[1]];
+    std::vector<float> sc1(A + o1.scale_off, A + o1.scale_off + o1.cout);
+    std::vector<float> sh1(A + o1.shift_off, A + o1.shift_off + o1.cout);
+    std::vector<float> up(o1.cout);
+    std::vector<int> ex(o1.cout);
+    bool ok = true;
+    int kmax = 0;
+    for (int c = 0; c < o1.cout; ++c) {
+      double bound = std::fabs((double)sh1[c]);
+      for (int t = 0; t < 27; ++t)
+        bound += std::fabs((double)A[o1.w_off + (size_t)t * o1.cout + c] * sc1[c]) * STEM_XMAX;
+      bound *= 1.0 + 1e-3;                       // fp32 accumulation, 16-bit weight rounding
+      int e = 0;
+      while (std::ldexp(1.0, e) < bound) ++e;
+      ok = ok && e <= 10;                        // keeps w2 * 2^e and x * 2^-k inside the half range
+      ex[c] = e;
+      kmax = std::max(kmax, e);
+    }
+    // The 2^-e[c] goes on as (input * 2^-k) * (weight * 2^(k - e[c])) with k = max e: the
+    // weights only grow (no half subnormals), the input's smallest step 1/|sd| * 2^-k
+    // stays a normal half - every factor is a power of two, so the fp32 accumulators are
+    // exactly 2^-e[c] times the unscaled ones.
+    for (int c = 0; c < o1.cout; ++c) {
+      sc1[c] = (float)std::ldexp((double)sc1[c], kmax - ex[c]);
+      sh1[c] = (float)std::ldexp((double)sh1[c], -ex[c]);
+      up[c] = (float)std::ldexp(1.0, ex[c]);
+    }
+    st->stem_in_scale = (float)std::ldexp(1.0, -kmax);
+    if (ok) {
+      std::vector<uint16_t> f;
+      fpl_pack_stem(A + o1.w_off, sc1.data(), o1.cout, &f);
+      st->off_w1s = all.size() * sizeof(uint16_t);
+      all.insert(all.end(), f.begin(), f.end());
+      // L2 with its input channels scaled up: W2[c][o] * up[c]
+      std::vector<float> w2((size_t)o2.cin * o2.cout);
+      for (int c = 0; c < o2.cin; ++c)
+        for (int o = 0; o < o2.cout; ++o)
+          w2[(size_t)c * o2.cout + o] = A[o2.w_off + (size_t)c * o2.cout + o] * up[c];
+      std::vector<float> sc2(A + o2.scale_off, A + o2.scale_off + o2.cout);
+      fpl_pack_frags(w2.data(), sc2.data(), 1, o2.cin, o2.cout, mblocks[1], ksteps[1], maps[1], &f);
+      st->off_w2s = all.size() * sizeof(uint16_t);
+      all.insert(all.end(), f.begin(), f.end());
+      st->off_s1s = shifts.size();
+      shifts.insert(shifts.end(), sh1.begin(), sh1.end());
+      while (shifts.size() % 4) shifts.push_back(0.f);
+      st->have_scaled = true;
+      for (uint16_t h : f) st->have_scaled = st->have_scaled && (h & 0x7C00u) != 0x7C00u;
+    }
+  }
   for (uint16_t h : all)
     FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
                 "a folded weight exceeds the IEEE-half range (65504); use precision "
@@ -1063,14 +1281,30 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
       a.w1 = (const h16x8 *)(F + st->off_w[0]);
       a.w2 = (const h16x8 *)(F + st->off_w[1]);
       a.shift1 = S + st->off_s[0]; a.shift2 = S + st->off_s[1];
+      // u8 input inside the bound the scaled set was built for: one-instruction ReLU
+      const float xmax = std::max(std::fabs(0.f - mean), std::fabs(255.f - mean)) / std::fabs(sd);
+      const bool clamp01 = st->have_scaled && src_dtype == FPL_U8 && xmax <= STEM_XMAX &&
+                           !getenv("FPL_STEM_NOCLAMP");
+      a.in_scale = 1.f;
+      if (clamp01) {
+        a.in_scale = st->stem_in_scale;
+        a.w1 = (const h16x8 *)(F + st->off_w1s);
+        a.w2 = (const h16x8 *)(F + st->off_w2s);
+        a.shift1 = S + st->off_s1s;
+      }
       a.p1 = (h16_t *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
-      dim3 grid((unsigned)ceil_div64(P1X, S_PX), (unsigned)ceil_div64(P1Y, S_PY),
-                (unsigned)ceil_div64(P1Z, S_PZ));
+      a.nbx = (int)ceil_div64(P1X, S_PX); a.nby = (int)ceil_div64(P1Y, S_PY);
+      a.nbz = (int)ceil_div64(P1Z, S_PZ);
+      // persistent: two workgroups per CU walk the blocks
+      const unsigned grid = (unsigned)std::min<int64_t>((int64_t)a.nbx * a.nby * a.nbz,
+                                                        (int64_t)ctx->n_cu * 2);
       TimedLaunch tl(ctx, "vgg_stem_pool_" FPL_PREC_STR);
-      if (src_dtype == FPL_U8)
-        FPLK(vgg_stem_pool)<uint8_t><<<grid, 256, 0, stream>>>(a);
+      if (clamp01)
+        FPLK(vgg_stem_pool)<uint8_t, true><<<grid, 256, 0, stream>>>(a);
+      else if (src_dtype == FPL_U8)
+        FPLK(vgg_stem_pool)<uint8_t, false><<<grid, 256, 0, stream>>>(a);
       else
-        FPLK(vgg_stem_pool)<float><<<grid, 256, 0, stream>>>(a);
+        FPLK(vgg_stem_pool)<float, false><<<grid, 256, 0, stream>>>(a);
     }
     {
       MidArgs a;

@@ -158,3 +158,40 @@ def test_z_chunked_scratch_equals_one_pass(ctx, kind, monkeypatch):
     many = prog.infer_volume(u8, (102,) * 3, (7,) * 3, **kw)
     assert np.array_equal(one, many)
     assert one[7:-7, 7:-7, 7:-7].std() > 1e-3
+
+
+def test_stem_one_instruction_relu_is_as_accurate_as_the_two_instruction_form(ctx):
+    """IEEE-half build, u8 input: conv3's output channels are scaled by 2^-e below 1 so
+    that ReLU + conversion is one `v_cvt_pk_f16_f32 ... clamp`, and conv1's input channels
+    by 2^e (vgg_fused.hip::vgg_prepare).  All factors are powers of two, so the only
+    difference to the unscaled weights (FPL_STEM_NOCLAMP=1: cvt + pk_max) is that
+    activations below 2^(e-14) land in the half subnormals: both forms must sit equally
+    close to the fp32 result, well inside the 1e-3 gate."""
+    import os
+    from flypylib_amd import FplNetwork
+    net = FplNetwork(fplmodels.vgg_like)
+    net.infer_sz = (46,) * 3
+    synth.synthetic_weights(net.train_single, 21)
+    net._set_infer()
+    u8 = synth.em_volume_u8(8, (90, 77, 83))
+    ref = net.infer(u8, normalize=(128., 33.), precision='f32')
+    a = net.infer(u8, normalize=(128., 33.), precision='f16')
+    os.environ['FPL_STEM_NOCLAMP'] = '1'
+    try:
+        b = net.infer(u8, normalize=(128., 33.), precision='f16')
+    finally:
+        del os.environ['FPL_STEM_NOCLAMP']
+    assert ref[10:-10, 10:-10, 10:-10].std() > 0
+    ea, eb = np.abs(a - ref), np.abs(b - ref)
+    assert ea.max() < 5e-4 and eb.max() < 5e-4
+    assert abs(ea.mean() - eb.mean()) < 0.05 * eb.mean()
+    assert np.abs(a - b).max() < 5e-4 and not np.array_equal(a, b)
+    # a normalisation outside the bound the scaled set was built for (|x| <= 8) falls
+    # back to the unscaled weights by itself
+    c = net.infer(u8, normalize=(128., 3.3), precision='f16')
+    os.environ['FPL_STEM_NOCLAMP'] = '1'
+    try:
+        d = net.infer(u8, normalize=(128., 3.3), precision='f16')
+    finally:
+        del os.environ['FPL_STEM_NOCLAMP']
+    assert np.array_equal(c, d)
