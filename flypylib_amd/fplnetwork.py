@@ -49,13 +49,41 @@ class InferNetwork:
         return self.program.forward(np.asarray(data_batch, np.float32))
 
 
+class _ReferenceUnpickler(pickle.Unpickler):
+    """a pickle written by the reference names `flypylib.fplnetwork.FplNetwork`, the model
+    factory `flypylib.fplmodels.<name>` and, in compile_args, its loss / metric functions:
+    all have same-named counterparts here"""
+
+    def find_class(self, module, name):
+        if module == 'flypylib' or module.startswith('flypylib.'):
+            module = 'flypylib_amd' + module[len('flypylib'):]
+        return super().find_class(module, name)
+
+
 def load_network(filepath, device=None):
-    """inverse of `FplNetwork.save_network` (reference fplnetwork.py:32-44)"""
+    """inverse of `FplNetwork.save_network` (reference fplnetwork.py:32-44).  Reads this
+    package's pair (pickle + `<path>.weights.npz`) and the reference's (pickle of a
+    `flypylib.fplnetwork.FplNetwork` + Keras `<path>.keras.h5`)."""
+    import os
     with open(filepath, 'rb') as fn:
-        network = pickle.load(fn)
+        network = _ReferenceUnpickler(fn).load()
+    # attributes a reference-written instance does not carry
+    for k, v in (('precision', 'f32'), ('_parallel', None), ('_parallel_devices', None),
+                 ('_trainer', None)):
+        if not hasattr(network, k):
+            setattr(network, k, v)
+    network.rf_size, network.rf_offset, network.rf_stride, network.infer_sz = (
+        tuple(network.rf_size), tuple(network.rf_offset), tuple(network.rf_stride),
+        tuple(network.infer_sz))
     network._device = runtime.default_device() if device is None else device
     network.train_single, _, _, _ = network.model()
-    network.train_single.load(filepath + '.weights.npz')
+    if os.path.exists(filepath + '.weights.npz'):
+        network.train_single.load(filepath + '.weights.npz')
+    elif os.path.exists(filepath + '.keras.h5'):
+        network.train_single.load(filepath + '.keras.h5')
+    else:
+        raise FileNotFoundError('%s: neither %s.weights.npz nor %s.keras.h5 (the reference\'s '
+                                'Keras file) is there' % (filepath, filepath, filepath))
     network.train_single.compile(**network.compile_args)
     network.train_network = network.train_single
     network._parallel = None
@@ -92,9 +120,15 @@ class FplNetwork:
         self._parallel = None
         self._parallel_devices = None
 
-    # ---- persistence (reference :81-97; Keras .h5 replaced by .npz) -----------
-    def save_network(self, filepath):
+    # ---- persistence (reference :81-97) ------------------------------------------------
+    def save_network(self, filepath, keras_h5=True):
+        """pickle + `<path>.weights.npz`, and (keras_h5) the weights once more as
+        `<path>.keras.h5` in Keras' layout - the file name and tree the reference writes
+        next to its pickle; it carries no `model_config`, so on the Keras side rebuild
+        the model from its factory and `load_weights` it"""
         self.train_single.save(filepath + '.weights.npz')
+        if keras_h5:
+            self.train_single.save(filepath + '.keras.h5')
         keep = (self.train_single, self.train_network, self.infer_network,
                 self._parallel)
         self.train_single = self.train_network = self.infer_network = None

@@ -206,12 +206,20 @@ class LayerGraph:
         self.compile_args = dict(compile_args)
 
     def save(self, path):
-        """weights checkpoint (npz; the reference writes Keras .h5 — h5py is
-        not available here, interchange is SURVEY section 8f item 2)"""
-        np.savez(path if path.endswith('.npz') else path + '.npz',
-                 *self.weights)
+        """weights checkpoint: a Keras-layout `.h5` (what the reference's `model.save`
+        calls write, fplnetwork.py:16-17,83; see keras_io.py) when `path` ends in .h5,
+        else the package's `.npz` (arrays in get_weights() order)"""
+        if path.endswith('.h5'):
+            from . import keras_io
+            keras_io.save_weights(self, path)
+        else:
+            np.savez(path if path.endswith('.npz') else path + '.npz', *self.weights)
 
     def load(self, path):
+        if path.endswith('.h5'):
+            from . import keras_io
+            keras_io.load_weights(self, path)
+            return
         with np.load(path if path.endswith('.npz') else path + '.npz') as z:
             self.set_weights([z['arr_%d' % i] for i in range(len(z.files))])
 

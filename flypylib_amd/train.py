@@ -4,8 +4,8 @@
 `fit_generator(network, generator, steps_per_epoch, epochs, log_file,
 save_filepath)` mirrors `train_network.fit_generator` with the reference's two
 callbacks: a CSV log (`CSVLogger`: epoch, acc, loss) and a per-epoch checkpoint
-'<save_filepath>_%03d' of the single-GPU weights (`multi_gpu_callback`,
-fplnetwork.py:9-17).
+'<save_filepath>_%03d.h5' (Keras weight layout, keras_io.py; plus the package's .npz)
+of the single-GPU weights (`multi_gpu_callback`, fplnetwork.py:9-17).
 
 Data parallelism.  The reference builds in-graph towers: the generator yields
 `batch_size * n_gpu` examples, tower i takes rows [i*batch_size, (i+1)*batch_size)
@@ -484,7 +484,10 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
                 writer.writerow(row)
                 f.flush()
             if rank == 0 and save_filepath:
+                # the reference's per-epoch '<prefix>_%03d.h5' (Keras layout) next to the
+                # package's own .npz
                 graph.save('%s_%03d' % (save_filepath, epoch))
+                graph.save('%s_%03d.h5' % (save_filepath, epoch))
     finally:
         network._train_steps_done = step_no
         batches.close()

@@ -274,7 +274,22 @@ def gen_synapses():
     np.savez_compressed(os.path.join(HERE, 'synapses.npz'), **out)
 
 
+def gen_keras_tiny():
+    """keras_tiny.h5 / .npz: NOT a reference output (h5py and Keras are absent here) - the
+    bytes of the package's own HDF5 writer (flypylib_amd/h5min.py, Keras weight layout)
+    for a 3-layer network with seeded weights, and the arrays they must read back as"""
+    from flypylib_amd import synth
+    from flypylib_amd.program import LayerGraph
+    g = LayerGraph(None, seed=3)
+    x = g.relu(g.bn(g.conv(g.input(), 4, 3)))
+    g.finish(g.conv(x, 1, 1, use_bias=True, activation='sigmoid'))
+    synth.synthetic_weights(g, 17)
+    g.save(os.path.join(HERE, 'keras_tiny.h5'))
+    np.savez(os.path.join(HERE, 'keras_tiny.npz'), *g.get_weights())
+
+
 if __name__ == '__main__':
+    gen_keras_tiny()
     gen_voxel2obj_seg()
     gen_synapses()
     gen_fri_get_image()

@@ -430,3 +430,31 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible(ctx):
     assert got[0][0] == got[1][0] == 'rccl'
     for a, b in zip(got[0][1], got[1][1]):
         assert np.array_equal(a, b)
+
+
+# ---- network interchange (reference fplnetwork.py:32-44,81-97) --------------------------
+def test_save_network_load_network_round_trip_incl_keras_h5(ctx, tmp_path):
+    """save_network writes pickle + .weights.npz + .keras.h5 (Keras weight layout);
+    load_network restores from either weight file - the reference's pair is pickle +
+    .keras.h5 - and the restored network infers bit-identically"""
+    import os
+    from flypylib_amd import fplnetwork
+    net = _vgg_net(seed=12)
+    u8 = synth.em_volume_u8(4, (50, 47, 44))
+    want = net.infer(u8, normalize=(128., 33.))
+    p = str(tmp_path / 'net.p')
+    net.save_network(p)
+    assert os.path.exists(p + '.keras.h5') and os.path.exists(p + '.weights.npz')
+    assert net.infer_network is not None                 # the live network is untouched
+    a = fplnetwork.load_network(p)
+    a.infer_sz = net.infer_sz
+    a._set_infer()
+    assert np.array_equal(a.infer(u8, normalize=(128., 33.)), want)
+    os.remove(p + '.weights.npz')                        # the reference's pair
+    b = fplnetwork.load_network(p)
+    b.infer_sz = net.infer_sz
+    b._set_infer()
+    assert np.array_equal(b.infer(u8, normalize=(128., 33.)), want)
+    os.remove(p + '.keras.h5')
+    with pytest.raises(FileNotFoundError, match='keras.h5'):
+        fplnetwork.load_network(p)

@@ -264,6 +264,7 @@ def test_fplnetwork_train_api_end_to_end(ctx, tmp_path):
     loss0, loss1 = float(rows[1].split(',')[2]), float(rows[2].split(',')[2])
     assert loss1 < loss0
     assert (tmp_path / 'epoch_000.npz').exists() and (tmp_path / 'epoch_001.npz').exists()
+    assert (tmp_path / 'epoch_000.h5').exists() and (tmp_path / 'epoch_001.h5').exists()   # the reference's name
     # the inference network was rebuilt from the trained weights
     net.infer_sz = (30, 30, 30)
     net._set_infer()

@@ -1,0 +1,211 @@
+"""Keras `.h5` interchange on the CPU: the package's HDF5 subset reader / writer (h5min),
+the layer matching of keras_io and the reference-pickle unpickler.
+
+No h5py-written file was available in the build container (h5py and Keras are absent):
+the reader is exercised on files from the in-repo writer, on a committed byte-level
+fixture of it (tests/golden/keras_tiny.h5) and on hand-assembled structures the writer
+itself never emits (continuation blocks, compact layout, version-2 dataspace / version-3
+attribute messages)."""
+import io
+import os
+import pickle
+import struct
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from flypylib_amd import fplmodels, h5min, keras_io, synth
+from flypylib_amd.program import LayerGraph
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _tiny_graph():
+    g = LayerGraph(None, seed=3)
+    x = g.relu(g.bn(g.conv(g.input(), 4, 3)))
+    return g.finish(g.conv(x, 1, 1, use_bias=True, activation='sigmoid'))
+
+
+def test_h5min_round_trip_types_groups_attributes():
+    rng = np.random.default_rng(0)
+    tree = {'attrs': {'names': np.array([b'a', b'longer_name']), 'n': np.int64(-7),
+                      'scalar_str': np.bytes_(b'tensorflow'), 'empty': np.zeros(0, 'S1'),
+                      'f': np.array([1.5, -2.25], np.float64)},
+            'datasets': {'f32': rng.normal(size=(3, 1, 5)).astype(np.float32),
+                         'f64': rng.normal(size=(4,)), 'u8': np.arange(7, dtype=np.uint8),
+                         'i32': np.array(-5, np.int32), 'f16': np.array([0.5, 2], np.float16)},
+            'groups': {'g1': {'groups': {'deep': {'datasets': {'k:0': np.ones((2, 2), np.float32)}}},
+                              'attrs': {'weight_names': np.array([b'deep/k:0'])}},
+                       'g0': {}}}
+    f = h5min.File(h5min.to_bytes(tree))
+    assert f.keys() == ['f16', 'f32', 'f64', 'g0', 'g1', 'i32', 'u8']
+    for k, v in tree['datasets'].items():
+        got = f[k][...]
+        assert got.dtype == v.dtype and got.shape == np.shape(v) and np.array_equal(got, v), k
+    assert f['i32'][()] == -5 and f['i32'].shape == ()
+    assert list(f.attrs['names']) == [b'a', b'longer_name'] and f.attrs['n'] == -7
+    assert f.attrs['scalar_str'] == b'tensorflow' and f.attrs['empty'].shape == (0,)
+    assert np.array_equal(f.attrs['f'], [1.5, -2.25])
+    assert np.array_equal(f['g1/deep/k:0'][...], np.ones((2, 2)))
+    assert f['g1'].attrs['weight_names'][0] == b'deep/k:0' and f['g0'].keys() == []
+    assert 'g1' in f and 'nope' not in f and 'g1/deep' in f
+    with pytest.raises(KeyError):
+        f['g1/nope']
+    # groups of any size: the writer raises the file's leaf K
+    big = {'datasets': {'d%03d' % i: np.float32(i) for i in range(300)}}
+    fb = h5min.File(h5min.to_bytes(big))
+    assert len(fb.keys()) == 300 and fb['d299'][()] == 299
+
+
+def test_h5min_reads_structures_its_writer_does_not_emit():
+    """object-header continuation block, compact layout, dataspace v2, attribute v3"""
+    w = h5min._Writer(4)
+    # dataset with a compact layout and a version-2 dataspace; its attribute sits in a
+    # continuation block
+    data = np.arange(6, dtype=np.float32).reshape(2, 3)
+    space_v2 = struct.pack('<BBBB', 2, 2, 0, 1) + struct.pack('<QQ', 2, 3)
+    layout = struct.pack('<BBH', 3, 0, data.nbytes) + data.tobytes()
+    nm = b'unit\0'
+    dt, ds = h5min._dtype_msg('S2'), struct.pack('<BBBB', 2, 0, 0, 0)
+    attr_v3 = struct.pack('<BBHHHB', 3, 0, len(nm), len(dt), len(ds), 0) + nm + dt + ds + b'mm'
+    cont_block = w.alloc(h5min._msg(0x000C, attr_v3))
+    cont_len = len(h5min._msg(0x000C, attr_v3))
+    hdr = w.header([h5min._msg(0x0001, space_v2), h5min._msg(0x0003, h5min._dtype_msg(np.float32)),
+                    h5min._msg(0x0008, layout),
+                    h5min._msg(0x0010, struct.pack('<QQ', cont_block, cont_len)),
+                    b''])
+    # the header announces one message more than its first block holds (the attribute)
+    w.buf[hdr + 2:hdr + 4] = struct.pack('<H', 5)
+    # a root group holding it: reuse the writer's group code for the links
+    tree_bytes = bytearray(h5min.to_bytes({'datasets': {'x': np.float32(0)}}))
+    base = h5min.File(bytes(tree_bytes))
+    # splice: append our objects after the small file and repoint the link 'x'
+    off = len(tree_bytes)
+    blob = bytes(w.buf[96:])
+    shift = off - 96
+    patched = bytearray(tree_bytes + blob)
+    # addresses inside the blob move by `shift`
+    new_hdr = hdr + shift
+    cm = new_hdr + 16 + len(h5min._msg(0x0001, space_v2)) + len(h5min._msg(0x0003, h5min._dtype_msg(np.float32))) \
+        + len(h5min._msg(0x0008, layout)) + 8
+    patched[cm:cm + 8] = struct.pack('<Q', cont_block + shift)
+    base._load()
+    old = base._links['x']
+    pos = bytes(patched).find(struct.pack('<Q', old), 96)
+    patched[pos:pos + 8] = struct.pack('<Q', new_hdr)
+    patched[40:48] = struct.pack('<Q', len(patched))           # end-of-file address
+    f = h5min.File(bytes(patched))
+    assert np.array_equal(f['x'][...], data) and f['x'].attrs['unit'] == b'mm'
+
+
+def test_h5min_names_what_it_cannot_read():
+    with pytest.raises(h5min.H5Unsupported, match='not an HDF5 file'):
+        h5min.File(b'\0' * 200)
+    b = bytearray(h5min.to_bytes({'datasets': {'x': np.float32(1)}}))
+    b[8] = 2
+    with pytest.raises(h5min.H5Unsupported, match='superblock version 2'):
+        h5min.File(bytes(b))
+
+
+def test_committed_fixture_reads_back(tmp_path):
+    """tests/golden/keras_tiny.h5: bytes of the writer for a 3-layer network, committed;
+    tests/golden/keras_tiny.npz: the arrays it must yield"""
+    want = np.load(os.path.join(GOLDEN, 'keras_tiny.npz'))
+    g = _tiny_graph()
+    keras_io.load_weights(g, os.path.join(GOLDEN, 'keras_tiny.h5'))
+    got = g.get_weights()
+    assert len(got) == len(want.files) == 7
+    for i, a in enumerate(got):
+        assert np.array_equal(a, want['arr_%d' % i])
+    f = h5min.File(os.path.join(GOLDEN, 'keras_tiny.h5'))
+    assert [n.decode() for n in f['model_weights'].attrs['layer_names']] == [
+        'input_1', 'conv3d_1', 'batch_normalization_1', 'activation_1', 'conv3d_2']
+    # the writer is deterministic: re-writing the same weights gives the committed bytes
+    g.save(str(tmp_path / 'again.h5'))
+    assert open(str(tmp_path / 'again.h5'), 'rb').read() == \
+        open(os.path.join(GOLDEN, 'keras_tiny.h5'), 'rb').read()
+
+
+@pytest.mark.parametrize('name', ['vgg_like', 'unet_like2', 'resnet_like'])
+def test_graph_round_trip_through_keras_layout(tmp_path, name):
+    g = getattr(fplmodels, name)()[0]
+    synth.synthetic_weights(g, 11)
+    for model_save in (True, False):
+        p = str(tmp_path / ('%s_%d.h5' % (name, model_save)))
+        keras_io.save_weights(g, p, as_model_save=model_save)
+        g2 = getattr(fplmodels, name)()[0]
+        g2.load(p)
+        for a, b in zip(g.get_weights(), g2.get_weights()):
+            assert np.array_equal(a, b)
+    f = h5min.File(p)
+    assert b'conv3d_1' in list(f.attrs['layer_names'])
+
+
+def test_layers_are_matched_by_creation_number_not_file_order():
+    """`model.layers` of a branched Keras model is depth-ordered, and a second model of
+    a session continues the name counters: conv3d_12 ... - the matching must not care"""
+    g = fplmodels.resnet_like()[0]
+    synth.synthetic_weights(g, 5)
+    layers = keras_io.keras_layers(h5min.File(h5min.to_bytes(keras_io.weight_tree(g))))
+    # renumber from 12 / 7 and shuffle the file order
+    renamed = []
+    for name, items in layers:
+        base, num = name.rsplit('_', 1)
+        renamed.append(('%s_%d' % (base, int(num) + (11 if base == 'conv3d' else 6)), items))
+    rng = np.random.default_rng(0)
+    shuffled = [renamed[i] for i in rng.permutation(len(renamed))]
+    assert [n for n, _ in shuffled] != [n for n, _ in renamed]
+    got = keras_io.graph_weights_from_layers(g, shuffled)
+    for a, b in zip(got, g.get_weights()):
+        assert np.array_equal(a, b)
+    # wrong architecture: named error, nothing assigned
+    with pytest.raises(ValueError, match='shape|layers'):
+        keras_io.graph_weights_from_layers(fplmodels.vgg_like()[0], shuffled)
+
+
+def test_reference_pickle_classes_map_onto_this_package():
+    """a pickle written by the reference names flypylib.fplnetwork.FplNetwork and
+    flypylib.fplmodels.<factory> / loss functions; none of those modules exists here"""
+    from flypylib_amd import fplnetwork
+    mods = {}
+    try:
+        for m in ('flypylib', 'flypylib.fplnetwork', 'flypylib.fplmodels'):
+            mods[m] = types.ModuleType(m)
+            sys.modules[m] = mods[m]
+
+        class FplNetwork:                       # stands in for the reference's class
+            pass
+        FplNetwork.__module__ = 'flypylib.fplnetwork'
+        FplNetwork.__qualname__ = 'FplNetwork'
+        mods['flypylib.fplnetwork'].FplNetwork = FplNetwork
+
+        def unet_like2(in_sz=24):
+            raise AssertionError('the reference factory must not run')
+
+        def masked_focal_loss(y_true, y_pred):
+            raise AssertionError
+        for fn in (unet_like2, masked_focal_loss):
+            fn.__module__ = 'flypylib.fplmodels'
+            fn.__qualname__ = fn.__name__
+            setattr(mods['flypylib.fplmodels'], fn.__name__, fn)
+        ref = FplNetwork()
+        # the attributes the reference's __init__ / save_network leave (fplnetwork.py:54-97)
+        ref.__dict__.update(model=unet_like2, rf_size=(24, 24, 24), rf_offset=(9, 9, 9),
+                            rf_stride=(1, 1, 1), infer_sz=(100, 100, 100), n_gpu=1,
+                            compile_args={'loss': masked_focal_loss, 'optimizer': 'adam',
+                                          'metrics': ['accuracy']},
+                            train_single=None, train_network=None, infer_network=None)
+        blob = pickle.dumps(ref)
+    finally:
+        for m in mods:
+            sys.modules.pop(m, None)
+    assert b'flypylib.fplnetwork' in blob and b'flypylib_amd' not in blob
+    with pytest.raises(ModuleNotFoundError):
+        pickle.loads(blob)
+    net = fplnetwork._ReferenceUnpickler(io.BytesIO(blob)).load()
+    assert type(net) is fplnetwork.FplNetwork
+    assert net.model is fplmodels.unet_like2
+    assert net.compile_args['loss'] == fplmodels.masked_focal_loss == 'masked_focal_loss'
+    assert net.rf_offset == (9, 9, 9) and net.train_single is None
