@@ -2,11 +2,15 @@
 
     python -m flypylib_amd.csrc.build [--force] [-j N]
 
-Each .hip translation unit is compiled to build/<name>.o (skipped when newer
-than its sources) and linked into flypylib_amd/lib/libfplhip.so.  hipcc
-cross-compiles without a GPU, so this runs in the CPU-only build container.
+Each .hip translation unit is compiled to build/<name>.o and linked into
+flypylib_amd/lib/libfplhip.so.  An object is reused only when the SHA-256 of what it
+was built from (its source, every header, the compiler flags) matches the stamp next
+to it - modification times say nothing on a tree that ships objects, and the driver's
+build check must compile what it ships.  hipcc cross-compiles without a GPU, so this
+runs in the CPU-only build container.
 """
 import argparse
+import hashlib
 import os
 import subprocess
 import sys
@@ -43,31 +47,46 @@ def _sources():
     return out
 
 
-def _headers_mtime():
-    hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h')]
+def _headers_digest():
+    """one digest over every header a translation unit may include"""
+    hs = sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.h'))
     hs.append(os.path.join(ROOT, 'include', 'fplhip.h'))
-    return max(os.path.getmtime(h) for h in hs)
+    h = hashlib.sha256()
+    for p in hs:
+        h.update(os.path.basename(p).encode() + b'\0')
+        h.update(open(p, 'rb').read())
+    return h.hexdigest()
 
 
-def _compile(unit, force, hdr_m):
+def _compile(unit, force, hdr_digest):
     src, stem, extra = unit
     obj = os.path.join(OBJ_DIR, stem + '.o')
+    stamp = obj + '.sha256'
     sp = os.path.join(HERE, src)
-    if (not force and os.path.exists(obj)
-            and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_m)):
+    h = hashlib.sha256()
+    h.update(open(sp, 'rb').read())
+    h.update(hdr_digest.encode())
+    h.update(' '.join(CXXFLAGS + extra).encode())
+    want = h.hexdigest()
+    if (not force and os.path.exists(obj) and os.path.exists(stamp)
+            and open(stamp).read().strip() == want):
         return obj, None
     cmd = [HIPCC] + CXXFLAGS + extra + ['-c', sp, '-o', obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True)
     if r.returncode != 0:
+        if os.path.exists(stamp):
+            os.remove(stamp)
         raise RuntimeError('hipcc failed for %s:\n%s' % (stem, r.stdout))
+    with open(stamp, 'w') as f:
+        f.write(want + '\n')
     return obj, r.stdout
 
 
 def build(force=False, jobs=4, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    hdr_m = _headers_mtime()
+    hdr_m = _headers_digest()
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         results = list(ex.map(lambda s: _compile(s, force, hdr_m), srcs))
@@ -76,13 +95,21 @@ def build(force=False, jobs=4, verbose=True):
     for u, (_, out) in zip(srcs, results):
         if out and verbose and out.strip():
             print('[%s]\n%s' % (u[1], out.strip()))
-    if (rebuilt or not os.path.exists(LIB)
-            or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)):
+    # the library carries the digest of the objects it was linked from
+    lh = hashlib.sha256()
+    for o in objs:
+        lh.update(open(o + '.sha256').read().encode())
+    lib_want = lh.hexdigest()
+    lib_stamp = LIB + '.sha256'
+    if (rebuilt or not os.path.exists(LIB) or not os.path.exists(lib_stamp)
+            or open(lib_stamp).read().strip() != lib_want):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n%s' % r.stdout)
+        with open(lib_stamp, 'w') as f:
+            f.write(lib_want + '\n')
         if verbose:
             print('linked %s (%d objects, rebuilt: %s)' % (
                 os.path.relpath(LIB, ROOT), len(objs), ', '.join(rebuilt) or '-'))

@@ -948,48 +948,36 @@ void vgg_state_free(fpl_ctx *ctx, void *p) {
   delete s;
 }
 
-bool is_vgg_like(const fpl_program *prog) {
+// The two VGG-style graphs of flypylib/fplmodels.py:102-172 differ only in the kernel
+// edge of the second convolution of each block: vgg_like 3,1 | 3,1 | 3,1,1,1 and
+// vgg_like2 3,3 | 3,3 | 3,1,1,1 (48 channels, 96 in the two "dense" layers, biased
+// sigmoid head, stride 4).  Returns 1 / 2 for those, 0 for anything else.
+static int vgg_variant(const fpl_program *prog) {
   static const int kinds[10] = {0, 0, 1, 0, 0, 1, 0, 0, 0, 0};
-  static const int ks[10] = {3, 1, 0, 3, 1, 0, 3, 1, 1, 1};
   static const int cin[10] = {1, 48, 48, 48, 48, 48, 48, 48, 96, 96};
   static const int cout[10] = {48, 48, 48, 48, 48, 48, 48, 96, 96, 1};
-  if (prog->ops.size() != 10) return false;
-  if (prog->stride[0] != 4 || prog->stride[1] != 4 || prog->stride[2] != 4) return false;
+  static const int ks_tail[4] = {3, 1, 1, 1};
+  if (prog->ops.size() != 10) return 0;
+  if (prog->stride[0] != 4 || prog->stride[1] != 4 || prog->stride[2] != 4) return 0;
+  const int k2 = prog->ops[1].k;                      // 1: vgg_like, 3: vgg_like2
+  if (k2 != 1 && k2 != 3) return 0;
   for (int i = 0; i < 10; ++i) {
     const fpl_op &op = prog->ops[i];
-    if (op.kind != kinds[i]) return false;
-    if (op.src0 != (i == 0 ? 0 : prog->ops[i - 1].dst)) return false;
+    if (op.kind != kinds[i]) return 0;
+    if (op.src0 != (i == 0 ? 0 : prog->ops[i - 1].dst)) return 0;
     if (op.kind == FPL_OP_CONV) {
-      if (op.k != ks[i] || op.cin != cin[i] || op.cout != cout[i]) return false;
-      if (op.act != (i == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return false;
+      const int k = i >= 6 ? ks_tail[i - 6] : ((i == 1 || i == 4) ? k2 : 3);
+      if (op.k != k || op.cin != cin[i] || op.cout != cout[i]) return 0;
+      if (op.act != (i == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return 0;
     } else if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) {
-      return false;
+      return 0;
     }
   }
-  return prog->out_tensor == prog->ops[9].dst;
+  if (prog->out_tensor != prog->ops[9].dst) return 0;
+  return k2 == 1 ? 1 : 2;
 }
-
-// vgg_like2: the second conv of each block is 3x3x3 too (flypylib/fplmodels.py:138-172)
-bool is_vgg_like2(const fpl_program *prog) {
-  static const int kinds[10] = {0, 0, 1, 0, 0, 1, 0, 0, 0, 0};
-  static const int ks[10] = {3, 3, 0, 3, 3, 0, 3, 1, 1, 1};
-  static const int cin[10] = {1, 48, 48, 48, 48, 48, 48, 48, 96, 96};
-  static const int cout[10] = {48, 48, 48, 48, 48, 48, 48, 96, 96, 1};
-  if (prog->ops.size() != 10) return false;
-  if (prog->stride[0] != 4 || prog->stride[1] != 4 || prog->stride[2] != 4) return false;
-  for (int i = 0; i < 10; ++i) {
-    const fpl_op &op = prog->ops[i];
-    if (op.kind != kinds[i]) return false;
-    if (op.src0 != (i == 0 ? 0 : prog->ops[i - 1].dst)) return false;
-    if (op.kind == FPL_OP_CONV) {
-      if (op.k != ks[i] || op.cin != cin[i] || op.cout != cout[i]) return false;
-      if (op.act != (i == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return false;
-    } else if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) {
-      return false;
-    }
-  }
-  return prog->out_tensor == prog->ops[9].dst;
-}
+bool is_vgg_like(const fpl_program *prog) { return vgg_variant(prog) == 1; }
+bool is_vgg_like2(const fpl_program *prog) { return vgg_variant(prog) == 2; }
 
 int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
   VggFastState *st = (VggFastState *)prog->fast_state_h16[FPL_H16_SLOT];

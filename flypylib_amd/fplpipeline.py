@@ -374,11 +374,16 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
     if dist is not None and world > 1:
         dist.barrier()
     locs, conf = [], []
+    missing = 0
     for rr in roi[0]:
         ff = fri_filename(working_dir, rr)
         if not os.path.isfile(ff):
             if dist is None and world > 1:
-                continue              # another rank's substack, no rendezvous to wait on
+                # WORLD_SIZE > 1 from the environment but no process group: the other
+                # ranks' substacks cannot be waited for - this rank returns its own part
+                # and all.p is NOT written (a silently incomplete merge is worse than none)
+                missing += 1
+                continue
             raise RuntimeError('substack result %s is missing' % ff)
         with open(ff, 'rb') as f_in:
             obj = pickle.load(f_in)
@@ -386,7 +391,13 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
         conf.append(obj['conf'])
     obj = {'locs': np.concatenate(locs) if locs else np.zeros((0, 3)),
            'conf': np.concatenate(conf) if conf else np.zeros(0)}
-    if rank == 0:
+    if missing:
+        import warnings
+        warnings.warn('full_roi_inference: %d of %d substacks belong to other ranks and there '
+                      'is no initialised process group to wait for them: all.p not written; '
+                      'run again once every rank has finished (finished substacks are reused)'
+                      % (missing, len(roi[0])))
+    elif rank == 0:
         with open('%s/all.p' % working_dir, 'wb') as f_out:
             pickle.dump(obj, f_out)
     return obj

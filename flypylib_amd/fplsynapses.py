@@ -11,69 +11,75 @@ import numpy as np
 from . import fplutils
 
 
+def _raveler_records(doc):
+    """{'data': [{'T-bar': {'location': [x, y, z], 'confidence': c}}, ...]}"""
+    tbars = [entry['T-bar'] for entry in doc['data']]
+    return ([t['location'] for t in tbars], [t['confidence'] for t in tbars], [])
+
+
+def _dvid_records(elements):
+    """[{'Kind': 'PreSyn', 'Pos': [x, y, z], 'Prop': {'conf': '0.9', 'err': ...}}, ...];
+    a list holding one such list is unwrapped; other kinds (PostSyn ...) are skipped;
+    a missing confidence reads as 1, a missing error estimate as None"""
+    if len(elements) == 1 and isinstance(elements[0], list):
+        elements = elements[0]
+    pre = [e for e in elements if e['Kind'] == 'PreSyn']
+    prop = [e['Prop'] for e in pre]
+    return ([e['Pos'] for e in pre],
+            [float(p['conf']) if 'conf' in p else 1.0 for p in prop],
+            [float(p['err']) if 'err' in p else None for p in prop])
+
+
 def load_from_json(fn, vol_sz=None, buffer=None):
-    """read T-bars from a json file (or json text): Raveler format
-    {'data': [{'T-bar': {'location', 'confidence'}}]} or DVID annotation elements
-    [{'Kind': 'PreSyn', 'Pos', 'Prop': {'conf', 'err'}}].  With `buffer` (and
-    `vol_sz`), points within the buffer of the volume faces are dropped.
-    -> {'locs': (N,3), 'conf': (N,), 'err': (N,)} (reference :11-76)"""
-    if os.path.isfile(fn):
-        with open(fn) as json_file:
-            data = json.load(json_file)
+    """T-bars of a json file (or json text) in either of the formats the reference's
+    tools exchange (reference fplsynapses.py:11-76): Raveler ({'data': [{'T-bar': ...}]})
+    or DVID annotation elements.  With `buffer` (and `vol_sz`) the points closer than
+    the buffer to a face of the volume are dropped.
+    -> {'locs': (N, 3), 'conf': (N,), 'err': (N,)}"""
+    text = open(fn).read() if os.path.isfile(fn) else fn
+    doc = json.loads(text)
+    if isinstance(doc, dict) and 'data' in doc:
+        locs, conf, err = _raveler_records(doc)
+    elif doc is None:
+        locs, conf, err = [], [], []
     else:
-        data = json.loads(fn)
-    locs, conf, err = [], [], []
-    if isinstance(data, dict) and 'data' in data.keys():        # Raveler format
-        for syn in data['data']:
-            locs.append(syn['T-bar']['location'])
-            conf.append(syn['T-bar']['confidence'])
-    elif data is not None:                                       # DVID format
-        if len(data) == 1 and isinstance(data[0], list):
-            data = data[0]
-        for syn in data:
-            if syn['Kind'] != 'PreSyn':
-                continue
-            conf.append(float(syn['Prop']['conf']) if 'conf' in syn['Prop'] else 1.0)
-            err.append(float(syn['Prop']['err']) if 'err' in syn['Prop'] else None)
-            locs.append(syn['Pos'])
+        locs, conf, err = _dvid_records(doc)
     locs, conf, err = np.asarray(locs), np.asarray(conf), np.asarray(err)
     if locs.size > 0 and buffer is not None and buffer != 0:
         assert vol_sz is not None, 'to apply buffer, must also supply volume size'
-        buffer = fplutils.to3d(buffer)
-        vol_sz = fplutils.to3d(vol_sz)
-        drop = np.zeros(locs.shape[0], bool)
-        for a in range(3):
-            drop |= (locs[:, a] < buffer[a]) | (locs[:, a] >= vol_sz[a] - buffer[a])
-        locs, conf = locs[~drop], conf[~drop]
+        lo = np.asarray(fplutils.to3d(buffer))
+        hi = np.asarray(fplutils.to3d(vol_sz)) - lo
+        inside = np.all((locs >= lo) & (locs < hi), axis=1)
+        locs, conf = locs[inside], conf[inside]
     return {'locs': locs, 'conf': conf, 'err': err}
 
 
-def tbars_to_json_format(tbars_np, json_file=None, user_name='$fpl', labels=None):
-    """DVID annotation elements for a {'locs','conf'} point list (reference :78-96)"""
-    tbars_json = []
-    locs, conf = tbars_np['locs'], tbars_np['conf']
-    for ii in np.arange(conf.size):
-        tt = {'Kind': 'PreSyn', 'Pos': locs[ii, :].astype('int').tolist(),
-              'Prop': {'conf': '%.03f' % conf[ii], 'user': user_name}}
-        if labels is not None:
-            tt['body ID'] = str(labels[ii])
-        tbars_json.append(tt)
+def _dump(obj, json_file):
     if json_file is not None:
-        with open(json_file, 'w') as f_out:
-            json.dump(tbars_json, f_out)
-    return tbars_json
+        with open(json_file, 'w') as out:
+            json.dump(obj, out)
+    return obj
+
+
+def tbars_to_json_format(tbars_np, json_file=None, user_name='$fpl', labels=None):
+    """DVID annotation elements of a {'locs', 'conf'} point list (reference :78-96):
+    integer positions, the confidence as a '%.03f' string, optionally the body id"""
+    positions = np.asarray(tbars_np['locs']).astype('int').tolist()
+    elements = [{'Kind': 'PreSyn', 'Pos': pos,
+                 'Prop': {'conf': '%.03f' % c, 'user': user_name}}
+                for pos, c in zip(positions, np.asarray(tbars_np['conf']).ravel())]
+    if labels is not None:
+        for element, body in zip(elements, labels):
+            element['body ID'] = str(body)
+    return _dump(elements, json_file)
 
 
 def tbars_to_json_format_raveler(tbars_np, json_file=None):
-    """Raveler-format json for a {'locs','conf'} point list (reference :98-111)"""
-    locs, conf = tbars_np['locs'], tbars_np['conf']
-    tbars_json = {'data': [{'T-bar': {'confidence': '%.03f' % conf[ii],
-                                      'location': locs[ii, :].astype('int').tolist()}}
-                           for ii in np.arange(conf.size)]}
-    if json_file is not None:
-        with open(json_file, 'w') as f_out:
-            json.dump(tbars_json, f_out)
-    return tbars_json
+    """Raveler json of a {'locs', 'conf'} point list (reference :98-111)"""
+    positions = np.asarray(tbars_np['locs']).astype('int').tolist()
+    doc = {'data': [{'T-bar': {'confidence': '%.03f' % c, 'location': pos}}
+                    for pos, c in zip(positions, np.asarray(tbars_np['conf']).ravel())]}
+    return _dump(doc, json_file)
 
 
 def write_labels_mask(tbars, roi_mask, radius_use, radius_ign, buffer_size, prefix):

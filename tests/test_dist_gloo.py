@@ -113,3 +113,94 @@ def test_slab_sharded_inference_two_ranks_gloo():
 def test_gradient_allreduce_two_ranks_gloo():
     err = _run(_train_worker)
     assert err < 1e-12
+
+
+# ---- the product's own reducers (flypylib_amd/train.py) with a stand-in trainer ---------
+class _FakeCtx:
+    def __init__(self, device, uuid):
+        self.device, self._uuid = device, uuid
+
+    def comm_info(self):
+        return dict(rank=0, nranks=0, lib='')
+
+    def device_uuid(self):
+        return self._uuid
+
+
+class _FakeTrainer:
+    """the three calls the reducers make on a _capi.Trainer"""
+
+    def __init__(self, grads, ctx):
+        self.g = np.asarray(grads, np.float32)
+        self.ctx = ctx
+
+    def get_grads_flat(self):
+        return self.g.copy()
+
+    def set_grads_flat(self, g):
+        self.g = np.asarray(g, np.float32).copy()
+
+
+def _reducer_worker(rank, world, port, out_q):
+    _init(rank, world, port)
+    from flypylib_amd import train
+    # both ranks report the same GPU: they cannot form an RCCL communicator, so
+    # setup_rank_comm must hand back the torch.distributed reducer (host-staged on gloo)
+    ctx = _FakeCtx(0, '0000:05:00.0')
+    red = train.setup_rank_comm(ctx, dist)
+    tr = _FakeTrainer(np.arange(5) * (rank + 1), ctx)
+    scale = red(tr)
+    # and through the module-level entry point fit_generator's protocol uses
+    tr2 = _FakeTrainer(np.full(3, 2.0 + rank), ctx)
+    scale2 = train.allreduce_grads(tr2)
+    out_q.put((rank, red.kind, scale, tr.g.copy(), scale2, tr2.g.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_product_reducers_two_ranks_sharing_a_gpu():
+    """train.setup_rank_comm / TorchDistReducer / allreduce_grads under a real 2-rank
+    gloo group (the towers' code path when ranks share a GPU; the RCCL branch needs two
+    devices and is covered on the GPU box)"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r = q.get(timeout=120)
+        got[r[0]] = r
+    for p in procs:
+        p.join(30)
+    for rank in (0, 1):
+        _, kind, scale, g, scale2, g2 = got[rank]
+        assert kind == 'torch.distributed' and scale == 0.5 and scale2 == 0.5
+        assert np.array_equal(g, np.arange(5) * 3.0)          # sum over the two ranks
+        assert np.array_equal(g2, np.full(3, 5.0))
+
+
+def test_host_tower_reducer_threads():
+    """HostTowerReducer: n towers of one process meet at a barrier, every one leaves
+    with the same sum"""
+    import threading
+    from flypylib_amd import train
+    n = 3
+    red = train.HostTowerReducer(n)
+    trainers = [_FakeTrainer(np.arange(4) + 10 * r, _FakeCtx(0, 'x')) for r in range(n)]
+    scales = [None] * n
+
+    def work(r):
+        for _ in range(2):                                   # two steps: the barrier re-arms
+            scales[r] = red(trainers[r], r)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    first = np.arange(4) * 3 + 30.0                          # sum of the towers, step 1
+    for r in range(n):
+        assert scales[r] == 1.0 / n
+        assert np.array_equal(trainers[r].g, first * 3)      # step 2 summed three equal arenas
