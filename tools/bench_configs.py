@@ -13,6 +13,10 @@
   pipeline  configs[4] shape at one substack: vgg_like bf16 inference of a 582^3
             substack + voxel2obj, detections diffed against the CPU oracle on the
             same prediction
+  c3share   configs[2] at its stated size: rank 0's slab of the 1024 x 2048 x 2048 volume
+            (2 of 13 tile rows + halo), bit-compared with the same rows of a whole-volume run
+  c5share   configs[4] at its stated size: rank 0's 64 of the 512 substacks of a 4096^3
+            synthetic ROI, one substack diffed against the CPU oracle
 These are NOT the driver's bench line (bench.py); they document where the other
 rows of SURVEY section 8 stand.
 """
@@ -239,6 +243,116 @@ def main():
             detections_identical_to_cpu_oracle=bool(same), cpu_oracle_v2o_s=t_cpu,
             kernel_ms_total=kern)
         print(json.dumps(res['full_roi_inference_%d' % n]), flush=True)
+        shutil.rmtree(wd, ignore_errors=True)
+    if 'c3share' in what:
+        # configs[2] at its stated size, one rank's share: unet_like2 over the
+        # 1024 x 2048 x 2048 volume is 13 tile rows of pitch 82 along z; 8 ranks take
+        # 2,2,2,2,2,1,1,1 of them.  Rank 0's slab (2 rows + halo = 182 z rows) runs as a
+        # standalone volume, as bench.py / torchrun ranks do, and is compared bit for bit
+        # with the same rows of a run over the WHOLE volume on this one GPU.
+        from flypylib_amd import multi_gpu
+        Z, Y, X = 1024, 2048, 2048
+        tile, off, world = 100, 9, 8
+        g = fplmodels.unet_like2(tile)[0]
+        synth.synthetic_weights(g, 7)
+        prog = _capi.Program(ctx, g, (1, 1, 1))
+        n_rows = multi_gpu.n_tile_rows(Z, tile, off)
+        parts = multi_gpu.slab_partition(n_rows, world)
+        zb, ze = parts[0]
+        pitch = tile - 2 * off
+        z_hi = min(ze * pitch + 2 * off, Z)
+        whole_src = torch.empty((Z, Y, X), dtype=torch.uint8, device='cuda')
+        ctx.synth_volume_u8(3, (Z, Y, X), out=whole_src)
+        whole_dst = torch.empty((Z, Y, X), dtype=torch.float32, device='cuda')
+        kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F16)
+        t0 = time.perf_counter()
+        prog.infer_volume(whole_src, (tile,) * 3, (off,) * 3, dst=whole_dst, dims=(Z, Y, X), **kw)
+        ctx.synchronize()
+        t_whole = time.perf_counter() - t0
+        slab_src = whole_src[:z_hi].contiguous()
+        slab_dst = torch.empty((z_hi, Y, X), dtype=torch.float32, device='cuda')
+        prog.infer_volume(slab_src, (tile,) * 3, (off,) * 3, dst=slab_dst, dims=(z_hi, Y, X), **kw)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        prog.infer_volume(slab_src, (tile,) * 3, (off,) * 3, dst=slab_dst, dims=(z_hi, Y, X), **kw)
+        ctx.synchronize()
+        t_slab = time.perf_counter() - t0
+        lo, hi = multi_gpu.slab_rows((zb, ze), Z, tile, off)
+        same = bool(torch.equal(slab_dst[lo:hi], whole_dst[lo:hi]))
+        own = (hi - lo - off) * (Y - 2 * off) * (X - 2 * off)     # valid voxels rank 0 owns
+        res['configs2_rank0_share'] = dict(
+            volume=[Z, Y, X], tile_rows=n_rows, partition=parts, rank0_rows=[lo, hi],
+            slab_dims=[z_hi, Y, X], seconds=t_slab, mvox_s=own / t_slab / 1e6,
+            tflops_algorithmic=own * 350720 / t_slab / 1e12,
+            whole_volume_seconds_one_gpu_cold=t_whole,
+            whole_volume_mvox_s=(Z - 18) * (Y - 18) * (X - 18) / t_whole / 1e6,
+            slab_rows_identical_to_whole=same, executor=ctx.last_path())
+        print(json.dumps(res['configs2_rank0_share']), flush=True)
+        del whole_src, whole_dst, slab_src, slab_dst
+    if 'c5share' in what:
+        # configs[4] at its stated size, one rank's share: the 4096^3 ROI is 512 substacks
+        # of 512^3 (+ 35 buffer: 582^3 cubes); with 8 ranks a rank takes every 8th = 64.
+        # Rank 3's share is run (x block 3: interior substacks; rank 0's all touch the x = 0
+        # face, where the zero fill outside the volume leaves next to no detections).
+        # RANK / WORLD_SIZE come from the environment as under torchrun; there is no process
+        # group here, so the merge step warns and returns the rank's own detections.
+        import pickle
+        import shutil
+        import tempfile
+        import warnings
+        from flypylib_amd import FplNetwork, fplpipeline
+        from oracle import voxel2obj_oracle
+        n = 4096
+        net = FplNetwork(fplmodels.vgg_like, precision='f16')
+        synth.synthetic_weights(net.train_single, 9)
+        net._set_infer()
+        wd = tempfile.mkdtemp(prefix='fri_')
+        src = 'synth://5,%d,%d,%d' % (n, n, n)
+        fplobjdetect.gen_full_tab_roi(wd + '/roi', src, None, step_size=512)
+        roi = fplobjdetect.roi_from_txt(wd + '/roi_00.txt')[0]
+        norm = [128., 33., 0.5]
+        share_rank = 3
+        os.environ['RANK'], os.environ['WORLD_SIZE'] = str(share_rank), '8'
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fplobjdetect.full_roi_inference(src, None, roi[:8], net, 0.1, wd + '/warm', norm)
+            ctx.timing(True); ctx.timing_reset()
+            t0 = time.perf_counter()
+            out = fplobjdetect.full_roi_inference(src, None, wd + '/roi_00.txt', net, 0.1,
+                                                  wd + '/work', norm)
+            dt = time.perf_counter() - t0
+        del os.environ['RANK'], os.environ['WORLD_SIZE']
+        kern = {k: round(v['ms'], 2) for k, v in ctx.timing_get().items()}
+        ctx.timing(False)
+        mine = roi[share_rank::8]
+        done = [ss for ss in roi if os.path.isfile(fplobjdetect.fri_filename(wd + '/work', ss))]
+        # the substack of the share with the most detections goes to the CPU oracle
+        counts = [len(pickle.load(open(fplobjdetect.fri_filename(wd + '/work', s_), 'rb'))['conf'])
+                  for s_ in mine]
+        ss = mine[int(np.argmax(counts))]
+        sz = ss.size + 70
+        cube = ctx.malloc((sz,) * 3, np.uint8)
+        pred = ctx.malloc((sz,) * 3, np.float32)
+        ctx.synth_substack_u8(5, (n, n, n), (sz,) * 3, [ss.z - 35, ss.y - 35, ss.x - 35], cube)
+        st = fplpipeline.normalisation_from_histogram(ctx.histogram_u8(cube), norm)
+        net.infer_network.program.infer_volume(cube, net.infer_sz, net.rf_offset, mean=st['mn_use'],
+                                               std=norm[1], precision=_capi.PREC_F16, dst=pred,
+                                               dims=(sz,) * 3)
+        t0 = time.perf_counter()
+        ref = voxel2obj_oracle.voxel2obj(pred.to_host(), 27, 5, (ss.x - 35, ss.y - 35, ss.z - 35), 35, 0.1)
+        t_cpu = time.perf_counter() - t0
+        got = pickle.load(open(fplobjdetect.fri_filename(wd + '/work', ss), 'rb'))
+        same = np.array_equal(ref['locs'], got['locs']) and np.array_equal(ref['conf'], got['conf'])
+        res['configs4_rank_share'] = dict(
+            roi=[n, n, n], rank=share_rank, world=8, substacks_total=len(roi), substacks_rank=len(mine),
+            detections_per_substack_max=int(max(counts)),
+            substacks_written=len(done), all_p_written=os.path.isfile(wd + '/work/all.p'),
+            seconds=dt, mvox_s_rank=len(mine) * 512 ** 3 / dt / 1e6,
+            detections_rank=int(len(out['conf'])), checked_substack=list(ss),
+            checked_substack_detections=int(len(got['conf'])),
+            detections_identical_to_cpu_oracle=bool(same), cpu_oracle_v2o_s=t_cpu,
+            kernel_ms_total=kern)
+        print(json.dumps(res['configs4_rank_share']), flush=True)
         shutil.rmtree(wd, ignore_errors=True)
     if a.out:
         json.dump(res, open(a.out, 'w'), indent=1)
