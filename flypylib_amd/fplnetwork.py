@@ -204,13 +204,8 @@ class FplNetwork:
         Returns float32 predictions of the same shape; the rf_offset border
         shell is zero."""
         if isinstance(image, str):
-            try:
-                import h5py
-            except ImportError:
-                raise ImportError('reading %r needs h5py, which is not '
-                                  'installed; pass an array' % image)
-            with h5py.File(image, 'r') as f:
-                image = f['/main'][:]
+            from . import keras_io
+            image = np.load(image) if image.endswith('.npy') else keras_io.read_main(image)
 
         assert self.infer_network is not None, \
             'network has not been trained'
@@ -235,7 +230,7 @@ class FplNetwork:
         """per-voxel log loss of the prediction on labelled, unmasked voxels
         (reference :191-220): confident negatives (loss < 0.005) are dropped, losses
         are clamped to the optional [lo, hi] thresholds.  `lm_prefix`: the reference's
-        '<prefix>labels.h5' / '<prefix>mask.h5' prefix (needs h5py) or a
+        '<prefix>labels.h5' / '<prefix>mask.h5' prefix or a
         (labels, mask) pair of arrays / .npy paths."""
         from .fplobjdetect import _load_main
         pred = self.infer(image, normalize=normalize)

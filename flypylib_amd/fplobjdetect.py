@@ -71,12 +71,7 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     """
     buffer_sz = fplutils.to3d(buffer_sz)
     if isinstance(pred, str):
-        try:
-            import h5py
-        except ImportError:
-            raise ImportError('reading %r needs h5py; pass an array' % pred)
-        with h5py.File(pred, 'r') as f:
-            pred = f['/main'][:]
+        pred = _load_main(pred)
     r = int(obj_min_dist)
     if isinstance(pred, np.ndarray):
         if pred.dtype != np.float32:
@@ -141,23 +136,21 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
 
 
 def _load_main(src):
+    """an array, a `.npy` path, or - as in the reference - an `.h5` path whose dataset
+    'main' holds the volume (h5py when installed, else the package's own reader)"""
     if isinstance(src, np.ndarray):
         return src
     if isinstance(src, str) and src.endswith('.npy'):
         return np.load(src)
-    try:
-        import h5py
-    except ImportError:
-        raise ImportError('reading %r needs h5py; pass arrays instead' % (src,))
-    with h5py.File(src, 'r') as f:
-        return f['/main'][:]
+    from . import keras_io
+    return keras_io.read_main(src)
 
 
 def gen_batches(train_data, context_sz, batch_sz, is_mask=False, rng=None):
     """generator of balanced training batches (reference fplobjdetect.py:27-130).
 
     train_data: sequence of (image, labels_prefix) as in the reference (h5 paths;
-    needs h5py) or of (image, labels, mask) arrays.  Yields
+    read with h5py or the package's own reader) or of (image, labels, mask) arrays.  Yields
     (data (B,s,s,s,1) float32, labels (B,1,1,1,1) uint8 or (B,6,6,6,1) if is_mask).
     Half of each batch is centred on label-0 voxels, half on label-1 voxels
     (interleaved), followed by rot90 / flip augmentation.
@@ -309,7 +302,7 @@ def aggregate_pr(results):
 def _volumes(train_data, half):
     """(image, labels, mask[, weights]) arrays per training volume with the mask
     cleared where a patch would not fit (reference :690-705); entries are
-    (image, labels_prefix[, weights]) h5 paths as in the reference (needs h5py) or
+    (image, labels_prefix[, weights]) h5 paths as in the reference or
     (image, labels, mask[, weights]) arrays / .npy paths"""
     vols = []
     for tr in train_data:

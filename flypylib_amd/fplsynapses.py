@@ -86,8 +86,9 @@ def write_labels_mask(tbars, roi_mask, radius_use, radius_ign, buffer_size, pref
     """training labels and mask around annotated T-bars (reference :251-310): label 1
     within `radius_use` of a T-bar; the mask is cleared in the shell between
     `radius_use` and `radius_ign` (neither positive nor negative) and within
-    `buffer_size` of the faces.  Written as '<prefix>_labels.npy' / '<prefix>_mask.npy'
-    (the reference writes .h5; h5py is not available here) and returned."""
+    `buffer_size` of the faces.  Written as the reference's '<prefix>_labels.h5' /
+    '<prefix>_mask.h5' (dataset 'main') and as '<prefix>_labels.npy' / '<prefix>_mask.npy',
+    and returned."""
     radius_use_flt = fplutils.set_filter(radius_use)
     if radius_ign is not None:
         radius_ign_flt = 1 - fplutils.set_filter(radius_ign)
@@ -112,6 +113,9 @@ def write_labels_mask(tbars, roi_mask, radius_use, radius_ign, buffer_size, pref
         sl[ax] = slice(0, buffer_size); mask[tuple(sl)] = 0
         sl[ax] = slice(-buffer_size, None); mask[tuple(sl)] = 0
     if prefix is not None:
+        from . import keras_io
         np.save('%s_labels.npy' % prefix, labels)
         np.save('%s_mask.npy' % prefix, mask)
+        keras_io.write_main('%s_labels.h5' % prefix, labels)
+        keras_io.write_main('%s_mask.h5' % prefix, mask)
     return labels, mask

@@ -42,6 +42,23 @@ def open_h5(path):
         return h5min.File(path)
 
 
+def read_main(path):
+    """the '/main' dataset of an .h5 volume file, as the reference stores images,
+    predictions, labels and masks (`fplnetwork.py:137-139`, `fplobjdetect.py:154-156`)"""
+    f = open_h5(path)
+    try:
+        return np.asarray(f['main'][...])
+    finally:
+        if hasattr(f, 'close'):
+            f.close()
+
+
+def write_main(path, array):
+    """one contiguous dataset 'main' (what `h5py.File(path).create_dataset('main',
+    data=array)` writes)"""
+    h5min.write(path, {'datasets': {'main': np.asarray(array)}})
+
+
 def _role(weight_name):
     """'conv3d_3/kernel:0' -> 'kernel'"""
     return weight_name.split('/')[-1].split(':')[0]

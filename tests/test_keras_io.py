@@ -209,3 +209,20 @@ def test_reference_pickle_classes_map_onto_this_package():
     assert net.model is fplmodels.unet_like2
     assert net.compile_args['loss'] == fplmodels.masked_focal_loss == 'masked_focal_loss'
     assert net.rf_offset == (9, 9, 9) and net.train_single is None
+
+
+def test_main_dataset_volume_files(tmp_path):
+    """'.h5' volumes with one dataset 'main' - how the reference stores images,
+    predictions, labels and masks - through _load_main / write_labels_mask"""
+    from flypylib_amd import fplobjdetect, fplsynapses
+    vol = (np.arange(4 * 5 * 6) % 251).astype(np.uint8).reshape(4, 5, 6)
+    p = str(tmp_path / 'v.h5')
+    keras_io.write_main(p, vol)
+    assert np.array_equal(keras_io.read_main(p), vol)
+    assert np.array_equal(fplobjdetect._load_main(p), vol)
+    tb = {'locs': np.array([[12, 14, 16]]), 'conf': np.ones(1)}
+    labels, mask = fplsynapses.write_labels_mask(tb, np.ones((36, 38, 40), 'uint8'), 3, 6, 4,
+                                                 str(tmp_path / 'lm'))
+    assert np.array_equal(keras_io.read_main(str(tmp_path / 'lm_labels.h5')), labels)
+    assert np.array_equal(keras_io.read_main(str(tmp_path / 'lm_mask.h5')), mask)
+    assert labels.sum() == 123            # set_filter(3): 123 voxels
