@@ -263,33 +263,22 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
         print('to process: %d' % len(todo))
 
     assert network.infer_network is not None, 'network has not been trained'
-    prog = network.infer_network.program
-    ctx = prog.ctx
+    prog0 = network.infer_network.program
+    dev = prog0.ctx.device
     prec = fplobjdetect_precision(network, precision)
-    # two lanes on the GPU: this thread prepares and infers substack i+1 on the
-    # network's context while a second thread post-processes substack i on a context of
-    # its own (its own HIP stream and voxel2obj state); predictions are double-buffered
-    from . import runtime
+    # Lanes on the GPU.  An inference lane (a host thread + context + copy of the program)
+    # prepares and infers its substacks; each has a post-processing lane of its own (a
+    # second thread + context: own HIP stream and voxel2obj state) that works on substack
+    # i while the inference lane is on i + 1, predictions double-buffered.  Both kinds go
+    # through host code between kernels (statistics, order statistics, NMS rounds), so one
+    # pair leaves the GPU idle while both sit there (18 % of the span in a kernel trace):
+    # FPL_PIPE_LANES pairs (default 3; 1536^3 on one GPU: 0.310 / 0.297 / 0.286 s with 1 / 2 / 3)
+    # interleave their substacks.
+    from . import _capi, runtime
     import queue
-    ctx_post = runtime.get_context(ctx.device, lane=1)
-    bufs = {}
-
-    def buffers(size):
-        if size not in bufs:
-            bufs[size] = (ctx.malloc((size,) * 3, np.uint8),
-                          [ctx.malloc((size,) * 3, np.float32) for _ in range(2)],
-                          [threading.Semaphore(1), threading.Semaphore(1)])
-        return bufs[size]
-
-    # host-side prefetch of the next cube (array sources); synthetic cubes are made
-    # on the device and need none
-    staged = {}
-
-    def stage(i):
-        if i < len(mine) and isinstance(src, _ArraySource):
-            ss = mine[i]
-            sz = ss.size + 2 * buffer_sz
-            staged[i] = src.cube_host([ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz], sz)
+    n_lanes = max(1, min(int(os.environ.get('FPL_PIPE_LANES', '3')), 4, max(len(mine), 1)))
+    failure = []
+    done_count = [0]
 
     def write_result(ss, out):
         tmp_fn = fri_filename(working_dir, ss) + '.tmp%d' % rank
@@ -297,79 +286,114 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
             pickle.dump(out, f_out)
         os.replace(tmp_fn, fri_filename(working_dir, ss))     # a resume never sees half a file
 
-    work = queue.Queue()
-    failure = []
+    def run_lane(lane, items):
+        ctx = prog0.ctx if lane == 0 else runtime.get_context(dev, lane=2 * lane)
+        prog = prog0 if lane == 0 else _capi.Program(ctx, network.infer_network.graph,
+                                                     network.rf_stride)
+        ctx_post = runtime.get_context(dev, lane=2 * lane + 1)
+        bufs = {}
 
-    def post_process():
-        while True:
-            item = work.get()
-            if item is None:
-                return
-            ss, pred, free, seg_kw = item
-            try:
-                if not failure:
-                    out = fplobjdetect.voxel2obj(
-                        pred, obj_min_dist, smoothing_sigma,
-                        (ss.x - buffer_sz, ss.y - buffer_sz, ss.z - buffer_sz),
-                        buffer_sz, thd, _ctx=ctx_post, **seg_kw)
-                    write_result(ss, out)
-            except BaseException as e:           # surfaces in the main thread below
-                failure.append(e)
-            finally:
-                free.release()
+        def buffers(size):
+            if size not in bufs:
+                bufs[size] = (ctx.malloc((size,) * 3, np.uint8),
+                              [ctx.malloc((size,) * 3, np.float32) for _ in range(2)],
+                              [threading.Semaphore(1), threading.Semaphore(1)])
+            return bufs[size]
 
-    poster = threading.Thread(target=post_process)
-    poster.start()
-    stage(0)
-    n_done = 0
-    try:
-        for i, ss in enumerate(mine):
-            if failure:
-                break
-            th = threading.Thread(target=stage, args=(i + 1,))
-            th.start()
-            image_sz = ss.size + 2 * buffer_sz
-            origin = [ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz]
-            cube, preds, sems = buffers(image_sz)
-            if isinstance(src, _ArraySource):
-                image = staged.pop(i)
-                have = image is not None
-                if have:
-                    cube.from_host(image)
-            else:
-                have = src.cube_device(ctx, origin, image_sz, cube)
-            if not have:
-                write_result(ss, {'locs': np.zeros((0, 3)), 'conf': np.zeros(0)})
-            else:
-                st = normalisation_from_histogram(ctx.histogram_u8(cube), image_normalize)
-                _write_norm(norm_dir, ss, buffer_sz, image_normalize, st)
-                sems[i % 2].acquire()             # its previous prediction is post-processed
-                prog.infer_volume(cube, network.infer_sz, network.rf_offset,
-                                  mean=st['mn_use'], std=image_normalize[1],
-                                  precision=prec, dst=preds[i % 2], dims=(image_sz,) * 3)
-                seg_kw = {}
-                if seg_src is not None:           # fri_postprocess, reference :1143-1150
-                    seg_dt = seg_src.arr.dtype if seg_src.arr.dtype.itemsize in (4, 8) \
-                        else np.uint64
-                    seg_kw = dict(seg=seg_src.cube_host(origin, image_sz, seg_dt), seg_dilate=8,
-                                  seg_sz_thd=5000, seg_force=10)
-                work.put((ss, preds[i % 2], sems[i % 2], seg_kw))
-            th.join()
-            n_done += 1
-            if rank == 0 and sys.stdout.isatty():
-                sys.stdout.write('\r%d' % n_done)
-                sys.stdout.flush()
-    finally:
-        work.put(None)
-        poster.join()
+        # host-side prefetch of the next cube (array sources); synthetic cubes are made
+        # on the device and need none
+        staged = {}
+
+        def stage(k):
+            if k < len(items) and isinstance(src, _ArraySource):
+                ss = items[k]
+                sz = ss.size + 2 * buffer_sz
+                staged[k] = src.cube_host([ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz], sz)
+
+        work = queue.Queue()
+
+        def post_process():
+            while True:
+                item = work.get()
+                if item is None:
+                    return
+                ss, pred, free, seg_kw = item
+                try:
+                    if not failure:
+                        out = fplobjdetect.voxel2obj(
+                            pred, obj_min_dist, smoothing_sigma,
+                            (ss.x - buffer_sz, ss.y - buffer_sz, ss.z - buffer_sz),
+                            buffer_sz, thd, _ctx=ctx_post, **seg_kw)
+                        write_result(ss, out)
+                except BaseException as e:           # surfaces in the main thread below
+                    failure.append(e)
+                finally:
+                    free.release()
+
+        poster = threading.Thread(target=post_process)
+        poster.start()
+        try:
+            stage(0)
+            for k, ss in enumerate(items):
+                if failure:
+                    break
+                th = threading.Thread(target=stage, args=(k + 1,))
+                th.start()
+                image_sz = ss.size + 2 * buffer_sz
+                origin = [ss.z - buffer_sz, ss.y - buffer_sz, ss.x - buffer_sz]
+                cube, preds, sems = buffers(image_sz)
+                if isinstance(src, _ArraySource):
+                    image = staged.pop(k)
+                    have = image is not None
+                    if have:
+                        cube.from_host(image)
+                else:
+                    have = src.cube_device(ctx, origin, image_sz, cube)
+                if not have:
+                    write_result(ss, {'locs': np.zeros((0, 3)), 'conf': np.zeros(0)})
+                else:
+                    st = normalisation_from_histogram(ctx.histogram_u8(cube), image_normalize)
+                    _write_norm(norm_dir, ss, buffer_sz, image_normalize, st)
+                    sems[k % 2].acquire()             # its previous prediction is post-processed
+                    prog.infer_volume(cube, network.infer_sz, network.rf_offset,
+                                      mean=st['mn_use'], std=image_normalize[1],
+                                      precision=prec, dst=preds[k % 2], dims=(image_sz,) * 3)
+                    seg_kw = {}
+                    if seg_src is not None:           # fri_postprocess, reference :1143-1150
+                        seg_dt = seg_src.arr.dtype if seg_src.arr.dtype.itemsize in (4, 8) \
+                            else np.uint64
+                        seg_kw = dict(seg=seg_src.cube_host(origin, image_sz, seg_dt), seg_dilate=8,
+                                      seg_sz_thd=5000, seg_force=10)
+                    work.put((ss, preds[k % 2], sems[k % 2], seg_kw))
+                th.join()
+                done_count[0] += 1
+                if rank == 0 and sys.stdout.isatty():
+                    sys.stdout.write('\r%d' % done_count[0])
+                    sys.stdout.flush()
+        except BaseException as e:
+            failure.append(e)
+        finally:
+            work.put(None)
+            poster.join()
+            for cube, preds, _ in bufs.values():
+                cube.free()
+                for pbuf in preds:
+                    pbuf.free()
+            if lane != 0:
+                prog.close()
+
+    lanes = [threading.Thread(target=run_lane, args=(l, mine[l::n_lanes]))
+             for l in range(1, n_lanes)]
+    for t in lanes:
+        t.start()
+    run_lane(0, mine[0::n_lanes])
+    for t in lanes:
+        t.join()
     if failure:
         raise failure[0]
-    for cube, preds, _ in bufs.values():
-        cube.free()
-        for pbuf in preds:
-            pbuf.free()
     if timings is not None:
-        timings['substacks'] = n_done
+        timings['substacks'] = done_count[0]
+        timings['lanes'] = n_lanes
 
     if dist is not None and world > 1:
         dist.barrier()
