@@ -319,9 +319,6 @@ __global__ __launch_bounds__(512) void gauss_z_win(
 #pragma unroll
     for (int j = WR; j >= 1; --j)
       acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
-#ifdef FPL_EXP_NOMATH
-    acc = win[WR + o] + win[o] + win[o + 2 * WR];
-#endif
     if (a0 + o < P0) dst[o * pplane] = (float)acc;
   }
 }
@@ -399,9 +396,6 @@ __global__ __launch_bounds__(512) void gauss_yx_fused(
 #pragma unroll
         for (int j = WR; j >= 1; --j)
           acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
-#ifdef FPL_EXP_NOMATH
-        acc = win[WR + o] + win[o] + win[o + 2 * WR];
-#endif
         colp[o * lrow] = (float)acc;
       }
     }
@@ -444,9 +438,6 @@ __global__ __launch_bounds__(512) void gauss_yx_fused(
         for (int j = WR; j >= 1; --j)
           acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
         const int x = x0 + k;
-#ifdef FPL_EXP_NOMATH
-        acc = win[WR + k] + win[k] + win[k + 2 * WR];
-#endif
         o[k] = (edge_zy || (r > 0 && (x < r || x >= P2 - r))) ? 0.f : (float)acc;
       }
       const int64_t flat = ((int64_t)z * P1 + y) * P2 + x0;

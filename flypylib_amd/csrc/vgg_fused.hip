@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256, STEM_WPS) void FPLK(vgg_stem_pool)(StemArgs a)
             a2[e][b] = mfma16(w2[0][b], h0, sh2[b]);
             a2[e][b] = mfma16(w2[1][b], h1, a2[e][b]);
           }
+
         }
 #pragma unroll
         for (int b = 0; b < 3; ++b)
