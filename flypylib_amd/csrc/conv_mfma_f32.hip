@@ -49,6 +49,62 @@ struct Conv3F {
   int cout;              // real output channels (<= 16*MB)
   int opitch;            // channel pitch of `out` (>= cout; a slice of a wider tensor)
   int OD, OH, OW, zblocks;
+  // fused epilogue (inference): act -> 1x1x1 conv `w1` [q][mb1][lane][4] + shift1, act1
+  // -> optional MaxPooling3D(2); `out` / `cout` / `opitch` then describe THAT result
+  // (pooled: (n, OD/2, OH/2, OW/2, cout))
+  const float *w1;
+  const float *shift1;
+  int act1, cout1;
+};
+
+__device__ __forceinline__ float act_f(float v, int act);
+
+// The accumulators of one fp32 layer are the B operands of the next: lane (c, g) holds
+// rows 4g..4g+3 of every 16-row block, and k-slot (j, g) of K-block q is channel
+// 16q + 4g + j - register j of block q, no lane movement (the fp32 form of the 16-bit
+// kernels' register chaining).  acc1[sub][m] += W1 frag (q, m) x act(acc[sub][q]).
+template <int MB, int MB1>
+struct Chain1F {
+  f32x4 w[MB][MB1];        // W1 fragments (q, m), this lane's 4 k-slots
+  f32x4 sh[MB1];           // shift1 of the lane's rows
+  __device__ __forceinline__ void load(const float *w1, const float *shift1, int cout1, int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < MB; ++q)
+#pragma unroll
+      for (int m = 0; m < MB1; ++m)
+        w[q][m] = *reinterpret_cast<const f32x4 *>(w1 + ((size_t)(q * MB1 + m) * 64 + lane) * 4);
+#pragma unroll
+    for (int m = 0; m < MB1; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * m + 4 * g + r;
+        sh[m][r] = co < cout1 ? shift1[co] : 0.f;
+      }
+  }
+  template <int NSUB>
+  __device__ __forceinline__ void apply(const f32x4 (&acc)[NSUB][MB], int act,
+                                        f32x4 (&acc1)[NSUB][MB1]) const {
+#pragma unroll
+    for (int m = 0; m < MB1; ++m)
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) acc1[sub][m] = sh[m];
+#pragma unroll
+    for (int q = 0; q < MB; ++q) {
+      f32x4 bq[NSUB];
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bq[sub][r] = act_f(acc[sub][q][r], act);
+#pragma unroll
+      for (int m = 0; m < MB1; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int sub = 0; sub < NSUB; ++sub)
+            acc1[sub][m] = mfma4(w[q][m][j], bq[sub][j], acc1[sub][m]);
+    }
+  }
 };
 
 template <int RING> struct WRegF {
@@ -153,7 +209,7 @@ __device__ __forceinline__ f32x4 act4(const f32x4 &v, int act) {
   return o;
 }
 
-template <int MB>
+template <int MB, int MB1 = 0, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
   constexpr int RING = KC * MB * 1024;
   constexpr int PIECES = TZ * TY * TX * 4;          // 4 x 16 B per voxel (16 ch)
@@ -261,14 +317,81 @@ __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
     }
   }
   const int oz = z0 + wave, ox = x0 + c;
+  if (MB1 == 0) {
 #pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
-    const int oy = y0 + sub;
-    if (oz < a.OD && oy < a.OH && ox < a.OW) {
-      float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.opitch;
+    for (int sub = 0; sub < 4; ++sub) {
+      const int oy = y0 + sub;
+      if (oz < a.OD && oy < a.OH && ox < a.OW) {
+        float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.opitch;
 #pragma unroll
-      for (int b = 0; b < MB; ++b)
-        store_quad(dst, 16 * b + 4 * g, a.cout, acc[sub][b], a.act);
+        for (int b = 0; b < MB; ++b)
+          store_quad(dst, 16 * b + 4 * g, a.cout, acc[sub][b], a.act);
+      }
+    }
+    return;
+  }
+  // fused epilogue: the 1x1x1 conv that follows, chained in registers
+  constexpr int M1 = MB1 > 0 ? MB1 : 1;
+  f32x4 acc1[4][M1];
+  {
+    Chain1F<MB, M1> ch;
+    ch.load(a.w1, a.shift1, a.cout1, lane);
+    ch.template apply<4>(acc, a.act, acc1);
+  }
+  if (!POOL) {
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int oy = y0 + sub;
+      if (oz < a.OD && oy < a.OH && ox < a.OW) {
+        float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.opitch;
+#pragma unroll
+        for (int m = 0; m < M1; ++m) store_quad(dst, 16 * m + 4 * g, a.cout1, acc1[sub][m], a.act1);
+      }
+    }
+    return;
+  }
+  // ... and MaxPooling3D(2) of the 4 x 4 x 16 block: y pairs are sub-steps of a lane, x
+  // pairs neighbouring lanes, z pairs neighbouring waves (through the idle tile LDS).
+  // act1 (ReLU or none) is monotone, so it is applied once, to the maximum.
+  f32x4 pm[2][M1];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int m = 0; m < M1; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = fmaxf(acc1[2 * s2][m][r], acc1[2 * s2 + 1][m][r]);
+        v = fmaxf(v, __shfl_xor(v, 1));
+        pm[s2][m][r] = v;
+      }
+  __syncthreads();                              // every wave is done with the tile
+  float *xch = reinterpret_cast<float *>(smem);   // [2 odd waves][2][M1][64 lanes][4]
+  if (wave & 1) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int m = 0; m < M1; ++m)
+        *reinterpret_cast<f32x4 *>(xch + ((((wave >> 1) * 2 + s2) * M1 + m) * 64 + lane) * 4) = pm[s2][m];
+  }
+  __syncthreads();
+  if ((wave & 1) == 0 && (c & 1) == 0) {
+    const int pz = (z0 + wave) / 2, px = (x0 + c) / 2;
+    const int PD = a.OD / 2, PH = a.OH / 2, PW = a.OW / 2;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int py = y0 / 2 + s2;
+      if (pz < PD && py < PH && px < PW) {
+        float *dst = a.out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * a.opitch;
+#pragma unroll
+        for (int m = 0; m < M1; ++m) {
+          const f32x4 other = *reinterpret_cast<const f32x4 *>(
+              xch + ((((wave >> 1) * 2 + s2) * M1 + m) * 64 + lane) * 4);
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(pm[s2][m][r], other[r]);
+          store_quad(dst, 16 * m + 4 * g, a.cout1, v, a.act1);
+        }
+      }
     }
   }
 }
@@ -350,6 +473,11 @@ struct StemF {
   int act;
   float *out; int cout; int OD, OH, OW, zblocks;
   double *stats;                 // STATS: part[blocks][2][cout], blocks in launch order
+  // fused form (stem_conv1_pool_f32): act -> 1x1x1 conv w1 + shift1, act1 -> pool(2);
+  // `out` is then the pooled (n, OD/2, OH/2, OW/2, cout1) tensor
+  const float *w1;
+  const float *shift1;
+  int act1, cout1;
 };
 
 template <int MB, bool STATS>
@@ -419,6 +547,91 @@ __global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
     __syncthreads();
     // finish() indexes rows by blockIdx.x: shift the base instead
     cs.finish(red, part + (blk - blockIdx.x) * 2 * a.cout, a.cout);
+  }
+}
+
+// conv3 1 -> cout, act, 1x1x1 conv, act1 and MaxPooling3D(2) in one kernel (the first
+// block of baseline / vgg-style / U-Net models): a wave task is 16 pre-pool x of one
+// POOLED (z, y) row, its four sub-steps walk the (dz, dy) window positions, so the pool
+// is an element-wise max of accumulators plus one lane exchange for the x pair.  The
+// full-resolution tensors (48 x 4 B per voxel, twice) never reach HBM.
+template <int MB, int MB1>
+__global__ __launch_bounds__(256) void stem_conv1_pool_f32(StemF a) {
+  __shared__ float tile[ST_TZ * ST_TY * ST_TX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int x0 = blockIdx.x * ST_X, y0 = blockIdx.y * ST_Y;
+  const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * ST_Z;
+  for (int i = tid; i < ST_TZ * ST_TY * ST_TX; i += 256) {
+    const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
+    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+    float v = 0.f;
+    if (z < a.D && y < a.H && x < a.W) v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
+    tile[i] = v;
+  }
+  int toff[8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = 16 * q + 4 * g + j;
+      toff[4 * q + j] = t < 27 ? ((t / 9) * ST_TY + (t / 3) % 3) * ST_TX + t % 3 : 0;
+    }
+  f32x4 w[2][MB], sh[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    w[0][b] = *reinterpret_cast<const f32x4 *>(a.w + ((0 * MB + b) * 64 + lane) * 4);
+    w[1][b] = *reinterpret_cast<const f32x4 *>(a.w + ((1 * MB + b) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * b + 4 * g + r;
+      sh[b][r] = co < a.cout ? a.shift[co] : 0.f;
+    }
+  }
+  // the chained conv's fragments stay in registers for the whole kernel (loaded inside
+  // the task loop they could not be hoisted past the output stores)
+  Chain1F<MB, MB1> ch;
+  ch.load(a.w1, a.shift1, a.cout1, lane);
+  __syncthreads();
+  const int PD = a.OD / 2, PH = a.OH / 2, PW = a.OW / 2;
+  for (int task = wave; task < (ST_Z / 2) * (ST_Y / 2) * (ST_X / 16); task += 4) {
+    const int xg = task % (ST_X / 16), pyl = (task / (ST_X / 16)) % (ST_Y / 2),
+              pzl = task / (ST_X / 16 * (ST_Y / 2));
+    f32x4 pm[MB1];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int zl = 2 * pzl + (sub >> 1), yl = 2 * pyl + (sub & 1);
+      const int base = (zl * ST_TY + yl) * ST_TX + 16 * xg + c;
+      float bv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = tile[base + toff[j]];
+      f32x4 acc[1][MB];
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        acc[0][b] = sh[b];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[0][b] = mfma4(w[q][b][j], bv[4 * q + j], acc[0][b]);
+      }
+      f32x4 acc1[1][MB1];
+      ch.template apply<1>(acc, a.act, acc1);
+#pragma unroll
+      for (int m = 0; m < MB1; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pm[m][r] = sub == 0 ? acc1[0][m][r] : fmaxf(pm[m][r], acc1[0][m][r]);
+    }
+#pragma unroll
+    for (int m = 0; m < MB1; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pm[m][r] = fmaxf(pm[m][r], __shfl_xor(pm[m][r], 1));
+    const int pz = z0 / 2 + pzl, py = y0 / 2 + pyl, px = (x0 + 16 * xg + c) / 2;
+    if ((c & 1) == 0 && pz < PD && py < PH && px < PW) {
+      float *dst = a.out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * a.cout1;
+#pragma unroll
+      for (int m = 0; m < MB1; ++m) store_quad(dst, 16 * m + 4 * g, a.cout1, pm[m], a.act1);
+    }
   }
 }
 
@@ -561,6 +774,32 @@ int launch3(fpl_ctx *ctx, Conv3F &a, int n) {
   return 0;
 }
 
+// conv3 + chained conv1 (+ pool): the (MB, MB1) pairs the reference's architectures need
+template <int MB, int MB1, bool POOL>
+int launch3_fused(fpl_ctx *ctx, Conv3F &a, int n) {
+  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024;
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_f32<MB, MB1, POOL>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
+  }
+  a.zblocks = (int)ceil_div64(a.OD, 4);
+  dim3 grid((unsigned)ceil_div64(a.OW, 16), (unsigned)ceil_div64(a.OH, 4), (unsigned)(n * a.zblocks));
+  TimedLaunch tl(ctx, POOL ? "mfma_conv3_conv1_pool_f32" : "mfma_conv3_conv1_f32");
+  conv3_f32<MB, MB1, POOL><<<grid, 256, SMEM, ctx->stream>>>(a);
+  return 0;
+}
+
+template <int MB, int MB1>
+int launch_stem_fused(fpl_ctx *ctx, StemF &a, int n) {
+  a.zblocks = (int)ceil_div64(a.OD, ST_Z);
+  dim3 grid((unsigned)ceil_div64(a.OW, ST_X), (unsigned)ceil_div64(a.OH, ST_Y), (unsigned)(n * a.zblocks));
+  TimedLaunch tl(ctx, "mfma_stem_conv1_pool_f32");
+  stem_conv1_pool_f32<MB, MB1><<<grid, 256, 0, ctx->stream>>>(a);
+  return 0;
+}
+
 template <int MB>
 int launch1(fpl_ctx *ctx, Conv1F &a) {
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
@@ -679,13 +918,45 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       }
       default: break;
     }
+    // conv3 -> conv1 (-> pool2) run as ONE kernel when the intermediate tensors have no
+    // other reader: the 1x1x1 conv is chained in registers, the pool is an epilogue
+    // (FPL_F32_UNFUSED=1: one kernel per op, for A/B runs)
+    int fuse1 = -1, fusep = -1;
+    if (op.kind == FPL_OP_CONV && op.k == 3 && i + 1 < prog->ops.size() && !getenv("FPL_F32_UNFUSED")) {
+      auto readers = [&](int t) {
+        int cnt = t == prog->out_tensor ? 1 : 0;
+        for (auto &o2 : prog->ops) cnt += (o2.src0 == t) + (o2.src1 == t);
+        return cnt;
+      };
+      const fpl_op &n1 = prog->ops[i + 1];
+      const int mb0 = (op.cout + 15) / 16, mb1 = (n1.cout + 15) / 16;
+      const bool pair_ok = (mb0 == mb1) && (mb0 == 2 || mb0 == 3 || mb0 == 4) && op.cout % 4 == 0;
+      if (n1.kind == FPL_OP_CONV && n1.k == 1 && n1.src0 == op.dst && readers(op.dst) == 1 &&
+          pair_ok && (op.act == FPL_ACT_RELU || op.act == FPL_ACT_NONE)) {
+        fuse1 = (int)i + 1;
+        if (i + 2 < prog->ops.size()) {
+          const fpl_op &n2 = prog->ops[i + 2];
+          if (n2.kind == FPL_OP_POOL && n2.src0 == n1.dst && readers(n1.dst) == 1 &&
+              n2.p[0] == 2 && n2.p[1] == 2 && n2.p[2] == 2 &&
+              (n1.act == FPL_ACT_RELU || n1.act == FPL_ACT_NONE))
+            fusep = (int)i + 2;
+        }
+        // the Cin = 1 kernel exists only in its pooled form (mb 2 / 3); a virtual input
+        // (up / crop / concat views are fine for the multi-channel kernel)
+        if (op.cin == 1 && (fusep < 0 || mb0 == 4)) fuse1 = fusep = -1;
+      }
+    }
     float *dst;
     int od = 0, oc = 0;
     if (op.kind == FPL_OP_CONV) { od = a.dim - (op.k - 1); oc = op.cout; }
     if (op.kind == FPL_OP_POOL) { od = a.dim / 2; oc = a.C; }
     if (op.kind == FPL_OP_ADD) { od = a.dim; oc = a.C; }
     FPL_REQUIRE(ctx, od > 0, "op %zu: tile %d is too small for this architecture", i, T);
-    if (op.dst == prog->out_tensor) {
+    const int od_conv = od;                       // conv3's own output edge
+    const fpl_op &last = fusep >= 0 ? prog->ops[fusep] : (fuse1 >= 0 ? prog->ops[fuse1] : op);
+    if (fuse1 >= 0) { oc = prog->ops[fuse1].cout; if (fusep >= 0) od = od / 2; }
+    FPL_REQUIRE(ctx, od > 0, "op %zu: tile %d is too small for this architecture", i, T);
+    if (last.dst == prog->out_tensor) {
       dst = out;
     } else {
       void *q;
@@ -727,8 +998,15 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       StemF c;
       c.in = a.p; c.D = c.H = c.W = a.D;
       c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off; c.act = op.act;
-      c.out = dst; c.cout = op.cout; c.OD = c.OH = c.OW = od; c.stats = nullptr;
+      c.out = dst; c.cout = op.cout; c.OD = c.OH = c.OW = od_conv; c.stats = nullptr;
       const int mb = (op.cout + 15) / 16;
+      if (fusep >= 0) {
+        const fpl_op &n1 = prog->ops[fuse1];
+        c.w1 = st->frags + st->off[fuse1]; c.shift1 = prog->arena_dev + n1.shift_off;
+        c.act1 = n1.act; c.cout1 = n1.cout;
+        if (mb == 2) FPL_TRY((launch_stem_fused<2, 2>(ctx, c, n)));
+        else FPL_TRY((launch_stem_fused<3, 3>(ctx, c, n)));
+      } else
       switch (mb) {
         case 1: FPL_TRY(launch_stem<1>(ctx, c, n)); break;
         case 2: FPL_TRY(launch_stem<2>(ctx, c, n)); break;
@@ -764,7 +1042,20 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
       }
       // the packed fragments assume channel chunks of the concatenated tensor in
       // order, each source starting on a 16-channel boundary
-      c.act = op.act; c.opitch = op.cout; c.OD = c.OH = c.OW = od;
+      c.act = op.act; c.opitch = op.cout; c.OD = c.OH = c.OW = od_conv;
+      c.w1 = nullptr; c.shift1 = nullptr; c.act1 = 0; c.cout1 = 0;
+      if (fuse1 >= 0) {
+        const fpl_op &n1 = prog->ops[fuse1];
+        const int mb = (op.cout + 15) / 16;
+        c.w = st->frags + st->off[i]; c.shift = prog->arena_dev + op.shift_off;
+        c.out = dst; c.cout = op.cout; c.opitch = n1.cout;
+        c.w1 = st->frags + st->off[fuse1]; c.shift1 = prog->arena_dev + n1.shift_off;
+        c.act1 = n1.act; c.cout1 = n1.cout;
+        const bool pl = fusep >= 0;
+        if (mb == 2) FPL_TRY(pl ? (launch3_fused<2, 2, true>(ctx, c, n)) : (launch3_fused<2, 2, false>(ctx, c, n)));
+        else if (mb == 3) FPL_TRY(pl ? (launch3_fused<3, 3, true>(ctx, c, n)) : (launch3_fused<3, 3, false>(ctx, c, n)));
+        else FPL_TRY(pl ? (launch3_fused<4, 4, true>(ctx, c, n)) : (launch3_fused<4, 4, false>(ctx, c, n)));
+      } else {
       size_t woff = st->off[i];
       for (int c0 = 0; c0 < op.cout; c0 += 64) {      // 64 output channels per launch
         const int cs = std::min(64, op.cout - c0), mb = (cs + 15) / 16;
@@ -778,8 +1069,14 @@ int fpl_forward_mfma_f32(fpl_ctx *ctx, fpl_program *prog, const float *in, int n
           case 4: FPL_TRY(launch3<4>(ctx, c, n)); break;
         }
       }
+      }
     }
     FPL_HIP(ctx, hipGetLastError());
+    if (fuse1 >= 0) {                 // the fused ops are done: their result is `last`'s
+      view[last.dst] = o;
+      i = (size_t)(fusep >= 0 ? fusep : fuse1);
+      continue;
+    }
     view[op.dst] = o;
   }
   return 0;
