@@ -245,3 +245,26 @@ def test_bad_arguments_raise_library_errors(ctx):
     for prec in (_capi.PREC_F32, _capi.PREC_BF16):
         with pytest.raises(_capi.FplHipError):
             pu.infer_volume(img, (26,) * 3, (9,) * 3, precision=prec)
+
+
+@pytest.mark.parametrize('name,tile', [('vgg_like', 46), ('unet_like', 34), ('unet_like2', 36),
+                                       ('baseline_model', 46)])
+def test_f32_fused_epilogues_equal_one_kernel_per_op(ctx, name, tile):
+    """fp32 MFMA executor: conv3 -> conv1 (-> pool) fused into one kernel (1x1 conv chained
+    in registers, pool in the epilogue) is the same k-ordered fmaf chain per output as the
+    separate kernels (FPL_F32_UNFUSED=1): bit-identical"""
+    import os
+    from flypylib_amd import FplNetwork
+    net = FplNetwork(getattr(fplmodels, name))
+    net.infer_sz = (tile,) * 3
+    synth.synthetic_weights(net.train_single, 4)
+    net._set_infer()
+    u8 = synth.em_volume_u8(12, (tile + 40, tile + 9, tile + 22))
+    a = net.infer(u8, normalize=(128., 33.))
+    assert ctx.last_path() == 'mfma_f32'
+    os.environ['FPL_F32_UNFUSED'] = '1'
+    try:
+        b = net.infer(u8, normalize=(128., 33.))
+    finally:
+        del os.environ['FPL_F32_UNFUSED']
+    assert a.std() > 0 and np.array_equal(a, b)
