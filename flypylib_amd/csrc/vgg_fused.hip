@@ -497,7 +497,7 @@ __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
 // and whose output rows share cache lines - meet in one L2.  (z neighbours never do, in
 // any order: they are thousands of workgroups apart.)
 struct BlockGrid { int nbx, nby, nbz; };
-inline unsigned block_grid_size(const BlockGrid &g) {
+__host__ __device__ inline unsigned block_grid_size(const BlockGrid &g) {
   return (unsigned)((int64_t)g.nbx * g.nby * ((g.nbz + 7) / 8 * 8));
 }
 __device__ __forceinline__ bool block_coords(const BlockGrid &g, int &xb, int &yb, int &zb) {
