@@ -13,49 +13,85 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
   return z ^ (z >> 31);
 }
 
-__device__ inline int synth_voxel(uint64_t seed, int64_t z, int64_t y, int64_t x) {
+// blob centre of the 64^3 lattice cell (cz, cy, cx), jittered by the hash
+struct SynthBlob {
+  int bz, by, bx;
+};
+__device__ inline SynthBlob synth_blob(uint64_t seed, int cz, int cy, int cx) {
+  const uint64_t hc = splitmix64((seed + 0x5851F42D4C957F2Dull) ^
+                                 splitmix64(((uint64_t)(int64_t)cz << 42) |
+                                            ((uint64_t)(int64_t)cy << 21) |
+                                            (uint64_t)(int64_t)cx));
+  return SynthBlob{(cz << 6) + 16 + (int)(hc & 31), (cy << 6) + 16 + (int)((hc >> 8) & 31),
+                   (cx << 6) + 16 + (int)((hc >> 16) & 31)};
+}
+
+// coordinates are < 2^21 (checked by the callers), so they are ints here
+__device__ inline int synth_voxel(uint64_t seed, int z, int y, int x, const SynthBlob &b) {
   const uint64_t idx = (((uint64_t)z << 42) | ((uint64_t)y << 21) | (uint64_t)x);
   const uint64_t h = splitmix64(seed ^ splitmix64(idx));
-  const int s4 = (int)(h & 255) + (int)((h >> 8) & 255) + (int)((h >> 16) & 255) +
-                 (int)((h >> 24) & 255);
+  const uint32_t lo = (uint32_t)h;
+  const int s4 = (int)(lo & 255u) + (int)((lo >> 8) & 255u) + (int)((lo >> 16) & 255u) +
+                 (int)(lo >> 24);
   int v = 128 + (((s4 - 510) * 57) >> 8);
-  // one dark blob (radius 7) per 64^3 lattice cell, centre jittered by the hash
-  const int64_t cz = z >> 6, cy = y >> 6, cx = x >> 6;
-  const uint64_t hc = splitmix64((seed + 0x5851F42D4C957F2Dull) ^
-                                 splitmix64(((uint64_t)cz << 42) |
-                                            ((uint64_t)cy << 21) | (uint64_t)cx));
-  const int64_t bz = (cz << 6) + 16 + (int64_t)(hc & 31);
-  const int64_t by = (cy << 6) + 16 + (int64_t)((hc >> 8) & 31);
-  const int64_t bx = (cx << 6) + 16 + (int64_t)((hc >> 16) & 31);
-  const int64_t d2 = (z - bz) * (z - bz) + (y - by) * (y - by) + (x - bx) * (x - bx);
-  if (d2 < 49) v -= (int)((60 * (49 - d2)) / 49);
+  // one dark blob (radius 7) per 64^3 lattice cell
+  const int dz = z - b.bz, dy = y - b.by, dx = x - b.bx;
+  if (abs(dz) < 7 && abs(dy) < 7 && abs(dx) < 7) {
+    const int d2 = dz * dz + dy * dy + dx * dx;
+    if (d2 < 49) v -= (60 * (49 - d2)) / 49;
+  }
   return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-__global__ void synth_u8(uint64_t seed, int64_t D0, int64_t D1, int64_t D2,
-                         int64_t o0, int64_t o1, int64_t o2,
-                         uint8_t *__restrict__ dst) {
-  const int64_t n = D0 * D1 * D2;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += stride) {
-    const int64_t x = i % D2, y = (i / D2) % D1, z = i / (D2 * D1);
-    dst[i] = (uint8_t)synth_voxel(seed, z + o0, y + o1, x + o2);
-  }
-}
+// Four consecutive voxels of the flat (D0, D1, D2) box per thread, one 32-bit store.
+// A workgroup's chunk starts at a flat index decoded once (64-bit); the threads step
+// from there in 32 bits.  CLIPPED: voxels outside [0, E) of the global volume are 0, as
+// fri_get_image (fplobjdetect.py:1044-1070) pads a substack + buffer at the faces.
+constexpr int SYN_PER_WG = 256 * 4;
 
-// substack read of the synthetic volume clipped to [0, extent): zeros outside, as
-// fri_get_image (fplobjdetect.py:1044-1070) pads a substack + buffer at the faces
-__global__ void synth_clipped_u8(uint64_t seed, int64_t E0, int64_t E1, int64_t E2,
-                                 int64_t D0, int64_t D1, int64_t D2, int64_t o0,
-                                 int64_t o1, int64_t o2, uint8_t *__restrict__ dst) {
-  const int64_t n = D0 * D1 * D2;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += stride) {
-    const int64_t x = i % D2 + o2, y = (i / D2) % D1 + o1, z = i / (D2 * D1) + o0;
-    const bool in = z >= 0 && y >= 0 && x >= 0 && z < E0 && y < E1 && x < E2;
-    dst[i] = in ? (uint8_t)synth_voxel(seed, z, y, x) : (uint8_t)0;
+template <bool CLIPPED>
+__global__ __launch_bounds__(256) void synth_u8(uint64_t seed, int E0, int E1, int E2, int D0,
+                                                int D1, int D2, int o0, int o1, int o2,
+                                                int64_t n, int64_t n_chunks,
+                                                uint8_t *__restrict__ dst) {
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t base = c * SYN_PER_WG;                 // uniform
+    const int64_t row0 = base / D2;
+    const uint32_t x0 = (uint32_t)(base - row0 * D2);
+    const uint32_t z0 = (uint32_t)(row0 / D1), y0 = (uint32_t)(row0 - (int64_t)z0 * D1);
+    const uint32_t off = x0 + 4u * threadIdx.x;
+    uint32_t dy = off / (uint32_t)D2;
+    int x = (int)(off - dy * (uint32_t)D2);
+    dy += y0;
+    const uint32_t dz = dy / (uint32_t)D1;
+    int y = (int)(dy - dz * (uint32_t)D1);
+    int z = (int)(z0 + dz);
+    const int64_t i = base + 4 * (int64_t)threadIdx.x;
+    if (i >= n) continue;
+    int cz = (z + o0) >> 6, cy = (y + o1) >> 6, cx = (x + o2) >> 6;
+    SynthBlob blob = synth_blob(seed, cz, cy, cx);
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int gz = z + o0, gy = y + o1, gx = x + o2;
+      if ((gz >> 6) != cz || (gy >> 6) != cy || (gx >> 6) != cx) {
+        cz = gz >> 6, cy = gy >> 6, cx = gx >> 6;
+        blob = synth_blob(seed, cz, cy, cx);
+      }
+      int v = 0;
+      const bool in = !CLIPPED || (gz >= 0 && gy >= 0 && gx >= 0 && gz < E0 && gy < E1 && gx < E2);
+      if (in && i + k < n) v = synth_voxel(seed, gz, gy, gx, blob);
+      word |= (uint32_t)v << (8 * k);
+      if (++x == D2) {
+        x = 0;
+        if (++y == D1) y = 0, ++z;
+      }
+    }
+    if (i + 4 <= n) {
+      *reinterpret_cast<uint32_t *>(dst + i) = word;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) dst[i + k] = (uint8_t)(word >> (8 * k));
+    }
   }
 }
 
@@ -93,7 +129,9 @@ extern "C" int fpl_synth_substack_u8(fpl_ctx *ctx, uint64_t seed, const int64_t 
   if (!ctx || !extent || !dims || !origin || !dst)
     return fpl_fail(ctx, "fpl_synth_substack_u8: NULL argument");
   for (int a = 0; a < 3; ++a)
-    FPL_REQUIRE(ctx, dims[a] > 0 && extent[a] > 0 && extent[a] < ((int64_t)1 << 21),
+    FPL_REQUIRE(ctx, dims[a] > 0 && dims[a] < ((int64_t)1 << 21) && extent[a] > 0 &&
+                         extent[a] < ((int64_t)1 << 21) && origin[a] > -((int64_t)1 << 21) &&
+                         origin[a] < ((int64_t)1 << 21),
                 "fpl_synth_substack_u8: axis %d out of the 2^21 coordinate range", a);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t n = dims[0] * dims[1] * dims[2];
@@ -104,13 +142,14 @@ extern "C" int fpl_synth_substack_u8(fpl_ctx *ctx, uint64_t seed, const int64_t 
     FPL_TRY(tmp.alloc((size_t)n, &p));
     d = (uint8_t *)p;
   }
-  const unsigned grid =
-      (unsigned)std::min<int64_t>(ceil_div64(n, 256), (int64_t)ctx->n_cu * 32);
+  FPL_REQUIRE(ctx, ((uintptr_t)d & 3) == 0, "fpl_synth_substack_u8: dst must be 4-byte aligned");
+  const int64_t n_chunks = ceil_div64(n, SYN_PER_WG);
+  const unsigned grid = (unsigned)std::min<int64_t>(n_chunks, (int64_t)ctx->n_cu * 32);
   {
     TimedLaunch tl(ctx, "synth_u8");
-    synth_clipped_u8<<<grid, 256, 0, ctx->stream>>>(seed, extent[0], extent[1], extent[2],
-                                                    dims[0], dims[1], dims[2], origin[0],
-                                                    origin[1], origin[2], d);
+    synth_u8<true><<<grid, 256, 0, ctx->stream>>>(
+        seed, (int)extent[0], (int)extent[1], (int)extent[2], (int)dims[0], (int)dims[1],
+        (int)dims[2], (int)origin[0], (int)origin[1], (int)origin[2], n, n_chunks, d);
   }
   FPL_HIP(ctx, hipGetLastError());
   if (dst_mem == FPL_MEM_HOST)
@@ -166,12 +205,14 @@ extern "C" int fpl_synth_volume_u8(fpl_ctx *ctx, uint64_t seed,
     FPL_TRY(tmp.alloc((size_t)n, &p));
     d = (uint8_t *)p;
   }
-  const unsigned grid =
-      (unsigned)std::min<int64_t>(ceil_div64(n, 256), (int64_t)ctx->n_cu * 32);
+  FPL_REQUIRE(ctx, ((uintptr_t)d & 3) == 0, "fpl_synth_volume_u8: dst must be 4-byte aligned");
+  const int64_t n_chunks = ceil_div64(n, SYN_PER_WG);
+  const unsigned grid = (unsigned)std::min<int64_t>(n_chunks, (int64_t)ctx->n_cu * 32);
   {
     TimedLaunch tl(ctx, "synth_u8");
-    synth_u8<<<grid, 256, 0, ctx->stream>>>(seed, dims[0], dims[1], dims[2],
-                                            origin[0], origin[1], origin[2], d);
+    synth_u8<false><<<grid, 256, 0, ctx->stream>>>(seed, 0, 0, 0, (int)dims[0], (int)dims[1],
+                                                   (int)dims[2], (int)origin[0], (int)origin[1],
+                                                   (int)origin[2], n, n_chunks, d);
   }
   FPL_HIP(ctx, hipGetLastError());
   if (dst_mem == FPL_MEM_HOST)

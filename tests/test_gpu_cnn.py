@@ -28,6 +28,28 @@ def test_synth_volume_device_matches_host(ctx):
     assert np.array_equal(dev, synth.em_volume_u8(99, dims, org))
 
 
+@pytest.mark.parametrize('dims,org', [((3, 5, 7), (0, 0, 0)), ((2, 3, 1), (62, 63, 64)),
+                                      ((9, 66, 130), (120, 1, 50)), ((1, 1, 4099), (7, 7, 60))])
+def test_synth_volume_ragged_sizes(ctx, dims, org):
+    """the kernel writes four voxels per thread: rows that are not multiples of four,
+    chunks that cross rows / planes / blob cells"""
+    assert np.array_equal(ctx.synth_volume_u8(5, dims, org), synth.em_volume_u8(5, dims, org))
+
+
+def test_synth_substack_clips_to_the_extent(ctx):
+    """`fri_get_image`'s zero padding outside the volume (fplobjdetect.py:1044-1070)"""
+    extent, size, origin = (70, 90, 80), 45, (-10, 60, 50)
+    dst = np.empty((size,) * 3, np.uint8)
+    ctx.synth_substack_u8(11, extent, (size,) * 3, origin, dst)
+    want = np.zeros((size,) * 3, np.uint8)
+    lo = [max(0, -o) for o in origin]
+    hi = [min(size, e - o) for e, o in zip(extent, origin)]
+    g0 = [o + l for o, l in zip(origin, lo)]
+    want[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = synth.em_volume_u8(
+        11, [h - l for h, l in zip(hi, lo)], g0)
+    assert np.array_equal(dst, want) and want.any()
+
+
 @pytest.mark.parametrize('k,cin,cout,act', [
     (3, 1, 48, 'relu'), (1, 48, 48, 'relu'), (3, 48, 48, 'relu'),
     (1, 48, 96, 'relu'), (1, 96, 1, 'sigmoid'), (3, 32, 64, None),
