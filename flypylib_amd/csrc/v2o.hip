@@ -784,7 +784,8 @@ __global__ void window_max(const unsigned long long *__restrict__ in,
   out[c] = m;
 }
 
-// counters: [0] live cells, [1] winners this round, [2] winners total
+// counters: [0] live cells, [1] winners this round, [2] winners total, [3] rounds that
+// had live cells
 __global__ void pick_winners(const unsigned long long *__restrict__ best,
                              const unsigned long long *__restrict__ wmax,
                              int64_t n_cells,
@@ -792,8 +793,10 @@ __global__ void pick_winners(const unsigned long long *__restrict__ best,
                              unsigned long long *__restrict__ round_list,
                              unsigned long long *__restrict__ all_list,
                              int64_t cap) {
+  if (counters[0] == 0) return;        // wmax is stale then
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cells) return;
+  if (c == 0) atomicAdd(&counters[3], 1ull);
   const unsigned long long b = best[c];
   if (b == 0 || b != wmax[c]) return;
   const unsigned long long slot = atomicAdd(&counters[1], 1ull);
@@ -1001,7 +1004,7 @@ struct RankQuery {
 // hist_dev: 2049 u64 (level 0 uses the first L0_BINS); scratch: n_pad floats.
 static int v2o_select(fpl_ctx *ctx, const V2oState &S, int64_t n_pad, const int64_t *ranks,
                       int32_t n_ranks, float *rank_values, unsigned long long *hist_dev,
-                      float *scratch, bool windowed, DevTemp &tmp) {
+                      float *scratch, bool windowed, DevTemp &tmp, float floor_v = 0.f) {
   hipStream_t st = ctx->stream;
   void *p;
     FPL_REQUIRE(ctx, rank_values, "fpl_v2o_smooth: rank_values is NULL");
@@ -1066,6 +1069,20 @@ static int v2o_select(fpl_ctx *ctx, const V2oState &S, int64_t n_pad, const int6
     std::vector<int> all(n_ranks);
     for (int i = 0; i < n_ranks; ++i) all[i] = i;
     FPL_TRY(resolve(0, 0u, all, windowed, false));
+    if (floor_v > 0.f) {
+      // the caller only uses max(statistic, floor) (fpl_v2o_set_floor): when every rank
+      // falls in a first-level bin below the floor's, each statistic is < floor and is
+      // reported as the floor - no compaction, no further levels, no further syncs
+      uint32_t fb;
+      memcpy(&fb, &floor_v, 4);
+      const uint32_t floor_bin = (fb | 0x80000000u) >> L0_SHIFT;
+      bool below = true;
+      for (int i = 0; i < n_ranks; ++i) below = below && (q[i].prefix >> L0_SHIFT) < floor_bin;
+      if (below) {
+        for (int i = 0; i < n_ranks; ++i) rank_values[i] = floor_v;
+        return 0;
+      }
+    }
     const uint32_t mask0 = (uint32_t)(L0_BINS - 1) << L0_SHIFT, mask1 = mask0 | (0x7FFu << 11);
     for (auto &grp : groups_of(all)) {
       {
@@ -1197,7 +1214,8 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
   S.cellmax_valid = cm_done;
 
   if (n_ranks > 0)
-    FPL_TRY(v2o_select(ctx, S, n_pad, ranks, n_ranks, rank_values, hist_dev, scratch, windowed, tmp));
+    FPL_TRY(v2o_select(ctx, S, n_pad, ranks, n_ranks, rank_values, hist_dev, scratch, windowed, tmp,
+                       floor_v));
   FPL_HIP(ctx, hipStreamSynchronize(st));
   S.valid = true;
   return 0;
@@ -1265,57 +1283,69 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   FPL_TRY(tmp.alloc((size_t)cap * 8, &p));
   unsigned long long *all_list = (unsigned long long *)p;
   FPL_TRY(tmp.alloc(4 * 8, &p));
-  unsigned long long *counters = (unsigned long long *)p;
+  unsigned long long *counters = (unsigned long long *)p;   // see pick_winners
   FPL_HIP(ctx, hipMemsetAsync(counters, 0, 4 * 8, st));
   const unsigned cgrid = (unsigned)ceil_div64(n_cells, 256);
   const unsigned bgrid = std::min<unsigned>(cgrid, (unsigned)ctx->n_cu * 8);   // cell_best: grid-stride
   unsigned long long host_cnt[4];
+  // live cells: keys per cell and their count in counters[0]
+  auto scan_cells = [&](bool first) {
+    TimedLaunch tl(ctx, "v2o_cell_best");
+    if (first && have_keys)
+      cell_threshold<<<bgrid, 256, 0, st>>>(best, n_cells, thresh, counters);
+    else if (P2 % CELL == 0)
+      cell_best<true><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
+                                             counters, first);
+    else
+      cell_best<false><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
+                                              counters, first);
+  };
+  scan_cells(true);
+  // A round = winners (cells whose key is the maximum of their window) -> clear their
+  // balls -> re-scan the cells the balls cut.  Every kernel of a round is a no-op once
+  // no cell is live, so rounds are enqueued NMS_BATCH at a time and the host looks at
+  // the counters once per batch (typical substacks finish in two rounds: one sync).
+  constexpr int NMS_BATCH = 2;
   int rounds = 0;
   for (;;) {
-    FPL_HIP(ctx, hipMemsetAsync(counters, 0, 2 * 8, st));   // live cells, round winners
-    {
-      TimedLaunch tl(ctx, "v2o_cell_best");
-      if (rounds == 0 && have_keys)
-        cell_threshold<<<bgrid, 256, 0, st>>>(best, n_cells, thresh, counters);
-      else if (P2 % CELL == 0)
-        cell_best<true><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
-                                               counters, rounds == 0);
-      else
-        cell_best<false><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
-                                                counters, rounds == 0);
-    }
-    {
-      TimedLaunch tl(ctx, "v2o_window_max");
-      window_max<2><<<cgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw, counters);
-      window_max<1><<<cgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw, counters);
-      window_max<0><<<cgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw, counters);
-    }
-    {
-      TimedLaunch tl(ctx, "v2o_pick_winners");
-      pick_winners<<<cgrid, 256, 0, st>>>(best, wa, n_cells, counters, round_list,
-                                          all_list, cap);
-    }
-    {
-      TimedLaunch tl(ctx, "v2o_clear_balls");
-      if (use_seg) {
-        const size_t lds = (size_t)2 * (2 * r + 1) * (2 * r + 1) * sizeof(unsigned long long);
-        clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, P1, P2, r,
-                                                best, C1, C2, S.seg, seg_dilate, seg_force);
-      } else {
-        clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, P1, P2,
-                                          r, best, C1, C2);
+    for (int b = 0; b < NMS_BATCH; ++b) {
+      FPL_HIP(ctx, hipMemsetAsync(counters + 1, 0, 8, st));   // winners of this round
+      {
+        TimedLaunch tl(ctx, "v2o_window_max");
+        window_max<2><<<cgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw, counters);
+        window_max<1><<<cgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw, counters);
+        window_max<0><<<cgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw, counters);
       }
+      {
+        TimedLaunch tl(ctx, "v2o_pick_winners");
+        pick_winners<<<cgrid, 256, 0, st>>>(best, wa, n_cells, counters, round_list,
+                                            all_list, cap);
+      }
+      {
+        TimedLaunch tl(ctx, "v2o_clear_balls");
+        if (use_seg) {
+          const size_t lds = (size_t)2 * (2 * r + 1) * (2 * r + 1) * sizeof(unsigned long long);
+          clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, P1, P2, r,
+                                                  best, C1, C2, S.seg, seg_dilate, seg_force);
+        } else {
+          clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, P1, P2,
+                                            r, best, C1, C2);
+        }
+      }
+      FPL_HIP(ctx, hipMemsetAsync(counters, 0, 8, st));       // live cells
+      scan_cells(false);
     }
     FPL_HIP(ctx, hipGetLastError());
     FPL_HIP(ctx, hipMemcpyAsync(host_cnt, counters, 4 * 8, hipMemcpyDeviceToHost, st));
     FPL_HIP(ctx, hipStreamSynchronize(st));
-    if (host_cnt[0] == 0) break;
-    ++rounds;
-    FPL_REQUIRE(ctx, host_cnt[1] > 0,
-                "fpl_v2o_nms: round %d made no progress (internal error)", rounds);
     FPL_REQUIRE(ctx, (int64_t)host_cnt[2] <= cap,
                 "fpl_v2o_nms: more than %lld detections; raise cap",
                 (long long)cap);
+    const int done = (int)host_cnt[3];
+    if (host_cnt[0] == 0) { rounds = done; break; }
+    FPL_REQUIRE(ctx, done == rounds + NMS_BATCH && host_cnt[1] > 0,
+                "fpl_v2o_nms: round %d made no progress (internal error)", done);
+    rounds = done;
   }
   const int64_t n = (int64_t)host_cnt[2];
   std::vector<unsigned long long> keys((size_t)n);

@@ -154,7 +154,11 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
  * (voxel2obj's is max(percentile, thd) >= thd, fplobjdetect.py:183-185).  The smoothing
  * pass then keeps per-cell candidate keys only above it and the NMS starts from them
  * instead of scanning the volume; a smaller threshold than promised is still handled
- * (by the scan).  Holds for one fpl_v2o_smooth. */
+ * (by the scan).  Order statistics: when every requested rank lies in a first-level
+ * radix bin below the floor's (all of them < floor), `rank_values` reports the floor
+ * itself for each - max(statistic, floor) is unchanged and the filtered scan + two
+ * radix levels are skipped; otherwise the values are exact.  Holds for one
+ * fpl_v2o_smooth. */
 int fpl_v2o_set_floor(fpl_ctx *ctx, float floor);
 /* Step 2: NMS over voxels with (double)value > thresh (and > 0) of the volume prepared
  * by step 1.  out_zyxv: rows (z, y, x in padded coordinates, value) as f64,

@@ -63,6 +63,41 @@ def test_order_statistics_exact(ctx):
     assert np.array_equal(vals, s[ranks])
 
 
+def test_order_statistics_with_a_floor(ctx):
+    """fpl_v2o_set_floor: statistics whose first radix bin lies below the floor's are
+    reported as the floor (the caller takes max(statistic, floor)); a rank at or above
+    that bin makes every value exact again; the threshold voxel2obj derives is the
+    oracle's in both regimes"""
+    pred = synth.blob_prob_volume(31, (80, 70, 90), period=32, radius=6.0)
+    r, sigma = 10, 3.0
+    w = fplobjdetect.gaussian_kernel1d(sigma)
+    n = int(np.prod([d + 2 * r for d in pred.shape]))
+    s = np.sort(voxel2obj_oracle.smooth_and_clear(pred, r, sigma).reshape(-1))
+    lo, hi, gamma = fplobjdetect.percentile_plan(n, 97, np.float32)
+    p97 = float(s[hi])
+    assert p97 > 0
+    # floor far above the percentile: shortcut
+    big = np.float32(s[-1] / 2)                # between the percentile and the maximum,
+    assert p97 * 2 < big                       # a power of two away from both
+    ctx.v2o_set_floor(big)
+    assert np.array_equal(ctx.v2o_smooth(pred, pred.shape, r, w, [lo, hi]), [big, big])
+    # floor below the percentile: exact
+    ctx.v2o_set_floor(np.float32(p97 / 64))
+    assert np.array_equal(ctx.v2o_smooth(pred, pred.shape, r, w, [lo, hi]), s[[lo, hi]])
+    # one rank below the floor's bin, one above: exact for both
+    ctx.v2o_set_floor(big)
+    assert np.array_equal(ctx.v2o_smooth(pred, pred.shape, r, w, [lo, n - 1]), s[[lo, n - 1]])
+    # the floor holds for one smoothing only
+    assert np.array_equal(ctx.v2o_smooth(pred, pred.shape, r, w, [lo, hi]), s[[lo, hi]])
+    for thd in (float(big), p97 / 64):
+        ref = voxel2obj_oracle.voxel2obj(pred, r, sigma, thd=thd)
+        got, info = fplobjdetect.voxel2obj(pred, r, sigma, thd=thd, return_info=True)
+        assert np.array_equal(got['locs'], ref['locs'])
+        assert np.array_equal(got['conf'], ref['conf'])
+        assert float(info['thresh']) == max(
+            float(fplobjdetect.percentile_lerp(s[lo], s[hi], gamma)), thd)
+
+
 def test_negative_and_empty_inputs(ctx):
     # all-negative predictions: threshold < 0 but nothing positive -> no points
     pred = -synth.hash_uniform_f32(6, (30, 30, 30)) - np.float32(0.1)

@@ -39,7 +39,7 @@ def main():
     ctx.timing(False)
     padded = (n + 54) ** 3
     res = dict(sub=n, ms=round(dt * 1e3, 3), kernel_ms_sum=round(sum(kern.values()), 3),
-               detections=len(out['conf']), rounds=info['rounds'],
+               detections=len(out['conf']), rounds=info['rounds'], thresh=float(info['thresh']),
                algorithmic_bytes=12 * padded, gb_s_algorithmic=round(12 * padded / dt / 1e9, 1),
                kernels=kern)
     print(json.dumps(res), flush=True)
