@@ -166,10 +166,10 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
     prob = torch.from_numpy(synth.blob_prob_volume(11, (n, n, n), period=64, radius=9.0)).cuda()
     from flypylib_amd import runtime
     vctx = runtime.get_context(ctx.device)           # the context voxel2obj runs on
-    fplobjdetect.voxel2obj(prob, 27, 5, (0, 0, 0), 35, 0.1)       # warm-up
-    vctx.timing(True)
+    vctx.timing(True)               # before the warm-up: the first timed call creates
+    fplobjdetect.voxel2obj(prob, 27, 5, (0, 0, 0), 35, 0.1)       # the HIP events it uses
     vctx.timing_reset()
-    reps = 3
+    reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
         out = fplobjdetect.voxel2obj(prob, 27, 5, (0, 0, 0), 35, 0.1)
@@ -192,10 +192,10 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
     rng = np.random.default_rng(0)
     data = rng.standard_normal((32, 64, 64, 64)).astype(np.float32)
     labels = (rng.random((32, 12, 12, 12)) > 0.9).astype(np.uint8)
+    ctx.timing(True)
     tr.step(data, labels, 0)
     tr.apply(1.0)
     ctx.synchronize()
-    ctx.timing(True)
     ctx.timing_reset()
     reps = 3
     t0 = time.perf_counter()

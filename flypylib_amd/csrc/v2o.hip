@@ -21,7 +21,21 @@
 
 #include "common.h"
 
+// The smoothing must round every product and every sum on its own, as scipy's C does on
+// x86-64.  hipcc's default for device code fuses a * b + c into v_fma_f64 across
+// statements and inlined functions, and `__dmul_rn` / `__dadd_rn` are plain `*` / `+` in
+// this toolchain's headers, so they do not stop it.  Two guards: the build passes
+// -ffp-contract=on (csrc/build.py), and this file switches contraction off and routes the
+// arithmetic through mul_rn / add_rn below, compiled under the pragma, so that the
+// property does not hang on a command line.  tests/test_host_logic.py disassembles this
+// file and fails on any fp64 FMA; tests/test_gpu_voxel2obj.py holds volumes on which
+// fused forms differ from scipy in a float32 voxel (about one per 3e9 voxel-passes).
+#pragma clang fp contract(off)
+
 namespace {
+
+__device__ __forceinline__ double mul_rn(double a, double b) { return a * b; }
+__device__ __forceinline__ double add_rn(double a, double b) { return a + b; }
 
 constexpr int CELL = 4;
 
@@ -36,7 +50,6 @@ __device__ __forceinline__ int64_t reflect_idx(int64_t i, int64_t n) {
 __device__ __forceinline__ int reflect1(int i, int n) {
   return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
 }
-
 // virtual zero-padded view of the unpadded prediction
 struct PadView {
   const float *pred;
@@ -63,9 +76,9 @@ __global__ __launch_bounds__(256) void gauss_pass(
     if (AXIS == 1) return (double)in[(z * P1 + reflect_idx(y + d, P1)) * P2 + x];
     return (double)in[(z * P1 + y) * P2 + reflect_idx(x + d, P2)];
   };
-  double acc = __dmul_rn(load(0), w[0]);
+  double acc = mul_rn(load(0), w[0]);
   for (int j = wr; j >= 1; --j)
-    acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(load(-j), load(j)), w[j]));
+    acc = add_rn(acc, mul_rn(add_rn(load(-j), load(j)), w[j]));
   float v = (float)acc;
   if (AXIS == 2 && r > 0 &&
       (z < r || y < r || x < r || z >= P0 - r || y >= P1 - r || x >= P2 - r))
@@ -139,10 +152,10 @@ __global__ __launch_bounds__(256) void gauss_pass_win(
 #pragma unroll
   for (int o = 0; o < OUT; ++o) {
     if (a0 + o >= PA) break;
-    double acc = __dmul_rn(win[WR + o], wk[0]);
+    double acc = mul_rn(win[WR + o], wk[0]);
 #pragma unroll
     for (int j = WR; j >= 1; --j)
-      acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
+      acc = add_rn(acc, mul_rn(add_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
     float v = (float)acc;
     const int64_t oz = AXIS == 0 ? a0 + o : z, oy = AXIS == 1 ? a0 + o : y,
                   ox = AXIS == 2 ? a0 + o : x;
@@ -217,10 +230,10 @@ __global__ __launch_bounds__(256) void gauss_x_lds(
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      double acc = __dmul_rn(win[WR + k], wk[0]);
+      double acc = mul_rn(win[WR + k], wk[0]);
 #pragma unroll
       for (int j = WR; j >= 1; --j)
-        acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
+        acc = add_rn(acc, mul_rn(add_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
       const int64_t x = x0 + k;
       o[k] = (edge_zy || (r > 0 && (x < r || x >= P2 - r))) ? 0.f : (float)acc;
     }
@@ -315,10 +328,10 @@ __global__ __launch_bounds__(512) void gauss_z_win(
   const int pplane = P1 * P2;
 #pragma unroll
   for (int o = 0; o < OUT; ++o) {
-    double acc = __dmul_rn(win[WR + o], wk[0]);
+    double acc = mul_rn(win[WR + o], wk[0]);
 #pragma unroll
     for (int j = WR; j >= 1; --j)
-      acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
+      acc = add_rn(acc, mul_rn(add_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
     if (a0 + o < P0) dst[o * pplane] = (float)acc;
   }
 }
@@ -392,10 +405,10 @@ __global__ __launch_bounds__(512) void gauss_yx_fused(
       float *colp = yx_tile + x + WR;
 #pragma unroll
       for (int o = 0; o < TY; ++o) {
-        double acc = __dmul_rn(win[WR + o], wk[0]);
+        double acc = mul_rn(win[WR + o], wk[0]);
 #pragma unroll
         for (int j = WR; j >= 1; --j)
-          acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
+          acc = add_rn(acc, mul_rn(add_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
         colp[o * lrow] = (float)acc;
       }
     }
@@ -433,10 +446,10 @@ __global__ __launch_bounds__(512) void gauss_yx_fused(
       float o[XO];
 #pragma unroll
       for (int k = 0; k < XO; ++k) {
-        double acc = __dmul_rn(win[WR + k], wk[0]);
+        double acc = mul_rn(win[WR + k], wk[0]);
 #pragma unroll
         for (int j = WR; j >= 1; --j)
-          acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
+          acc = add_rn(acc, mul_rn(add_rn(win[WR + k - j], win[WR + k + j]), wk[j]));
         const int x = x0 + k;
         o[k] = (edge_zy || (r > 0 && (x < r || x >= P2 - r))) ? 0.f : (float)acc;
       }

@@ -63,6 +63,39 @@ def test_order_statistics_exact(ctx):
     assert np.array_equal(vals, s[ranks])
 
 
+# (seed, shape, r, sigma): volumes on which a smoothing pass that fuses a * b + c into
+# one rounding differs from scipy (x86-64: two roundings) in at least one float32 voxel
+# - found with tools/dev/find_fma_witness.py for two fused forms (every product fused;
+# the form hipcc's default contraction produces).  The build never shipped a fused pass
+# (-ffp-contract=on in csrc/build.py, the pragma in v2o.hip; tests/test_host_logic.py
+# disassembles and checks); these are the parity cases that would notice one.
+FMA_WITNESSES = [
+    (5261, (36, 40, 44), 10, 5.0), (5909, (36, 40, 44), 10, 5.0),
+    (232, (40, 36, 44), 6, 3.0), (12132, (40, 36, 44), 6, 3.0),
+    (6085, (44, 40, 36), 4, 2.0), (13566, (44, 40, 36), 4, 2.0),
+    (647, (40, 44, 36), 3, 1.5), (6023, (40, 44, 36), 3, 1.5),
+]
+
+
+@pytest.mark.parametrize('seed,shape,r,sigma', FMA_WITNESSES)
+def test_smoothing_rounds_products_and_sums_separately(ctx, seed, shape, r, sigma, monkeypatch):
+    pred = synth.hash_uniform_f32(seed, shape)
+    want_r = voxel2obj_oracle.smooth_and_clear(pred, r, sigma)
+    w = fplobjdetect.gaussian_kernel1d(sigma)
+    for env in (None, 'FPL_V2O_UNFUSED'):
+        if env:
+            monkeypatch.setenv(env, '1')
+        ctx.v2o_smooth(pred, pred.shape, r, w, [])
+        assert np.array_equal(ctx.v2o_smoothed(want_r.shape), want_r), env
+        if env:
+            monkeypatch.delenv(env)
+    # the witness voxel may sit in the margin a radius r zeroes: run unpadded as well
+    padded = np.pad(pred, r, 'constant')
+    ctx.v2o_smooth(padded, padded.shape, 0, w, [])
+    assert np.array_equal(ctx.v2o_smoothed(padded.shape),
+                          voxel2obj_oracle.smooth_and_clear(padded, 0, sigma))
+
+
 def test_order_statistics_with_a_floor(ctx):
     """fpl_v2o_set_floor: statistics whose first radix bin lies below the floor's are
     reported as the floor (the caller takes max(statistic, floor)); a rank at or above

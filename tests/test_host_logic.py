@@ -218,3 +218,29 @@ def test_keras_h5_converter_walks_layers_in_get_weights_order(tmp_path):
     assert all(np.array_equal(a, b) for a, b in zip(g2.get_weights(), ws))
     with pytest.raises(SystemExit):
         conv.check_against(got[:-1], 'vgg_like')
+
+
+def test_voxel2obj_smoothing_compiles_without_fp64_fma(tmp_path):
+    """scipy's Gaussian filter rounds every product and every sum separately (C on x86-64);
+    hipcc would fuse them into v_fma_f64 by default.  Compile v2o.hip to device assembly
+    with the build's own flags and look: the smoothing kernels must hold v_mul_f64 and
+    v_add_f64 and no fp64 FMA anywhere in the file."""
+    import shutil
+    import subprocess
+    from flypylib_amd.csrc import build
+    if not shutil.which(build.HIPCC) and not os.path.exists(build.HIPCC):
+        pytest.skip('hipcc not available')
+    asm = tmp_path / 'v2o.s'
+    flags = [f for f in build.CXXFLAGS if f != '-fPIC']
+    subprocess.run([build.HIPCC] + flags + ['-I' + os.path.join(build.ROOT, 'include'), '-S',
+                                            '--cuda-device-only', '-o', str(asm),
+                                            os.path.join(build.HERE, 'v2o.hip')],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    text = asm.read_text()
+    assert not re.search(r'v_fma(c|ak|mk)?_f64', text), 'fp64 FMA in v2o.hip device code'
+    # per smoothing kernel: the separately rounded product and sum are there
+    for kernel in ('gauss_z_win', 'gauss_yx_fused', 'gauss_pass_win', 'gauss_x_lds', 'gauss_pass'):
+        bodies = re.findall(r'^_ZN[^\n]*%sI[^\n]*:[^\n]*\n(.*?)s_endpgm' % kernel, text, re.S | re.M)
+        assert bodies, kernel
+        for body in bodies:
+            assert 'v_mul_f64' in body and 'v_add_f64' in body, kernel

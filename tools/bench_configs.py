@@ -39,6 +39,8 @@ def main():
     ap.add_argument('--vgg2-size', type=int, default=1024)
     ap.add_argument('--sub', type=int, default=582)
     ap.add_argument('--roi-size', type=int, default=1536)
+    ap.add_argument('--skip-oracle', action='store_true',
+                    help='roi: do not re-derive one substack on the CPU oracle (for traces)')
     ap.add_argument('--out', default=None)
     a = ap.parse_args()
     import torch
@@ -220,6 +222,11 @@ def main():
         dt = time.perf_counter() - t0
         kern = {k: round(v['ms'], 2) for k, v in ctx.timing_get().items()}
         ctx.timing(False)
+        if a.skip_oracle:
+            print(json.dumps(dict(substacks=len(roi), seconds=dt, mvox_s=n ** 3 / dt / 1e6,
+                                  detections=int(len(out['conf'])))), flush=True)
+            shutil.rmtree(wd, ignore_errors=True)
+            return
         # one substack re-derived and post-processed by the CPU oracle
         ss = roi[len(roi) // 2]
         sz = ss.size + 70

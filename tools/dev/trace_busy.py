@@ -28,7 +28,7 @@ for name, b in (('longest burst', best),):
             pe = e
     by = {}
     for s, e, n in b:
-        k = n.split('(')[0].replace('(anonymous namespace)::', '').replace('void ', '')[:40]
+        k = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][:40]
         by[k] = by.get(k, 0) + (e - s)
     print('%s: %d kernels, span %.2f ms, busy (union) %.2f ms = %.1f %%, sum of kernel times %.2f ms'
           % (name, len(b), (t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0),
