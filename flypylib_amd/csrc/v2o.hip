@@ -781,7 +781,13 @@ __global__ void window_max(const unsigned long long *__restrict__ in,
                            int64_t C1, int64_t C2, int hw,
                            const unsigned long long *__restrict__ counters) {
   if (counters[0] == 0) return;        // no live cell left: the closing round is a no-op
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-contiguous block order: the blocks an XCD receives (b, b + 8, ...) cover one
+  // slab of z, so the 2 hw + 1 rows / planes a cell reads are re-used in THAT XCD's L2
+  // (round-robin order made every XCD read the whole array: 296 / 234 MB from HBM per
+  // y / z pass over a 32 MB array)
+  const unsigned per_xcd = gridDim.x >> 3;           // the grid is a multiple of 8
+  const int64_t blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t c = blk * blockDim.x + threadIdx.x;
   if (c >= C0 * C1 * C2) return;
   const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
   const int64_t pos = AXIS == 0 ? cz : (AXIS == 1 ? cy : cx);
@@ -1299,6 +1305,7 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   unsigned long long *counters = (unsigned long long *)p;   // see pick_winners
   FPL_HIP(ctx, hipMemsetAsync(counters, 0, 4 * 8, st));
   const unsigned cgrid = (unsigned)ceil_div64(n_cells, 256);
+  const unsigned wgrid = (cgrid + 7u) / 8u * 8u;       // window_max: whole XCD rounds
   const unsigned bgrid = std::min<unsigned>(cgrid, (unsigned)ctx->n_cu * 8);   // cell_best: grid-stride
   unsigned long long host_cnt[4];
   // live cells: keys per cell and their count in counters[0]
@@ -1325,9 +1332,9 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
       FPL_HIP(ctx, hipMemsetAsync(counters + 1, 0, 8, st));   // winners of this round
       {
         TimedLaunch tl(ctx, "v2o_window_max");
-        window_max<2><<<cgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw, counters);
-        window_max<1><<<cgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw, counters);
-        window_max<0><<<cgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw, counters);
+        window_max<2><<<wgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw, counters);
+        window_max<1><<<wgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw, counters);
+        window_max<0><<<wgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw, counters);
       }
       {
         TimedLaunch tl(ctx, "v2o_pick_winners");
