@@ -803,6 +803,119 @@ __global__ void window_max(const unsigned long long *__restrict__ in,
   out[c] = m;
 }
 
+// The same window maxima with fewer loads.  x pass: a workgroup stages 256 consecutive
+// cells and hw neighbours on either side in LDS and every thread reads its window there
+// (the plain kernel loads 2 hw + 1 values per cell from L1 / L2).  y / z passes: a thread
+// owns WM_OUTS consecutive cells along the pass axis at one x (lanes along x: coalesced),
+// loads the WM_OUTS + 2 HW values once and derives the WM_OUTS window maxima from a shared
+// core plus running suffix / prefix maxima (~4 comparisons per output instead of 2 HW).
+// Work items are ordered so that the blocks of an XCD cover a slab ACROSS the pass axis:
+// no halo is shared between XCDs.
+constexpr int WM_OUTS = 8;
+
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) {
+  return a > b ? a : b;
+}
+
+__global__ __launch_bounds__(256) void window_max_x(
+    const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
+    int64_t n_cells, int C2, int hw, const unsigned long long *__restrict__ counters) {
+  if (counters[0] == 0) return;
+  __shared__ unsigned long long sh[256 + 2 * 32];
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t c0 = blk * 256;
+  if (c0 >= n_cells) return;                       // whole workgroup
+  const int t = threadIdx.x;
+  for (int i = t; i < 256 + 2 * hw; i += 256) {
+    const int64_t c = c0 - hw + i;
+    sh[i] = (c >= 0 && c < n_cells) ? in[c] : 0ull;
+  }
+  __syncthreads();
+  const int64_t c = c0 + t;
+  if (c >= n_cells) return;
+  const int cx = (int)(c % C2);
+  const int lo = cx - hw < 0 ? -cx : -hw, hi = cx + hw >= C2 ? C2 - 1 - cx : hw;
+  unsigned long long m = 0;
+  for (int k = lo; k <= hi; ++k) m = umax64(m, sh[t + hw + k]);
+  out[c] = m;
+}
+
+// AXIS 1: windows along y (stride C2), AXIS 0: along z (stride C1 * C2)
+template <int AXIS, int HW>
+__global__ __launch_bounds__(256) void window_max_seg(
+    const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
+    int C0, int C1, int C2, const unsigned long long *__restrict__ counters) {
+  if (counters[0] == 0) return;
+  constexpr int W = 2 * HW + 1, NV = WM_OUTS + 2 * HW;
+  const int n = AXIS == 0 ? C0 : C1;               // length of the pass axis
+  const int other = AXIS == 0 ? C1 : C0;           // the axis the XCD slabs cut
+  const int nseg = (n + WM_OUTS - 1) / WM_OUTS;
+  const int64_t n_items = (int64_t)other * nseg * C2;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t item = blk * 256 + threadIdx.x;
+  if (item >= n_items) return;
+  const int cx = (int)(item % C2);
+  const int64_t rest = item / C2;
+  const int sg = (int)(rest % nseg), o = (int)(rest / nseg);
+  const int64_t stride = AXIS == 0 ? (int64_t)C1 * C2 : C2;
+  const int64_t base = AXIS == 0 ? (int64_t)o * C2 + cx : (int64_t)o * C1 * C2 + cx;
+  const int p0 = sg * WM_OUTS;                     // first output position
+  unsigned long long v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = p0 - HW + i;
+    const int pc = p < 0 ? 0 : (p >= n ? n - 1 : p);
+    const unsigned long long x = in[base + pc * stride];
+    v[i] = (p >= 0 && p < n) ? x : 0ull;
+  }
+  unsigned long long res[WM_OUTS];
+  if (W >= WM_OUTS) {
+    // every window [i, i + W - 1], i < WM_OUTS, holds [WM_OUTS - 1, W - 1]
+    unsigned long long core = v[WM_OUTS - 1];
+#pragma unroll
+    for (int i = WM_OUTS; i < W; ++i) core = umax64(core, v[i]);
+    unsigned long long run = 0;
+    unsigned long long left[WM_OUTS];
+    left[WM_OUTS - 1] = 0;
+#pragma unroll
+    for (int i = WM_OUTS - 2; i >= 0; --i) { run = umax64(run, v[i]); left[i] = run; }
+    run = 0;
+    res[0] = umax64(core, left[0]);
+#pragma unroll
+    for (int i = 1; i < WM_OUTS; ++i) {
+      run = umax64(run, v[W - 1 + i]);
+      res[i] = umax64(umax64(core, left[i]), run);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WM_OUTS; ++i) {
+      unsigned long long m = v[i];
+#pragma unroll
+      for (int k = 1; k < W; ++k) m = umax64(m, v[i + k]);
+      res[i] = m;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WM_OUTS; ++i)
+    if (p0 + i < n) out[base + (int64_t)(p0 + i) * stride] = res[i];
+}
+
+template <int HW>
+static void launch_window_max_seg(hipStream_t st, const unsigned long long *best,
+                                  unsigned long long *wa, unsigned long long *wb, int C0, int C1,
+                                  int C2, int64_t n_cells, const unsigned long long *counters) {
+  const unsigned gx = (unsigned)((ceil_div64(n_cells, 256) + 7) / 8 * 8);
+  window_max_x<<<gx, 256, 0, st>>>(best, wa, n_cells, C2, HW, counters);
+  const int64_t ny = (int64_t)C0 * ceil_div64(C1, WM_OUTS) * C2;
+  const unsigned gy = (unsigned)((ceil_div64(ny, 256) + 7) / 8 * 8);
+  window_max_seg<1, HW><<<gy, 256, 0, st>>>(wa, wb, C0, C1, C2, counters);
+  const int64_t nz = (int64_t)C1 * ceil_div64(C0, WM_OUTS) * C2;
+  const unsigned gz = (unsigned)((ceil_div64(nz, 256) + 7) / 8 * 8);
+  window_max_seg<0, HW><<<gz, 256, 0, st>>>(wb, wa, C0, C1, C2, counters);
+}
+
 // counters: [0] live cells, [1] winners this round, [2] winners total, [3] rounds that
 // had live cells
 __global__ void pick_winners(const unsigned long long *__restrict__ best,
@@ -1332,9 +1445,22 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
       FPL_HIP(ctx, hipMemsetAsync(counters + 1, 0, 8, st));   // winners of this round
       {
         TimedLaunch tl(ctx, "v2o_window_max");
-        window_max<2><<<wgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw, counters);
-        window_max<1><<<wgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw, counters);
-        window_max<0><<<wgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw, counters);
+        const bool seg_ok = hw >= 1 && hw <= 8 && n_cells < ((int64_t)1 << 31) &&
+                            !getenv("FPL_V2O_WMAX_PLAIN");
+        switch (seg_ok ? hw : 0) {
+          case 1: launch_window_max_seg<1>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          case 2: launch_window_max_seg<2>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          case 3: launch_window_max_seg<3>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          case 4: launch_window_max_seg<4>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          case 5: launch_window_max_seg<5>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          case 6: launch_window_max_seg<6>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          case 7: launch_window_max_seg<7>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          case 8: launch_window_max_seg<8>(st, best, wa, wb, (int)C0, (int)C1, (int)C2, n_cells, counters); break;
+          default:
+            window_max<2><<<wgrid, 256, 0, st>>>(best, wa, C0, C1, C2, hw, counters);
+            window_max<1><<<wgrid, 256, 0, st>>>(wa, wb, C0, C1, C2, hw, counters);
+            window_max<0><<<wgrid, 256, 0, st>>>(wb, wa, C0, C1, C2, hw, counters);
+        }
       }
       {
         TimedLaunch tl(ctx, "v2o_pick_winners");
