@@ -694,59 +694,99 @@ __global__ __launch_bounds__(256) void key_histogram(
 // clear_balls) are re-scanned; the others keep their key.
 constexpr unsigned long long CELL_DIRTY = 1ull;    // no live key has value bits 0
 
+// device counters of the NMS (unsigned long long each)
+enum { CNT_LIVE = 0,      // cells with a live key
+       CNT_ROUND = 1,     // winners of the current round
+       CNT_DIRTY = 2,     // cells on the current round's re-scan list
+       CNT_TOTAL = 3,     // winners so far
+       CNT_ROUNDS = 4,    // rounds that had live cells
+       CNT_N = 8 };
+
+// best live key of cell c: its largest voxel that passes the threshold (0: none)
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void cell_best(const float *__restrict__ s, double thresh,
-                          int64_t P0, int64_t P1, int64_t P2, int64_t C0,
-                          int64_t C1, int64_t C2,
-                          unsigned long long *__restrict__ best,
-                          unsigned long long *__restrict__ counters, int first_round) {
-  // grid-stride over the cells; the live-cell count goes to counters[0] with ONE atomic
-  // per workgroup (one per wave on a single address cost 0.15 ms a round)
-  __shared__ unsigned wcount[4];
-  const int64_t n_cells = C0 * C1 * C2;
-  unsigned mine = 0;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
-       c += (int64_t)gridDim.x * blockDim.x) {
-    unsigned long long b = first_round ? CELL_DIRTY : best[c];
-    if (b == CELL_DIRTY) {
-      b = 0;
-      const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
+__device__ __forceinline__ unsigned long long scan_cell(const float *__restrict__ s, double thresh,
+                                                        int64_t P0, int64_t P1, int64_t P2,
+                                                        int64_t C1, int64_t C2, int64_t c) {
+  unsigned long long b = 0;
+  const int64_t cx = c % C2, cy = (c / C2) % C1, cz = c / (C2 * C1);
 #pragma unroll
-      for (int dz = 0; dz < CELL; ++dz)
+  for (int dz = 0; dz < CELL; ++dz)
 #pragma unroll
-        for (int dy = 0; dy < CELL; ++dy) {
-          const int64_t z = cz * CELL + dz, y = cy * CELL + dy;
-          if (z >= P0 || y >= P1) continue;
-          const float *rowp = s + (z * P1 + y) * P2 + cx * CELL;
-          float v[4];
-          if (ALIGNED) {               // P2 % 4 == 0: the cell row is one aligned 16-B piece
-            const float4 q = *reinterpret_cast<const float4 *>(rowp);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-          } else {
+    for (int dy = 0; dy < CELL; ++dy) {
+      const int64_t z = cz * CELL + dz, y = cy * CELL + dy;
+      if (z >= P0 || y >= P1) continue;
+      const float *rowp = s + (z * P1 + y) * P2 + cx * CELL;
+      float v[4];
+      if (ALIGNED) {               // P2 % 4 == 0: the cell row is one aligned 16-B piece
+        const float4 q = *reinterpret_cast<const float4 *>(rowp);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
 #pragma unroll
-            for (int dx = 0; dx < CELL; ++dx) v[dx] = cx * CELL + dx < P2 ? rowp[dx] : 0.f;
-          }
+        for (int dx = 0; dx < CELL; ++dx) v[dx] = cx * CELL + dx < P2 ? rowp[dx] : 0.f;
+      }
 #pragma unroll
-          for (int dx = 0; dx < CELL; ++dx)
-            if ((double)v[dx] > thresh && v[dx] > 0.f) {
-              const uint32_t flat = (uint32_t)((z * P1 + y) * P2 + cx * CELL + dx);
-              const unsigned long long k =
-                  ((unsigned long long)__float_as_uint(v[dx]) << 32) | (0xFFFFFFFFu - flat);
-              b = k > b ? k : b;
-            }
+      for (int dx = 0; dx < CELL; ++dx)
+        if ((double)v[dx] > thresh && v[dx] > 0.f) {
+          const uint32_t flat = (uint32_t)((z * P1 + y) * P2 + cx * CELL + dx);
+          const unsigned long long k =
+              ((unsigned long long)__float_as_uint(v[dx]) << 32) | (0xFFFFFFFFu - flat);
+          b = k > b ? k : b;
         }
-      best[c] = b;
     }
-    mine += b != 0;
-  }
+  return b;
+}
+
+// adds the workgroup's count of live cells to counters[CNT_LIVE] with ONE atomic (one per
+// wave on a single address cost 0.15 ms a round)
+__device__ __forceinline__ void add_live(unsigned mine, unsigned long long *counters) {
+  __shared__ unsigned wcount[8];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
   if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    if (tot) atomicAdd(&counters[0], (unsigned long long)tot);
+    unsigned tot = 0;
+    for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) tot += wcount[w];
+    if (tot) atomicAdd(&counters[CNT_LIVE], (unsigned long long)tot);
   }
+}
+
+// first round without keys from the smoothing pass: every cell, grid-stride
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void cell_best(const float *__restrict__ s, double thresh,
+                          int64_t P0, int64_t P1, int64_t P2, int64_t C0,
+                          int64_t C1, int64_t C2,
+                          unsigned long long *__restrict__ best,
+                          unsigned long long *__restrict__ counters) {
+  const int64_t n_cells = C0 * C1 * C2;
+  unsigned mine = 0;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
+       c += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long b = scan_cell<ALIGNED>(s, thresh, P0, P1, P2, C1, C2, c);
+    best[c] = b;
+    mine += b != 0;
+  }
+  add_live(mine, counters);
+}
+
+// later rounds: only the cells a cleared ball cut through (clear_balls lists them and
+// takes them out of the live count; the ones that still hold a live voxel come back)
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void cell_rescan(const float *__restrict__ s, double thresh,
+                          int64_t P0, int64_t P1, int64_t P2, int64_t C1, int64_t C2,
+                          unsigned long long *__restrict__ best,
+                          const unsigned int *__restrict__ dirty_list,
+                          unsigned long long *__restrict__ counters) {
+  const int64_t n = (int64_t)counters[CNT_DIRTY];
+  unsigned mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = dirty_list[i];
+    const unsigned long long b = scan_cell<ALIGNED>(s, thresh, P0, P1, P2, C1, C2, c);
+    best[c] = b;
+    mine += b != 0;
+  }
+  add_live(mine, counters);
 }
 
 // round 0 from the keys the fused y+x pass took (per cell: its largest positive voxel):
@@ -754,7 +794,6 @@ __global__ __launch_bounds__(256) void cell_best(const float *__restrict__ s, do
 __global__ __launch_bounds__(256) void cell_threshold(unsigned long long *__restrict__ best,
                                                       int64_t n_cells, double thresh,
                                                       unsigned long long *__restrict__ counters) {
-  __shared__ unsigned wcount[4];
   unsigned mine = 0;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_cells;
        c += (int64_t)gridDim.x * blockDim.x) {
@@ -765,14 +804,7 @@ __global__ __launch_bounds__(256) void cell_threshold(unsigned long long *__rest
     }
     mine += b != 0;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-  if ((threadIdx.x & 63) == 0) wcount[threadIdx.x >> 6] = mine;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    if (tot) atomicAdd(&counters[0], (unsigned long long)tot);
-  }
+  add_live(mine, counters);
 }
 
 template <int AXIS>
@@ -780,7 +812,7 @@ __global__ void window_max(const unsigned long long *__restrict__ in,
                            unsigned long long *__restrict__ out, int64_t C0,
                            int64_t C1, int64_t C2, int hw,
                            const unsigned long long *__restrict__ counters) {
-  if (counters[0] == 0) return;        // no live cell left: the closing round is a no-op
+  if (counters[CNT_LIVE] == 0) return;  // no live cell left: the closing round is a no-op
   // XCD-contiguous block order: the blocks an XCD receives (b, b + 8, ...) cover one
   // slab of z, so the 2 hw + 1 rows / planes a cell reads are re-used in THAT XCD's L2
   // (round-robin order made every XCD read the whole array: 296 / 234 MB from HBM per
@@ -820,7 +852,7 @@ __device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsig
 __global__ __launch_bounds__(256) void window_max_x(
     const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
     int64_t n_cells, int C2, int hw, const unsigned long long *__restrict__ counters) {
-  if (counters[0] == 0) return;
+  if (counters[CNT_LIVE] == 0) return;
   __shared__ unsigned long long sh[256 + 2 * 32];
   const unsigned per_xcd = gridDim.x >> 3;
   const int64_t blk = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -846,7 +878,7 @@ template <int AXIS, int HW>
 __global__ __launch_bounds__(256) void window_max_seg(
     const unsigned long long *__restrict__ in, unsigned long long *__restrict__ out,
     int C0, int C1, int C2, const unsigned long long *__restrict__ counters) {
-  if (counters[0] == 0) return;
+  if (counters[CNT_LIVE] == 0) return;
   constexpr int W = 2 * HW + 1, NV = WM_OUTS + 2 * HW;
   const int n = AXIS == 0 ? C0 : C1;               // length of the pass axis
   const int other = AXIS == 0 ? C1 : C0;           // the axis the XCD slabs cut
@@ -916,8 +948,6 @@ static void launch_window_max_seg(hipStream_t st, const unsigned long long *best
   window_max_seg<0, HW><<<gz, 256, 0, st>>>(wb, wa, C0, C1, C2, counters);
 }
 
-// counters: [0] live cells, [1] winners this round, [2] winners total, [3] rounds that
-// had live cells
 __global__ void pick_winners(const unsigned long long *__restrict__ best,
                              const unsigned long long *__restrict__ wmax,
                              int64_t n_cells,
@@ -925,25 +955,72 @@ __global__ void pick_winners(const unsigned long long *__restrict__ best,
                              unsigned long long *__restrict__ round_list,
                              unsigned long long *__restrict__ all_list,
                              int64_t cap) {
-  if (counters[0] == 0) return;        // wmax is stale then
+  if (counters[CNT_LIVE] == 0) return;        // wmax is stale then
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cells) return;
-  if (c == 0) atomicAdd(&counters[3], 1ull);
+  if (c == 0) atomicAdd(&counters[CNT_ROUNDS], 1ull);
   const unsigned long long b = best[c];
   if (b == 0 || b != wmax[c]) return;
-  const unsigned long long slot = atomicAdd(&counters[1], 1ull);
+  const unsigned long long slot = atomicAdd(&counters[CNT_ROUND], 1ull);
   round_list[slot] = b;             // one winner per cell at most: fits n_cells
-  const unsigned long long g = atomicAdd(&counters[2], 1ull);
+  const unsigned long long g = atomicAdd(&counters[CNT_TOTAL], 1ull);
   if ((int64_t)g < cap) all_list[g] = b;
+}
+
+// A cleared ball takes voxels from cell c (`dead`: all of them).  Several balls of a round
+// may touch one cell, so the hand-over goes through an exchange: whoever swaps out a LIVE
+// key takes the cell out of the live count and - unless the cell is dead - puts it on the
+// round's re-scan list (once).  Appends are staged in LDS (`stage`, `n_stage`), one global
+// atomic per ball.
+constexpr int CLR_STAGE = 6144;               // >= the 17^3 cells of a bounding box at r = 31;
+                                              // beyond it appends go straight to the list
+__device__ __forceinline__ void touch_cell(unsigned long long *__restrict__ best, int64_t c,
+                                           bool dead, unsigned int *stage, unsigned int *n_stage,
+                                           unsigned int *n_gone,
+                                           unsigned int *__restrict__ dirty_list,
+                                           unsigned long long *__restrict__ counters) {
+  const unsigned long long old = atomicExch(&best[c], dead ? 0ull : CELL_DIRTY);
+  if (old == 0ull) {
+    if (!dead) best[c] = 0ull;                // it held no live voxel: nothing to re-scan
+    return;
+  }
+  if (old == CELL_DIRTY) return;              // another ball of this round listed it
+  atomicAdd(n_gone, 1u);
+  if (dead) return;
+  const unsigned int slot = atomicAdd(n_stage, 1u);
+  if (slot < (unsigned)CLR_STAGE) stage[slot] = (unsigned int)c;
+  else dirty_list[atomicAdd(&counters[CNT_DIRTY], 1ull)] = (unsigned int)c;
+}
+// the staged cells of one ball -> the global list; live count down by `n_gone`
+__device__ __forceinline__ void flush_stage(const unsigned int *stage, unsigned int *n_stage,
+                                            unsigned int *n_gone, unsigned int *base,
+                                            unsigned int *__restrict__ dirty_list,
+                                            unsigned long long *__restrict__ counters) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (*n_stage > (unsigned)CLR_STAGE) *n_stage = (unsigned)CLR_STAGE;
+    *base = *n_stage ? (unsigned int)atomicAdd(&counters[CNT_DIRTY], (unsigned long long)*n_stage) : 0u;
+    if (*n_gone) atomicAdd(&counters[CNT_LIVE], (unsigned long long)(0ull - *n_gone));
+  }
+  __syncthreads();
+  for (unsigned int i = threadIdx.x; i < *n_stage; i += blockDim.x) dirty_list[*base + i] = stage[i];
+  __syncthreads();
+  if (threadIdx.x == 0) { *n_stage = 0u; *n_gone = 0u; }
+  __syncthreads();
 }
 
 // one block per winner: clear the r-ball in the live volume
 __global__ __launch_bounds__(256) void clear_balls(
     const unsigned long long *__restrict__ round_list,
-    const unsigned long long *__restrict__ counters, float *__restrict__ live,
+    unsigned long long *__restrict__ counters, float *__restrict__ live,
     int64_t P1, int64_t P2, int r,
-    unsigned long long *__restrict__ best, int64_t C1, int64_t C2) {
-  const unsigned long long nwin = counters[1];
+    unsigned long long *__restrict__ best, int64_t C1, int64_t C2,
+    unsigned int *__restrict__ dirty_list) {
+  __shared__ unsigned int stage[CLR_STAGE];
+  __shared__ unsigned int n_stage, n_gone, stage_base;
+  if (threadIdx.x == 0) { n_stage = 0u; n_gone = 0u; }
+  __syncthreads();
+  const unsigned long long nwin = counters[CNT_ROUND];
   for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
     const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(round_list[wi] & 0xFFFFFFFFu);
     const int64_t x = flat % P2, y = (flat / P2) % P1, z = flat / (P2 * P1);
@@ -980,8 +1057,10 @@ __global__ __launch_bounds__(256) void clear_balls(
       span2(cy * CELL, y, ny2, fy2);
       span2(cx * CELL, x, nx2, fx2);
       if (nz2 + ny2 + nx2 > r * r) continue;                  // untouched
-      best[(cz * C1 + cy) * C2 + cx] = fz2 + fy2 + fx2 <= r * r ? 0ull : CELL_DIRTY;
+      touch_cell(best, (cz * C1 + cy) * C2 + cx, fz2 + fy2 + fx2 <= r * r, stage, &n_stage,
+                 &n_gone, dirty_list, counters);
     }
+    flush_stage(stage, &n_stage, &n_gone, &stage_base, dirty_list, counters);
   }
 }
 
@@ -1052,16 +1131,21 @@ __global__ void seg_zero_small(const unsigned long long *__restrict__ seg, int64
 // (2r+1 <= 64), built with a ballot; rows live in LDS.
 __global__ __launch_bounds__(256) void clear_balls_seg(
     const unsigned long long *__restrict__ round_list,
-    const unsigned long long *__restrict__ counters, float *__restrict__ live,
+    unsigned long long *__restrict__ counters, float *__restrict__ live,
     int64_t P1, int64_t P2, int r,
     unsigned long long *__restrict__ best, int64_t C1, int64_t C2,
-    const unsigned long long *__restrict__ seg, int dilate, int force) {
+    const unsigned long long *__restrict__ seg, int dilate, int force,
+    unsigned int *__restrict__ dirty_list) {
   extern __shared__ unsigned long long rows_lds[];       // 2 x side*side
+  __shared__ unsigned int stage[CLR_STAGE];
+  __shared__ unsigned int n_stage, n_gone, stage_base;
+  if (threadIdx.x == 0) { n_stage = 0u; n_gone = 0u; }
+  __syncthreads();
   const int side = 2 * r + 1, nrows = side * side;
   unsigned long long *ma = rows_lds, *mb = rows_lds + nrows;
   const unsigned long long full = side == 64 ? ~0ull : ((1ull << side) - 1ull);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long nwin = counters[1];
+  const unsigned long long nwin = counters[CNT_ROUND];
   for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
     const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(round_list[wi] & 0xFFFFFFFFu);
     const int64_t x = flat % P2, y = (flat / P2) % P1, z = flat / (P2 * P1);
@@ -1117,8 +1201,10 @@ __global__ __launch_bounds__(256) void clear_balls_seg(
               nx = (int)((x + r) / CELL - cx0 + 1);
     for (int i = threadIdx.x; i < nz * ny * nx; i += blockDim.x) {
       const int64_t cz = cz0 + i / (ny * nx), cy = cy0 + (i / nx) % ny, cx = cx0 + i % nx;
-      best[(cz * C1 + cy) * C2 + cx] = CELL_DIRTY;
+      touch_cell(best, (cz * C1 + cy) * C2 + cx, false, stage, &n_stage, &n_gone, dirty_list,
+                 counters);
     }
+    flush_stage(stage, &n_stage, &n_gone, &stage_base, dirty_list, counters);
   }
 }
 
@@ -1414,35 +1500,37 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   unsigned long long *round_list = (unsigned long long *)p;
   FPL_TRY(tmp.alloc((size_t)cap * 8, &p));
   unsigned long long *all_list = (unsigned long long *)p;
-  FPL_TRY(tmp.alloc(4 * 8, &p));
-  unsigned long long *counters = (unsigned long long *)p;   // see pick_winners
-  FPL_HIP(ctx, hipMemsetAsync(counters, 0, 4 * 8, st));
+  FPL_TRY(tmp.alloc((size_t)n_cells * sizeof(unsigned int), &p));
+  unsigned int *dirty_list = (unsigned int *)p;             // cells to re-scan, per round
+  FPL_TRY(tmp.alloc(CNT_N * 8, &p));
+  unsigned long long *counters = (unsigned long long *)p;   // CNT_*
+  FPL_HIP(ctx, hipMemsetAsync(counters, 0, CNT_N * 8, st));
   const unsigned cgrid = (unsigned)ceil_div64(n_cells, 256);
   const unsigned wgrid = (cgrid + 7u) / 8u * 8u;       // window_max: whole XCD rounds
   const unsigned bgrid = std::min<unsigned>(cgrid, (unsigned)ctx->n_cu * 8);   // cell_best: grid-stride
-  unsigned long long host_cnt[4];
-  // live cells: keys per cell and their count in counters[0]
-  auto scan_cells = [&](bool first) {
+  unsigned long long host_cnt[CNT_N];
+  const bool aligned = P2 % CELL == 0;
+  // live cells: keys per cell and their count in counters[CNT_LIVE]
+  {
     TimedLaunch tl(ctx, "v2o_cell_best");
-    if (first && have_keys)
+    if (have_keys)
       cell_threshold<<<bgrid, 256, 0, st>>>(best, n_cells, thresh, counters);
-    else if (P2 % CELL == 0)
-      cell_best<true><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
-                                             counters, first);
+    else if (aligned)
+      cell_best<true><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best, counters);
     else
-      cell_best<false><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best,
-                                              counters, first);
-  };
-  scan_cells(true);
+      cell_best<false><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C0, C1, C2, best, counters);
+  }
   // A round = winners (cells whose key is the maximum of their window) -> clear their
-  // balls -> re-scan the cells the balls cut.  Every kernel of a round is a no-op once
-  // no cell is live, so rounds are enqueued NMS_BATCH at a time and the host looks at
-  // the counters once per batch (typical substacks finish in two rounds: one sync).
+  // balls (the cells a ball cuts go on a list and out of the live count) -> re-scan the
+  // listed cells.  Every kernel of a round is a no-op once no cell is live, so rounds are
+  // enqueued NMS_BATCH at a time and the host looks at the counters once per batch
+  // (typical substacks finish in two rounds: one sync).
   constexpr int NMS_BATCH = 2;
   int rounds = 0;
   for (;;) {
     for (int b = 0; b < NMS_BATCH; ++b) {
-      FPL_HIP(ctx, hipMemsetAsync(counters + 1, 0, 8, st));   // winners of this round
+      // winners and re-scan list of this round
+      FPL_HIP(ctx, hipMemsetAsync(counters + CNT_ROUND, 0, 2 * 8, st));
       {
         TimedLaunch tl(ctx, "v2o_window_max");
         const bool seg_ok = hw >= 1 && hw <= 8 && n_cells < ((int64_t)1 << 31) &&
@@ -1471,29 +1559,36 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
         TimedLaunch tl(ctx, "v2o_clear_balls");
         if (use_seg) {
           const size_t lds = (size_t)2 * (2 * r + 1) * (2 * r + 1) * sizeof(unsigned long long);
-          clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, P1, P2, r,
-                                                  best, C1, C2, S.seg, seg_dilate, seg_force);
+          clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, P1, P2, r, best, C1,
+                                                  C2, S.seg, seg_dilate, seg_force, dirty_list);
         } else {
-          clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, P1, P2,
-                                            r, best, C1, C2);
+          clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, P1, P2, r, best, C1, C2,
+                                            dirty_list);
         }
       }
-      FPL_HIP(ctx, hipMemsetAsync(counters, 0, 8, st));       // live cells
-      scan_cells(false);
+      {
+        TimedLaunch tl(ctx, "v2o_cell_best");
+        if (aligned)
+          cell_rescan<true><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C1, C2, best,
+                                                   dirty_list, counters);
+        else
+          cell_rescan<false><<<bgrid, 256, 0, st>>>(live, thresh, P0, P1, P2, C1, C2, best,
+                                                    dirty_list, counters);
+      }
     }
     FPL_HIP(ctx, hipGetLastError());
-    FPL_HIP(ctx, hipMemcpyAsync(host_cnt, counters, 4 * 8, hipMemcpyDeviceToHost, st));
+    FPL_HIP(ctx, hipMemcpyAsync(host_cnt, counters, CNT_N * 8, hipMemcpyDeviceToHost, st));
     FPL_HIP(ctx, hipStreamSynchronize(st));
-    FPL_REQUIRE(ctx, (int64_t)host_cnt[2] <= cap,
+    FPL_REQUIRE(ctx, (int64_t)host_cnt[CNT_TOTAL] <= cap,
                 "fpl_v2o_nms: more than %lld detections; raise cap",
                 (long long)cap);
-    const int done = (int)host_cnt[3];
-    if (host_cnt[0] == 0) { rounds = done; break; }
-    FPL_REQUIRE(ctx, done == rounds + NMS_BATCH && host_cnt[1] > 0,
+    const int done = (int)host_cnt[CNT_ROUNDS];
+    if (host_cnt[CNT_LIVE] == 0) { rounds = done; break; }
+    FPL_REQUIRE(ctx, done == rounds + NMS_BATCH && host_cnt[CNT_ROUND] > 0,
                 "fpl_v2o_nms: round %d made no progress (internal error)", done);
     rounds = done;
   }
-  const int64_t n = (int64_t)host_cnt[2];
+  const int64_t n = (int64_t)host_cnt[CNT_TOTAL];
   std::vector<unsigned long long> keys((size_t)n);
   if (n)
     FPL_HIP(ctx, hipMemcpy(keys.data(), all_list, (size_t)n * 8,
