@@ -63,6 +63,32 @@ def test_order_statistics_exact(ctx):
     assert np.array_equal(vals, s[ranks])
 
 
+def test_order_statistics_on_adversarial_values(ctx):
+    """the radix select itself, fed through an identity smoothing (one tap of weight 1):
+    negatives, signed zeros, denormals, every edge k / 1024 of the linear first-level
+    bins with its two float neighbours, powers of two down to 2^-60, values >= 1, inf"""
+    rng = np.random.default_rng(7)
+    k = np.arange(0, 1025, dtype=np.float32) / np.float32(1024)
+    special = np.concatenate([
+        k, np.nextafter(k, np.float32(-1)), np.nextafter(k, np.float32(2)),
+        np.float32(2.0) ** -np.arange(0, 61, dtype=np.float32),
+        -np.float32(2.0) ** -np.arange(0, 61, dtype=np.float32),
+        np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39, 1e30, -1e30, np.inf, -np.inf, 1.0, 1.5],
+                 np.float32)])
+    shape = (24, 50, 60)
+    n = int(np.prod(shape))
+    vals = rng.uniform(-1.0, 2.0, n).astype(np.float32)
+    vals[rng.choice(n, n // 3, replace=False)] = rng.uniform(0.5, 0.75, n // 3).astype(np.float32)
+    pos = rng.choice(n, special.size, replace=False)
+    vals[pos] = special
+    pred = vals.reshape(shape)
+    s = np.sort(vals)
+    ranks = sorted(set([0, 1, n - 2, n - 1] + [int(x) for x in rng.integers(0, n, 40)]
+                       + [int(np.searchsorted(s, v)) for v in special[::37]]))
+    got = ctx.v2o_smooth(pred, shape, 0, np.array([1.0]), ranks)
+    assert np.array_equal(got, s[ranks])
+
+
 # (seed, shape, r, sigma): volumes on which a smoothing pass that fuses a * b + c into
 # one rounding differs from scipy (x86-64: two roundings) in at least one float32 voxel
 # - found with tools/dev/find_fma_witness.py for two fused forms (every product fused;
