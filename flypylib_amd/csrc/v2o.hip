@@ -1009,7 +1009,11 @@ __device__ __forceinline__ void flush_stage(const unsigned int *stage, unsigned 
   __syncthreads();
 }
 
-// one block per winner: clear the r-ball in the live volume
+// CLR_PARTS workgroups per winner (a round's winners are few and a ball is 82 519 voxels
+// and ~2 500 cells at r = 27: one workgroup per ball left most of the chip idle for the
+// ~90 us a ball takes): clear the r-ball in the live volume
+constexpr int CLR_PARTS = 4;
+constexpr int CLR_ROWS = 1024;                // rows of one part of the cube, r <= 31
 __global__ __launch_bounds__(256) void clear_balls(
     const unsigned long long *__restrict__ round_list,
     unsigned long long *__restrict__ counters, float *__restrict__ live,
@@ -1018,28 +1022,69 @@ __global__ __launch_bounds__(256) void clear_balls(
     unsigned int *__restrict__ dirty_list) {
   __shared__ unsigned int stage[CLR_STAGE];
   __shared__ unsigned int n_stage, n_gone, stage_base;
-  if (threadIdx.x == 0) { n_stage = 0u; n_gone = 0u; }
+  __shared__ int64_t row_off[CLR_ROWS];
+  __shared__ short row_hx[CLR_ROWS];
+  __shared__ int tab_part;                     // which part's rows the table holds
+  if (threadIdx.x == 0) { n_stage = 0u; n_gone = 0u; tab_part = -1; }
   __syncthreads();
   const unsigned long long nwin = counters[CNT_ROUND];
-  for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
+  for (unsigned long long w = blockIdx.x; w < nwin * CLR_PARTS; w += gridDim.x) {
+    const unsigned long long wi = w / CLR_PARTS;
+    const int part = (int)(w % CLR_PARTS);
     const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(round_list[wi] & 0xFFFFFFFFu);
     const int64_t x = flat % P2, y = (flat / P2) % P1, z = flat / (P2 * P1);
     const int side = 2 * r + 1;
     const int rows = side * side;
-    for (int row = threadIdx.x / 8; row < rows; row += blockDim.x / 8) {
-      const int dz = row / side - r, dy = row % side - r;
-      const int rem = r * r - dz * dz - dy * dy;
-      if (rem < 0) continue;
-      int hx = (int)sqrtf((float)rem);
-      while ((hx + 1) * (hx + 1) <= rem) ++hx;
-      while (hx * hx > rem) --hx;
-      float *rowp = live + ((z + dz) * P1 + (y + dy)) * P2 + x;
-      for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0.f;
+    const int row_lo = (int)((int64_t)rows * part / CLR_PARTS),
+              row_hi = (int)((int64_t)rows * (part + 1) / CLR_PARTS);
+    // eight lanes per (dz, dy) row of the cube, 32 rows per workgroup iteration.  The row
+    // geometry (offset from the centre, half width) is the same for every ball: a table
+    // per workgroup, one entry per thread instead of once per lane and row (one wave per
+    // row - contiguous 220-B stores - was 2.5x slower: the index arithmetic, not the
+    // store shape, is what a ball costs)
+    if (row_hi - row_lo <= CLR_ROWS) {
+      if (tab_part != part) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < row_hi - row_lo; i += blockDim.x) {
+          const int row = row_lo + i;
+          const int dz = row / side - r, dy = row % side - r;
+          const int rem = r * r - dz * dz - dy * dy;
+          int hx = -1;
+          if (rem >= 0) {
+            hx = (int)sqrtf((float)rem);
+            while ((hx + 1) * (hx + 1) <= rem) ++hx;
+            while (hx * hx > rem) --hx;
+          }
+          row_hx[i] = (short)hx;
+          row_off[i] = ((int64_t)dz * P1 + dy) * P2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) tab_part = part;
+        __syncthreads();
+      }
+      float *centre = live + (z * P1 + y) * P2 + x;
+      for (int i = (int)threadIdx.x / 8; i < row_hi - row_lo; i += blockDim.x / 8) {
+        const int hx = row_hx[i];
+        float *rowp = centre + row_off[i];
+        for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0.f;
+      }
+    } else {
+      for (int row = row_lo + (int)threadIdx.x / 8; row < row_hi; row += blockDim.x / 8) {
+        const int dz = row / side - r, dy = row % side - r;
+        const int rem = r * r - dz * dz - dy * dy;
+        if (rem < 0) continue;
+        int hx = (int)sqrtf((float)rem);
+        while ((hx + 1) * (hx + 1) <= rem) ++hx;
+        while (hx * hx > rem) --hx;
+        float *rowp = live + ((z + dz) * P1 + (y + dy)) * P2 + x;
+        for (int dx = -hx + (int)(threadIdx.x % 8); dx <= hx; dx += 8) rowp[dx] = 0.f;
+      }
     }
     // cached keys of the cells in the ball's bounding box (the r shell of the padded
     // volume keeps every ball inside it): a cell wholly inside the ball has no live
     // voxel left (key 0), a cell the ball does not reach keeps its key, only the cells
-    // the sphere cuts through are re-scanned next round
+    // the sphere cuts through are re-scanned next round.  (Every part clears its voxels
+    // and hands over its cells in one kernel; the re-scan is the next kernel.)
     const int64_t cz0 = (z - r) / CELL, cy0 = (y - r) / CELL, cx0 = (x - r) / CELL;
     const int nz = (int)((z + r) / CELL - cz0 + 1), ny = (int)((y + r) / CELL - cy0 + 1),
               nx = (int)((x + r) / CELL - cx0 + 1);
@@ -1050,7 +1095,10 @@ __global__ __launch_bounds__(256) void clear_balls(
       const int f = -a > b ? -a : b;
       near2 = n * n; far2 = f * f;
     };
-    for (int i = threadIdx.x; i < nz * ny * nx; i += blockDim.x) {
+    const int ncell = nz * ny * nx;
+    const int cell_lo = (int)((int64_t)ncell * part / CLR_PARTS),
+              cell_hi = (int)((int64_t)ncell * (part + 1) / CLR_PARTS);
+    for (int i = cell_lo + (int)threadIdx.x; i < cell_hi; i += blockDim.x) {
       const int64_t cz = cz0 + i / (ny * nx), cy = cy0 + (i / nx) % ny, cx = cx0 + i % nx;
       int nz2, fz2, ny2, fy2, nx2, fx2;
       span2(cz * CELL, z, nz2, fz2);
