@@ -233,6 +233,8 @@ def main():
     ap.add_argument('--tile', type=int, default=102,
                     help='reference infer_sz (tile lattice pitch = tile-14)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='print the cpu_baseline object and exit (what the main run spawns)')
     ap.add_argument('--no-legs', action='store_true',
                     help='skip the secondary legs (other precisions / sizes / configs)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -244,10 +246,23 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
 
-    # the CPU leg first: the GPU legs then run back to back to the end of the process
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
+    # the CPU leg first, in a process of its own (before this one touches the GPU): its
+    # 16-thread pool and buffers are gone when the GPU legs run back to back to the end of
+    # this process (left in-process, the pool cost the host-bound legs ~0.4 ms per call)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            cpu = json.loads(r.stdout.strip().splitlines()[-1])
+        except (IndexError, ValueError):
+            sys.stderr.write('cpu_baseline child failed (rc %d), running in-process:\n%s\n'
+                             % (r.returncode, r.stderr[-2000:]))
+            cpu = cpu_baseline()
 
     import torch
     import torch.distributed as dist

@@ -16,7 +16,7 @@ tests)
 bench)
   python bench.py > $out/${tag}_bench1024_f16.json 2> $out/bench_f16.err
   cut -c1-200 $out/${tag}_bench1024_f16.json
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --no-legs > $out/trace_bench.json 2> $out/trace.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --no-legs --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.err
   find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_bench1024_f16_kernel_stats.csv \;
   rm -rf $out/trace
   python tools/bench_v2o.py --reps 10 --out $out/${tag}_v2o582_bench.json > $out/v2o.log 2>&1; tail -1 $out/v2o.log
