@@ -346,7 +346,9 @@ def main():
     if world == 1 and pmc_path:
         for k, v in json.load(open(pmc_path))['kernels'].items():
             if 'hbm_bytes_per_dispatch' in v:
-                traffic_by_kernel[k] = v['hbm_bytes_per_dispatch']
+                # rocprofv3 names template instances ("vgg_mid_pool_f16<false>"); the
+                # library's timing names do not carry the arguments
+                traffic_by_kernel[k.split('<')[0]] = v['hbm_bytes_per_dispatch']
 
     # dominant kernel roofline (this rank; ranks are symmetric)
     roof = None
