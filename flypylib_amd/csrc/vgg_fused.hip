@@ -136,6 +136,37 @@ __device__ __forceinline__ void stem_load_rows(const StemArgs &a, const StemBloc
   }
 }
 
+// Row addresses inside the task loop.  stem_row_ptr per row is ~35 scalar instructions
+// (a division by 18, 64-bit products, clamps) - 105 of the ~460 instructions a wave
+// issues per task.  Per block they are computed once, vectorised: lane l holds, for tile
+// row wrow0 + l, the element offset of the (clamped) row from the block's (clamped)
+// origin row, bit 31 = the row exists.  A task then needs one v_readlane per row.
+template <typename SRC>
+__device__ __forceinline__ unsigned stem_row_tab(const StemArgs &a, const StemBlock &b, int wrow0,
+                                                 int lane, const SRC *&base) {
+  const int row = wrow0 + (lane < S_WROWS ? lane : S_WROWS - 1);
+  const int64_t z = b.gz0 + row / S_TY, y = b.gy0 + row % S_TY;
+  const bool ok = z < a.z_hi && y < a.SY;
+  const int64_t zc = z < a.z_hi ? z : a.z_hi - 1, yc = y < a.SY ? y : a.SY - 1;
+  const int64_t zb = b.gz0 < a.z_hi ? b.gz0 : a.z_hi - 1, yb = b.gy0 < a.SY ? b.gy0 : a.SY - 1;
+  base = (const SRC *)a.src + (zb * a.SY + yb) * a.SX;
+  // <= S_TZ planes from the origin: fits 31 bits (checked at launch)
+  const unsigned rel = (unsigned)(((zc - zb) * a.SY + (yc - yb)) * a.SX);
+  return rel | (ok ? 0x80000000u : 0u);
+}
+
+// the loads of tile rows wrow0 + idx0 .. + S_RPT - 1 through the table
+template <typename SRC>
+__device__ __forceinline__ void stem_load_rows_tab(const SRC *base, unsigned tab, unsigned xc,
+                                                   int idx0, StemRows<SRC> &r) {
+#pragma unroll
+  for (int k = 0; k < S_RPT; ++k) {
+    const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)tab, idx0 + k);
+    r.ok[k] = (t >> 31) != 0u;
+    r.v[k] = (base + (t & 0x7FFFFFFFu))[xc];
+  }
+}
+
 // normalise (v - mean) / sd, round to 16 bits; zero past the volume end.  For u8
 // sources the 256 possible values go through a per-WG lookup table: the divide +
 // convert happen once per value, not once per voxel.
@@ -275,6 +306,9 @@ __global__ __launch_bounds__(256, STEM_WPS) void FPLK(vgg_stem_pool)(StemArgs a)
     const bool has_next = qn < nblocks;                 // uniform
     const StemBlock nxt = stem_block(a, has_next ? qn : q, lane);
     const StemBlock nx2 = stem_block(a, clampq(qn + G, has_next ? qn : q), lane);
+    const SRC *base_n, *base_2;
+    const unsigned tab_n = stem_row_tab<SRC>(a, nxt, wrow0, lane, base_n);
+    const unsigned tab_2 = stem_row_tab<SRC>(a, nx2, wrow0, lane, base_2);
     const unsigned char *tb = reinterpret_cast<const unsigned char *>(tiles[cur]);
     unsigned short *tnext = tiles[cur ^ 1];
 #pragma unroll 1
@@ -287,10 +321,10 @@ __global__ __launch_bounds__(256, STEM_WPS) void FPLK(vgg_stem_pool)(StemArgs a)
       stem_convert_rows<SRC>(a, nxt, lut, rr, hb);
       const int grow = wrow0 + (S_RPT * ti < S_WROWS ? S_RPT * ti : S_WROWS - S_RPT);
       const bool last = ti + 1 == S_TASKS;
-      StemBlock lb = nxt;
-      if (last) lb = nx2;
-      int lrow = wrow0 + S_RPT * (ti + 1);
-      lrow = last ? wrow0 : (lrow < wrow1 ? lrow : wrow1 - S_RPT);
+      const SRC *lbase = last ? base_2 : base_n;
+      const unsigned ltab = last ? tab_2 : tab_n, lxc = last ? nx2.xc : nxt.xc;
+      int lidx = S_RPT * (ti + 1);                    // row index inside the wave's 45
+      lidx = last ? 0 : (lidx < S_WROWS ? lidx : S_WROWS - S_RPT);
       const int task = wave + 4 * ti;
       const int row = task >> 1, xh = task & 1;
       const int pzl = row / S_PY, pyl = row % S_PY;
@@ -332,7 +366,7 @@ __global__ __launch_bounds__(256, STEM_WPS) void FPLK(vgg_stem_pool)(StemArgs a)
             poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
         if (sp == 1) {
           stem_write_rows(tnext, grow, lane, hb);
-          stem_load_rows<SRC>(a, lb, lrow, rr);
+          stem_load_rows_tab<SRC>(lbase, ltab, lxc, lidx, rr);
         }
       }
       u32x2 pooled[3];
@@ -1284,6 +1318,9 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
       a.p1 = (h16_t *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
       a.nbx = (int)ceil_div64(P1X, S_PX); a.nby = (int)ceil_div64(P1Y, S_PY);
       a.nbz = (int)ceil_div64(P1Z, S_PZ);
+      FPL_REQUIRE(ctx, (int64_t)S_TZ * SY * SX < ((int64_t)1 << 31),
+                  "vgg fused path: a %lld x %lld plane is too large for the stem's 31-bit row "
+                  "offsets", (long long)SY, (long long)SX);
       // persistent: two workgroups per CU walk the blocks
       const unsigned grid = (unsigned)std::min<int64_t>((int64_t)a.nbx * a.nby * a.nbz,
                                                         (int64_t)ctx->n_cu * 2);
