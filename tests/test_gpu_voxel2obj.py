@@ -38,7 +38,11 @@ def test_golden_cases_bit_exact(ctx, golden):
     ((120, 110, 130), 27, 5.0, 0, 0),
     ((160, 160, 160), 27, 5.0, 0.02, 30),
     ((90, 140, 75), 9, 2.0, 0.2, (3, 4, 5)),
-    ((64, 64, 200), 15, 3.0, 0, 0)])
+    ((64, 64, 200), 15, 3.0, 0, 0),
+    # radii beyond the tabulated fast paths: window of 2 * 10 + 1 cells (plain window-max
+    # kernels), 81^2 cube rows per ball (untabulated row geometry), 23^3 cells per ball
+    ((120, 100, 130), 40, 3.0, 0.05, 0),
+    ((70, 150, 90), 33, 2.0, 0, 2)])
 def test_matches_oracle_on_seeded_volumes(ctx, shape, r, sigma, thd, buf):
     pred = synth.blob_prob_volume(77, shape, period=32, radius=7.0)
     ref = voxel2obj_oracle.voxel2obj(pred, r, sigma, (3, 2, 1), buf, thd)
