@@ -8,7 +8,7 @@ from oracle import cnn_oracle, infer_oracle
 
 pytestmark = pytest.mark.gpu
 EMU_TOL = {'bf16': 1e-2, 'f16': 2e-3}
-F32_TOL = {'bf16': 5e-2, 'f16': 1e-3}       # f16 meets the north star's 1e-3 gate
+F32_TOL = {'bf16': 1.5e-2, 'f16': 1e-3}       # f16 meets the north star's 1e-3 gate
 PREC = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16}
 
 

@@ -16,7 +16,7 @@ from oracle import cnn_oracle, infer_oracle
 
 pytestmark = pytest.mark.gpu
 EMU_TOL = {'bf16': 1e-2, 'f16': 2e-3}   # worst voxel: one-ulp flips at rounding points, amplified
-BF16_TOL = 5e-2      # bf16 vs fp32 probabilities, max abs
+BF16_TOL = 8e-3      # bf16 vs fp32 probabilities, max abs (observed <= 1.3e-3 over these cases)
 F16_TOL = 1e-3       # f16 vs fp32 probabilities, max abs: the north-star gate
 PREC = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16}
 KINDS = ['bf16', 'f16']
