@@ -288,7 +288,76 @@ def gen_keras_tiny():
     np.savez(os.path.join(HERE, 'keras_tiny.npz'), *g.get_weights())
 
 
+
+def training_volumes(seed, shape):
+    """seeded (image f32, labels u8, mask u8) for the training-generator fixtures; shared
+    with tests/test_training_data.py (same code there: the fixture holds outputs only)"""
+    im = synth.em_volume_u8(seed, shape).astype(np.float32)
+    ll = (synth.hash_uniform_f32(seed + 100, shape) > np.float32(0.97)).astype(np.uint8)
+    mm = np.ones(shape, np.uint8)
+    mm[: shape[0] // 3, : shape[1] // 2, :] = 0
+    return im, ll, mm
+
+
+def gen_training_generators():
+    """gen_batches / gen_volume / gen_volume2 of the REFERENCE on seeded .h5 volumes
+    (reference fplobjdetect.py:27-130, 524-658, 660-822).  The reference reads its inputs
+    with h5py, absent here: for this run `h5py.File(path)['/main'][:]` is served by the
+    package's own HDF5 reader (flypylib_amd/h5min.py) on files written by its writer -
+    the arrays the reference sees are exactly the arrays below, and everything after the
+    read (sampling order, np.random call order, augmentation) is the reference's code."""
+    import tempfile
+    import types
+    from flypylib_amd import h5min, keras_io
+
+    class _File:
+        def __init__(self, path, mode='r'):
+            self._f = h5min.File(path)
+
+        def __getitem__(self, key):
+            return self._f[key.lstrip('/')]
+
+    shim = types.ModuleType('h5py')
+    shim.File = _File
+    sys.modules['h5py'] = shim
+    fplobjdetect.h5py = shim
+    wd = tempfile.mkdtemp(prefix='gen_')
+    shapes = [(40, 44, 48), (36, 52, 40)]
+    train = []
+    for v, shape in enumerate(shapes):
+        im, ll, mm = training_volumes(50 + v, shape)
+        keras_io.write_main('%s/im%d.h5' % (wd, v), im)
+        keras_io.write_main('%s/v%d_labels.h5' % (wd, v), ll)
+        keras_io.write_main('%s/v%d_mask.h5' % (wd, v), mm)
+        train.append(('%s/im%d.h5' % (wd, v), '%s/v%d_' % (wd, v)))
+    out = {'shapes': np.array(shapes), 'vol_seeds': np.array([50, 51])}
+    cases = [
+        ('batches', lambda: fplobjdetect.gen_batches(train, (12, 10, 10), 6), 7, 3),
+        ('batches_mask', lambda: fplobjdetect.gen_batches(train, (12, 12, 12), 4, True), 8, 3),
+        ('volume', lambda: fplobjdetect.gen_volume(train, (24, 24, 24), 3, 0.5), 9, 4),
+        ('volume2', lambda: fplobjdetect.gen_volume2(train, (24, 24, 24), 3, 0.5), 10, 3),
+        ('volume2_noise', lambda: fplobjdetect.gen_volume2(train, (24, 24, 24), 2, 0.3,
+                                                            noise_aug=[0.05, 0.1]), 11, 3),
+    ]
+    for name, make, seed, n in cases:
+        np.random.seed(seed)
+        gen = make()
+        for i in range(n):
+            d, lab = next(gen)
+            # whole batches as checksums; the labels (small) and one example in full
+            out['%s_data_sha_%d' % (name, i)] = np.array(sha(np.ascontiguousarray(d)))
+            out['%s_labels_%d' % (name, i)] = np.array(lab)
+            if i == 0:
+                out['%s_example0' % name] = np.array(d[0, ..., 0])
+        out['%s_seed' % name] = np.array(seed)
+        print(name, 'ok', d.shape, lab.shape, int(lab.sum()))
+    np.savez_compressed(os.path.join(HERE, 'training_generators.npz'), **out)
+
+
 if __name__ == '__main__':
+    if 'generators' in sys.argv[1:]:
+        gen_training_generators()
+        sys.exit(0)
     gen_keras_tiny()
     gen_voxel2obj_seg()
     gen_synapses()

@@ -1,8 +1,13 @@
 """Training data path of the U-Nets (reference fplobjdetect.py:660-839,
 fplnetwork.py:191-220): gen_volume2, voxel_loss, write_sampling_weights - host
-logic, checked through constructed cases (the reference needs h5py files for these;
-no goldens)."""
+logic, checked through constructed cases and - gen_batches, gen_volume, gen_volume2 -
+against the reference's own outputs on seeded .h5 volumes
+(tests/golden/training_generators.npz; the reference's h5py reads were served by the
+package's HDF5 reader when the fixture was made)."""
+import os
+
 import numpy as np
+import pytest
 
 from flypylib_amd import FplNetwork, fplobjdetect
 
@@ -164,3 +169,51 @@ def test_gen_volume_cycles_volumes_and_respects_ratio():
             n_pos[vol] += int(centre.max() == 1)
     assert n_pos[2] == 0 and 55 < n_pos[0] < 95 and 55 < n_pos[1] < 95     # ~75 % of 100
     assert fplobjdetect.get_out_sz(18) == 6 and fplobjdetect.get_out_sz(24) == 10   # unet_like sizes
+
+
+# ---- the reference's own generators, pinned (tests/golden/training_generators.npz holds
+#      the outputs of flypylib's gen_batches / gen_volume / gen_volume2 on these inputs,
+#      generated by tests/golden/make_golden.py::gen_training_generators) ---------------
+def _training_volumes(seed, shape):
+    """same inputs as make_golden.py::training_volumes"""
+    from flypylib_amd import synth
+    im = synth.em_volume_u8(seed, shape).astype(np.float32)
+    ll = (synth.hash_uniform_f32(seed + 100, shape) > np.float32(0.97)).astype(np.uint8)
+    mm = np.ones(shape, np.uint8)
+    mm[: shape[0] // 3, : shape[1] // 2, :] = 0
+    return im, ll, mm
+
+
+@pytest.mark.parametrize('name,n', [('batches', 3), ('batches_mask', 3), ('volume', 4),
+                                    ('volume2', 3), ('volume2_noise', 3)])
+def test_generators_match_the_reference_outputs(tmp_path, name, n):
+    """inputs as .h5 files (read back by the package's own HDF5 reader), the global numpy
+    RNG seeded as in the fixture run: batches bit-identical to the reference's"""
+    import hashlib
+    from flypylib_amd import keras_io
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'training_generators.npz'))
+    train = []
+    for v, (shape, seed) in enumerate(zip(gold['shapes'], gold['vol_seeds'])):
+        im, ll, mm = _training_volumes(int(seed), tuple(int(d) for d in shape))
+        keras_io.write_main(str(tmp_path / ('im%d.h5' % v)), im)
+        keras_io.write_main(str(tmp_path / ('v%d_labels.h5' % v)), ll)
+        keras_io.write_main(str(tmp_path / ('v%d_mask.h5' % v)), mm)
+        train.append((str(tmp_path / ('im%d.h5' % v)), str(tmp_path / ('v%d_' % v))))
+    make = {
+        'batches': lambda: fplobjdetect.gen_batches(train, (12, 10, 10), 6),
+        'batches_mask': lambda: fplobjdetect.gen_batches(train, (12, 12, 12), 4, True),
+        'volume': lambda: fplobjdetect.gen_volume(train, (24, 24, 24), 3, 0.5),
+        'volume2': lambda: fplobjdetect.gen_volume2(train, (24, 24, 24), 3, 0.5),
+        'volume2_noise': lambda: fplobjdetect.gen_volume2(train, (24, 24, 24), 2, 0.3,
+                                                           noise_aug=[0.05, 0.1]),
+    }[name]
+    np.random.seed(int(gold['%s_seed' % name]))
+    gen = make()
+    for i in range(n):
+        d, lab = next(gen)
+        assert d.dtype == np.float32 and lab.dtype == np.uint8
+        assert np.array_equal(lab, gold['%s_labels_%d' % (name, i)]), (name, i)
+        if i == 0:
+            assert np.array_equal(d[0, ..., 0], gold['%s_example0' % name]), name
+        got = hashlib.sha256(np.ascontiguousarray(d).tobytes()).hexdigest()
+        assert got == str(gold['%s_data_sha_%d' % (name, i)]), (name, i)
