@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gauss_pass(
 
 // Register-window form of one pass: a thread produces OUT consecutive outputs along
 // AXIS from OUT + 2*WR loaded values (3.5 loads per output for WR = 10 instead of
-// 21; 2.25 with the 16 outputs of passes 0 and 1); lanes run along x, so the loads of
+// 21; 2.25 with 16 outputs per thread); lanes run along x, so the loads of
 // passes 0 and 1 are coalesced.  Same
 // arithmetic order as gauss_pass.
 template <int AXIS, int WR>
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void gauss_x_lds(
 // scipy does).  The 1-D grid is decoded per workgroup (uniform) so that the blocks an
 // XCD receives (b, b + 8, ...) walk consecutive z blocks of one strip: the 2*WR halo
 // planes a block shares with its z neighbour are L2 hits instead of HBM re-reads.
-constexpr int GZ_OUT = 16;
+constexpr int GZ_OUT = 12;       // 8 / 12 / 16 / 24 outputs per thread: 0.62 / 0.54 / 0.57 / 0.59 ms
 
 template <int WR>
 __global__ __launch_bounds__(512) void gauss_z_win(
@@ -346,7 +346,9 @@ __global__ __launch_bounds__(512) void gauss_z_win(
 // 4 B/voxel write and one read less); arithmetic and rounding points are unchanged.
 // The 1-D grid is decoded so that the blocks an XCD receives (b, b + 8, ...) walk the
 // y tiles of consecutive planes: y neighbours share their 2*WR halo rows in that L2.
-constexpr int GYX_TY = 16;
+// 12 rows: the tile is 33 KiB at P2 = 636 and four workgroups fit a CU (16 rows, three
+// workgroups: 1.07 ms against 0.94; 8 rows: 0.97).
+constexpr int GYX_TY = 12;
 
 template <int WR>
 __global__ __launch_bounds__(512) void gauss_yx_fused(
