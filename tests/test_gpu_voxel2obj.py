@@ -54,6 +54,26 @@ def test_matches_oracle_on_seeded_volumes(ctx, shape, r, sigma, thd, buf):
     assert info['rounds'] >= 1
 
 
+def test_dense_noise_many_rounds(ctx):
+    """uniform noise, small radius: thousands of detections over many NMS rounds, the
+    percentile (not thd) as threshold, a first-level radix bin that holds a large part of
+    the volume - the regime the substack pipeline's random-weight predictions are in"""
+    pred = synth.hash_uniform_f32(91, (96, 100, 104))
+    for r, sigma, thd in ((5, 1.5, 0), (4, 2.0, 0.2)):
+        ref = voxel2obj_oracle.voxel2obj(pred, r, sigma, (0, 0, 0), 0, thd)
+        got, info = fplobjdetect.voxel2obj(pred, r, sigma, (0, 0, 0), 0, thd, return_info=True)
+        assert len(ref['conf']) > 1000 and info['rounds'] >= 5
+        assert np.array_equal(got['locs'], ref['locs'])
+        assert np.array_equal(got['conf'], ref['conf'])
+    # the same volume, half of it lifted into [0.5, 0.75): ONE first-level bin holds more
+    # than 1/8 of the voxels (the histogram-first order of the radix select)
+    lifted = pred.copy()
+    lifted[:48] = np.float32(0.5) + lifted[:48] * np.float32(0.25)
+    ref = voxel2obj_oracle.voxel2obj(lifted, 5, 1.5, (0, 0, 0), 0, 0)
+    got = fplobjdetect.voxel2obj(lifted, 5, 1.5, (0, 0, 0), 0, 0)
+    assert np.array_equal(got['locs'], ref['locs']) and np.array_equal(got['conf'], ref['conf'])
+
+
 def test_order_statistics_exact(ctx):
     pred = synth.hash_uniform_f32(5, (50, 60, 70))
     r, sigma = 6, 2.0
