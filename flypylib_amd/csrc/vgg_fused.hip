@@ -647,6 +647,187 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
 }
 
 // -------------------------------------------------------------------------------
+// K2 with 8 sub-steps per wave (FPL_MID8=1; experiment of round 2).  vgg_mid_pool's
+// waves fetch every weight fragment for 4 sub-steps (64 voxels): 9/10 of what the CU's
+// vector-memory return path carries, and that path is 76 % busy.  Here a wave covers
+// 8 sub-steps - half the weight bytes per MFMA.  512 outputs per workgroup need a tile
+// twice as large; two workgroups per CU then only fit with HALF the channels resident:
+// the K loop runs over (27 taps x 24 channels) twice, refilling the tile in between
+// (2 x 21 K-steps instead of 41).  Pre-pool block 8 x 4 x 16 (pooled 4 x 2 x 8); wave =
+// pooled rows (2 pzp, pyl) and (2 pzp + 1, pyl); sub-step = (row of the pair, dz, dy).
+// -------------------------------------------------------------------------------
+constexpr int M8_TZ = 10, M8_TY = 6, M8_TX = 18;
+constexpr int M8_VOX = 48;                               // bytes per voxel of a half tile
+constexpr int M8_TILE_BYTES = ((M8_TZ * M8_TY * M8_TX * M8_VOX + 1023) / 1024) * 1024;
+constexpr int M8_KSTEPS = 21;                            // 27 * 24 = 648 -> 20.25 steps of 32
+constexpr int M8_KTAB = 24;
+constexpr int M8_SMEM = M8_TILE_BYTES + 4 * M8_KTAB * 4;
+static_assert(2 * M8_SMEM <= 160 * 1024, "two mid8 workgroups must fit one CU");
+
+__device__ __forceinline__ unsigned m8_kslot(int idx) {
+  const int g = idx / M8_KTAB;
+  int st = idx % M8_KTAB;
+  st = st < M8_KSTEPS ? st : M8_KSTEPS - 1;
+  const int f0 = 32 * st + 8 * g;
+  const int tap = f0 / 24, ch0 = f0 % 24;
+  if (tap >= 27) return 0u;                              // zero weights
+  return (unsigned)((((tap / 9) * M8_TY + (tap / 3) % 3) * M8_TX + tap % 3) * M8_VOX + ch0 * 2);
+}
+
+// channels [24 h, 24 h + 24) of the block's input region, by LDS-DMA (stage_tile with
+// three 16-B pieces per voxel)
+__device__ __forceinline__ void m8_stage_half(const h16_t *act, int AZ, int AY, int AX, int z0,
+                                              int y0, int x0, int h, unsigned char *tile,
+                                              int wave, int lane) {
+  constexpr int RC = M8_TX * 3;                           // 16-B pieces per row
+  constexpr int TOTAL = M8_TZ * M8_TY * RC;
+  constexpr int PIECES = (TOTAL + 63) / 64;
+  constexpr int DR = 256 / RC, DC = 256 % RC;
+  static_assert(DR + 1 < M8_TY, "a step wraps at most one z row");
+  const int idx0 = wave * 64 + lane;
+  int row = idx0 / RC, cw = idx0 % RC;
+  int rz = row / M8_TY, ry = row % M8_TY;
+  const int zmax = AZ - 1 - z0, ymax = AY - 1 - y0, xmax = AX - 1 - x0;
+  const unsigned SY = (unsigned)AX * VOX_BYTES, SZ = (unsigned)AY * SY;
+  const unsigned char *base = reinterpret_cast<const unsigned char *>(
+      act + (((int64_t)z0 * AY + y0) * AX + x0) * CH) + h * M8_VOX;
+  for (int p = wave; p < PIECES; p += 4) {
+    const bool past = rz >= M8_TZ;
+    const int rzc = past ? M8_TZ - 1 : rz, ryc = past ? M8_TY - 1 : ry, cwc = past ? RC - 1 : cw;
+    const int vx = cwc / 3, pc = cwc - 3 * vx;
+    const int zc = rzc < zmax ? rzc : zmax, yc = ryc < ymax ? ryc : ymax, xc = vx < xmax ? vx : xmax;
+    const unsigned off = (unsigned)zc * SZ + (unsigned)yc * SY + (unsigned)(xc * VOX_BYTES + pc * 16);
+    glds16(base + off, tile + (size_t)p * 1024);
+    cw += DC;
+    int dr = DR;
+    if (cw >= RC) { cw -= RC; ++dr; }
+    ry += dr;
+    if (ry >= M8_TY) { ry -= M8_TY; ++rz; }
+  }
+}
+
+struct Mid8Args {
+  const h16_t *p1;
+  int P1Z, P1Y, P1X;
+  const unsigned char *w3h;      // [half][M8_KSTEPS][3] fragments
+  const h16x8 *w4;
+  const float *shift3, *shift4;
+  h16_t *p2;
+  int P2Z, P2Y, P2X;
+  BlockGrid bg;
+};
+
+__global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool8)(Mid8Args a) {
+  unsigned char *tile = smem;
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M8_TILE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int xb, yb, zb;
+  if (!block_coords(a.bg, xb, yb, zb)) return;
+  const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 4;
+  if (tid < 4 * M8_KTAB) kofftab[tid] = m8_kslot(tid);
+  const int pzp = wave >> 1, pyl = wave & 1;
+  const unsigned vbase = (unsigned)((((4 * pzp) * M8_TY + 2 * pyl) * M8_TX + c) * M8_VOX);
+  auto sub_off = [](int sub) -> unsigned {
+    return (unsigned)((((2 * (sub >> 2) + ((sub >> 1) & 1)) * M8_TY + (sub & 1)) * M8_TX) * M8_VOX);
+  };
+  f32x4 acc[8][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    f32x4 sh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = a.shift3[16 * b + 4 * g + r];
+#pragma unroll
+    for (int sub = 0; sub < 8; ++sub) acc[sub][b] = sh;
+  }
+  constexpr int WQ8 = 3, BQ = 4;                 // weight K-steps / activation fragments in flight
+  const unsigned *ktab = kofftab + g * M8_KTAB;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();                      // every wave has left the first half's tile
+    m8_stage_half(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0, h, tile, wave, lane);
+    const unsigned char *wl = a.w3h + (size_t)h * M8_KSTEPS * 3 * 1024 + lane * 16;
+    h16x8 wq[WQ8][3];
+#pragma unroll
+    for (int d = 0; d < WQ8; ++d)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * 3 + b) * 1024);
+    __syncthreads();                             // tile (LDS-DMA) + table visible
+    // activation fragments run BQ - 1 (sub-step, K-step) pairs ahead of their MFMAs
+    u32x4 kv = *reinterpret_cast<const u32x4 *>(ktab);
+    h16x8 br[BQ];
+    auto frag = [&](int t, const u32x4 &k) {
+      return *reinterpret_cast<const h16x8 *>(tile + vbase + k[(t >> 3) & 3] + sub_off(t & 7));
+    };
+#pragma unroll
+    for (int t = 0; t < BQ - 1; ++t) br[t] = frag(t, kv);
+#pragma unroll
+    for (int st = 0; st < M8_KSTEPS; ++st) {
+      u32x4 kn = kv;
+      if ((st + 1) % 4 == 0 && st + 1 < M8_KSTEPS) kn = *reinterpret_cast<const u32x4 *>(ktab + st + 1);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int sub = 0; sub < 8; ++sub) {
+        const int t = st * 8 + sub, tn = t + BQ - 1;
+        if (tn < M8_KSTEPS * 8) br[tn % BQ] = frag(tn, (tn >> 3) / 4 == st / 4 ? kv : kn);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wq[st % WQ8][b], br[t % BQ], acc[sub][b]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      kv = kn;
+      if (st + WQ8 < M8_KSTEPS) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          wq[st % WQ8][b] =
+              *reinterpret_cast<const h16x8 *>(wl + (size_t)((st + WQ8) * 3 + b) * 1024);
+      }
+    }
+  }
+
+  // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions of
+  // each of the wave's two pooled rows
+  h16x8 w4[2][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    w4[0][b] = a.w4[(0 * 3 + b) * 64 + lane];
+    w4[1][b] = a.w4[(1 * 3 + b) * 64 + lane];
+  }
+  f32x4 sh4[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[16 * b + 4 * g + r];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int sub = 4 * q + s4;
+      const h16x8 h0 = pack_relu(acc[sub][0], acc[sub][1]);
+      const h16x8 h1 = pack_relu_lo(acc[sub][2]);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        f32x4 a4 = mfma16(w4[0][b], h0, sh4[b]);
+        a4 = mfma16(w4[1][b], h1, a4);
+        pool_relu_h16(pooled[b], a4);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      pooled[b][0] = pk_max_i16(pooled[b][0], (unsigned)__shfl_xor((int)pooled[b][0], 1));
+      pooled[b][1] = pk_max_i16(pooled[b][1], (unsigned)__shfl_xor((int)pooled[b][1], 1));
+    }
+    const int pz = pz0 + 2 * pzp + q, py = py0 + pyl, px = px0 + (c >> 1);
+    if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
+      h16_t *dst = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * CH + 4 * g;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------
 // K3: conv3 48->48 + BN + ReLU on P2 and the 1x1 head.  Same structure as K2 (two
 // workgroups per CU) without the pool: block 4(z) x 4(y) x 16(x), wave = z,
 // sub-steps = the 4 y rows.
@@ -972,6 +1153,9 @@ struct VggFastState {
   bool have_scaled = false;
   size_t off_w1s = 0, off_w2s = 0, off_s1s = 0;
   float stem_in_scale = 1.f;
+  // vgg_like: L3 fragments in the K order of vgg_mid_pool8 (two halves of 24 channels)
+  size_t off_w3h = 0;
+  bool have_w3h = false;
 };
 
 constexpr float STEM_XMAX = 8.f;   // |(v - mean) / sd| bound the scaled set is built for
@@ -1056,6 +1240,26 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
     shifts.insert(shifts.end(), A + op.shift_off, A + op.shift_off + op.cout);
     while (shifts.size() % 4) shifts.push_back(0.f);
   }
+  st->have_w3h = false;
+  if (!v2) {
+    // L3 once more in vgg_mid_pool8's K order: two halves of 24 input channels, each
+    // (tap, channel-in-half) flattened into 21 K-steps
+    const fpl_op &o3 = prog->ops[conv_ops[2]];
+    std::vector<float> sc3(A + o3.scale_off, A + o3.scale_off + o3.cout);
+    st->off_w3h = all.size() * sizeof(uint16_t);
+    for (int h = 0; h < 2; ++h) {
+      std::vector<float> wh((size_t)27 * 24 * o3.cout);
+      for (int tap = 0; tap < 27; ++tap)
+        for (int ch = 0; ch < 24; ++ch)
+          for (int co = 0; co < o3.cout; ++co)
+            wh[((size_t)tap * 24 + ch) * o3.cout + co] =
+                A[o3.w_off + ((size_t)tap * o3.cin + 24 * h + ch) * o3.cout + co];
+      std::vector<uint16_t> f;
+      fpl_pack_frags(wh.data(), sc3.data(), 27, 24, o3.cout, 3, M8_KSTEPS, SLOT_SPATIAL, &f);
+      all.insert(all.end(), f.begin(), f.end());
+    }
+    st->have_w3h = true;
+  }
   st->have_scaled = false;
 #ifdef FPL_F16
   if (!v2) {
@@ -1130,6 +1334,8 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_c5_tail),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, M8_SMEM));
   if (v2) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg2_conv3)<true, true, uint8_t>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
@@ -1365,6 +1571,14 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
         }
         fprintf(stderr, "[FPL_DIAG_MID] %zu WGs: mean cycles fill %.0f  kloop %.0f  epilogue %.0f  total %.0f\n",
                 real, fill / real, loop / real, epi / real, tot / real);
+      } else if (st->have_w3h && getenv("FPL_MID8")) {
+        Mid8Args b;
+        b.p1 = a.p1; b.P1Z = P1Z; b.P1Y = P1Y; b.P1X = P1X;
+        b.w3h = F + st->off_w3h; b.w4 = a.w4; b.shift3 = a.shift3; b.shift4 = a.shift4;
+        b.p2 = a.p2; b.P2Z = P2Z; b.P2Y = P2Y; b.P2X = P2X;
+        b.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 4)};
+        TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
+        FPLK(vgg_mid_pool8)<<<block_grid_size(b.bg), 256, M8_SMEM, stream>>>(b);
       } else {
         TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
         FPLK(vgg_mid_pool)<false><<<grid, 256, M_SMEM, stream>>>(a);
