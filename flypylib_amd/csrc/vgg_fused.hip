@@ -662,6 +662,7 @@ constexpr int M8_TILE_BYTES = ((M8_TZ * M8_TY * M8_TX * M8_VOX + 1023) / 1024) *
 constexpr int M8_KSTEPS = 21;                            // 27 * 24 = 648 -> 20.25 steps of 32
 constexpr int M8_KTAB = 24;
 constexpr int M8_SMEM = M8_TILE_BYTES + 4 * M8_KTAB * 4;
+constexpr int M4H_SMEM = ((6 * M8_TY * M8_TX * M8_VOX + 1023) / 1024) * 1024 + 4 * M8_KTAB * 4;
 static_assert(2 * M8_SMEM <= 160 * 1024, "two mid8 workgroups must fit one CU");
 
 __device__ __forceinline__ unsigned m8_kslot(int idx) {
@@ -676,11 +677,12 @@ __device__ __forceinline__ unsigned m8_kslot(int idx) {
 
 // channels [24 h, 24 h + 24) of the block's input region, by LDS-DMA (stage_tile with
 // three 16-B pieces per voxel)
+template <int TZ>
 __device__ __forceinline__ void m8_stage_half(const h16_t *act, int AZ, int AY, int AX, int z0,
                                               int y0, int x0, int h, unsigned char *tile,
                                               int wave, int lane) {
   constexpr int RC = M8_TX * 3;                           // 16-B pieces per row
-  constexpr int TOTAL = M8_TZ * M8_TY * RC;
+  constexpr int TOTAL = TZ * M8_TY * RC;
   constexpr int PIECES = (TOTAL + 63) / 64;
   constexpr int DR = 256 / RC, DC = 256 % RC;
   static_assert(DR + 1 < M8_TY, "a step wraps at most one z row");
@@ -692,8 +694,8 @@ __device__ __forceinline__ void m8_stage_half(const h16_t *act, int AZ, int AY, 
   const unsigned char *base = reinterpret_cast<const unsigned char *>(
       act + (((int64_t)z0 * AY + y0) * AX + x0) * CH) + h * M8_VOX;
   for (int p = wave; p < PIECES; p += 4) {
-    const bool past = rz >= M8_TZ;
-    const int rzc = past ? M8_TZ - 1 : rz, ryc = past ? M8_TY - 1 : ry, cwc = past ? RC - 1 : cw;
+    const bool past = rz >= TZ;
+    const int rzc = past ? TZ - 1 : rz, ryc = past ? M8_TY - 1 : ry, cwc = past ? RC - 1 : cw;
     const int vx = cwc / 3, pc = cwc - 3 * vx;
     const int zc = rzc < zmax ? rzc : zmax, yc = ryc < ymax ? ryc : ymax, xc = vx < xmax ? vx : xmax;
     const unsigned off = (unsigned)zc * SZ + (unsigned)yc * SY + (unsigned)(xc * VOX_BYTES + pc * 16);
@@ -717,35 +719,43 @@ struct Mid8Args {
   BlockGrid bg;
 };
 
-__global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool8)(Mid8Args a) {
+// NSUB = 8: pre-pool block 8 x 4 x 16 (tile depth 10), two workgroups per CU.
+// NSUB = 4: the shipped kernel's block 4 x 4 x 16 on 31 KiB half tiles (tile depth 6): the
+// weight traffic of the shipped kernel, but WPS = 3 or 4 workgroups fit a CU.
+template <int NSUB, int WPS>
+__global__ __launch_bounds__(256, WPS) void FPLK(vgg_mid_pool8)(Mid8Args a) {
+  constexpr int TZ = NSUB == 8 ? M8_TZ : 6;
+  constexpr int TILE_BYTES = ((TZ * M8_TY * M8_TX * M8_VOX + 1023) / 1024) * 1024;
+  constexpr int ROWS = NSUB / 4;                 // pooled rows per wave
   unsigned char *tile = smem;
-  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M8_TILE_BYTES);
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   int xb, yb, zb;
   if (!block_coords(a.bg, xb, yb, zb)) return;
-  const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 4;
+  const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 2 * ROWS;
   if (tid < 4 * M8_KTAB) kofftab[tid] = m8_kslot(tid);
   const int pzp = wave >> 1, pyl = wave & 1;
-  const unsigned vbase = (unsigned)((((4 * pzp) * M8_TY + 2 * pyl) * M8_TX + c) * M8_VOX);
+  const unsigned vbase =
+      (unsigned)((((2 * ROWS * pzp) * M8_TY + 2 * pyl) * M8_TX + c) * M8_VOX);
   auto sub_off = [](int sub) -> unsigned {
     return (unsigned)((((2 * (sub >> 2) + ((sub >> 1) & 1)) * M8_TY + (sub & 1)) * M8_TX) * M8_VOX);
   };
-  f32x4 acc[8][3];
+  f32x4 acc[NSUB][3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     f32x4 sh;
 #pragma unroll
     for (int r = 0; r < 4; ++r) sh[r] = a.shift3[16 * b + 4 * g + r];
 #pragma unroll
-    for (int sub = 0; sub < 8; ++sub) acc[sub][b] = sh;
+    for (int sub = 0; sub < NSUB; ++sub) acc[sub][b] = sh;
   }
   constexpr int WQ8 = 3, BQ = 4;                 // weight K-steps / activation fragments in flight
   const unsigned *ktab = kofftab + g * M8_KTAB;
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();                      // every wave has left the first half's tile
-    m8_stage_half(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0, h, tile, wave, lane);
+    m8_stage_half<TZ>(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0, h, tile, wave, lane);
     const unsigned char *wl = a.w3h + (size_t)h * M8_KSTEPS * 3 * 1024 + lane * 16;
     h16x8 wq[WQ8][3];
 #pragma unroll
@@ -758,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool8)(Mid8Args a) {
     u32x4 kv = *reinterpret_cast<const u32x4 *>(ktab);
     h16x8 br[BQ];
     auto frag = [&](int t, const u32x4 &k) {
-      return *reinterpret_cast<const h16x8 *>(tile + vbase + k[(t >> 3) & 3] + sub_off(t & 7));
+      return *reinterpret_cast<const h16x8 *>(tile + vbase + k[(t / NSUB) & 3] + sub_off(t % NSUB));
     };
 #pragma unroll
     for (int t = 0; t < BQ - 1; ++t) br[t] = frag(t, kv);
@@ -768,9 +778,10 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool8)(Mid8Args a) {
       if ((st + 1) % 4 == 0 && st + 1 < M8_KSTEPS) kn = *reinterpret_cast<const u32x4 *>(ktab + st + 1);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int sub = 0; sub < 8; ++sub) {
-        const int t = st * 8 + sub, tn = t + BQ - 1;
-        if (tn < M8_KSTEPS * 8) br[tn % BQ] = frag(tn, (tn >> 3) / 4 == st / 4 ? kv : kn);
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const int t = st * NSUB + sub, tn = t + BQ - 1;
+        if (tn < M8_KSTEPS * NSUB)
+          br[tn % BQ] = frag(tn, (tn / NSUB) / 4 == st / 4 ? kv : kn);
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wq[st % WQ8][b], br[t % BQ], acc[sub][b]);
       }
@@ -799,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool8)(Mid8Args a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[16 * b + 4 * g + r];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < ROWS; ++q) {
     u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -818,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool8)(Mid8Args a) {
       pooled[b][0] = pk_max_i16(pooled[b][0], (unsigned)__shfl_xor((int)pooled[b][0], 1));
       pooled[b][1] = pk_max_i16(pooled[b][1], (unsigned)__shfl_xor((int)pooled[b][1], 1));
     }
-    const int pz = pz0 + 2 * pzp + q, py = py0 + pyl, px = px0 + (c >> 1);
+    const int pz = pz0 + ROWS * pzp + q, py = py0 + pyl, px = px0 + (c >> 1);
     if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
       h16_t *dst = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * CH + 4 * g;
 #pragma unroll
@@ -1334,8 +1345,12 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_c5_tail),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8),
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8)<8, 2>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M8_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8)<4, 3>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, M4H_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8)<4, 4>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, M4H_SMEM));
   if (v2) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg2_conv3)<true, true, uint8_t>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
@@ -1572,13 +1587,21 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
         fprintf(stderr, "[FPL_DIAG_MID] %zu WGs: mean cycles fill %.0f  kloop %.0f  epilogue %.0f  total %.0f\n",
                 real, fill / real, loop / real, epi / real, tot / real);
       } else if (st->have_w3h && getenv("FPL_MID8")) {
+        // 1: 8 sub-steps per wave; 3 / 4: 4 sub-steps on half tiles, 3 / 4 workgroups per CU
+        const int mode = atoi(getenv("FPL_MID8"));
         Mid8Args b;
         b.p1 = a.p1; b.P1Z = P1Z; b.P1Y = P1Y; b.P1X = P1X;
         b.w3h = F + st->off_w3h; b.w4 = a.w4; b.shift3 = a.shift3; b.shift4 = a.shift4;
         b.p2 = a.p2; b.P2Z = P2Z; b.P2Y = P2Y; b.P2X = P2X;
-        b.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 4)};
+        b.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2),
+                         (int)ceil_div64(P2Z, mode >= 3 ? 2 : 4)};
         TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
-        FPLK(vgg_mid_pool8)<<<block_grid_size(b.bg), 256, M8_SMEM, stream>>>(b);
+        if (mode == 3)
+          FPLK(vgg_mid_pool8)<4, 3><<<block_grid_size(b.bg), 256, M4H_SMEM, stream>>>(b);
+        else if (mode == 4)
+          FPLK(vgg_mid_pool8)<4, 4><<<block_grid_size(b.bg), 256, M4H_SMEM, stream>>>(b);
+        else
+          FPLK(vgg_mid_pool8)<8, 2><<<block_grid_size(b.bg), 256, M8_SMEM, stream>>>(b);
       } else {
         TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
         FPLK(vgg_mid_pool)<false><<<grid, 256, M_SMEM, stream>>>(a);
