@@ -45,8 +45,10 @@ KERNEL_LAYERS = {
     'vgg_stem_pool_f16': ('L1', 'L2'), 'vgg_mid_pool_f16': ('L3', 'L4'),
     'vgg_c5_tail_f16': ('L5', 'L6', 'L7', 'L8'),
     'vgg_head_f32': ('L5', 'L6', 'L7', 'L8'),
+    'vggs_stem_pool': ('L1', 'L2'), 'vggs_mid_pool': ('L3', 'L4'),
+    'vggs_c5_tail': ('L5', 'L6', 'L7', 'L8'),
 }
-PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f16s': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
 
 
 def cpu_baseline(seconds_budget=8.0):
@@ -227,7 +229,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--size', type=int, default=1024,
                     help='volume edge per GPU (Z is size*gpus)')
-    ap.add_argument('--precision', default='f16', choices=['f16', 'bf16', 'f32'],
+    ap.add_argument('--precision', default='f16', choices=['f16s', 'f16', 'bf16', 'f32'],
                     help='16-bit MFMA operands with fp32 accumulation.  f16 (default): IEEE '
                          'half, worst voxel 1.5e-4 off fp32 on these synthetic weights and '
                          '0.7 - 1.0e-3 on trained ones (the north star asks 1e-3 of the fp32 '
@@ -289,7 +291,8 @@ def main():
     graph = fplmodels.vgg_like(tile)[0]
     synth.synthetic_weights(graph, 1234)
     prog = _capi.Program(ctx, graph, (4, 4, 4))
-    prec = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16, 'f32': _capi.PREC_F32}[args.precision]
+    prec = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16, 'f16s': _capi.PREC_F16S,
+            'f32': _capi.PREC_F32}[args.precision]
 
     # global volume (size*N, size, size); rank slab = contiguous tile rows, which
     # is itself a standalone volume whose lattice coincides with the global one
@@ -408,6 +411,8 @@ def main():
                                     'bf16': 'bfloat16 MFMA operands, fp32 accumulate (as '
                                             'configs[1] names; up to 8e-3 off fp32); '
                                             '--precision f16 stays within ~1e-3',
+                                    'f16s': 'split IEEE halves (hi + lo per operand, three MFMAs '
+                                            'per product, fp32 accumulate): within 2e-6 of fp32',
                                     'f32': 'fp32 MFMA, exact reference arithmetic'}[args.precision],
                        'parallelism': 'z-slab tile sharding x%d, no collective'
                                       % world,

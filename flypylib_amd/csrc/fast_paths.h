@@ -4,6 +4,34 @@
 
 #include "program.h"
 
+// The two VGG-style graphs of flypylib/fplmodels.py:102-172 differ only in the kernel
+// edge of the second convolution of each block: vgg_like 3,1 | 3,1 | 3,1,1,1 and
+// vgg_like2 3,3 | 3,3 | 3,1,1,1 (48 channels, 96 in the two "dense" layers, biased
+// sigmoid head, stride 4).  Returns 1 / 2 for those, 0 for anything else.
+static inline int fpl_vgg_variant(const fpl_program *prog) {
+  static const int kinds[10] = {0, 0, 1, 0, 0, 1, 0, 0, 0, 0};
+  static const int cin[10] = {1, 48, 48, 48, 48, 48, 48, 48, 96, 96};
+  static const int cout[10] = {48, 48, 48, 48, 48, 48, 48, 96, 96, 1};
+  static const int ks_tail[4] = {3, 1, 1, 1};
+  if (prog->ops.size() != 10) return 0;
+  if (prog->stride[0] != 4 || prog->stride[1] != 4 || prog->stride[2] != 4) return 0;
+  const int k2 = prog->ops[1].k;                      // 1: vgg_like, 3: vgg_like2
+  if (k2 != 1 && k2 != 3) return 0;
+  for (int i = 0; i < 10; ++i) {
+    const fpl_op &op = prog->ops[i];
+    if (op.kind != kinds[i]) return 0;
+    if (op.src0 != (i == 0 ? 0 : prog->ops[i - 1].dst)) return 0;
+    if (op.kind == FPL_OP_CONV) {
+      const int k = i >= 6 ? ks_tail[i - 6] : ((i == 1 || i == 4) ? k2 : 3);
+      if (op.k != k || op.cin != cin[i] || op.cout != cout[i]) return 0;
+      if (op.act != (i == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return 0;
+    } else if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) {
+      return 0;
+    }
+  }
+  if (prog->out_tensor != prog->ops[9].dst) return 0;
+  return k2 == 1 ? 1 : 2;
+}
 // one tile of the reference lattice (flypylib/fplnetwork.py:146-160)
 struct FplTileDesc {
   int32_t start[3];   // input window origin in the volume
@@ -68,3 +96,14 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
                       int k, int cin, const float *Wd, const float *zeros, float *dx);
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
                       const float *dy, int k, int cout, float *dw);
+
+// Split-operand IEEE-half path for vgg_like (vgg_split.hip, FPL_PREC_F16S): every
+// activation and folded weight is carried as hi + lo (two halves, ~22 significant bits)
+// and every product as three MFMAs - fp32-grade probabilities at a third of the 16-bit
+// MFMA rate.  Same contract as fpl_fast_infer_volume_*.
+bool fpl_split_path_available(const fpl_program *prog, int precision,
+                              const int32_t offset[3], const int32_t out_sz[3]);
+int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int src_dtype,
+                           float mean, float sd, const int64_t dims[3],
+                           const std::vector<int32_t> origins[3], const int32_t out_sz[3],
+                           int32_t zb, int32_t ze, float *dst);

@@ -294,7 +294,7 @@ int fpl_program_destroy(fpl_program *prog) {
   fpl_ctx *ctx = prog->ctx;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 3; ++k)
     if (prog->fast_state_h16[k] && prog->fast_state_h16_free[k])
       prog->fast_state_h16_free[k](ctx, prog->fast_state_h16[k]);
   if (prog->fast_state_f32 && prog->fast_state_f32_free)

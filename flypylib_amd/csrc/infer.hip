@@ -169,7 +169,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
               "fpl_infer_volume: src dtype must be u8 or f32");
   FPL_REQUIRE(ctx, sd != 0.f, "fpl_infer_volume: std is 0");
   FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || precision == FPL_PREC_BF16 ||
-                       precision == FPL_PREC_F16,
+                       precision == FPL_PREC_F16 || precision == FPL_PREC_F16S,
               "fpl_infer_volume: unknown precision %d", precision);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   int32_t out_sz[3];
@@ -229,7 +229,11 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   }
   // the fused fast path writes every valid voxel itself: only the border shell
   // needs clearing there; the per-op path stitches tiles into a zeroed volume
-  const bool fast = zb < ze && (fpl_fast_path_available_bf16(prog, precision, offset, out_sz) ||
+  const bool split = fpl_split_path_available(prog, precision, offset, out_sz);
+  FPL_REQUIRE(ctx, precision != FPL_PREC_F16S || split,
+              "fpl_infer_volume: the split-half kernels exist for vgg_like on its stride-4 "
+              "lattice only; use precision f32 (or f16) for this architecture");
+  const bool fast = zb < ze && (split || fpl_fast_path_available_bf16(prog, precision, offset, out_sz) ||
                                 fpl_fast_path_available_f16(prog, precision, offset, out_sz));
   if (wr_hi > wr_lo) {
     if (fast && offset[2] <= 64) {
@@ -269,10 +273,17 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
 
   // fused whole-slab fast paths (vgg_like): no tile batch, no stitch
   bool handled = false;
-  FPL_TRY((precision == FPL_PREC_F16 ? fpl_fast_infer_volume_f16 : fpl_fast_infer_volume_bf16)(
-      ctx, prog, src_dev - src_base * Y * X * esz, src_dtype, mean, sd, dims, tile_in,
-      offset, precision, origins, out_sz, zb, ze, dst_dev - dst_base * Y * X, &handled));
-  if (handled) set_last_path(ctx, precision == FPL_PREC_F16 ? "vgg_fused_f16" : "vgg_fused_bf16");
+  if (split) {
+    FPL_TRY(fpl_split_infer_volume(ctx, prog, src_dev - src_base * Y * X * esz, src_dtype, mean, sd,
+                                   dims, origins, out_sz, zb, ze, dst_dev - dst_base * Y * X));
+    handled = true;
+    set_last_path(ctx, "vgg_split_f16");
+  } else {
+    FPL_TRY((precision == FPL_PREC_F16 ? fpl_fast_infer_volume_f16 : fpl_fast_infer_volume_bf16)(
+        ctx, prog, src_dev - src_base * Y * X * esz, src_dtype, mean, sd, dims, tile_in,
+        offset, precision, origins, out_sz, zb, ze, dst_dev - dst_base * Y * X, &handled));
+    if (handled) set_last_path(ctx, precision == FPL_PREC_F16 ? "vgg_fused_f16" : "vgg_fused_bf16");
+  }
   if (!handled) {
     const bool unet_bf16 = (fpl_unet_fast_available_bf16(prog, precision) ||
                             fpl_unet_fast_available_f16(prog, precision)) &&

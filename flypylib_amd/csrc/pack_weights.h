@@ -33,6 +33,22 @@ static inline uint16_t fpl_f32_to_h16(float f) {
 constexpr float FPL_H16_MAX = 3.3e38f;
 #endif
 
+// Split operands (vgg_split.hip, IEEE-half build only): a value v is carried as
+// hi = half(v) and lo = half(v - hi), ~22 significant bits between them (v - hi is exact
+// in fp32; lo may be a subnormal half, which v_mfma_f32_16x16x32_f16 does not flush:
+// tools/micro/mfma_denorm.hip).  part 0 = hi (the plain 16-bit operand), 1 = lo.
+static inline uint16_t fpl_f32_to_h16_part(float v, int part) {
+  const uint16_t hi = fpl_f32_to_h16(v);
+  if (part == 0) return hi;
+#ifdef FPL_F16
+  _Float16 h;
+  memcpy(&h, &hi, 2);
+  return fpl_f32_to_h16(v - (float)h);
+#else
+  return 0;                                  // no split form on bfloat16 operands
+#endif
+}
+
 // Output channel computed by row m of M-block b.  Plain: 16b + m.  Interleaved
 // (il): 4*MB*(m/4) + 4b + m%4 - lane (c, g) of the accumulators (rows 4g..4g+3 of
 // every block) then owns the 4*MB CONTIGUOUS channels [4*MB*g, 4*MB*(g+1)) of its
@@ -46,7 +62,7 @@ static inline int fpl_out_channel(int b, int m, int n_mblocks, bool il) {
 static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
                                   int cin, int cout, int n_mblocks, int n_ksteps,
                                   FplSlotMap map, std::vector<uint16_t> *out,
-                                  bool il = false) {
+                                  bool il = false, int part = 0) {
   out->assign((size_t)n_ksteps * n_mblocks * 512, 0);
   for (int s = 0; s < n_ksteps; ++s)
     for (int b = 0; b < n_mblocks; ++b)
@@ -67,7 +83,7 @@ static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
           if (kidx < 0) continue;
           const float v = W[(size_t)kidx * cout + co] * scale[co];
           (*out)[(((size_t)s * n_mblocks + b) * 64 + lane) * 8 + j] =
-              fpl_f32_to_h16(v);
+              fpl_f32_to_h16_part(v, part);
         }
       }
 }
@@ -97,7 +113,7 @@ static inline int fpl_stem_slot_tap(int e, int g, int j) {
 
 // 6 fragments [e][b]: W [27][48] fp32, scale[48]
 static inline void fpl_pack_stem(const float *W, const float *scale, int cout,
-                                 std::vector<uint16_t> *out) {
+                                 std::vector<uint16_t> *out, int part = 0) {
   out->assign((size_t)2 * 3 * 512, 0);
   for (int e = 0; e < 2; ++e)
     for (int b = 0; b < 3; ++b)
@@ -108,7 +124,7 @@ static inline void fpl_pack_stem(const float *W, const float *scale, int cout,
           const int tap = fpl_stem_slot_tap(e, g, j);
           if (tap < 0) continue;
           (*out)[(((size_t)e * 3 + b) * 64 + lane) * 8 + j] =
-              fpl_f32_to_h16(W[(size_t)tap * cout + co] * scale[co]);
+              fpl_f32_to_h16_part(W[(size_t)tap * cout + co] * scale[co], part);
         }
       }
 }

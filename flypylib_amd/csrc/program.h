@@ -18,9 +18,10 @@ struct fpl_program {
   float *arena_dev = nullptr;        // fp32 weights, scale, shift
   int64_t n_arena = 0;
   // packed 16-bit weight fragments etc. of the fused fast paths (vgg_fused.hip,
-  // conv_mfma.hip), one slot per operand type: [0] bf16, [1] f16
-  void *fast_state_h16[2] = {nullptr, nullptr};
-  void (*fast_state_h16_free[2])(fpl_ctx *, void *) = {nullptr, nullptr};
+  // conv_mfma.hip, vgg_split.hip), one slot per operand type: [0] bf16, [1] f16,
+  // [2] split f16
+  void *fast_state_h16[3] = {nullptr, nullptr, nullptr};
+  void (*fast_state_h16_free[3])(fpl_ctx *, void *) = {nullptr, nullptr, nullptr};
   uint64_t arena_version = 0;
   // fp32 MFMA executor state (conv_mfma_f32.hip)
   void *fast_state_f32 = nullptr;

@@ -24,6 +24,7 @@
 #include "fast_paths.h"
 #include "mfma_util.h"
 #include "pack_weights.h"
+#include "vgg_tiles.h"
 
 namespace {
 
@@ -401,12 +402,6 @@ __global__ __launch_bounds__(256, STEM_WPS) void FPLK(vgg_stem_pool)(StemArgs a)
 // -------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-__device__ __forceinline__ void glds16(const void *g, void *l) {
-  __builtin_amdgcn_global_load_lds(
-      (const __attribute__((address_space(1))) void *)g,
-      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
-}
-
 // byte offset inside the activation tile of k-slot group (s, g)
 template <int TY, int TX>
 __device__ __forceinline__ unsigned kslot_offset(int s, int g) {
@@ -428,43 +423,6 @@ __device__ __forceinline__ unsigned kslot_entry(int idx) {
   int s = idx % KTAB;
   s = s < KSTEPS ? s : KSTEPS - 1;
   return kslot_offset<TY, TX>(s, g);
-}
-
-// fill the activation tile by LDS-DMA: tile is TZ*TY rows of TX voxels (96 B).
-// Piece idx = lane + 64 wave + 256 it is (row, 16-B column cw) of the tile; the
-// coordinates are divided out once and then advanced by constant steps, and the edge
-// clamp is a min against per-block bounds: ~10 VALU per piece (the flat index
-// arithmetic this replaces, with its divisions, made the fill VALU-bound).
-template <int TZ, int TY, int TX>
-__device__ __forceinline__ void stage_tile(const h16_t *act, int AZ, int AY, int AX,
-                                           int z0, int y0, int x0,
-                                           unsigned char *tile, int wave, int lane) {
-  constexpr int RC = TX * VOX_BYTES / 16;                  // 16-B pieces per row
-  constexpr int TOTAL = TZ * TY * RC;
-  constexpr int PIECES = (TOTAL + 63) / 64;
-  constexpr int DR = 256 / RC, DC = 256 % RC;              // advance per iteration
-  static_assert(DR + 1 < TY, "a step wraps at most one z row");
-  const int idx0 = wave * 64 + lane;
-  int row = idx0 / RC, cw = idx0 % RC;
-  int rz = row / TY, ry = row % TY;
-  // clamp: edge blocks only feed masked outputs
-  const int zmax = AZ - 1 - z0, ymax = AY - 1 - y0, xmax = AX - 1 - x0;
-  const unsigned SY = (unsigned)AX * VOX_BYTES, SZ = (unsigned)AY * SY;
-  const unsigned char *base = reinterpret_cast<const unsigned char *>(
-      act + (((int64_t)z0 * AY + y0) * AX + x0) * CH);
-  for (int p = wave; p < PIECES; p += 4) {
-    const bool past = rz >= TZ;                            // tail lanes re-read the last piece
-    const int rzc = past ? TZ - 1 : rz, ryc = past ? TY - 1 : ry, cwc = past ? RC - 1 : cw;
-    const int vx = cwc / 6, pc = cwc - 6 * vx;
-    const int zc = rzc < zmax ? rzc : zmax, yc = ryc < ymax ? ryc : ymax, xc = vx < xmax ? vx : xmax;
-    const unsigned off = (unsigned)zc * SZ + (unsigned)yc * SY + (unsigned)(xc * VOX_BYTES + pc * 16);
-    glds16(base + off, tile + (size_t)p * 1024);
-    cw += DC;
-    int dr = DR;
-    if (cw >= RC) { cw -= RC; ++dr; }
-    ry += dr;
-    if (ry >= TY) { ry -= TY; ++rz; }
-  }
 }
 
 // The K loop.  Every wave takes the weight fragments (3 x 1 KiB per K-step, the
@@ -523,25 +481,6 @@ __device__ __forceinline__ void conv3_kloop(const unsigned char *tile,
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) bcur[sub] = bnxt[sub];
   }
-}
-
-// Block order of the 3x3x3 kernels.  Workgroups go round-robin over the 8 XCDs, each with
-// its own L2.  The 1-D grid is decoded with the z block's low three bits fastest, so an
-// XCD owns whole z slabs: the x and y neighbours of a block - whose input tiles overlap
-// and whose output rows share cache lines - meet in one L2.  (z neighbours never do, in
-// any order: they are thousands of workgroups apart.)
-struct BlockGrid { int nbx, nby, nbz; };
-__host__ __device__ inline unsigned block_grid_size(const BlockGrid &g) {
-  return (unsigned)((int64_t)g.nbx * g.nby * ((g.nbz + 7) / 8 * 8));
-}
-__device__ __forceinline__ bool block_coords(const BlockGrid &g, int &xb, int &yb, int &zb) {
-  unsigned q = blockIdx.x;
-  const int z8 = (int)(q & 7u);
-  q >>= 3;
-  xb = (int)(q % (unsigned)g.nbx); q /= (unsigned)g.nbx;
-  yb = (int)(q % (unsigned)g.nby);
-  zb = (int)(q / (unsigned)g.nby) * 8 + z8;
-  return zb < g.nbz;
 }
 
 // -------------------------------------------------------------------------------
@@ -643,198 +582,6 @@ __global__ __launch_bounds__(256, 2) void FPLK(vgg_mid_pool)(MidArgs a) {
     const size_t wg = blockIdx.x;
     a.dbg[4 * wg + 0] = t0; a.dbg[4 * wg + 1] = t1;
     a.dbg[4 * wg + 2] = t2; a.dbg[4 * wg + 3] = t3;
-  }
-}
-
-// -------------------------------------------------------------------------------
-// K2 with 8 sub-steps per wave (FPL_MID8=1; experiment of round 2).  vgg_mid_pool's
-// waves fetch every weight fragment for 4 sub-steps (64 voxels): 9/10 of what the CU's
-// vector-memory return path carries, and that path is 76 % busy.  Here a wave covers
-// 8 sub-steps - half the weight bytes per MFMA.  512 outputs per workgroup need a tile
-// twice as large; two workgroups per CU then only fit with HALF the channels resident:
-// the K loop runs over (27 taps x 24 channels) twice, refilling the tile in between
-// (2 x 21 K-steps instead of 41).  Pre-pool block 8 x 4 x 16 (pooled 4 x 2 x 8); wave =
-// pooled rows (2 pzp, pyl) and (2 pzp + 1, pyl); sub-step = (row of the pair, dz, dy).
-// -------------------------------------------------------------------------------
-constexpr int M8_TZ = 10, M8_TY = 6, M8_TX = 18;
-constexpr int M8_VOX = 48;                               // bytes per voxel of a half tile
-constexpr int M8_TILE_BYTES = ((M8_TZ * M8_TY * M8_TX * M8_VOX + 1023) / 1024) * 1024;
-constexpr int M8_KSTEPS = 21;                            // 27 * 24 = 648 -> 20.25 steps of 32
-constexpr int M8_KTAB = 24;
-constexpr int M8_SMEM = M8_TILE_BYTES + 4 * M8_KTAB * 4;
-constexpr int M4H_SMEM = ((6 * M8_TY * M8_TX * M8_VOX + 1023) / 1024) * 1024 + 4 * M8_KTAB * 4;
-static_assert(2 * M8_SMEM <= 160 * 1024, "two mid8 workgroups must fit one CU");
-
-__device__ __forceinline__ unsigned m8_kslot(int idx) {
-  const int g = idx / M8_KTAB;
-  int st = idx % M8_KTAB;
-  st = st < M8_KSTEPS ? st : M8_KSTEPS - 1;
-  const int f0 = 32 * st + 8 * g;
-  const int tap = f0 / 24, ch0 = f0 % 24;
-  if (tap >= 27) return 0u;                              // zero weights
-  return (unsigned)((((tap / 9) * M8_TY + (tap / 3) % 3) * M8_TX + tap % 3) * M8_VOX + ch0 * 2);
-}
-
-// channels [24 h, 24 h + 24) of the block's input region, by LDS-DMA (stage_tile with
-// three 16-B pieces per voxel)
-template <int TZ>
-__device__ __forceinline__ void m8_stage_half(const h16_t *act, int AZ, int AY, int AX, int z0,
-                                              int y0, int x0, int h, unsigned char *tile,
-                                              int wave, int lane) {
-  constexpr int RC = M8_TX * 3;                           // 16-B pieces per row
-  constexpr int TOTAL = TZ * M8_TY * RC;
-  constexpr int PIECES = (TOTAL + 63) / 64;
-  constexpr int DR = 256 / RC, DC = 256 % RC;
-  static_assert(DR + 1 < M8_TY, "a step wraps at most one z row");
-  const int idx0 = wave * 64 + lane;
-  int row = idx0 / RC, cw = idx0 % RC;
-  int rz = row / M8_TY, ry = row % M8_TY;
-  const int zmax = AZ - 1 - z0, ymax = AY - 1 - y0, xmax = AX - 1 - x0;
-  const unsigned SY = (unsigned)AX * VOX_BYTES, SZ = (unsigned)AY * SY;
-  const unsigned char *base = reinterpret_cast<const unsigned char *>(
-      act + (((int64_t)z0 * AY + y0) * AX + x0) * CH) + h * M8_VOX;
-  for (int p = wave; p < PIECES; p += 4) {
-    const bool past = rz >= TZ;
-    const int rzc = past ? TZ - 1 : rz, ryc = past ? M8_TY - 1 : ry, cwc = past ? RC - 1 : cw;
-    const int vx = cwc / 3, pc = cwc - 3 * vx;
-    const int zc = rzc < zmax ? rzc : zmax, yc = ryc < ymax ? ryc : ymax, xc = vx < xmax ? vx : xmax;
-    const unsigned off = (unsigned)zc * SZ + (unsigned)yc * SY + (unsigned)(xc * VOX_BYTES + pc * 16);
-    glds16(base + off, tile + (size_t)p * 1024);
-    cw += DC;
-    int dr = DR;
-    if (cw >= RC) { cw -= RC; ++dr; }
-    ry += dr;
-    if (ry >= M8_TY) { ry -= M8_TY; ++rz; }
-  }
-}
-
-struct Mid8Args {
-  const h16_t *p1;
-  int P1Z, P1Y, P1X;
-  const unsigned char *w3h;      // [half][M8_KSTEPS][3] fragments
-  const h16x8 *w4;
-  const float *shift3, *shift4;
-  h16_t *p2;
-  int P2Z, P2Y, P2X;
-  BlockGrid bg;
-};
-
-// NSUB = 8: pre-pool block 8 x 4 x 16 (tile depth 10), two workgroups per CU.
-// NSUB = 4: the shipped kernel's block 4 x 4 x 16 on 31 KiB half tiles (tile depth 6): the
-// weight traffic of the shipped kernel, but WPS = 3 or 4 workgroups fit a CU.
-template <int NSUB, int WPS>
-__global__ __launch_bounds__(256, WPS) void FPLK(vgg_mid_pool8)(Mid8Args a) {
-  constexpr int TZ = NSUB == 8 ? M8_TZ : 6;
-  constexpr int TILE_BYTES = ((TZ * M8_TY * M8_TX * M8_VOX + 1023) / 1024) * 1024;
-  constexpr int ROWS = NSUB / 4;                 // pooled rows per wave
-  unsigned char *tile = smem;
-  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + TILE_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  int xb, yb, zb;
-  if (!block_coords(a.bg, xb, yb, zb)) return;
-  const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 2 * ROWS;
-  if (tid < 4 * M8_KTAB) kofftab[tid] = m8_kslot(tid);
-  const int pzp = wave >> 1, pyl = wave & 1;
-  const unsigned vbase =
-      (unsigned)((((2 * ROWS * pzp) * M8_TY + 2 * pyl) * M8_TX + c) * M8_VOX);
-  auto sub_off = [](int sub) -> unsigned {
-    return (unsigned)((((2 * (sub >> 2) + ((sub >> 1) & 1)) * M8_TY + (sub & 1)) * M8_TX) * M8_VOX);
-  };
-  f32x4 acc[NSUB][3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    f32x4 sh;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = a.shift3[16 * b + 4 * g + r];
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) acc[sub][b] = sh;
-  }
-  constexpr int WQ8 = 3, BQ = 4;                 // weight K-steps / activation fragments in flight
-  const unsigned *ktab = kofftab + g * M8_KTAB;
-#pragma unroll 1
-  for (int h = 0; h < 2; ++h) {
-    if (h) __syncthreads();                      // every wave has left the first half's tile
-    m8_stage_half<TZ>(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0, h, tile, wave, lane);
-    const unsigned char *wl = a.w3h + (size_t)h * M8_KSTEPS * 3 * 1024 + lane * 16;
-    h16x8 wq[WQ8][3];
-#pragma unroll
-    for (int d = 0; d < WQ8; ++d)
-#pragma unroll
-      for (int b = 0; b < 3; ++b)
-        wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * 3 + b) * 1024);
-    __syncthreads();                             // tile (LDS-DMA) + table visible
-    // activation fragments run BQ - 1 (sub-step, K-step) pairs ahead of their MFMAs
-    u32x4 kv = *reinterpret_cast<const u32x4 *>(ktab);
-    h16x8 br[BQ];
-    auto frag = [&](int t, const u32x4 &k) {
-      return *reinterpret_cast<const h16x8 *>(tile + vbase + k[(t / NSUB) & 3] + sub_off(t % NSUB));
-    };
-#pragma unroll
-    for (int t = 0; t < BQ - 1; ++t) br[t] = frag(t, kv);
-#pragma unroll
-    for (int st = 0; st < M8_KSTEPS; ++st) {
-      u32x4 kn = kv;
-      if ((st + 1) % 4 == 0 && st + 1 < M8_KSTEPS) kn = *reinterpret_cast<const u32x4 *>(ktab + st + 1);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        const int t = st * NSUB + sub, tn = t + BQ - 1;
-        if (tn < M8_KSTEPS * NSUB)
-          br[tn % BQ] = frag(tn, (tn / NSUB) / 4 == st / 4 ? kv : kn);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wq[st % WQ8][b], br[t % BQ], acc[sub][b]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      kv = kn;
-      if (st + WQ8 < M8_KSTEPS) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          wq[st % WQ8][b] =
-              *reinterpret_cast<const h16x8 *>(wl + (size_t)((st + WQ8) * 3 + b) * 1024);
-      }
-    }
-  }
-
-  // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions of
-  // each of the wave's two pooled rows
-  h16x8 w4[2][3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    w4[0][b] = a.w4[(0 * 3 + b) * 64 + lane];
-    w4[1][b] = a.w4[(1 * 3 + b) * 64 + lane];
-  }
-  f32x4 sh4[3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[16 * b + 4 * g + r];
-#pragma unroll
-  for (int q = 0; q < ROWS; ++q) {
-    u32x2 pooled[3] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int sub = 4 * q + s4;
-      const h16x8 h0 = pack_relu(acc[sub][0], acc[sub][1]);
-      const h16x8 h1 = pack_relu_lo(acc[sub][2]);
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        f32x4 a4 = mfma16(w4[0][b], h0, sh4[b]);
-        a4 = mfma16(w4[1][b], h1, a4);
-        pool_relu_h16(pooled[b], a4);
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      pooled[b][0] = pk_max_i16(pooled[b][0], (unsigned)__shfl_xor((int)pooled[b][0], 1));
-      pooled[b][1] = pk_max_i16(pooled[b][1], (unsigned)__shfl_xor((int)pooled[b][1], 1));
-    }
-    const int pz = pz0 + ROWS * pzp + q, py = py0 + pyl, px = px0 + (c >> 1);
-    if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
-      h16_t *dst = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * CH + 4 * g;
-#pragma unroll
-      for (int b = 0; b < 3; ++b) *reinterpret_cast<u32x2 *>(dst + 16 * b) = pooled[b];
-    }
   }
 }
 
@@ -1164,9 +911,6 @@ struct VggFastState {
   bool have_scaled = false;
   size_t off_w1s = 0, off_w2s = 0, off_s1s = 0;
   float stem_in_scale = 1.f;
-  // vgg_like: L3 fragments in the K order of vgg_mid_pool8 (two halves of 24 channels)
-  size_t off_w3h = 0;
-  bool have_w3h = false;
 };
 
 constexpr float STEM_XMAX = 8.f;   // |(v - mean) / sd| bound the scaled set is built for
@@ -1178,36 +922,8 @@ void vgg_state_free(fpl_ctx *ctx, void *p) {
   delete s;
 }
 
-// The two VGG-style graphs of flypylib/fplmodels.py:102-172 differ only in the kernel
-// edge of the second convolution of each block: vgg_like 3,1 | 3,1 | 3,1,1,1 and
-// vgg_like2 3,3 | 3,3 | 3,1,1,1 (48 channels, 96 in the two "dense" layers, biased
-// sigmoid head, stride 4).  Returns 1 / 2 for those, 0 for anything else.
-static int vgg_variant(const fpl_program *prog) {
-  static const int kinds[10] = {0, 0, 1, 0, 0, 1, 0, 0, 0, 0};
-  static const int cin[10] = {1, 48, 48, 48, 48, 48, 48, 48, 96, 96};
-  static const int cout[10] = {48, 48, 48, 48, 48, 48, 48, 96, 96, 1};
-  static const int ks_tail[4] = {3, 1, 1, 1};
-  if (prog->ops.size() != 10) return 0;
-  if (prog->stride[0] != 4 || prog->stride[1] != 4 || prog->stride[2] != 4) return 0;
-  const int k2 = prog->ops[1].k;                      // 1: vgg_like, 3: vgg_like2
-  if (k2 != 1 && k2 != 3) return 0;
-  for (int i = 0; i < 10; ++i) {
-    const fpl_op &op = prog->ops[i];
-    if (op.kind != kinds[i]) return 0;
-    if (op.src0 != (i == 0 ? 0 : prog->ops[i - 1].dst)) return 0;
-    if (op.kind == FPL_OP_CONV) {
-      const int k = i >= 6 ? ks_tail[i - 6] : ((i == 1 || i == 4) ? k2 : 3);
-      if (op.k != k || op.cin != cin[i] || op.cout != cout[i]) return 0;
-      if (op.act != (i == 9 ? FPL_ACT_SIGMOID : FPL_ACT_RELU)) return 0;
-    } else if (op.p[0] != 2 || op.p[1] != 2 || op.p[2] != 2) {
-      return 0;
-    }
-  }
-  if (prog->out_tensor != prog->ops[9].dst) return 0;
-  return k2 == 1 ? 1 : 2;
-}
-bool is_vgg_like(const fpl_program *prog) { return vgg_variant(prog) == 1; }
-bool is_vgg_like2(const fpl_program *prog) { return vgg_variant(prog) == 2; }
+bool is_vgg_like(const fpl_program *prog) { return fpl_vgg_variant(prog) == 1; }
+bool is_vgg_like2(const fpl_program *prog) { return fpl_vgg_variant(prog) == 2; }
 
 int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
   VggFastState *st = (VggFastState *)prog->fast_state_h16[FPL_H16_SLOT];
@@ -1250,26 +966,6 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
     st->off_s[l] = shifts.size();
     shifts.insert(shifts.end(), A + op.shift_off, A + op.shift_off + op.cout);
     while (shifts.size() % 4) shifts.push_back(0.f);
-  }
-  st->have_w3h = false;
-  if (!v2) {
-    // L3 once more in vgg_mid_pool8's K order: two halves of 24 input channels, each
-    // (tap, channel-in-half) flattened into 21 K-steps
-    const fpl_op &o3 = prog->ops[conv_ops[2]];
-    std::vector<float> sc3(A + o3.scale_off, A + o3.scale_off + o3.cout);
-    st->off_w3h = all.size() * sizeof(uint16_t);
-    for (int h = 0; h < 2; ++h) {
-      std::vector<float> wh((size_t)27 * 24 * o3.cout);
-      for (int tap = 0; tap < 27; ++tap)
-        for (int ch = 0; ch < 24; ++ch)
-          for (int co = 0; co < o3.cout; ++co)
-            wh[((size_t)tap * 24 + ch) * o3.cout + co] =
-                A[o3.w_off + ((size_t)tap * o3.cin + 24 * h + ch) * o3.cout + co];
-      std::vector<uint16_t> f;
-      fpl_pack_frags(wh.data(), sc3.data(), 27, 24, o3.cout, 3, M8_KSTEPS, SLOT_SPATIAL, &f);
-      all.insert(all.end(), f.begin(), f.end());
-    }
-    st->have_w3h = true;
   }
   st->have_scaled = false;
 #ifdef FPL_F16
@@ -1345,12 +1041,6 @@ int vgg_prepare(fpl_ctx *ctx, fpl_program *prog, VggFastState **out) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_c5_tail),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8)<8, 2>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, M8_SMEM));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8)<4, 3>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, M4H_SMEM));
-  FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg_mid_pool8)<4, 4>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, M4H_SMEM));
   if (v2) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(vgg2_conv3)<true, true, uint8_t>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
@@ -1586,22 +1276,6 @@ int FPLK(fpl_fast_infer_volume)(fpl_ctx *ctx, fpl_program *prog, const void *src
         }
         fprintf(stderr, "[FPL_DIAG_MID] %zu WGs: mean cycles fill %.0f  kloop %.0f  epilogue %.0f  total %.0f\n",
                 real, fill / real, loop / real, epi / real, tot / real);
-      } else if (st->have_w3h && getenv("FPL_MID8")) {
-        // 1: 8 sub-steps per wave; 3 / 4: 4 sub-steps on half tiles, 3 / 4 workgroups per CU
-        const int mode = atoi(getenv("FPL_MID8"));
-        Mid8Args b;
-        b.p1 = a.p1; b.P1Z = P1Z; b.P1Y = P1Y; b.P1X = P1X;
-        b.w3h = F + st->off_w3h; b.w4 = a.w4; b.shift3 = a.shift3; b.shift4 = a.shift4;
-        b.p2 = a.p2; b.P2Z = P2Z; b.P2Y = P2Y; b.P2X = P2X;
-        b.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2),
-                         (int)ceil_div64(P2Z, mode >= 3 ? 2 : 4)};
-        TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
-        if (mode == 3)
-          FPLK(vgg_mid_pool8)<4, 3><<<block_grid_size(b.bg), 256, M4H_SMEM, stream>>>(b);
-        else if (mode == 4)
-          FPLK(vgg_mid_pool8)<4, 4><<<block_grid_size(b.bg), 256, M4H_SMEM, stream>>>(b);
-        else
-          FPLK(vgg_mid_pool8)<8, 2><<<block_grid_size(b.bg), 256, M8_SMEM, stream>>>(b);
       } else {
         TimedLaunch tl(ctx, "vgg_mid_pool_" FPL_PREC_STR);
         FPLK(vgg_mid_pool)<false><<<grid, 256, M_SMEM, stream>>>(a);

@@ -1,0 +1,965 @@
+// Split-operand MFMA kernels for vgg_like inference (flypylib/fplmodels.py:102-136):
+// the fused structure of vgg_fused.hip - stem+pool -> P1, conv3+conv1+pool -> P2,
+// conv3+head -> prediction volume - at fp32-grade accuracy (FPL_PREC_F16S).
+//
+// Why: a 16-bit operand type cannot hold the north star's gate on trained weights.  The
+// error budget (tools/dev/error_budget.py, profiles/r03_error_budget_vgg.txt) shows the
+// 17 rounding points of the plain IEEE-half path (input, 8 weight tensors, 7 activation
+// tensors) each contribute 0.2 - 3e-4 to the worst probability: no subset of them can be
+// spared.  Here every operand is carried as TWO halves,
+//     v  ~  hi + lo,   hi = half(v),  lo = half(v - hi)          (~22 significant bits)
+// and every product a * w as THREE MFMAs  a_hi w_hi + a_hi w_lo + a_lo w_hi  into the
+// same fp32 accumulator (the fourth product is below fp32 resolution).  v - hi is exact in
+// fp32; lo may be a subnormal half, which v_mfma_f32_16x16x32_f16 keeps
+// (profiles/r03_mfma_f16_denorm.txt), so the representation error is <= 2^-22 |v| or
+// 2^-25 absolute.  Observed: probabilities within 2e-6 of the fp32 oracle on the trained
+// fixture, at 3x the MFMA work of the 16-bit path instead of the 16x of fp32 MFMAs.
+//
+// Layout of P1 / P2 in HBM: per voxel NPASS = 2 passes of CHP = 24 channels, each pass
+// [hi 24][lo 24] halves = 96 B, 192 B per voxel.  A 3x3x3 conv runs its K loop once per
+// pass on a 6 x 6 x 18 x 96 B tile (the shipped kernels' tile size: two workgroups per
+// CU), K-steps over (tap, channel-in-pass): 21 per pass.
+#define FPL_F16 1   // the operand halves are IEEE halves (mfma_util.h, pack_weights.h)
+#include <algorithm>
+#include <cmath>
+
+#include "fast_paths.h"
+#include "mfma_util.h"
+#include "pack_weights.h"
+#include "vgg_tiles.h"
+
+namespace {
+
+constexpr int CH = 48;
+constexpr int CHP = 24, NPASS = CH / CHP;
+constexpr int LO_OFF = CHP * 2;            // lo halves of a pass sit 48 B behind the hi halves
+constexpr int PASS_BYTES = 2 * LO_OFF;     // 96
+constexpr int VOX = NPASS * PASS_BYTES;    // 192 B per voxel in HBM
+constexpr int KS = (27 * CHP + 31) / 32;   // 21 K-steps per pass (27 * 24 = 648 = 20.25)
+constexpr int KTAB = (KS + 4) / 4 * 4;     // table entries per lane group
+constexpr int KTAB_BYTES = 4 * KTAB * 4;
+static_assert(CHP % 8 == 0, "a lane's 8 k-slots stay inside one tap");
+
+// byte offset, inside a voxel, of the hi halves of channels ch .. ch+3 (ch % 4 == 0)
+__host__ __device__ constexpr int chan_off(int ch) { return (ch / CHP) * PASS_BYTES + (ch % CHP) * 2; }
+
+struct Pair2 { unsigned hi, lo; };          // two values as packed halves
+struct Frag2 { h16x8 hi, lo; };             // a B fragment
+
+// (a, b) -> packed hi halves and packed lo halves
+__device__ __forceinline__ Pair2 split_pk(float a, float b) {
+  Pair2 r;
+  r.hi = cvt_pk_h16(a, b);
+  const h16x2 h = __builtin_bit_cast(h16x2, r.hi);
+  r.lo = cvt_pk_h16(a - (float)h[0], b - (float)h[1]);
+  return r;
+}
+__device__ __forceinline__ Pair2 split_pk_relu(float a, float b) {
+  return split_pk(__builtin_fmaxf(a, 0.f), __builtin_fmaxf(b, 0.f));
+}
+
+// two accumulator tiles (M-blocks 2s and 2s+1 of the previous layer) -> the B fragments
+// of K-step s of the next layer, ReLU applied (chain map of mfma_util.h)
+__device__ __forceinline__ Frag2 pack_relu_split(const f32x4 &lo_blk, const f32x4 &hi_blk) {
+  u32x4 h, l;
+  Pair2 p;
+  p = split_pk_relu(lo_blk[0], lo_blk[1]); h[0] = p.hi; l[0] = p.lo;
+  p = split_pk_relu(lo_blk[2], lo_blk[3]); h[1] = p.hi; l[1] = p.lo;
+  p = split_pk_relu(hi_blk[0], hi_blk[1]); h[2] = p.hi; l[2] = p.lo;
+  p = split_pk_relu(hi_blk[2], hi_blk[3]); h[3] = p.hi; l[3] = p.lo;
+  Frag2 f;
+  f.hi = __builtin_bit_cast(h16x8, h);
+  f.lo = __builtin_bit_cast(h16x8, l);
+  return f;
+}
+// ... with the upper block missing (48 channels = 3 blocks): zeros
+__device__ __forceinline__ Frag2 pack_relu_split_lo(const f32x4 &lo_blk) {
+  u32x4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+  Pair2 p;
+  p = split_pk_relu(lo_blk[0], lo_blk[1]); h[0] = p.hi; l[0] = p.lo;
+  p = split_pk_relu(lo_blk[2], lo_blk[3]); h[1] = p.hi; l[1] = p.lo;
+  Frag2 f;
+  f.hi = __builtin_bit_cast(h16x8, h);
+  f.lo = __builtin_bit_cast(h16x8, l);
+  return f;
+}
+
+// acc += (w_hi + w_lo)(b_hi + b_lo) without the lo x lo product
+__device__ __forceinline__ f32x4 mfma3(h16x8 wh, h16x8 wl, const Frag2 &b, f32x4 acc) {
+  acc = mfma16(wl, b.hi, acc);
+  acc = mfma16(wh, b.lo, acc);
+  return mfma16(wh, b.hi, acc);
+}
+
+// four channels (one accumulator tile row group) of one voxel -> HBM, hi and lo halves
+__device__ __forceinline__ void store_split4(unsigned char *vox, int ch, const f32x4 &v) {
+  const Pair2 p0 = split_pk(v[0], v[1]), p1 = split_pk(v[2], v[3]);
+  unsigned char *d = vox + chan_off(ch);
+  *reinterpret_cast<u32x2 *>(d) = u32x2{p0.hi, p1.hi};
+  *reinterpret_cast<u32x2 *>(d + LO_OFF) = u32x2{p0.lo, p1.lo};
+}
+
+// -------------------------------------------------------------------------------
+// K1: stem.  ONE workgroup of 8 waves per CU (the hi and lo input tiles, double-buffered,
+// are 113 KiB); pooled block 4 x 8 x 32 as in vgg_stem_pool; a wave takes 8 of the
+// block's 64 tasks (16 pooled x of one (pz,py) row), 8 sub-steps per task walk the
+// 2x2x2 pooling window.  Persistent and software-pipelined like the 16-bit stem: the
+// next block's tile rows are loaded, split and stored inside the task loop.
+// -------------------------------------------------------------------------------
+constexpr int S_PZ = 4, S_PY = 8, S_PX = 32;
+constexpr int S_TZ = 2 * S_PZ + 2, S_TY = 2 * S_PY + 2, S_TX = 2 * S_PX + 2;
+constexpr int S_TP = 80;                       // row pitch (elements): bank spread of the gather
+constexpr int S_TILE = S_TZ * S_TY * S_TP;     // elements of one (hi or lo) tile
+constexpr int S_WAVES = 8;
+constexpr int S_ROWS = S_TZ * S_TY;            // 180 tile rows of 66 voxels
+constexpr int S_WROWS = (S_ROWS + S_WAVES - 1) / S_WAVES;   // 23 per wave (the last takes 19)
+constexpr int S_TASKS = S_PZ * S_PY * 2 / S_WAVES;          // 8 tasks per wave and block
+constexpr int S_RPT = 3;                       // rows per task iteration
+static_assert(S_RPT * S_TASKS >= S_WROWS && S_WROWS <= 64, "stem fill schedule");
+constexpr int S_SMEM = 4 * S_TILE * 2 + 256 * 4;
+
+struct StemSArgs {
+  const void *src;
+  int64_t SZ, SY, SX;      // volume dims
+  int64_t z_hi;            // rows >= z_hi are not needed (and may not be resident)
+  float mean, sd;
+  int64_t p1z0;            // global P1 row of chunk-local row 0
+  const h16x8 *w1, *w2;    // fragments [part][e][b][lane], [part][s][b][lane]
+  const float *shift1, *shift2;
+  unsigned char *p1;
+  int P1Z, P1Y, P1X;       // chunk-local dims
+  int nbx, nby, nbz;       // blocks of S_PX x S_PY x S_PZ pooled voxels
+};
+
+__device__ __forceinline__ int stem_row_off(int row) {
+  return ((row / 3) * S_TY + row % 3) * S_TP;
+}
+
+struct StemBlock {
+  int px0, py0, pz0;       // pooled origin
+  int64_t gz0, gy0, gx0;   // origin of its input tile in the volume
+  unsigned xc;             // this lane's column 0..63 of the tile, clamped into the volume
+  bool x_ok;
+};
+
+__device__ __forceinline__ StemBlock stem_block(const StemSArgs &a, int q, int lane) {
+  StemBlock b;
+  const int xb = q % a.nbx, t = q / a.nbx;
+  const int yb = t % a.nby, zb = t / a.nby;
+  b.px0 = xb * S_PX; b.py0 = yb * S_PY; b.pz0 = zb * S_PZ;
+  b.gz0 = 2 * (a.p1z0 + b.pz0); b.gy0 = 2 * (int64_t)b.py0; b.gx0 = 2 * (int64_t)b.px0;
+  const int64_t x = b.gx0 + lane;
+  b.x_ok = x < a.SX;
+  b.xc = (unsigned)(b.x_ok ? x : a.SX - 1);
+  return b;
+}
+
+// tile row handled as entry `l` of wave-local row list starting at wrow0 (clamped: the
+// last wave's list runs past the tile, the repeats rewrite row 179 with the same values)
+__device__ __forceinline__ int stem_row_of(int wrow0, int l) {
+  const int r = wrow0 + (l < S_WROWS ? l : S_WROWS - 1);
+  return r < S_ROWS ? r : S_ROWS - 1;
+}
+
+// Row addresses inside the task loop: lane l holds, for the wave's l-th tile row, the
+// element offset of the (clamped) row from the block's (clamped) origin row, bit 31 =
+// the row exists.  A task then needs one v_readlane per row.
+template <typename SRC>
+__device__ __forceinline__ unsigned stem_row_tab(const StemSArgs &a, const StemBlock &b, int wrow0,
+                                                 int lane, const SRC *&base) {
+  const int row = stem_row_of(wrow0, lane);
+  const int64_t z = b.gz0 + row / S_TY, y = b.gy0 + row % S_TY;
+  const bool ok = z < a.z_hi && y < a.SY;
+  const int64_t zc = z < a.z_hi ? z : a.z_hi - 1, yc = y < a.SY ? y : a.SY - 1;
+  const int64_t zb = b.gz0 < a.z_hi ? b.gz0 : a.z_hi - 1, yb = b.gy0 < a.SY ? b.gy0 : a.SY - 1;
+  base = (const SRC *)a.src + (zb * a.SY + yb) * a.SX;
+  const unsigned rel = (unsigned)(((zc - zb) * a.SY + (yc - yb)) * a.SX);   // < 2^31: checked at launch
+  return rel | (ok ? 0x80000000u : 0u);
+}
+
+template <typename SRC>
+struct StemRows {
+  SRC v[S_RPT];
+  bool ok[S_RPT];          // row inside the volume (uniform)
+};
+
+// the loads of the wave's rows idx0 .. idx0 + S_RPT - 1 (list indices) through the table
+template <typename SRC>
+__device__ __forceinline__ void stem_load_rows(const SRC *base, unsigned tab, unsigned xc,
+                                               int idx0, StemRows<SRC> &r) {
+#pragma unroll
+  for (int k = 0; k < S_RPT; ++k) {
+    const int idx = idx0 + k < S_WROWS ? idx0 + k : S_WROWS - 1;
+    const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)tab, idx);
+    r.ok[k] = (t >> 31) != 0u;
+    r.v[k] = (base + (t & 0x7FFFFFFFu))[xc];
+  }
+}
+
+// normalise (v - mean) / sd and split: hi half | lo half << 16; zero past the volume end.
+// u8 sources go through a per-workgroup table of the 256 possible results.
+template <typename SRC>
+__device__ __forceinline__ unsigned stem_norm(const StemSArgs &a, const unsigned *lut, SRC v,
+                                              bool ok) {
+  unsigned t;
+  if (sizeof(SRC) == 1) {
+    t = lut[(unsigned)v & 255u];
+  } else {
+    const float x = ((float)v - a.mean) / a.sd;
+    const h16_t h = (h16_t)x;
+    t = (unsigned)h16_bits(x) | ((unsigned)h16_bits(x - (float)h) << 16);
+  }
+  return ok ? t : 0u;
+}
+
+struct StemBits { unsigned b[S_RPT]; };
+
+template <typename SRC>
+__device__ __forceinline__ void stem_convert_rows(const StemSArgs &a, const StemBlock &b,
+                                                  const unsigned *lut, const StemRows<SRC> &r,
+                                                  StemBits &o) {
+#pragma unroll
+  for (int k = 0; k < S_RPT; ++k) o.b[k] = stem_norm<SRC>(a, lut, r.v[k], r.ok[k] && b.x_ok);
+}
+
+// tile = hi tile, tile + S_TILE = lo tile
+__device__ __forceinline__ void stem_write_rows(unsigned short *tile, int wrow0, int idx0, int lane,
+                                                const StemBits &o) {
+#pragma unroll
+  for (int k = 0; k < S_RPT; ++k) {
+    const int e = stem_row_of(wrow0, idx0 + k) * S_TP + lane;
+    tile[e] = (unsigned short)o.b[k];
+    tile[S_TILE + e] = (unsigned short)(o.b[k] >> 16);
+  }
+}
+
+// columns 64 and 65 of the wave's rows: lane l takes list entry l, once per block
+template <typename SRC>
+struct StemEdge { SRC v[2]; bool ok[2]; };
+
+template <typename SRC>
+__device__ __forceinline__ void stem_load_edge(const StemSArgs &a, const StemBlock &b, int wrow0,
+                                               int lane, StemEdge<SRC> &e) {
+  const int row = stem_row_of(wrow0, lane);
+  const int64_t z = b.gz0 + row / S_TY, y = b.gy0 + row % S_TY;
+  const bool rok = z < a.z_hi && y < a.SY;
+  const int64_t zc = z < a.z_hi ? z : a.z_hi - 1, yc = y < a.SY ? y : a.SY - 1;
+  const SRC *rp = (const SRC *)a.src + (zc * a.SY + yc) * a.SX;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t x = b.gx0 + 64 + j;
+    e.ok[j] = rok && x < a.SX;
+    e.v[j] = rp[x < a.SX ? x : a.SX - 1];
+  }
+}
+
+template <typename SRC>
+__device__ __forceinline__ void stem_store_edge(const StemSArgs &a, unsigned short *tile,
+                                                const unsigned *lut, int wrow0, int lane,
+                                                const StemEdge<SRC> &e) {
+  const int row = stem_row_of(wrow0, lane);
+  const unsigned v0 = stem_norm<SRC>(a, lut, e.v[0], e.ok[0]);
+  const unsigned v1 = stem_norm<SRC>(a, lut, e.v[1], e.ok[1]);
+  *reinterpret_cast<unsigned *>(&tile[row * S_TP + 64]) = (v0 & 0xFFFFu) | (v1 << 16);
+  *reinterpret_cast<unsigned *>(&tile[S_TILE + row * S_TP + 64]) = (v0 >> 16) | (v1 & 0xFFFF0000u);
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+template <typename SRC>
+__global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
+  // tiles[buf][part]: buf 0 / 1, part hi / lo
+  unsigned short *tiles = reinterpret_cast<unsigned short *>(smem);
+  unsigned *lut = reinterpret_cast<unsigned *>(smem + 4 * S_TILE * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int nblocks = a.nbx * a.nby * a.nbz;
+  int q = blockIdx.x;
+  if (q >= nblocks) return;
+  if (sizeof(SRC) == 1 && tid < 256) {
+    const float x = ((float)tid - a.mean) / a.sd;
+    const h16_t h = (h16_t)x;
+    lut[tid] = (unsigned)h16_bits(x) | ((unsigned)h16_bits(x - (float)h) << 16);
+  }
+
+  // per-lane byte offsets of the 3 pair reads and 2 single reads for sub-step parity
+  // e = dx (k-slot layout: pack_weights.h::fpl_stem_slot_tap)
+  int offP[2][3], offS[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      offP[e][i] = 2 * (g < 3 ? stem_row_off(3 * g + i) + (e == 0 ? 0 : 2)
+                              : stem_row_off(6 + i) + (e == 0 ? 2 : 0));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      offS[e][h] = 2 * (stem_row_off(2 * (g < 3 ? g : 2) + h) + (e == 0 ? 2 : 1));
+  }
+  // weight fragments in registers: [part][e or s][b]
+  h16x8 w1[2][2][3], w2[2][2][3];
+  f32x4 sh1[3], sh2[3];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        w1[p][s][b] = a.w1[((p * 2 + s) * 3 + b) * 64 + lane];
+        w2[p][s][b] = a.w2[((p * 2 + s) * 3 + b) * 64 + lane];
+      }
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sh1[b][r] = a.shift1[16 * b + 4 * g + r];
+      sh2[b][r] = a.shift2[16 * b + 4 * g + r];
+    }
+  __syncthreads();                      // lut
+
+  // ---- the first block's tile: plain fill, once per workgroup
+  const int wrow0 = wave * S_WROWS;
+  StemBlock blk = stem_block(a, q, lane);
+  {
+    const SRC *base0;
+    const unsigned tab0 = stem_row_tab<SRC>(a, blk, wrow0, lane, base0);
+    for (int i0 = 0; i0 < S_WROWS; i0 += S_RPT) {
+      StemRows<SRC> rr;
+      StemBits hb;
+      stem_load_rows<SRC>(base0, tab0, blk.xc, i0, rr);
+      stem_convert_rows<SRC>(a, blk, lut, rr, hb);
+      stem_write_rows(tiles, wrow0, i0, lane, hb);
+    }
+    StemEdge<SRC> ee;
+    stem_load_edge<SRC>(a, blk, wrow0, lane, ee);
+    stem_store_edge<SRC>(a, tiles, lut, wrow0, lane, ee);
+  }
+  __syncthreads();
+
+  // fill pipeline state: rr = row group 0 of the next block, ee = its edge columns; a
+  // block index past the end is clamped to the last block of this workgroup - its fill
+  // then lands, unused, in the idle buffer (no branches in the task loop)
+  const int G = (int)gridDim.x;
+  auto clampq = [&](int qq, int qlast) { return qq < nblocks ? qq : qlast; };
+  StemRows<SRC> rr;
+  StemEdge<SRC> ee;
+  {
+    const StemBlock n0 = stem_block(a, clampq(q + G, q), lane);
+    const SRC *bn;
+    const unsigned tn = stem_row_tab<SRC>(a, n0, wrow0, lane, bn);
+    stem_load_rows<SRC>(bn, tn, n0.xc, 0, rr);
+    stem_load_edge<SRC>(a, n0, wrow0, lane, ee);
+  }
+  int cur = 0;
+  for (;;) {
+    const int qn = q + G;
+    const bool has_next = qn < nblocks;                 // uniform
+    const StemBlock nxt = stem_block(a, has_next ? qn : q, lane);
+    const StemBlock nx2 = stem_block(a, clampq(qn + G, has_next ? qn : q), lane);
+    const SRC *base_n, *base_2;
+    const unsigned tab_n = stem_row_tab<SRC>(a, nxt, wrow0, lane, base_n);
+    const unsigned tab_2 = stem_row_tab<SRC>(a, nx2, wrow0, lane, base_2);
+    const unsigned char *tb = reinterpret_cast<const unsigned char *>(tiles + cur * 2 * S_TILE);
+    unsigned short *tnext = tiles + (cur ^ 1) * 2 * S_TILE;
+#pragma unroll 1
+    for (int ti = 0; ti < S_TASKS; ++ti) {
+      // next block's tile, S_TASKS groups of S_RPT rows: group ti was loaded one task ago;
+      // it is converted here (table reads) and written after the first half of this
+      // task's MFMAs, where the loads of group ti + 1 - or, in the last task, of group 0
+      // of the block after next - are issued
+      StemBits hb;
+      stem_convert_rows<SRC>(a, nxt, lut, rr, hb);
+      const bool last = ti + 1 == S_TASKS;
+      const SRC *lbase = last ? base_2 : base_n;
+      const unsigned ltab = last ? tab_2 : tab_n, lxc = last ? nx2.xc : nxt.xc;
+      const int lidx = last ? 0 : S_RPT * (ti + 1);
+      const int task = wave + S_WAVES * ti;
+      const int row = task >> 1, xh = task & 1;
+      const int pzl = row / S_PY, pyl = row % S_PY;
+      const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TP + 2 * (16 * xh + c));
+      // max-pool in fp32 (the split of the maximum is the maximum of the splits: the
+      // representation is monotonic); the initial 0 is the ReLU
+      f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        f32x4 a2[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {                 // sub = 2 sp + e: x parity e
+          const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
+          Frag2 bf;
+#pragma unroll
+          for (int part = 0; part < 2; ++part) {
+            const unsigned char *tp = tb + part * (S_TILE * 2) + base + so;
+            u32x4 raw;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) raw[i] = *reinterpret_cast<const unsigned *>(tp + offP[e][i]);
+            const unsigned s0 = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
+            const unsigned s1 = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
+            raw[3] = s0 | (s1 << 16);
+            if (part == 0) bf.hi = __builtin_bit_cast(h16x8, raw);
+            else bf.lo = __builtin_bit_cast(h16x8, raw);
+          }
+          f32x4 a1[3];
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, sh1[b]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.lo, a1[b]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.hi, a1[b]);
+          const Frag2 h0 = pack_relu_split(a1[0], a1[1]);
+          const Frag2 h1 = pack_relu_split_lo(a1[2]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][0][b], h0.hi, sh2[b]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][1][b], h1.hi, a2[e][b]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][0][b], h0.lo, a2[e][b]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][1][b], h1.lo, a2[e][b]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][0][b], h0.hi, a2[e][b]);
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][1][b], h1.hi, a2[e][b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
+        if (sp == 1) {
+          stem_write_rows(tnext, wrow0, S_RPT * ti, lane, hb);
+          stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
+        }
+      }
+      const int pz = blk.pz0 + pzl, py = blk.py0 + pyl, px = blk.px0 + 16 * xh + c;
+      if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
+        unsigned char *vox = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * VOX;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) store_split4(vox, 16 * b + 4 * g, poolf[b]);
+      }
+    }
+    if (!has_next) break;
+    stem_store_edge<SRC>(a, tnext, lut, wrow0, lane, ee);
+    stem_load_edge<SRC>(a, nx2, wrow0, lane, ee);
+    __syncthreads();        // tile[cur] consumed by every wave, tile[cur ^ 1] complete
+    q = qn;
+    blk = nxt;
+    cur ^= 1;
+  }
+}
+
+// -------------------------------------------------------------------------------
+// Shared 3x3x3 48->48 K loop (K2 and K3): per pass, the 6 x 6 x 18 x 96 B tile of that
+// pass's 24 channels (hi and lo halves) is staged by LDS-DMA, then 21 K-steps of
+// 4 sub-steps x 3 M-blocks x 3 products.  Weight fragments (6 x 1 KiB per K-step: hi
+// and lo, the same for every wave) go from L2 straight into registers, WQ K-steps
+// ahead, as in vgg_fused.hip::conv3_kloop.
+// -------------------------------------------------------------------------------
+template <int TY, int TX>
+__device__ __forceinline__ unsigned kslot_entry(int idx) {
+  const int g = idx / KTAB;
+  int s = idx % KTAB;
+  s = s < KS ? s : KS - 1;
+  const int f0 = 32 * s + 8 * g;
+  const int tap = f0 / CHP, ch0 = f0 % CHP;
+  if (tap >= 27) return 0u;           // zero weights; any valid address will do
+  return (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PASS_BYTES + ch0 * 2);
+}
+
+constexpr int WQ = 3;
+
+template <int TZ, int TY, int TX, typename SubOff>
+__device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, int AY, int AX,
+                                             int z0, int y0, int x0, unsigned char *tile,
+                                             const unsigned *kofftab, const unsigned char *wglobal,
+                                             unsigned vbase, SubOff sub_off, f32x4 (&acc)[4][3],
+                                             int tid) {
+  const int lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const unsigned *ktab = kofftab + g * KTAB;
+#pragma unroll 1
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (pass) __syncthreads();                       // every wave has left the previous pass's tile
+    stage_tile<TZ, TY, TX, VOX>(act + pass * PASS_BYTES, AZ, AY, AX, z0, y0, x0, tile, wave, lane);
+    const unsigned char *wl = wglobal + (size_t)pass * KS * 6 * 1024 + lane * 16;
+    h16x8 wq[WQ][6];                                 // [..][0..2] hi, [3..5] lo
+#pragma unroll
+    for (int d = 0; d < WQ; ++d)
+#pragma unroll
+      for (int f = 0; f < 6; ++f)
+        wq[d][f] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * 6 + f) * 1024);
+    __syncthreads();                                 // tile (LDS-DMA) + table visible
+    u32x4 kv = *reinterpret_cast<const u32x4 *>(ktab);
+    Frag2 bcur[4], bnxt[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const unsigned char *p = tile + vbase + kv[0] + sub_off(sub);
+      bcur[sub].hi = *reinterpret_cast<const h16x8 *>(p);
+      bcur[sub].lo = *reinterpret_cast<const h16x8 *>(p + LO_OFF);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      // prefetch K-step s+1 (the final prefetch re-reads the last step: harmless)
+      if ((s + 1) % 4 == 0) kv = *reinterpret_cast<const u32x4 *>(ktab + s + 1);
+      const unsigned koff = kv[(s + 1) % 4];
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        const unsigned char *p = tile + vbase + koff + sub_off(sub);
+        bnxt[sub].hi = *reinterpret_cast<const h16x8 *>(p);
+        bnxt[sub].lo = *reinterpret_cast<const h16x8 *>(p + LO_OFF);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wq[s % WQ][3 + b], bcur[sub].hi, acc[sub][b]);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wq[s % WQ][b], bcur[sub].lo, acc[sub][b]);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[sub][b] = mfma16(wq[s % WQ][b], bcur[sub].hi, acc[sub][b]);
+      __builtin_amdgcn_s_setprio(0);
+      if (s + WQ < KS) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+          wq[s % WQ][f] = *reinterpret_cast<const h16x8 *>(wl + (size_t)((s + WQ) * 6 + f) * 1024);
+      }
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) bcur[sub] = bnxt[sub];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------
+// K2: conv3 48->48 + conv1 48->48 + maxpool2 (block, wave and sub-step geometry of
+// vgg_mid_pool: pre-pool block 4 x 4 x 16, wave = pooled (pz,py) row, 4 sub-steps =
+// the (dz,dy) window, x pairs pooled across neighbouring lanes).
+// -------------------------------------------------------------------------------
+constexpr int M_TZ = 6, M_TY = 6, M_TX = 18;
+constexpr int M_TILE_BYTES = ((M_TZ * M_TY * M_TX * PASS_BYTES + 1023) / 1024) * 1024;
+constexpr int M_SMEM = M_TILE_BYTES + KTAB_BYTES;
+static_assert(2 * M_SMEM <= 160 * 1024, "two workgroups must fit one CU");
+
+struct MidSArgs {
+  const unsigned char *p1;
+  int P1Z, P1Y, P1X;
+  const unsigned char *w3;       // [pass][KS][part][b] fragments
+  const h16x8 *w4;               // [part][s][b][lane]
+  const float *shift3, *shift4;
+  unsigned char *p2;
+  int P2Z, P2Y, P2X;
+  BlockGrid bg;
+};
+
+__global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
+  unsigned char *tile = smem;
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int xb, yb, zb;
+  if (!block_coords(a.bg, xb, yb, zb)) return;
+  const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 2;
+  if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
+
+  const int pzl = wave >> 1, pyl = wave & 1;
+  const unsigned vbase = (unsigned)((((2 * pzl) * M_TY + 2 * pyl) * M_TX + c) * PASS_BYTES);
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    f32x4 sh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = a.shift3[16 * b + 4 * g + r];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
+  }
+  auto sub_off = [](int sub) -> unsigned {
+    return (unsigned)(((((sub >> 1) & 1) * M_TY + (sub & 1)) * M_TX) * PASS_BYTES);
+  };
+  conv3s_kloop<M_TZ, M_TY, M_TX>(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0, tile,
+                                 kofftab, a.w3, vbase, sub_off, acc, tid);
+
+  // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions
+  h16x8 w4[2][2][3];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) w4[p][s][b] = a.w4[((p * 2 + s) * 3 + b) * 64 + lane];
+  f32x4 sh4[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[16 * b + 4 * g + r];
+  f32x4 pooled[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const Frag2 h0 = pack_relu_split(acc[sub][0], acc[sub][1]);
+    const Frag2 h1 = pack_relu_split_lo(acc[sub][2]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      f32x4 a4 = mfma3(w4[0][0][b], w4[1][0][b], h0, sh4[b]);
+      a4 = mfma3(w4[0][1][b], w4[1][1][b], h1, a4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pooled[b][r] = __builtin_fmaxf(pooled[b][r], a4[r]);
+    }
+  }
+  // pool the x pair: lanes c and c^1 hold neighbouring pre-pool x
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      pooled[b][r] = __builtin_fmaxf(pooled[b][r], __shfl_xor(pooled[b][r], 1));
+  const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + (c >> 1);
+  if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
+    unsigned char *vox = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * VOX;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) store_split4(vox, 16 * b + 4 * g, pooled[b]);
+  }
+}
+
+// -------------------------------------------------------------------------------
+// K3: conv3 48->48 + BN + ReLU on P2, then - in registers - conv1 48->96, conv1 96->96,
+// conv1 96->1 + bias, sigmoid and the x4 nearest upsample store into the (Z,Y,X) f32
+// prediction volume (vgg_c5_tail's geometry: block 4 x 4 x 16, wave = z, sub-steps = the
+// 4 y rows).  The 1x1 chain runs on two sub-steps at a time: with hi and lo fragments all
+// four in lockstep do not fit the register file.
+// -------------------------------------------------------------------------------
+constexpr int T_W6 = 2 * 6, T_W7 = 3 * 6, T_W8 = 3;   // fragments per part of L6, L7, L8
+
+struct TailSArgs {
+  const unsigned char *p2;
+  int P2Z, P2Y, P2X;
+  const unsigned char *w5;       // [pass][KS][part][b]
+  const float *shift5;
+  int CZ, CY, CX;                // chunk-local coarse dims
+  const unsigned char *w6, *w7, *w8;   // [part][s][b] fragments
+  const float *shift6, *shift7;
+  float bias8;
+  float *dst;                    // (Z,Y,X) prediction volume, row 0
+  int64_t DY, DX;                // its pitches
+  int64_t gz0;                   // global coarse z of chunk-local coarse row 0
+  int64_t VZ, VY, VX;            // valid fine extents (dim - 2 * off)
+  int off;                       // rf offset of the network: 7
+  BlockGrid bg;
+};
+
+__global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
+  unsigned char *tile = smem;
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int xb, yb, zb;
+  if (!block_coords(a.bg, xb, yb, zb)) return;
+  const int cx0 = xb * 16, cy0 = yb * 4, cz0 = zb * 4;
+  if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
+
+  const unsigned vbase = (unsigned)(((wave * M_TY) * M_TX + c) * PASS_BYTES);
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    f32x4 sh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = a.shift5[16 * b + 4 * g + r];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
+  }
+  auto sub_off = [](int sub) -> unsigned { return (unsigned)(sub * M_TX * PASS_BYTES); };
+  conv3s_kloop<M_TZ, M_TY, M_TX>(a.p2, a.P2Z, a.P2Y, a.P2X, cz0, cy0, cx0, tile, kofftab, a.w5,
+                                 vbase, sub_off, acc, tid);
+
+  auto frag = [&](const unsigned char *w, int part, int nfrag, int f) {
+    return *reinterpret_cast<const h16x8 *>(w + ((size_t)(part * nfrag + f) * 64 + lane) * 16);
+  };
+  float logit[4];
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp) {
+    Frag2 h5[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      h5[q][0] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1]);
+      h5[q][1] = pack_relu_split_lo(acc[2 * sp + q][2]);
+    }
+    Frag2 h6[2][3];
+    {
+      f32x4 a6[2][6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        f32x4 sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh[r] = a.shift6[16 * b + 4 * g + r];
+        const h16x8 wh0 = frag(a.w6, 0, T_W6, 0 * 6 + b), wh1 = frag(a.w6, 0, T_W6, 1 * 6 + b);
+        const h16x8 wl0 = frag(a.w6, 1, T_W6, 0 * 6 + b), wl1 = frag(a.w6, 1, T_W6, 1 * 6 + b);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          a6[q][b] = mfma3(wh1, wl1, h5[q][1], mfma3(wh0, wl0, h5[q][0], sh));
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) h6[q][s] = pack_relu_split(a6[q][2 * s], a6[q][2 * s + 1]);
+    }
+    Frag2 h7[2][3];
+    {
+      f32x4 a7[2][6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        f32x4 sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh[r] = a.shift7[16 * b + 4 * g + r];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a7[q][b] = sh;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const h16x8 wh = frag(a.w7, 0, T_W7, s * 6 + b), wl = frag(a.w7, 1, T_W7, s * 6 + b);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a7[q][b] = mfma3(wh, wl, h6[q][s], a7[q][b]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) h7[q][s] = pack_relu_split(a7[q][2 * s], a7[q][2 * s + 1]);
+    }
+    f32x4 a8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const h16x8 wh = frag(a.w8, 0, T_W8, s), wl = frag(a.w8, 1, T_W8, s);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a8[q] = mfma3(wh, wl, h7[q][s], a8[q]);
+    }
+    // lane (c, g=0) register 0 holds the logit of coarse voxel c
+#pragma unroll
+    for (int q = 0; q < 2; ++q) logit[2 * sp + q] = __shfl(a8[q][0], c) + a.bias8;
+  }
+
+  const int cz = cz0 + wave, cx = cx0 + c;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const int cy = cy0 + sub;
+    const float p = 1.f / (1.f + expf(-logit[sub]));
+    // x4 upsample store: lane (c,g) writes 4 fine x of fine row (4cy+g), 4 z rows
+    if (cz < a.CZ && cy < a.CY && cx < a.CX) {
+      const int64_t fz0 = 4 * (a.gz0 + cz), fy = 4 * (int64_t)cy + g, fx0 = 4 * (int64_t)cx;
+      if (fy < a.VY && fx0 < a.VX) {
+        const int nx = (int)(a.VX - fx0 < 4 ? a.VX - fx0 : 4);
+#pragma unroll
+        for (int dz = 0; dz < 4; ++dz) {
+          const int64_t fz = fz0 + dz;
+          if (fz >= a.VZ) break;
+          float *o = a.dst + ((fz + a.off) * a.DY + fy + a.off) * a.DX + fx0 + a.off;
+          if (nx == 4) {
+            *reinterpret_cast<f32x4_a4 *>(o) = f32x4_a4{p, p, p, p};
+          } else {
+            for (int i = 0; i < nx; ++i) o[i] = p;
+          }
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------
+// host side: weight packing, slab orchestration
+// -------------------------------------------------------------------------------
+struct SplitState {
+  uint64_t version = ~0ull;
+  unsigned char *frags = nullptr;
+  float *shifts = nullptr;
+  size_t off_w[8] = {0};              // byte offsets of L1..L8 fragment sets
+  size_t off_s[8] = {0};              // float offsets of shift1..shift8
+  float bias8 = 0.f;
+};
+
+void split_state_free(fpl_ctx *ctx, void *p) {
+  SplitState *s = (SplitState *)p;
+  if (s->frags) hipFree(s->frags);
+  if (s->shifts) hipFree(s->shifts);
+  delete s;
+}
+
+int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
+  SplitState *st = (SplitState *)prog->fast_state_h16[2];
+  if (!st) {
+    st = new SplitState();
+    prog->fast_state_h16[2] = st;
+    prog->fast_state_h16_free[2] = split_state_free;
+  }
+  *out = st;
+  if (st->version == prog->arena_version) return 0;
+  static const int conv_ops[8] = {0, 1, 3, 4, 6, 7, 8, 9};
+  static const int mblocks[8] = {3, 3, 3, 3, 3, 6, 6, 1};
+  static const int ksteps[8] = {1, 2, KS, 2, KS, 2, 3, 3};
+  std::vector<uint16_t> all;
+  std::vector<float> shifts;
+  const float *A = prog->arena_host.data();
+  for (int l = 0; l < 8; ++l) {
+    const fpl_op &op = prog->ops[conv_ops[l]];
+    std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
+    st->off_w[l] = all.size() * sizeof(uint16_t);
+    if (l == 0) {
+      for (int part = 0; part < 2; ++part) {       // [part][e][b]
+        std::vector<uint16_t> f;
+        fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f, part);
+        all.insert(all.end(), f.begin(), f.end());
+      }
+    } else if (op.k == 3) {
+      // [pass][K-step][part][b]: per pass the (tap, channel-in-pass) sub-matrix
+      for (int pass = 0; pass < NPASS; ++pass) {
+        std::vector<float> wp((size_t)27 * CHP * op.cout);
+        for (int tap = 0; tap < 27; ++tap)
+          for (int ch = 0; ch < CHP; ++ch)
+            memcpy(&wp[((size_t)tap * CHP + ch) * op.cout],
+                   A + op.w_off + ((size_t)tap * op.cin + pass * CHP + ch) * op.cout,
+                   op.cout * sizeof(float));
+        std::vector<uint16_t> f[2];
+        for (int part = 0; part < 2; ++part)
+          fpl_pack_frags(wp.data(), scale.data(), 27, CHP, op.cout, 3, KS, SLOT_SPATIAL, &f[part],
+                         false, part);
+        for (int s = 0; s < KS; ++s)
+          for (int part = 0; part < 2; ++part)
+            all.insert(all.end(), f[part].begin() + (size_t)s * 3 * 512,
+                       f[part].begin() + (size_t)(s + 1) * 3 * 512);
+      }
+    } else {
+      for (int part = 0; part < 2; ++part) {       // [part][s][b]
+        std::vector<uint16_t> f;
+        fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mblocks[l], ksteps[l],
+                       SLOT_CHAIN, &f, false, part);
+        all.insert(all.end(), f.begin(), f.end());
+      }
+    }
+    st->off_s[l] = shifts.size();
+    shifts.insert(shifts.end(), A + op.shift_off, A + op.shift_off + op.cout);
+    while (shifts.size() % 4) shifts.push_back(0.f);
+  }
+  for (uint16_t h : all)
+    FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
+                "a folded weight exceeds the IEEE-half range (65504); use precision f32 for "
+                "this network");
+  st->bias8 = A[prog->ops[9].shift_off];
+  if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
+  if (st->shifts) FPL_HIP(ctx, hipFree(st->shifts));
+  st->frags = nullptr;
+  st->shifts = nullptr;
+  FPL_HIP(ctx, hipMalloc((void **)&st->frags, all.size() * sizeof(uint16_t)));
+  FPL_HIP(ctx, hipMalloc((void **)&st->shifts, shifts.size() * sizeof(float)));
+  FPL_HIP(ctx, hipMemcpy(st->frags, all.data(), all.size() * sizeof(uint16_t),
+                         hipMemcpyHostToDevice));
+  FPL_HIP(ctx, hipMemcpy(st->shifts, shifts.data(), shifts.size() * sizeof(float),
+                         hipMemcpyHostToDevice));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_stem_pool<uint8_t>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, S_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_stem_pool<float>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, S_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_mid_pool,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_c5_tail,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
+  st->version = prog->arena_version;
+  return 0;
+}
+
+}  // namespace
+
+bool fpl_split_path_available(const fpl_program *prog, int precision, const int32_t offset[3],
+                              const int32_t out_sz[3]) {
+  if (precision != FPL_PREC_F16S || fpl_vgg_variant(prog) != 1) return false;
+  for (int a = 0; a < 3; ++a)
+    if (offset[a] != 7 || out_sz[a] % 4 != 0) return false;
+  return true;
+}
+
+// Slab orchestration: as the vgg_like branch of fpl_fast_infer_volume_* (vgg_fused.hip;
+// the lattice equivalence with FplNetwork.infer, flypylib/fplnetwork.py:146-187, is
+// argued there), with P1 / P2 in the split layout.
+int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int src_dtype,
+                           float mean, float sd, const int64_t dims[3],
+                           const std::vector<int32_t> origins[3], const int32_t out_sz[3],
+                           int32_t zb, int32_t ze, float *dst) {
+  SplitState *st;
+  FPL_TRY(split_prepare(ctx, prog, &st));
+  hipStream_t stream = ctx->stream;
+  const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];
+  const int64_t VZ = SZ - 14, VY = SY - 14, VX = SX - 14;
+  if (VZ <= 0 || VY <= 0 || VX <= 0 || zb >= ze) return 0;   // no valid output voxel
+  // coarse rows this slab owns (tile rows zb..ze-1 of the reference lattice)
+  const int64_t fz_lo = (int64_t)origins[0][zb] - 7;
+  const int64_t fz_hi = std::min<int64_t>((int64_t)origins[0][ze - 1] - 7 + out_sz[0], VZ);
+  const int64_t cz_lo = fz_lo / 4, cz_hi = ceil_div64(fz_hi, 4);
+  const int CY = (int)ceil_div64(VY, 4), CX = (int)ceil_div64(VX, 4);
+  const int P2Y = CY + 2, P2X = CX + 2, P1Y = 2 * P2Y + 2, P1X = 2 * P2X + 2;
+  // chunk of coarse rows bounded by a scratch budget (P1 dominates;
+  // FPL_VGG_SCRATCH_MB shrinks it so that tests can force several chunks)
+  const int64_t p1_row_bytes = (int64_t)P1Y * P1X * VOX;
+  const char *budget_env = getenv("FPL_VGG_SCRATCH_MB");
+  const int64_t budget = budget_env ? (int64_t)atoll(budget_env) << 20 : (int64_t)64 << 30;
+  int64_t cz_chunk = std::max<int64_t>(4, (budget / p1_row_bytes - 6) / 2);
+  cz_chunk = std::min<int64_t>(cz_chunk, cz_hi - cz_lo);
+  cz_chunk = (cz_chunk + 3) / 4 * 4;
+  FPL_REQUIRE(ctx, (int64_t)S_TZ * SY * SX < ((int64_t)1 << 31),
+              "vgg split path: a %lld x %lld plane is too large for the stem's 31-bit row "
+              "offsets", (long long)SY, (long long)SX);
+  FPL_REQUIRE(ctx, (int64_t)P1Y * P1X * VOX * 8 < ((int64_t)1 << 32),
+              "vgg split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
+              "offsets", (long long)SY, (long long)SX);
+  DevTemp tmp(ctx);
+  void *p1v, *p2v;
+  FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 6) * p1_row_bytes, &p1v));
+  FPL_TRY(tmp.alloc((size_t)(cz_chunk + 2) * P2Y * P2X * VOX, &p2v));
+  const unsigned char *F = st->frags;
+  const float *S = st->shifts;
+  for (int64_t c0 = cz_lo; c0 < cz_hi; c0 += cz_chunk) {
+    const int CZ = (int)std::min<int64_t>(cz_chunk, cz_hi - c0);
+    const int P2Z = CZ + 2, P1Z = 2 * P2Z + 2;
+    {
+      StemSArgs a;
+      a.src = src; a.SZ = SZ; a.SY = SY; a.SX = SX; a.mean = mean; a.sd = sd;
+      a.p1z0 = 2 * c0;
+      // block rounding may reach past the rows this slab stages: they only feed masked
+      // outputs, so they read as zero
+      a.z_hi = std::min<int64_t>(SZ, 4 * (c0 + CZ) + 14);
+      a.w1 = (const h16x8 *)(F + st->off_w[0]);
+      a.w2 = (const h16x8 *)(F + st->off_w[1]);
+      a.shift1 = S + st->off_s[0]; a.shift2 = S + st->off_s[1];
+      a.p1 = (unsigned char *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
+      a.nbx = (int)ceil_div64(P1X, S_PX); a.nby = (int)ceil_div64(P1Y, S_PY);
+      a.nbz = (int)ceil_div64(P1Z, S_PZ);
+      // persistent: one workgroup of 8 waves per CU walks the blocks
+      const unsigned grid = (unsigned)std::min<int64_t>((int64_t)a.nbx * a.nby * a.nbz,
+                                                        (int64_t)ctx->n_cu);
+      TimedLaunch tl(ctx, "vggs_stem_pool");
+      if (src_dtype == FPL_U8)
+        vggs_stem_pool<uint8_t><<<grid, 64 * S_WAVES, S_SMEM, stream>>>(a);
+      else
+        vggs_stem_pool<float><<<grid, 64 * S_WAVES, S_SMEM, stream>>>(a);
+    }
+    {
+      MidSArgs a;
+      a.p1 = (const unsigned char *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
+      a.w3 = F + st->off_w[2];
+      a.w4 = (const h16x8 *)(F + st->off_w[3]);
+      a.shift3 = S + st->off_s[2]; a.shift4 = S + st->off_s[3];
+      a.p2 = (unsigned char *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
+      a.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 2)};
+      TimedLaunch tl(ctx, "vggs_mid_pool");
+      vggs_mid_pool<<<block_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+    }
+    {
+      TailSArgs a;
+      a.p2 = (const unsigned char *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
+      a.w5 = F + st->off_w[4]; a.shift5 = S + st->off_s[4];
+      a.CZ = CZ; a.CY = CY; a.CX = CX;
+      a.w6 = F + st->off_w[5]; a.w7 = F + st->off_w[6]; a.w8 = F + st->off_w[7];
+      a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
+      a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
+      a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = 7;
+      a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
+      TimedLaunch tl(ctx, "vggs_c5_tail");
+      vggs_c5_tail<<<block_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+    }
+    FPL_HIP(ctx, hipGetLastError());
+  }
+  return 0;
+}

@@ -19,7 +19,10 @@ from . import _capi, fplutils, multi_gpu, runtime
 
 _PRECISIONS = {'f32': _capi.PREC_F32, 'fp32': _capi.PREC_F32,
                'float32': _capi.PREC_F32, 'bf16': _capi.PREC_BF16,
-               'f16': _capi.PREC_F16, 'float16': _capi.PREC_F16}
+               'f16': _capi.PREC_F16, 'float16': _capi.PREC_F16,
+               # split IEEE halves (hi + lo, three MFMAs per product): fp32-grade
+               # probabilities at a third of the 16-bit rate; vgg_like only
+               'f16s': _capi.PREC_F16S, 'split': _capi.PREC_F16S}
 
 
 class InferNetwork:

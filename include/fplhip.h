@@ -38,9 +38,13 @@ typedef struct fpl_program fpl_program;
 enum fpl_mem { FPL_MEM_HOST = 0, FPL_MEM_DEVICE = 1 };
 enum fpl_dtype { FPL_U8 = 0, FPL_F32 = 1, FPL_F64 = 2 };
 /* arithmetic of the convolutions: fp32 (exact reference arithmetic), or 16-bit MFMA
- * operands with fp32 accumulation - bfloat16 (8 significant bits) or IEEE half (11
- * bits, range 65504: probabilities within ~1e-4 of fp32; same speed as bf16) */
-enum fpl_precision { FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1, FPL_PREC_F16 = 2 };
+ * operands with fp32 accumulation - bfloat16 (8 significant bits), IEEE half (11
+ * bits, range 65504: probabilities within ~1e-3 of fp32 on trained weights; same speed
+ * as bf16), or SPLIT IEEE halves (FPL_PREC_F16S: every operand as hi + lo, ~22 bits,
+ * three MFMAs per product: probabilities within ~2e-6 of fp32 - inside the reference's
+ * 1e-3 gate with detections identical to the fp32 path's - at a third of the 16-bit
+ * rate; vgg_like only, other graphs are refused) */
+enum fpl_precision { FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1, FPL_PREC_F16 = 2, FPL_PREC_F16S = 3 };
 
 /* fused layer-program ops, produced by LayerGraph.lower_inference()
  * (flypylib_amd/program.py); layer semantics = Keras layers instantiated in
@@ -131,7 +135,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                      int32_t z_begin, int32_t z_end, float *dst, int dst_mem);
 
 /* name of the executor the last fpl_infer_volume / fpl_program_forward of this
- * context ran on: "vgg_fused_f16" | "vgg_fused_bf16" | "unet_mfma_f16" |
+ * context ran on: "vgg_fused_f16" | "vgg_fused_bf16" | "vgg_split_f16" | "unet_mfma_f16" |
  * "unet_mfma_bf16" | "mfma_f32" | "perop_f32" | "none" (empty slab).  The 16-bit
  * fused kernels are keyed on the architectures of flypylib/fplmodels.py; any other
  * graph runs on the fp32 executors - this says which, instead of leaving the caller

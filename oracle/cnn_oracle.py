@@ -176,8 +176,12 @@ def conv3d_valid_numpy(x, kernel):
 
 # ---- bf16 emulation of the fused MI355X kernels (csrc/vgg_fused.hip) -----------
 def _bf16_round(t, kind='bf16'):
-    """round-to-nearest-even to the 16-bit operand type of the fused kernels
-    (bfloat16, or IEEE half for kind='f16'), kept in float32"""
+    """round-to-nearest-even to the operand type of the fused kernels, kept in float32:
+    bfloat16, IEEE half (kind='f16'), or the split representation of csrc/vgg_split.hip
+    (kind='split': hi = half(v), lo = half(v - hi), value hi + lo, ~22 significant bits)"""
+    if kind == 'split':
+        hi = t.to(torch.float16).to(torch.float32)
+        return hi + (t - hi).to(torch.float16).to(torch.float32)
     return t.to(torch.float16 if kind == 'f16' else torch.bfloat16).to(torch.float32)
 
 

@@ -1,72 +1,52 @@
-"""The 1e-3 probability gate of the north star on TRAINED weights (not only the
-synthetic glorot + random-BN weights of the other tests): vgg_like and unet_like2 are
-trained for a few hundred steps on synthetic blobs with the HIP engine, then the fused
-16-bit inference of the trained network is held against (a) the fp32 MFMA path of the
-same library and (b) the CPU oracle.  Training is not bit-reproducible (the weight
-gradients are summed with float atomics), so every run tests a slightly different network:
-over a dozen runs the worst f16 voxel of the 110^3 volume was 6.5e-4 ... 1.004e-3 off fp32
-(mean 4e-6 ... 1.2e-5) - AT the 1e-3 the north star asks of the fp32 path, not safely
-inside it.  The test therefore bounds the maximum at 2e-3, the mean at 3e-5 and the share
-of voxels beyond 5e-4 at 1 % (observed 0.03 - 0.2 %); bf16 - 8 significant bits - is bounded at what it delivers;
-the detections of the f16 and fp32 predictions are compared."""
+"""The 1e-3 probability gate of the north star on TRAINED weights - the committed fixture
+tests/golden/trained_{vgg_like,unet_like2}.npz (trained once on a GPU box by
+tools/make_trained_fixture.py; training is not bit-reproducible, a committed file is),
+not only the synthetic glorot + random-BN weights of the other tests.
+
+What is held, per precision, against the fp32 path of the same library (itself held to
+1e-4 of the CPU oracle here, 2e-7 typical):
+
+  f16s  split IEEE halves (vgg_like): fp32-grade - max |dp| < 1e-5 - and the detections
+        of its prediction are IDENTICAL to those of the fp32 prediction (same voxels,
+        confidences within 1e-5), also on a 582^3 substack at the pipeline's voxel2obj
+        parameters.  This is the path that meets "within 1e-3, identical detections".
+  f16   plain IEEE half: inside the 1e-3 gate on this fixture (8.3e-4 / 7.0e-4 observed)
+        but without margin, and its detections may differ from fp32's in a tie-break.
+  bf16  bounded at what 8 significant bits deliver.
+"""
 import numpy as np
 import pytest
 
-from flypylib_amd import FplNetwork, fplmodels, fplobjdetect
-from oracle import cnn_oracle, infer_oracle
+from flypylib_amd import fplobjdetect
+from oracle import cnn_oracle
+from tests.trained_fixture import RECIPES, blob_region, blob_region_u8, trained_network
 
 pytestmark = pytest.mark.gpu
 
 
-def _blob_region(seed, n, radius=3, step=16):
-    rs = np.random.RandomState(seed)
-    im = rs.randn(n, n, n).astype(np.float32) * 0.5
-    grid = np.arange(12, n - 12, step)
-    locs = np.array([(x, y, z) for z in grid for y in grid for x in grid], np.int64)
-    locs = locs + rs.randint(-3, 4, locs.shape)
-    zz, yy, xx = np.meshgrid(*(np.arange(-radius, radius + 1),) * 3, indexing='ij')
-    ball = zz ** 2 + yy ** 2 + xx ** 2 <= radius ** 2
-    labels = np.zeros((n, n, n), np.uint8)
-    for x, y, z in locs:
-        sl = (slice(z - radius, z + radius + 1), slice(y - radius, y + radius + 1),
-              slice(x - radius, x + radius + 1))
-        im[sl][ball] -= 2.5
-        labels[sl][ball] = 1
-    return im, labels, locs
+def _same_detections(a, b, conf_tol):
+    assert len(a['conf']) == len(b['conf']), (len(a['conf']), len(b['conf']))
+    assert np.array_equal(a['locs'], b['locs'])
+    np.testing.assert_allclose(a['conf'], b['conf'], rtol=0, atol=conf_tol)
 
 
-def _train(factory, steps, batch, dense):
-    net = FplNetwork(factory)
-    im, labels, _ = _blob_region(1, 96)
-    mask = np.ones_like(labels)
-    if dense:
-        gen = fplobjdetect.gen_volume2([[im, labels, mask]], net.rf_size, batch, 0.5,
-                                       rng=np.random.RandomState(0))
-    else:
-        gen = fplobjdetect.gen_batches([[im, labels, mask]], net.rf_size, batch,
-                                       rng=np.random.RandomState(0))
-    net.train(gen, steps, 1, None, None)
-    return net
-
-
-@pytest.mark.parametrize('name,steps,batch,dense,tile,off', [
-    ('vgg_like', 700, 32, False, 46, 7), ('unet_like2', 500, 16, True, 52, 9)])
-def test_gate_on_trained_weights(ctx, name, steps, batch, dense, tile, off):
-    net = _train(getattr(fplmodels, name), steps, batch, dense)
-    net.infer_sz = (tile,) * 3
-    net._set_infer()
-    im, _, locs = _blob_region(2, 110)
+@pytest.mark.parametrize('name', ['vgg_like', 'unet_like2'])
+def test_gate_on_trained_weights(ctx, name):
+    r = RECIPES[name]
+    tile, off = r['tile'], r['off']
+    net = trained_network(name)
+    im, _, locs = blob_region(2, 110)
     p32 = net.infer(im, precision='f32')
     p16 = net.infer(im, precision='f16')
     pb16 = net.infer(im, precision='bf16')
     # the trained network does something: confident on blobs, quiet elsewhere
     assert p32.max() > 0.8 and np.median(p32[off:-off, off:-off, off:-off]) < 0.2
     d16, db16 = np.abs(p16 - p32), np.abs(pb16 - p32)
-    assert d16.max() < 2e-3 and d16.mean() < 3e-5 and np.mean(d16 > 5e-4) < 1e-2, \
-        'f16 vs fp32 on trained %s: max %g mean %g' % (name, d16.max(), d16.mean())
-    assert db16.max() < 3e-2 and np.mean(db16 > 1e-3) < 0.02, (db16.max(), np.mean(db16 > 1e-3))
     print('%s trained: f16 max %.2e mean %.2e | bf16 max %.2e mean %.2e, %.3f %% of voxels > 1e-3'
           % (name, d16.max(), d16.mean(), db16.max(), db16.mean(), 100 * np.mean(db16 > 1e-3)))
+    assert d16.max() < 1e-3 and d16.mean() < 3e-5, \
+        'f16 vs fp32 on trained %s: max %g mean %g' % (name, d16.max(), d16.mean())
+    assert db16.max() < 3e-2 and np.mean(db16 > 1e-3) < 0.02, (db16.max(), np.mean(db16 > 1e-3))
     # fp32 library path vs the CPU oracle on one tile of the same trained weights
     g = net.infer_network.graph
     x0 = 20
@@ -75,18 +55,44 @@ def test_gate_on_trained_weights(ctx, name, steps, batch, dense, tile, off):
                                     upsample_stride=net.rf_stride)[0, ..., 0]
     got = net.infer_network.predict(tile_in)[0, ..., 0]
     assert np.abs(got - want).max() < 1e-4
-    # the detections of the f16 and of the fp32 prediction: the same objects.  (Point
-    # lists are bit-identical for the SAME prediction - test_gpu_voxel2obj.py; two
-    # predictions 1e-4 apart may break a tie between neighbouring voxels differently.)
     kw = dict(obj_min_dist=6, smoothing_sigma=1.5, buffer_sz=off + 2, thd=0.5)
     a = fplobjdetect.voxel2obj(p32, **kw)
+    assert len(a['conf']) > 20
+    # ... and they are the planted blobs
+    hit = np.linalg.norm(a['locs'][:, None, :] - locs[None, :, :].astype(float), axis=2).min(axis=1)
+    assert np.mean(hit <= 4.0) > 0.8
+    if name == 'vgg_like':
+        ps = net.infer(im, precision='f16s')
+        ds = np.abs(ps - p32)
+        print('%s trained: f16s max %.2e mean %.2e' % (name, ds.max(), ds.mean()))
+        assert ds.max() < 1e-5, 'split halves vs fp32 on trained %s: max %g' % (name, ds.max())
+        _same_detections(a, fplobjdetect.voxel2obj(ps, **kw), 1e-5)
+    # plain f16: the same objects, up to a tie-break between neighbouring voxels
     b = fplobjdetect.voxel2obj(p16, **kw)
-    assert len(a['conf']) > 20 and abs(len(a['conf']) - len(b['conf'])) <= 1
+    assert abs(len(a['conf']) - len(b['conf'])) <= 1
     dist = np.linalg.norm(a['locs'][:, None, :] - b['locs'][None, :, :], axis=2)
     near = dist.min(axis=1)
     assert np.mean(near <= 2.0) >= 0.98, np.sort(near)[-5:]
     matched = dist.argmin(axis=1)[near <= 2.0]
     np.testing.assert_allclose(a['conf'][near <= 2.0], b['conf'][matched], atol=2e-3)
-    # and they are the planted blobs
-    hit = np.linalg.norm(a['locs'][:, None, :] - locs[None, :, :].astype(float), axis=2).min(axis=1)
-    assert np.mean(hit <= 4.0) > 0.8
+
+
+def test_split_detections_identical_on_a_substack(ctx):
+    """one substack of the pipeline (512 + 2 * 35 = 582 voxels, uint8 in, r = 27, sigma = 5,
+    `fplobjdetect.py:845,1031-1034`): voxel2obj of the split-half prediction == voxel2obj of
+    the fp32 prediction - same voxels in the same order, confidences within 1e-5 - and the
+    probabilities within 1e-5"""
+    net = trained_network('vgg_like', tile=102)
+    u8, _, locs = blob_region_u8(5, 582)
+    norm = (128.0, 33.0)
+    p32 = net.infer(u8, normalize=norm, precision='f32')
+    ps = net.infer(u8, normalize=norm, precision='f16s')
+    d = np.abs(ps - p32)
+    print('582^3 substack: f16s vs fp32 max %.2e mean %.2e' % (d.max(), d.mean()))
+    assert d.max() < 1e-5
+    kw = dict(obj_min_dist=27, smoothing_sigma=5, buffer_sz=35, thd=0.1)
+    a = fplobjdetect.voxel2obj(p32, **kw)
+    b = fplobjdetect.voxel2obj(ps, **kw)
+    print('detections', len(a['conf']))
+    assert len(a['conf']) > 100
+    _same_detections(a, b, 1e-5)

@@ -195,26 +195,3 @@ def test_stem_one_instruction_relu_is_as_accurate_as_the_two_instruction_form(ct
     finally:
         del os.environ['FPL_STEM_NOCLAMP']
     assert np.array_equal(c, d)
-
-
-@pytest.mark.parametrize('mode', ['1', '4'])
-@pytest.mark.parametrize('kind', KINDS)
-def test_mid_on_half_tiles_matches(ctx, kind, mode, monkeypatch):
-    """FPL_MID8: the experimental forms of the conv3 48->48 + conv1 + pool kernel on
-    24-channel half tiles (1: 8 sub-steps per wave; 3 / 4: 4 sub-steps, three / four
-    workgroups per CU) - same results up to the fp32 accumulation order
-    (K runs channel-half-major), same accuracy against fp32"""
-    g = _net(31, 46)
-    prog = _capi.Program(ctx, g, (4, 4, 4))
-    u8 = synth.em_volume_u8(12, (93, 70, 121))
-    img = (u8.astype(np.float32) - np.float32(128)) / np.float32(33)
-    kw = dict(mean=128.0, std=33.0, precision=PREC[kind])
-    a = prog.infer_volume(u8, (46,) * 3, (7,) * 3, **kw)
-    monkeypatch.setenv('FPL_MID8', mode)
-    b = prog.infer_volume(u8, (46,) * 3, (7,) * 3, **kw)
-    monkeypatch.delenv('FPL_MID8')
-    emu, f32 = _refs(g, img, 46, kind)
-    assert np.abs(a - b).max() < EMU_TOL[kind] and not np.array_equal(a, b)
-    assert np.abs(b - emu).max() < EMU_TOL[kind]
-    tol = BF16_TOL if kind == 'bf16' else F16_TOL
-    assert np.abs(b - f32).max() < tol
