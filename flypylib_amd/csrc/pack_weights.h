@@ -88,6 +88,30 @@ static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
       }
 }
 
+// One K-step of a register-chained 1x1 conv whose two k-slot halves are chosen freely:
+// k-slot (g, j) = channel 16 * blk[j >> 2] + 4g + (j & 3) of the previous layer, weights
+// taken as part[j >> 2] (hi / lo, fpl_f32_to_h16_part).  The split kernels use it for the
+// last, half-empty K-step of a 48-channel input: [block 2 hi | block 2 lo] against
+// [w_lo | w_hi] gives both cross products in ONE MFMA, and against [w_hi | w_lo] the
+// hi x hi (and, for free, lo x lo) product.  Appends n_mblocks fragments to *out.
+static inline void fpl_pack_chain_step(const float *W, const float *scale, int cin, int cout,
+                                       int n_mblocks, const int blk[2], const int part[2],
+                                       std::vector<uint16_t> *out) {
+  const size_t base = out->size();
+  out->resize(base + (size_t)n_mblocks * 512, 0);
+  for (int b = 0; b < n_mblocks; ++b)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = lane & 15, g = lane >> 4, co = 16 * b + m;
+      if (co >= cout) continue;
+      for (int j = 0; j < 8; ++j) {
+        const int c = 16 * blk[j >> 2] + 4 * g + (j & 3);
+        if (c >= cin) continue;
+        (*out)[base + (((size_t)b * 64 + lane) * 8 + j)] =
+            fpl_f32_to_h16_part(W[(size_t)c * cout + co] * scale[co], part[j >> 2]);
+      }
+    }
+}
+
 // ---- stem (conv3 1->48) k-slot layout ------------------------------------------
 // The input tile sits in LDS as bf16; a lane's base x is even, so per tap row
 // (tz,ty) one (tx,tx+1) pair is an aligned 32-bit read.  For sub-step parity

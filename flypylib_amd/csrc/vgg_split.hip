@@ -46,16 +46,28 @@ __host__ __device__ constexpr int chan_off(int ch) { return (ch / CHP) * PASS_BY
 struct Pair2 { unsigned hi, lo; };          // two values as packed halves
 struct Frag2 { h16x8 hi, lo; };             // a B fragment
 
-// (a, b) -> packed hi halves and packed lo halves
+// (a, b) -> packed hi halves and packed lo halves.  lo = half(v - hi) is one
+// v_fma_mix{lo,hi}_f16 per value: fma(hi as f16, -1, v) is exact in fp32, rounded once to
+// the half it writes (hipcc emits two conversions back, a packed subtract and a packed
+// conversion for the same arithmetic - 4 instructions instead of 2 in kernels whose VALU
+// issue is what the MFMAs wait for).
 __device__ __forceinline__ Pair2 split_pk(float a, float b) {
   Pair2 r;
   r.hi = cvt_pk_h16(a, b);
-  const h16x2 h = __builtin_bit_cast(h16x2, r.hi);
-  r.lo = cvt_pk_h16(a - (float)h[0], b - (float)h[1]);
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r.lo)
+      : "v"(r.hi), "v"(a), "v"(b));
   return r;
 }
+// ReLU as an integer max with 0 (negative floats are negative integers; -0.0 included):
+// one v_max_i32, where fmaxf costs a canonicalising v_max_f32 more per value
+__device__ __forceinline__ float relu_f32(float a) {
+  const int i = __builtin_bit_cast(int, a);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
 __device__ __forceinline__ Pair2 split_pk_relu(float a, float b) {
-  return split_pk(__builtin_fmaxf(a, 0.f), __builtin_fmaxf(b, 0.f));
+  return split_pk(relu_f32(a), relu_f32(b));
 }
 
 // two accumulator tiles (M-blocks 2s and 2s+1 of the previous layer) -> the B fragments
@@ -72,16 +84,27 @@ __device__ __forceinline__ Frag2 pack_relu_split(const f32x4 &lo_blk, const f32x
   f.lo = __builtin_bit_cast(h16x8, l);
   return f;
 }
-// ... with the upper block missing (48 channels = 3 blocks): zeros
-__device__ __forceinline__ Frag2 pack_relu_split_lo(const f32x4 &lo_blk) {
-  u32x4 h = {0u, 0u, 0u, 0u}, l = {0u, 0u, 0u, 0u};
+// The third M-block of a 48-channel layer fills only half a K-step: its hi and lo halves
+// share ONE fragment [hi | lo] (k-slots j < 4: hi, j >= 4: lo).  Against the weight step
+// [w_lo | w_hi] it yields both cross products in one MFMA, against [w_hi | w_lo] the
+// hi x hi product (and the lo x lo one, for free): 2 MFMAs where separate hi and lo
+// fragments need 3 half-empty ones (pack_weights.h::fpl_pack_chain_step).
+__device__ __forceinline__ h16x8 pack_relu_split_x(const f32x4 &blk) {
+  u32x4 v;
   Pair2 p;
-  p = split_pk_relu(lo_blk[0], lo_blk[1]); h[0] = p.hi; l[0] = p.lo;
-  p = split_pk_relu(lo_blk[2], lo_blk[3]); h[1] = p.hi; l[1] = p.lo;
-  Frag2 f;
-  f.hi = __builtin_bit_cast(h16x8, h);
-  f.lo = __builtin_bit_cast(h16x8, l);
-  return f;
+  p = split_pk_relu(blk[0], blk[1]); v[0] = p.hi; v[2] = p.lo;
+  p = split_pk_relu(blk[2], blk[3]); v[1] = p.hi; v[3] = p.lo;
+  return __builtin_bit_cast(h16x8, v);
+}
+
+// A 1x1 conv on a 48-channel register-chained input, one M-block: w = the block's four
+// weight steps [blocks 0,1 hi], [blocks 0,1 lo], [blk 2: w_lo | w_hi], [blk 2: w_hi | w_lo]
+__device__ __forceinline__ f32x4 chain48(const h16x8 (&w)[4], const Frag2 &h01, h16x8 hx, f32x4 acc) {
+  acc = mfma16(w[1], h01.hi, acc);
+  acc = mfma16(w[0], h01.lo, acc);
+  acc = mfma16(w[2], hx, acc);
+  acc = mfma16(w[3], hx, acc);
+  return mfma16(w[0], h01.hi, acc);
 }
 
 // acc += (w_hi + w_lo)(b_hi + b_lo) without the lo x lo product
@@ -124,7 +147,7 @@ struct StemSArgs {
   int64_t z_hi;            // rows >= z_hi are not needed (and may not be resident)
   float mean, sd;
   int64_t p1z0;            // global P1 row of chunk-local row 0
-  const h16x8 *w1, *w2;    // fragments [part][e][b][lane], [part][s][b][lane]
+  const h16x8 *w1, *w2;    // fragments [part][e][b][lane]; chain48 steps [4][b][lane]
   const float *shift1, *shift2;
   unsigned char *p1;
   int P1Z, P1Y, P1X;       // chunk-local dims
@@ -296,7 +319,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       offS[e][h] = 2 * (stem_row_off(2 * (g < 3 ? g : 2) + h) + (e == 0 ? 2 : 1));
   }
   // weight fragments in registers: [part][e or s][b]
-  h16x8 w1[2][2][3], w2[2][2][3];
+  h16x8 w1[2][2][3], w2[4][3];
   f32x4 sh1[3], sh2[3];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         w1[p][s][b] = a.w1[((p * 2 + s) * 3 + b) * 64 + lane];
-        w2[p][s][b] = a.w2[((p * 2 + s) * 3 + b) * 64 + lane];
+        w2[2 * p + s][b] = a.w2[((2 * p + s) * 3 + b) * 64 + lane];
       }
 #pragma unroll
   for (int b = 0; b < 3; ++b)
@@ -406,19 +429,18 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
 #pragma unroll
           for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.hi, a1[b]);
           const Frag2 h0 = pack_relu_split(a1[0], a1[1]);
-          const Frag2 h1 = pack_relu_split_lo(a1[2]);
+          const h16x8 hx = pack_relu_split_x(a1[2]);
+          // conv1 48->48 as chain48, M-blocks interleaved (independent accumulators)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][0][b], h0.hi, sh2[b]);
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][b], h0.hi, sh2[b]);
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][1][b], h1.hi, a2[e][b]);
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.lo, a2[e][b]);
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][0][b], h0.lo, a2[e][b]);
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[2][b], hx, a2[e][b]);
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][1][b], h1.lo, a2[e][b]);
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[3][b], hx, a2[e][b]);
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][0][b], h0.hi, a2[e][b]);
-#pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][1][b], h1.hi, a2[e][b]);
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.hi, a2[e][b]);
         }
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -545,7 +567,7 @@ struct MidSArgs {
   const unsigned char *p1;
   int P1Z, P1Y, P1X;
   const unsigned char *w3;       // [pass][KS][part][b] fragments
-  const h16x8 *w4;               // [part][s][b][lane]
+  const h16x8 *w4;               // chain48 steps [4][b][lane]
   const float *shift3, *shift4;
   unsigned char *p2;
   int P2Z, P2Y, P2X;
@@ -580,13 +602,11 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
                                  kofftab, a.w3, vbase, sub_off, acc, tid);
 
   // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions
-  h16x8 w4[2][2][3];
+  h16x8 w4[3][4];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) w4[p][s][b] = a.w4[((p * 2 + s) * 3 + b) * 64 + lane];
+    for (int b = 0; b < 3; ++b) w4[b][s] = a.w4[(s * 3 + b) * 64 + lane];
   f32x4 sh4[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b)
@@ -596,11 +616,10 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
     const Frag2 h0 = pack_relu_split(acc[sub][0], acc[sub][1]);
-    const Frag2 h1 = pack_relu_split_lo(acc[sub][2]);
+    const h16x8 hx = pack_relu_split_x(acc[sub][2]);
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      f32x4 a4 = mfma3(w4[0][0][b], w4[1][0][b], h0, sh4[b]);
-      a4 = mfma3(w4[0][1][b], w4[1][1][b], h1, a4);
+      const f32x4 a4 = chain48(w4[b], h0, hx, sh4[b]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) pooled[b][r] = __builtin_fmaxf(pooled[b][r], a4[r]);
     }
@@ -626,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
 // 4 y rows).  The 1x1 chain runs on two sub-steps at a time: with hi and lo fragments all
 // four in lockstep do not fit the register file.
 // -------------------------------------------------------------------------------
-constexpr int T_W6 = 2 * 6, T_W7 = 3 * 6, T_W8 = 3;   // fragments per part of L6, L7, L8
+constexpr int T_W7 = 3 * 6, T_W8 = 3;   // fragments per part of L7, L8
 
 struct TailSArgs {
   const unsigned char *p2;
@@ -634,7 +653,7 @@ struct TailSArgs {
   const unsigned char *w5;       // [pass][KS][part][b]
   const float *shift5;
   int CZ, CY, CX;                // chunk-local coarse dims
-  const unsigned char *w6, *w7, *w8;   // [part][s][b] fragments
+  const unsigned char *w6, *w7, *w8;   // L6: chain48 steps [4][b]; L7, L8: [part][s][b]
   const float *shift6, *shift7;
   float bias8;
   float *dst;                    // (Z,Y,X) prediction volume, row 0
@@ -675,11 +694,12 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
   float logit[4];
 #pragma unroll
   for (int sp = 0; sp < 2; ++sp) {
-    Frag2 h5[2][2];
+    Frag2 h5[2];
+    h16x8 h5x[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      h5[q][0] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1]);
-      h5[q][1] = pack_relu_split_lo(acc[2 * sp + q][2]);
+      h5[q] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1]);
+      h5x[q] = pack_relu_split_x(acc[2 * sp + q][2]);
     }
     Frag2 h6[2][3];
     {
@@ -689,11 +709,11 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
         f32x4 sh;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sh[r] = a.shift6[16 * b + 4 * g + r];
-        const h16x8 wh0 = frag(a.w6, 0, T_W6, 0 * 6 + b), wh1 = frag(a.w6, 0, T_W6, 1 * 6 + b);
-        const h16x8 wl0 = frag(a.w6, 1, T_W6, 0 * 6 + b), wl1 = frag(a.w6, 1, T_W6, 1 * 6 + b);
+        h16x8 w6[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          a6[q][b] = mfma3(wh1, wl1, h5[q][1], mfma3(wh0, wl0, h5[q][0], sh));
+        for (int s = 0; s < 4; ++s) w6[s] = frag(a.w6, 0, 0, s * 6 + b);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a6[q][b] = chain48(w6, h5[q], h5x[q], sh);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -822,6 +842,14 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
             all.insert(all.end(), f[part].begin() + (size_t)s * 3 * 512,
                        f[part].begin() + (size_t)(s + 1) * 3 * 512);
       }
+    } else if (op.cin == CH) {
+      // chain48 steps: [blocks 0,1 hi], [blocks 0,1 lo], [blk 2: lo | hi], [blk 2: hi | lo]
+      static const int blk[4][2] = {{0, 1}, {0, 1}, {2, 2}, {2, 2}};
+      static const int part[4][2] = {{0, 0}, {1, 1}, {1, 0}, {0, 1}};
+      std::vector<uint16_t> f;
+      for (int s = 0; s < 4; ++s)
+        fpl_pack_chain_step(A + op.w_off, scale.data(), op.cin, op.cout, mblocks[l], blk[s], part[s], &f);
+      all.insert(all.end(), f.begin(), f.end());
     } else {
       for (int part = 0; part < 2; ++part) {       // [part][s][b]
         std::vector<uint16_t> f;

@@ -83,7 +83,11 @@ def test_split_detections_identical_on_a_substack(ctx):
     the fp32 prediction - same voxels in the same order, confidences within 1e-5 - and the
     probabilities within 1e-5"""
     net = trained_network('vgg_like', tile=102)
-    u8, _, locs = blob_region_u8(5, 582)
+    # blobs 48 +- 3 voxels apart: further than obj_min_dist, as T-bars are - every blob is
+    # one smoothed peak.  (At the training pitch of 16 the sigma-5 smoothing leaves a
+    # nearly flat field whose 3 276 maxima are decided by differences of 1e-7: there even
+    # two fp32 implementations disagree on a handful of tie-breaks.)
+    u8, _, locs = blob_region_u8(5, 582, step=48)
     norm = (128.0, 33.0)
     p32 = net.infer(u8, normalize=norm, precision='f32')
     ps = net.infer(u8, normalize=norm, precision='f16s')
@@ -94,5 +98,7 @@ def test_split_detections_identical_on_a_substack(ctx):
     a = fplobjdetect.voxel2obj(p32, **kw)
     b = fplobjdetect.voxel2obj(ps, **kw)
     print('detections', len(a['conf']))
-    assert len(a['conf']) > 100
+    assert len(a['conf']) > 500
     _same_detections(a, b, 1e-5)
+    hit = np.linalg.norm(a['locs'][:, None, :] - locs[None, :, :].astype(float), axis=2).min(axis=1)
+    assert np.mean(hit <= 4.0) > 0.95
