@@ -11,12 +11,18 @@ h5py / libhdf5 emit for such files (default `libver='earliest'`) is read here di
   datatype (fixed-point, IEEE float, fixed-length string), layout v3 (compact and
   contiguous), attribute messages v1 - v3
 
-Anything else (chunked or filtered datasets, new-style groups, variable-length strings,
-superblock >= 2) raises `H5Unsupported` naming the feature - convert such a file with
-h5py (`tools/keras_h5_to_npz.py`).  The writer emits the same subset (one symbol-table
-node per group, leaf K raised so that it fits) and exists for round-trip tests and for
-`FplNetwork.save_network`; NO h5py-written file was available in the build container, so
-the reader is pinned only by the format specification and by its own writer.
+plus variable-length strings (how h5py >= 3 stores a Python `str` attribute such as
+`keras_version`, `backend`, `model_config`): a (length, global-heap collection, index)
+triple resolved through the 'GCOL' heap.  Attributes are parsed LAZILY, one name at a
+time: an attribute or dataset the loader never touches cannot make a file unreadable.
+What remains outside the subset (chunked or filtered datasets, dense attribute storage,
+new-style groups, version-2 object headers, superblock >= 2) raises `H5Unsupported`
+naming the feature when - and only when - the object that needs it is accessed; convert
+such a file with h5py (`tools/keras_h5_to_npz.py`).  The writer emits the same subset
+(one symbol-table node per group, leaf K raised so that it fits) for
+`FplNetwork.save_network`.  Pinned both ways by the C library (tests/test_keras_io.py):
+libhdf5 opens and reads every file the writer produces, and the reader reads
+tests/golden/keras_libhdf5.h5, which libhdf5 wrote (tests/golden/make_h5_fixture.py).
 
     f = h5min.File(path)            # or File(bytes)
     f.attrs['layer_names']          # numpy arrays (strings as bytes)
@@ -35,6 +41,9 @@ UNDEF = 0xFFFFFFFFFFFFFFFF
 
 class H5Unsupported(NotImplementedError):
     pass
+
+
+VLEN_STR = 'vlen_str'          # what _parse_datatype returns for variable-length strings
 
 
 # ---- reader ---------------------------------------------------------------------------
@@ -72,8 +81,9 @@ def _parse_datatype(b, off):
     if cls == 3:                                   # fixed-length string
         return np.dtype('S%d' % size)
     if cls == 9:
-        raise H5Unsupported('variable-length datatype (h5py str attribute); re-save with '
-                            'fixed-length bytes or convert with h5py')
+        if bits & 0x0F == 1:                       # variable-length STRING (h5py `str`)
+            return VLEN_STR
+        raise H5Unsupported('variable-length sequence datatype')
     raise H5Unsupported('datatype class %d' % cls)
 
 
@@ -124,9 +134,24 @@ class _Object:
         return [(o, n) for t, o, n in self.msgs if t == mtype]
 
     def attrs(self):
-        b = self.f._b
-        out = {}
-        for off, n in self.find(0x000C):
+        return Attrs(self)
+
+
+class Attrs:
+    """the attributes of one object, parsed one name at a time (`[]`, `in`, `get`, `keys`)"""
+
+    def __init__(self, obj):
+        self._o = obj
+        self._index = None
+        self._cache = {}
+
+    def _scan(self):
+        """name -> (datatype offset, dataspace offset, data offset); no value is parsed"""
+        if self._index is not None:
+            return self._index
+        b = self._o.f._b
+        idx = {}
+        for off, n in self._o.find(0x000C):
             ver = b.u(off, 1)
             name_sz, dt_sz, ds_sz = b.u(off + 2, 2), b.u(off + 4, 2), b.u(off + 6, 2)
             if ver == 1:
@@ -142,18 +167,60 @@ class _Object:
                 dt_off, p = p, p + dt_sz
                 ds_off, p = p, p + ds_sz
             else:
-                raise H5Unsupported('attribute message version %d' % ver)
-            dtype = _parse_datatype(b, dt_off)
-            shape = _parse_dataspace(b, ds_off)
-            if shape is None:
-                out[name] = None
-                continue
+                continue                           # an attribute nobody may ask for
+            idx[name] = (dt_off, ds_off, p)
+        self._index = idx
+        return idx
+
+    def _dense(self):
+        """attributes moved out of the object header into a fractal heap (attribute-info
+        message with a defined heap address)?"""
+        info = self._o.find(0x0015)
+        if not info:
+            return False
+        b, off = self._o.f._b, info[0][0]
+        flags = b.u(off + 1, 1)
+        return b.u(off + 2 + (2 if flags & 1 else 0), 8) != UNDEF
+
+    def keys(self):
+        if self._dense():
+            raise H5Unsupported('dense attribute storage (more attributes than fit the object '
+                                'header): the attribute list is not readable')
+        return sorted(self._scan())
+
+    def __contains__(self, name):
+        if name in self._scan():
+            return True
+        if self._dense():
+            raise H5Unsupported('dense attribute storage: cannot tell whether %r exists' % name)
+        return False
+
+    def get(self, name, default=None):
+        return self[name] if name in self else default
+
+    def __getitem__(self, name):
+        if name in self._cache:
+            return self._cache[name]
+        if name not in self:
+            raise KeyError(name)
+        f = self._o.f
+        b = f._b
+        dt_off, ds_off, p = self._scan()[name]
+        dtype = _parse_datatype(b, dt_off)
+        shape = _parse_dataspace(b, ds_off)
+        if shape is None:
+            val = None
+        elif dtype is VLEN_STR:
+            count = int(np.prod(shape)) if shape else 1
+            vals = [f._global_heap_object(b.u(p + 16 * i + 4, 8), b.u(p + 16 * i + 12, 4),
+                                          b.u(p + 16 * i, 4)) for i in range(count)]
+            val = vals[0] if shape == () else np.array(vals, dtype=object).reshape(shape)
+        else:
             count = int(np.prod(shape)) if shape else 1
             arr = np.frombuffer(b.bytes(p, count * dtype.itemsize), dtype=dtype).reshape(shape)
-            out[name] = arr[()] if shape == () else arr.copy()
-        if self.find(0x0015):
-            raise H5Unsupported('dense attribute storage')
-        return out
+            val = arr[()] if shape == () else arr.copy()
+        self._cache[name] = val
+        return val
 
 
 class Dataset:
@@ -286,6 +353,26 @@ class File(Group):
         self._cache = {}
         Group.__init__(self, self, _Object(self, self._base + b.u(root + 8, 8)), '/')
 
+    def _global_heap_object(self, collection, index, length):
+        """object `index` of the global heap collection at `collection` (the payload of a
+        variable-length value), as bytes of `length`"""
+        b = self._b
+        p = self._base + collection
+        if collection == UNDEF or collection == 0:
+            return b''                               # an empty / never-written string
+        if b.bytes(p, 4) != b'GCOL':
+            raise H5Unsupported('global heap collection signature')
+        size = b.u(p + 8, 8)
+        q, end = p + 16, p + size
+        while q + 16 <= end:
+            idx, osz = b.u(q, 2), b.u(q + 8, 8)
+            if idx == index:
+                return b.bytes(q + 16, min(length, osz))
+            if idx == 0:                             # the free-space object ends the list
+                break
+            q += 16 + _pad8(osz)
+        raise H5Unsupported('global heap object %d not found' % index)
+
     def _open(self, ohdr, name):
         if ohdr not in self._cache:
             obj = _Object(self, self._base + ohdr)
@@ -377,7 +464,9 @@ class _Writer:
             raw = n.encode('utf8') + b'\0'
             heap += raw + b'\0' * (_pad8(len(raw)) - len(raw))
         heap_data = self.alloc(bytes(heap))
-        heap_addr = self.alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), UNDEF, heap_data))
+        # 'offset to head of free list' = 1 is libhdf5's H5HL_FREE_NULL ("no free block");
+        # the library rejects anything else that is not a valid offset ("bad heap free list")
+        heap_addr = self.alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), 1, heap_data))
         snod = b'SNOD' + struct.pack('<BxH', 1, len(names))
         for n in names:
             snod += struct.pack('<QQII16x', offs[n], children[n], 0, 0)

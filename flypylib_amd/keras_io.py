@@ -142,17 +142,12 @@ def weight_tree(graph):
     """the `save_weights` tree of a graph (h5min.write's input): Keras' automatic layer
     names in creation order, one group per layer of the graph (weightless ones included,
     as Keras lists them)"""
-    counts = {}
-    cls = {'conv': 'conv3d', 'bn': 'batch_normalization', 'relu': 'activation',
-           'pool': 'max_pooling3d', 'drop': 'dropout', 'up': 'up_sampling3d',
-           'crop': 'cropping3d', 'concat': 'concatenate', 'add': 'add', 'input': 'input'}
     roles = {'conv': ['kernel', 'bias'], 'bn': ['gamma', 'beta', 'moving_mean',
                                                 'moving_variance']}
+    names = _layer_names(graph)
     layer_names, groups = [], {}
     for node in graph.nodes:
-        base = cls[node.kind]
-        counts[base] = counts.get(base, 0) + 1
-        name = '%s_%d' % (base, counts[base])
+        name = names[node.idx]
         layer_names.append(name.encode())
         wn, ds = [], {}
         for role, slot in zip(roles.get(node.kind, []), node.weight_slots):
@@ -168,14 +163,117 @@ def weight_tree(graph):
             'groups': groups}
 
 
+_KERAS_CLASS = {'conv': ('Conv3D', 'conv3d'), 'bn': ('BatchNormalization', 'batch_normalization'),
+                'relu': ('Activation', 'activation'), 'pool': ('MaxPooling3D', 'max_pooling3d'),
+                'drop': ('Dropout', 'dropout'), 'up': ('UpSampling3D', 'up_sampling3d'),
+                'crop': ('Cropping3D', 'cropping3d'), 'concat': ('Concatenate', 'concatenate'),
+                'add': ('Add', 'add'), 'input': ('InputLayer', 'input')}
+
+
+def _layer_names(graph):
+    """Keras' automatic layer names, per class in creation order (node index -> name)"""
+    counts, names = {}, {}
+    for node in graph.nodes:
+        base = _KERAS_CLASS[node.kind][1]
+        counts[base] = counts.get(base, 0) + 1
+        names[node.idx] = '%s_%d' % (base, counts[base])
+    return names
+
+
+def model_config(graph):
+    """`{'class_name': 'Model', 'config': model.get_config()}` as Keras 2.0 - 2.1 writes it
+    into the `model_config` attribute of `model.save` files (`keras/engine/topology.py`
+    `Container.get_config`, the layers' `get_config`): what the reference's
+    `load_model(path + '.keras.h5', custom_objects=...)` (`fplnetwork.py:36-40`) rebuilds
+    the network from.  Layer arguments are those `flypylib/fplmodels.py:67-526` passes,
+    everything else the Keras defaults of that era."""
+    names = _layer_names(graph)
+    zeros = {'class_name': 'Zeros', 'config': {}}
+    ones = {'class_name': 'Ones', 'config': {}}
+    glorot = {'class_name': 'VarianceScaling',
+              'config': {'scale': 1.0, 'mode': 'fan_avg', 'distribution': 'uniform', 'seed': None}}
+    layers = []
+    for node in graph.nodes:
+        name, a = names[node.idx], node.attrs
+        cfg = {'name': name, 'trainable': True}
+        if node.kind == 'input':
+            spatial = list(graph.in_sz) if graph.in_sz is not None else [None, None, None]
+            cfg = {'batch_input_shape': [None] + spatial + [1], 'dtype': 'float32',
+                   'sparse': False, 'name': name}
+        elif node.kind == 'conv':
+            k = int(a['k'])
+            cfg.update(filters=int(node.channels), kernel_size=[k, k, k], strides=[1, 1, 1],
+                       padding='valid', data_format='channels_last', dilation_rate=[1, 1, 1],
+                       activation=a['activation'] or 'linear', use_bias=bool(a['use_bias']),
+                       kernel_initializer=glorot, bias_initializer=zeros,
+                       kernel_regularizer=None, bias_regularizer=None,
+                       activity_regularizer=None, kernel_constraint=None, bias_constraint=None)
+        elif node.kind == 'bn':
+            cfg.update(axis=-1, momentum=0.99, epsilon=0.001, center=True, scale=True,
+                       beta_initializer=zeros, gamma_initializer=ones,
+                       moving_mean_initializer=zeros, moving_variance_initializer=ones,
+                       beta_regularizer=None, gamma_regularizer=None, beta_constraint=None,
+                       gamma_constraint=None)
+        elif node.kind == 'relu':
+            cfg.update(activation='relu')
+        elif node.kind == 'pool':
+            n = int(a['n'])
+            cfg.update(pool_size=[n, n, n], padding='valid', strides=[n, n, n],
+                       data_format='channels_last')
+        elif node.kind == 'drop':
+            cfg.update(rate=float(a['rate']), noise_shape=None, seed=None)
+        elif node.kind == 'up':
+            cfg.update(size=[int(f) for f in a['n']], data_format='channels_last')
+        elif node.kind == 'crop':
+            cfg.update(cropping=[[int(lo), int(hi)] for lo, hi in a['c']],
+                       data_format='channels_last')
+        elif node.kind == 'concat':
+            cfg.update(axis=-1)
+        inbound = [[[names[i], 0, 0, {}] for i in node.inputs]] if node.inputs else []
+        layers.append({'name': name, 'class_name': _KERAS_CLASS[node.kind][0], 'config': cfg,
+                       'inbound_nodes': inbound})
+    return {'class_name': 'Model',
+            'config': {'name': 'model_1', 'layers': layers,
+                       'input_layers': [[names[graph.inputs_node.idx], 0, 0]],
+                       'output_layers': [[names[graph.output.idx], 0, 0]]}}
+
+
+def training_config(compile_args):
+    """the `training_config` attribute of a `model.save` file (`keras/models.py`
+    `save_model`): optimizer class + hyper-parameters (as float32 values, which is what
+    `K.get_value` returns), loss and metrics by name.  The reference compiles with
+    `'adam'` and either Keras' `binary_crossentropy` or one of its own masked losses
+    (`fplnetwork.py:74-77`, `fplmodels.py:300`); functions are stored by `__name__`."""
+    ca = dict(compile_args or {})
+
+    def name(x):
+        return x if isinstance(x, str) else getattr(x, '__name__', str(x))
+    f32 = lambda v: float(np.float32(v))            # noqa: E731
+    opt = ca.get('optimizer', 'adam')
+    if name(opt).lower() != 'adam':
+        raise ValueError('training_config: optimizer %r (the engine trains with Adam)' % (opt,))
+    return {'optimizer_config': {'class_name': 'Adam',
+                                 'config': {'lr': f32(1e-3), 'beta_1': f32(0.9),
+                                            'beta_2': f32(0.999), 'epsilon': 1e-08, 'decay': 0.0}},
+            'loss': name(ca.get('loss', 'binary_crossentropy')),
+            'metrics': [name(m) for m in ca.get('metrics', [])],
+            'sample_weight_mode': None, 'loss_weights': None}
+
+
 def save_weights(graph, path, as_model_save=True):
-    """write `graph`'s weights as a Keras .h5.  as_model_save: under the group
-    'model_weights', where `model.save` puts them (Keras' `load_weights` accepts both
-    layouts); no `model_config` is written - on the Keras side rebuild the network from
-    its factory and call `load_weights`."""
+    """write `graph`'s weights as a Keras .h5.  as_model_save: the file `model.save`
+    writes (`fplnetwork.py:16-17,83`) - the weights under the group 'model_weights' and the
+    root attributes `model_config` / `training_config` / `keras_version` / `backend`, so
+    that the reference's `load_model(path, custom_objects)` can rebuild and load the
+    network; otherwise the bare `save_weights` layout.  Optimizer state
+    (`optimizer_weights`) is not written: `load_model` then starts Adam afresh."""
+    import json
     tree = weight_tree(graph)
     if as_model_save:
         attrs = {k: tree['attrs'].pop(k) for k in ('backend', 'keras_version')}
-        tree = {'attrs': attrs, 'groups': {'model_weights': tree}}
+        tree = {'attrs': dict(attrs), 'groups': {'model_weights': tree}}
         tree['groups']['model_weights']['attrs'].update(attrs)
+        tree['attrs']['model_config'] = np.bytes_(json.dumps(model_config(graph)).encode('utf8'))
+        tree['attrs']['training_config'] = np.bytes_(
+            json.dumps(training_config(graph.compile_args)).encode('utf8'))
     h5min.write(path, tree)

@@ -276,8 +276,10 @@ def gen_synapses():
 
 def gen_keras_tiny():
     """keras_tiny.h5 / .npz: NOT a reference output (h5py and Keras are absent here) - the
-    bytes of the package's own HDF5 writer (flypylib_amd/h5min.py, Keras weight layout)
-    for a 3-layer network with seeded weights, and the arrays they must read back as"""
+    bytes of the package's own HDF5 writer (flypylib_amd/h5min.py, Keras `model.save`
+    layout) for a 3-layer network with seeded weights, and the arrays they must read back
+    as.  (The reader's fixture from the real library is keras_libhdf5.h5,
+    make_h5_fixture.py; tests/test_keras_io.py also opens this file with libhdf5.)"""
     from flypylib_amd import synth
     from flypylib_amd.program import LayerGraph
     g = LayerGraph(None, seed=3)

@@ -458,3 +458,37 @@ def test_save_network_load_network_round_trip_incl_keras_h5(ctx, tmp_path):
     os.remove(p + '.keras.h5')
     with pytest.raises(FileNotFoundError, match='keras.h5'):
         fplnetwork.load_network(p)
+
+
+def test_load_network_from_a_keras_file_written_by_libhdf5(ctx, tmp_path):
+    """the reference's pair - pickle + `<path>.keras.h5` - with the `.h5` written by the
+    HDF5 C library the way h5py >= 3 / tf.keras write it (variable-length string
+    attributes, an optimizer group with a chunked dataset): load_network reads it with the
+    package's own reader and the restored network infers bit-identically"""
+    import json
+    import os
+    from flypylib_amd import fplnetwork, keras_io
+    from tests import h5lib
+    if not h5lib.available():
+        pytest.skip('no libhdf5 to write the file with')
+    net = _vgg_net(seed=14)
+    u8 = synth.em_volume_u8(6, (47, 50, 44))
+    want = net.infer(u8, normalize=(128., 33.))
+    p = str(tmp_path / 'ref.p')
+    net.save_network(p, keras_h5=False)
+    os.remove(p + '.weights.npz')
+    g = net.train_single
+    tree = keras_io.weight_tree(g)
+    tree['attrs'].update(keras_version='2.2.4', backend='tensorflow')
+    root = {'attrs': {'keras_version': '2.2.4', 'backend': 'tensorflow',
+                      'model_config': json.dumps(keras_io.model_config(g)),
+                      'training_config': json.dumps(keras_io.training_config(g.compile_args))},
+            'groups': {'model_weights': tree,
+                       'optimizer_weights': {
+                           'attrs': {'weight_names': np.array(['Adam/m_0:0'], dtype=object)},
+                           'datasets': {'m_0:0': (np.zeros((8, 8), np.float32), (4, 4))}}}}
+    h5lib.write_tree(p + '.keras.h5', root)
+    a = fplnetwork.load_network(p)
+    a.infer_sz = net.infer_sz
+    a._set_infer()
+    assert np.array_equal(a.infer(u8, normalize=(128., 33.)), want)

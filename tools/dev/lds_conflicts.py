@@ -88,3 +88,29 @@ if __name__ == '__main__':
     print('24 ch planar (48 B voxel, hi tile / lo tile):',
           mid_split_general(24, 48, lambda k: 16 * k, lambda k: 16 * k))
     print('48 ch planar per-wave (96 B voxel) = shipped:', mid_split_general(48, 96, lambda k: 16 * k, lambda k: 16 * k))
+
+
+def pass8(vox_bytes, lo_off, TY=6, TX=18):
+    """8-channel passes: K-step s covers taps 4s .. 4s+3, lane group g reads tap 4s + g:
+    16 B of hi halves at vox * vox_bytes, the lo halves lo_off behind"""
+    worst, total, n = 0, 0, 0
+    for lo in (0, lo_off):
+        for s in range(7):
+            addr = []
+            for lane in range(64):
+                c, g = lane & 15, lane >> 4
+                tap = 4 * s + g
+                if tap >= 27:
+                    tap = 0
+                vox = ((tap // 9) * TY + (tap // 3) % 3) * TX + tap % 3 + c
+                addr.append(vox * vox_bytes + lo)
+            cyc = cycles_b128(addr)
+            worst = max(worst, cyc)
+            total += cyc
+            n += 1
+    return worst, total / n
+
+
+if __name__ == '__main__':
+    for vb, lo in ((32, 16), (48, 16), (48, 32), (40, 16), (80, 16), (96, 16), (96, 48)):
+        print('8-channel passes, voxel %d B, lo at +%d:' % (vb, lo), pass8(vb, lo))
