@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_F16, PREC_F16S = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 
 
@@ -89,6 +89,7 @@ SIGNATURES = {
     'fpl_comm_unique_id': (C.c_int, [_vp]),
     'fpl_comm_init': (C.c_int, [_vp, _i32, _i32, _vp]),
     'fpl_comm_destroy': (C.c_int, [_vp]),
+    'fpl_comm_abort': (C.c_int, [_vp]),
     'fpl_comm_info': (C.c_int, [_vp, _pi32, _pi32, C.c_char_p, C.c_size_t]),
     'fpl_comm_allreduce_sum_f32': (C.c_int, [_vp, _vp, _i64]),
     'fpl_comm_broadcast_f32': (C.c_int, [_vp, _vp, _i64, _i32]),
@@ -223,6 +224,10 @@ class Context:
 
     def comm_destroy(self):
         self.check(self.lib.fpl_comm_destroy(self.h))
+
+    def comm_abort(self):
+        """drop the communicator without waiting for pending collectives (a peer died)"""
+        self.check(self.lib.fpl_comm_abort(self.h))
 
     def comm_info(self):
         rank, n = C.c_int32(), C.c_int32()

@@ -24,6 +24,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;     // optional symbol
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
                             ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t,
@@ -50,14 +51,20 @@ int load_rccl(fpl_ctx *ctx) {
   };
   void *h = nullptr;
   const char *used = nullptr;
+  // the FIRST failure that is not a mere "not loaded yet" is the informative one (the
+  // FPL_RCCL_LIB path, or the plain soname); dlerror() clears itself when read
+  char first_err[256] = {0};
   for (const Try &t : tries) {
     if (!t.name || !t.name[0]) continue;
     h = dlopen(t.name, t.flags);
     if (h) { used = t.name; break; }
+    const char *e = dlerror();
+    if (e && !first_err[0] && !(t.flags & RTLD_NOLOAD))
+      snprintf(first_err, sizeof(first_err), "%s", e);
   }
   if (!h)
     return fpl_fail(ctx, "fpl_comm: cannot open librccl (%s); set FPL_RCCL_LIB",
-                    dlerror() ? dlerror() : "not found");
+                    first_err[0] ? first_err : "not found");
   RcclApi api;
   api.handle = h;
   snprintf(api.path, sizeof(api.path), "%s", used);
@@ -76,6 +83,7 @@ int load_rccl(fpl_ctx *ctx) {
   FPL_SYM(Broadcast, "ncclBroadcast");
   FPL_SYM(GetErrorString, "ncclGetErrorString");
 #undef FPL_SYM
+  api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
   g_rccl = api;
   return 0;
 }
@@ -140,6 +148,20 @@ int fpl_comm_destroy(fpl_ctx *ctx) {
     FPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   fpl_comm_release(ctx);
+  return 0;
+}
+
+int fpl_comm_abort(fpl_ctx *ctx) {
+  if (!ctx) return fpl_fail(nullptr, "fpl_comm_abort: ctx is NULL");
+  // no stream synchronisation: the point is to get out of a collective that will never
+  // complete because a peer is gone.  May be called from another host thread.
+  if (ctx->comm && g_rccl.handle) {
+    if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)ctx->comm);
+    else g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+  }
+  ctx->comm = nullptr;
+  ctx->comm_rank = 0;
+  ctx->comm_nranks = 1;
   return 0;
 }
 

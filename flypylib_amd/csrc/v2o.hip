@@ -1177,49 +1177,71 @@ __global__ void seg_zero_small(const unsigned long long *__restrict__ seg, int64
 // one workgroup per winner: the part of its r-ball that lies in its own segment (mask
 // of the (2r+1)^3 cube, grown `dilate` times by the 6-neighbour cross, zero beyond the
 // cube - scipy.ndimage.binary_dilation(iterations=dilate)) plus the ball of radius
-// `force` is cleared in the live volume.  A cube row (z,y) is one 64-bit mask
-// (2r+1 <= 64), built with a ballot; rows live in LDS.
+// `force` is cleared in the live volume.  A cube row (z,y) is a bit mask of W 64-bit
+// words (2r+1 <= 64 W), built with ballots.  W = 1 (obj_min_dist <= 31, every caller of the
+// reference uses 27): both row sets live in LDS; W > 1: in a per-workgroup slice of
+// `rows_glob` (the cube of r = 40 is 2 x 105 KB: past the LDS).
+__device__ __forceinline__ unsigned long long bit_range(int lo, int hi, int w) {
+  // bits lo..hi (inclusive) of a row, as they fall into word w
+  const int a = (lo > 64 * w ? lo : 64 * w) - 64 * w;
+  const int e = (hi < 64 * w + 63 ? hi : 64 * w + 63) - 64 * w;
+  if (a > e) return 0ull;
+  const int n = e - a + 1;
+  return (n == 64 ? ~0ull : ((1ull << n) - 1ull)) << a;
+}
+
+template <int W>
 __global__ __launch_bounds__(256) void clear_balls_seg(
     const unsigned long long *__restrict__ round_list,
     unsigned long long *__restrict__ counters, float *__restrict__ live,
     int64_t P1, int64_t P2, int r,
     unsigned long long *__restrict__ best, int64_t C1, int64_t C2,
     const unsigned long long *__restrict__ seg, int dilate, int force,
-    unsigned int *__restrict__ dirty_list) {
-  extern __shared__ unsigned long long rows_lds[];       // 2 x side*side
+    unsigned int *__restrict__ dirty_list, unsigned long long *__restrict__ rows_glob) {
+  extern __shared__ unsigned long long rows_lds[];       // W == 1: 2 x side*side
   __shared__ unsigned int stage[CLR_STAGE];
   __shared__ unsigned int n_stage, n_gone, stage_base;
   if (threadIdx.x == 0) { n_stage = 0u; n_gone = 0u; }
   __syncthreads();
   const int side = 2 * r + 1, nrows = side * side;
-  unsigned long long *ma = rows_lds, *mb = rows_lds + nrows;
-  const unsigned long long full = side == 64 ? ~0ull : ((1ull << side) - 1ull);
+  unsigned long long *ma = W == 1 ? rows_lds : rows_glob + (size_t)blockIdx.x * 2 * nrows * W;
+  unsigned long long *mb = ma + (size_t)nrows * W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long nwin = counters[CNT_ROUND];
   for (unsigned long long wi = blockIdx.x; wi < nwin; wi += gridDim.x) {
     const uint32_t flat = 0xFFFFFFFFu - (uint32_t)(round_list[wi] & 0xFFFFFFFFu);
     const int64_t x = flat % P2, y = (flat / P2) % P1, z = flat / (P2 * P1);
     const unsigned long long id = seg[flat];
-    __syncthreads();                       // previous winner done with the LDS rows
+    __syncthreads();                       // previous winner done with the rows
     for (int row = wave; row < nrows; row += 4) {
       const int dz = row / side - r, dy = row % side - r;
-      bool same = false;
-      if (lane < side)
-        same = seg[((z + dz) * P1 + (y + dy)) * P2 + x - r + lane] == id;
-      const unsigned long long m = __ballot(same);
-      if (lane == 0) ma[row] = m;
+      const unsigned long long *srow = seg + ((z + dz) * P1 + (y + dy)) * P2 + x - r;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const int xi = 64 * w + lane;
+        const bool same = xi < side && srow[xi] == id;
+        const unsigned long long m = __ballot(same);
+        if (lane == 0) ma[(size_t)row * W + w] = m;
+      }
     }
     __syncthreads();
     for (int it = 0; it < dilate; ++it) {
       for (int row = threadIdx.x; row < nrows; row += 256) {
         const int rz = row / side, ry = row % side;
-        unsigned long long m = ma[row];
-        m |= (m << 1) | (m >> 1);
-        if (rz > 0) m |= ma[row - side];
-        if (rz + 1 < side) m |= ma[row + side];
-        if (ry > 0) m |= ma[row - 1];
-        if (ry + 1 < side) m |= ma[row + 1];
-        mb[row] = m & full;
+        unsigned long long m[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) m[w] = ma[(size_t)row * W + w];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          unsigned long long v = m[w] | (m[w] << 1) | (m[w] >> 1);
+          if (w > 0) v |= m[w - 1] >> 63;
+          if (w + 1 < W) v |= m[w + 1] << 63;
+          if (rz > 0) v |= ma[(size_t)(row - side) * W + w];
+          if (rz + 1 < side) v |= ma[(size_t)(row + side) * W + w];
+          if (ry > 0) v |= ma[(size_t)(row - 1) * W + w];
+          if (ry + 1 < side) v |= ma[(size_t)(row + 1) * W + w];
+          mb[(size_t)row * W + w] = v & bit_range(0, side - 1, w);
+        }
       }
       __syncthreads();
       unsigned long long *t = ma; ma = mb; mb = t;
@@ -1227,24 +1249,27 @@ __global__ __launch_bounds__(256) void clear_balls_seg(
     for (int row = wave; row < nrows; row += 4) {
       const int dz = row / side - r, dy = row % side - r;
       const int rem = r * r - dz * dz - dy * dy;
-      unsigned long long bits = 0;
+      int hx = -1, hf = -1;
       if (rem >= 0) {
-        int hx = (int)sqrtf((float)rem);
+        hx = (int)sqrtf((float)rem);
         while ((hx + 1) * (hx + 1) <= rem) ++hx;
         while (hx * hx > rem) --hx;
-        const unsigned long long ball =
-            (2 * hx + 1 == 64 ? ~0ull : ((1ull << (2 * hx + 1)) - 1ull)) << (r - hx);
-        bits = ball & ma[row];
       }
       const int remf = force * force - dz * dz - dy * dy;
       if (force > 0 && remf >= 0) {
-        int hf = (int)sqrtf((float)remf);
+        hf = (int)sqrtf((float)remf);
         while ((hf + 1) * (hf + 1) <= remf) ++hf;
         while (hf * hf > remf) --hf;
-        bits |= ((1ull << (2 * hf + 1)) - 1ull) << (r - hf);
       }
-      if (lane < side && ((bits >> lane) & 1ull))
-        live[((z + dz) * P1 + (y + dy)) * P2 + x - r + lane] = 0.f;
+      float *lrow = live + ((z + dz) * P1 + (y + dy)) * P2 + x - r;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        unsigned long long bits = 0;
+        if (hx >= 0) bits = bit_range(r - hx, r + hx, w) & ma[(size_t)row * W + w];
+        if (hf >= 0) bits |= bit_range(r - hf, r + hf, w);
+        const int xi = 64 * w + lane;
+        if (xi < side && ((bits >> lane) & 1ull)) lrow[xi] = 0.f;
+      }
     }
     const int64_t cz0 = (z - r) / CELL, cy0 = (y - r) / CELL, cx0 = (x - r) / CELL;
     const int nz = (int)((z + r) / CELL - cz0 + 1), ny = (int)((y + r) / CELL - cy0 + 1),
@@ -1571,6 +1596,15 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
   unsigned long long *all_list = (unsigned long long *)p;
   FPL_TRY(tmp.alloc((size_t)n_cells * sizeof(unsigned int), &p));
   unsigned int *dirty_list = (unsigned int *)p;             // cells to re-scan, per round
+  // segmentation-aware suppression with rows wider than 64 voxels: the two row sets of
+  // every workgroup's cube live in global memory
+  unsigned long long *seg_rows = nullptr;
+  constexpr int SEG_WGS = 1024;
+  if (use_seg && 2 * r + 1 > 64) {
+    const size_t W = (2 * r + 1 + 63) / 64 <= 2 ? 2 : 4;
+    FPL_TRY(tmp.alloc((size_t)SEG_WGS * 2 * (2 * r + 1) * (2 * r + 1) * W * 8, &p));
+    seg_rows = (unsigned long long *)p;
+  }
   FPL_TRY(tmp.alloc(CNT_N * 8, &p));
   unsigned long long *counters = (unsigned long long *)p;   // CNT_*
   FPL_HIP(ctx, hipMemsetAsync(counters, 0, CNT_N * 8, st));
@@ -1627,9 +1661,20 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
       {
         TimedLaunch tl(ctx, "v2o_clear_balls");
         if (use_seg) {
-          const size_t lds = (size_t)2 * (2 * r + 1) * (2 * r + 1) * sizeof(unsigned long long);
-          clear_balls_seg<<<1024, 256, lds, st>>>(round_list, counters, live, P1, P2, r, best, C1,
-                                                  C2, S.seg, seg_dilate, seg_force, dirty_list);
+          const size_t rows = (size_t)2 * (2 * r + 1) * (2 * r + 1) * sizeof(unsigned long long);
+          const int W = (2 * r + 1 + 63) / 64;
+          if (W == 1)
+            clear_balls_seg<1><<<SEG_WGS, 256, rows, st>>>(round_list, counters, live, P1, P2, r, best,
+                                                           C1, C2, S.seg, seg_dilate, seg_force,
+                                                           dirty_list, nullptr);
+          else if (W == 2)
+            clear_balls_seg<2><<<SEG_WGS, 256, 0, st>>>(round_list, counters, live, P1, P2, r, best, C1,
+                                                        C2, S.seg, seg_dilate, seg_force, dirty_list,
+                                                        seg_rows);
+          else
+            clear_balls_seg<4><<<SEG_WGS, 256, 0, st>>>(round_list, counters, live, P1, P2, r, best, C1,
+                                                        C2, S.seg, seg_dilate, seg_force, dirty_list,
+                                                        seg_rows);
         } else {
           clear_balls<<<1024, 256, 0, st>>>(round_list, counters, live, P1, P2, r, best, C1, C2,
                                             dirty_list);
@@ -1691,8 +1736,8 @@ int fpl_v2o_nms_seg(fpl_ctx *ctx, double thresh, int32_t seg_dilate, int32_t seg
   if (!ctx) return fpl_fail(nullptr, "fpl_v2o_nms_seg: ctx is NULL");
   FPL_REQUIRE(ctx, ctx->v2o.valid && ctx->v2o.seg_valid,
               "fpl_v2o_nms_seg: call fpl_v2o_smooth and fpl_v2o_set_seg first");
-  FPL_REQUIRE(ctx, 2 * ctx->v2o.r + 1 <= 64,
-              "fpl_v2o_nms_seg: obj_min_dist %d > 31 (a cube row must fit a 64-bit mask)",
+  FPL_REQUIRE(ctx, 2 * ctx->v2o.r + 1 <= 256,
+              "fpl_v2o_nms_seg: obj_min_dist %d > 127 (a cube row is at most four 64-bit masks)",
               ctx->v2o.r);
   FPL_REQUIRE(ctx, seg_dilate >= 0 && seg_force >= 0 && seg_force <= ctx->v2o.r,
               "fpl_v2o_nms_seg: seg_dilate %d / seg_force %d out of range", seg_dilate, seg_force);
@@ -1700,7 +1745,7 @@ int fpl_v2o_nms_seg(fpl_ctx *ctx, double thresh, int32_t seg_dilate, int32_t seg
   // drive several GPUs, one context each; setting it twice is harmless)
   static bool attr_set[FPL_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)clear_balls_seg,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)clear_balls_seg<1>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 63 * 63 * 8));
     attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }

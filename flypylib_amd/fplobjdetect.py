@@ -67,7 +67,7 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     suppresses only the voxels of its ball that lie in its own segment - its mask
     within the (2r+1)^3 cube, grown by `seg_dilate` binary-dilation iterations - plus
     the ball of radius `seg_force`; `seg_sz_thd` first zeroes the smoothed prediction
-    inside segments of fewer voxels (obj_min_dist <= 31 in this mode).
+    inside segments of fewer voxels (obj_min_dist <= 127 in this mode).
     """
     buffer_sz = fplutils.to3d(buffer_sz)
     if isinstance(pred, str):

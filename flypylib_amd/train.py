@@ -227,6 +227,10 @@ class TowerGroup:
             self.trainers.append(_capi.Trainer(ctx, graph, loss=loss, **opt_args))
         self._jobs = [queue.Queue() for _ in range(self.n)]
         self._done = queue.Queue()
+        self._broken = None
+        # a tower that neither answers nor fails within this many seconds is taken for
+        # stuck in a collective whose peer is gone (FPL_TOWER_TIMEOUT overrides)
+        self.timeout = float(os.environ.get('FPL_TOWER_TIMEOUT', '600'))
         self._host = HostTowerReducer(self.n) if (shared or os.environ.get(
             'FPL_TRAIN_REDUCE') == 'host') and self.n > 1 else None
         self.reduce_kind = 'host' if self._host else ('rccl' if self.n > 1 else 'none')
@@ -275,16 +279,50 @@ class TowerGroup:
                 self._done.put((rank, e))
 
     def _collect(self):
+        """one answer per tower.  A tower that raised leaves its peers inside an RCCL
+        collective (ncclCommInitRank / ncclAllReduce) that can never complete: as soon as
+        one error - or no answer within `timeout` - is seen, the communicators of ALL
+        towers are aborted from this thread, which releases the blocked ones; the group is
+        then unusable and says so."""
+        if self._broken is not None:
+            raise RuntimeError('this tower group failed earlier (%s); build a new one with '
+                               'make_train_parallel' % self._broken)
         out = [None] * self.n
-        err = None
-        for _ in range(self.n):
-            rank, res = self._done.get()
+        errs = []
+        got = 0
+        while got < self.n:
+            try:
+                rank, res = self._done.get(timeout=30.0 if errs else self.timeout)
+            except queue.Empty:
+                if not errs:
+                    errs.append(TimeoutError('a training tower did not answer within %.0f s'
+                                             % self.timeout))
+                    self._abort_comms()
+                    continue
+                break                                   # aborted and still silent: give up
+            got += 1
             if isinstance(res, BaseException):
-                err = err or res
+                if not errs:
+                    self._abort_comms()
+                errs.append(res)
             out[rank] = res
-        if err is not None:
+        if errs:
+            # the cause, not the peers' "barrier broken" echo of it
+            err = next((e for e in errs if not isinstance(e, threading.BrokenBarrierError)),
+                       errs[0])
+            self._broken = '%s: %s' % (type(err).__name__, err)
             raise err
         return out
+
+    def _abort_comms(self):
+        if self._host is not None:
+            self._host.abort()
+        if self.reduce_kind == 'rccl':
+            for ctx in self.ctxs:
+                try:
+                    ctx.comm_abort()
+                except Exception:                       # best effort: we are already failing
+                    pass
 
     def set_weights(self, weights):
         for q in self._jobs:
@@ -313,7 +351,7 @@ class TowerGroup:
         for q in self._jobs:
             q.put(None)
         for t in self._threads:
-            t.join()
+            t.join(None if self._broken is None else 5.0)    # daemon threads: never hang here
         for tr, ctx in zip(self.trainers, self.ctxs):
             tr.close()
             if self.reduce_kind == 'rccl' and ctx.comm_info()['nranks']:
@@ -488,9 +526,20 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
                 # package's own .npz
                 graph.save('%s_%03d' % (save_filepath, epoch))
                 graph.save('%s_%03d.h5' % (save_filepath, epoch))
-    finally:
+    except BaseException:
+        # the training error is the one to report: a generator that does not stop in
+        # time must not replace it (nor keep the log file open)
         network._train_steps_done = step_no
-        batches.close()
         if writer:
             f.close()
+        try:
+            batches.close(timeout=5.0)
+        except RuntimeError as e:
+            import warnings
+            warnings.warn(str(e))
+        raise
+    network._train_steps_done = step_no
+    if writer:
+        f.close()
+    batches.close()
     return history

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 5
+#define FPL_ABI_VERSION 6
 
 typedef struct fpl_ctx fpl_ctx;
 typedef struct fpl_program fpl_program;
@@ -181,7 +181,8 @@ int fpl_v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
  * (possibly edited) smoothed volume.  nms_seg: a pick suppresses only the part of its
  * ball inside its own segment (the segment's mask in the (2r+1)^3 cube grown by
  * seg_dilate iterations of the 6-neighbour dilation) plus the ball of radius
- * seg_force (0 = none); obj_min_dist <= 31. */
+ * seg_force (0 = none); obj_min_dist <= 127 (rows of the (2r+1)^3 cube are bit masks of up
+ * to four 64-bit words; <= 31 - one word, every caller of the reference uses 27 - runs from LDS). */
 int fpl_v2o_set_seg(fpl_ctx *ctx, const void *seg, int32_t seg_bytes, int seg_mem,
                     const int64_t dims[3], int64_t sz_thd);
 int fpl_v2o_select(fpl_ctx *ctx, const int64_t *ranks, int32_t n_ranks, float *rank_values);
@@ -277,6 +278,10 @@ int fpl_comm_unique_id(uint8_t out[FPL_COMM_ID_BYTES]);
 int fpl_comm_init(fpl_ctx *ctx, int32_t rank, int32_t nranks,
                   const uint8_t unique_id[FPL_COMM_ID_BYTES]);
 int fpl_comm_destroy(fpl_ctx *ctx);
+/* tear the communicator down WITHOUT waiting for enqueued collectives (ncclCommAbort):
+ * for the surviving ranks / towers after a peer failed, whose all-reduce would otherwise
+ * block for ever; callable from another host thread than the one stuck in the collective */
+int fpl_comm_abort(fpl_ctx *ctx);
 /* nranks = 0 when the context has no communicator; lib_path = the librccl in use */
 int fpl_comm_info(fpl_ctx *ctx, int32_t *rank, int32_t *nranks, char *lib_path,
                   size_t lib_path_cap);

@@ -104,6 +104,10 @@ V2O_SEG_CASES = [
     ('seg_force', 'uniform', 43, (40, 44, 48), 6, 1.5, 0.1, 3, 5, 20, 0, None, None, 2),
     ('seg_small', 'blobs', 44, (56, 48, 52), 9, 2.0, 0.05, 0, 6, 8, 30, 1, 60, None),
     ('seg_all', 'blobs', 45, (64, 60, 56), 9, 3.0, 0.05, (2, 3, 4), 7, 15, 20, 3, 40, 4),
+    # obj_min_dist beyond 31: a cube row no longer fits one 64-bit mask (two / four words)
+    ('seg_r33', 'blobs', 46, (72, 80, 88), 33, 4.0, 0.05, 3, 8, 10, 0, 2, None, 6),
+    ('seg_r40', 'blobs', 47, (90, 84, 96), 40, 5.0, 0.02, 0, 9, 14, 25, 1, 50, None),
+    ('seg_r70', 'uniform', 48, (150, 40, 44), 70, 2.0, 0.1, 0, 10, 6, 0, None, None, 3),
 ]
 
 

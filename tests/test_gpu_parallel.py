@@ -213,6 +213,40 @@ def test_two_towers_equal_one_step_on_the_concatenated_batch(ctx, tmp_path):
     two.train_network.close()
 
 
+def test_a_failing_tower_fails_the_step_instead_of_hanging_it(ctx, tmp_path):
+    """one tower raises in its step: its peer would wait for it for ever (host barrier here,
+    ncclAllReduce on two GPUs) - the group aborts the reduction, reports THAT error, and
+    refuses further steps; and a tower that simply never answers trips the timeout"""
+    import time
+    B, S = 4, 12
+    net = FplNetwork(_bn_free_model)
+    net.make_train_parallel(2, B, S, devices=[0, 0])
+    batches = _batches(2, 2, 2 * B, S, 3)
+    net.train(_gen(batches), 1, 1, None, None)               # builds the towers
+    towers = net.train_network._towers
+
+    def boom(*a, **k):
+        raise ValueError('tower 1 fell over')
+    towers.trainers[1].step = boom
+    t0 = time.time()
+    with pytest.raises(ValueError, match='tower 1 fell over'):
+        net.train(_gen(batches), 1, 1, str(tmp_path / 'log.csv'), None)
+    assert time.time() - t0 < 60
+    with pytest.raises(RuntimeError, match='failed earlier'):
+        towers.step(*batches[0], B, 0)
+    net.train_network.close()
+    # a silent tower: the timeout, not a hang
+    net2 = FplNetwork(_bn_free_model)
+    net2.make_train_parallel(2, B, S, devices=[0, 0])
+    net2.train(_gen(batches), 1, 1, None, None)
+    towers2 = net2.train_network._towers
+    towers2.timeout = 3.0
+    towers2.trainers[0].step = lambda *a, **k: time.sleep(8)
+    with pytest.raises(TimeoutError, match='did not answer'):
+        towers2.step(*batches[0], B, 1)
+    net2.train_network.close()
+
+
 def test_towers_follow_the_documented_bn_rule(ctx):
     """vgg_like (BatchNorm, Dropout): after one tower step every tower holds
     Adam(mean of the tower gradients) and moving statistics + mean of the towers' own
