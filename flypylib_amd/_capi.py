@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
 
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
-PREC_F32, PREC_BF16, PREC_F16, PREC_F16S = 0, 1, 2, 3
+PREC_AUTO, PREC_F32, PREC_BF16, PREC_F16, PREC_F16S = -1, 0, 1, 2, 3
 ABI_VERSION = 6
 COMM_ID_BYTES = 128
 

@@ -169,7 +169,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
               "fpl_infer_volume: src dtype must be u8 or f32");
   FPL_REQUIRE(ctx, sd != 0.f, "fpl_infer_volume: std is 0");
   FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || precision == FPL_PREC_BF16 ||
-                       precision == FPL_PREC_F16 || precision == FPL_PREC_F16S,
+                       precision == FPL_PREC_F16 || precision == FPL_PREC_F16S ||
+                       precision == FPL_PREC_AUTO,
               "fpl_infer_volume: unknown precision %d", precision);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   int32_t out_sz[3];
@@ -229,6 +230,9 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   }
   // the fused fast path writes every valid voxel itself: only the border shell
   // needs clearing there; the per-op path stitches tiles into a zeroed volume
+  if (precision == FPL_PREC_AUTO)
+    precision = fpl_split_path_available(prog, FPL_PREC_F16S, offset, out_sz) ? FPL_PREC_F16S
+                                                                              : FPL_PREC_F32;
   const bool split = fpl_split_path_available(prog, precision, offset, out_sz);
   FPL_REQUIRE(ctx, precision != FPL_PREC_F16S || split,
               "fpl_infer_volume: the split-half kernels exist for vgg_like on its stride-4 "

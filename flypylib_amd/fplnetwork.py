@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _capi, fplutils, multi_gpu, runtime
 
-_PRECISIONS = {'f32': _capi.PREC_F32, 'fp32': _capi.PREC_F32,
+_PRECISIONS = {'auto': _capi.PREC_AUTO, 'f32': _capi.PREC_F32, 'fp32': _capi.PREC_F32,
                'float32': _capi.PREC_F32, 'bf16': _capi.PREC_BF16,
                'f16': _capi.PREC_F16, 'float16': _capi.PREC_F16,
                # split IEEE halves (hi + lo, three MFMAs per product): fp32-grade
@@ -71,7 +71,7 @@ def load_network(filepath, device=None):
     with open(filepath, 'rb') as fn:
         network = _ReferenceUnpickler(fn).load()
     # attributes a reference-written instance does not carry
-    for k, v in (('precision', 'f32'), ('_parallel', None), ('_parallel_devices', None),
+    for k, v in (('precision', 'auto'), ('_parallel', None), ('_parallel_devices', None),
                  ('_trainer', None)):
         if not hasattr(network, k):
             setattr(network, k, v)
@@ -97,7 +97,7 @@ def load_network(filepath, device=None):
 class FplNetwork:
     """3D-CNN voxel classifier: training by generator, full-volume inference"""
 
-    def __init__(self, model, device=None, precision='f32'):
+    def __init__(self, model, device=None, precision='auto'):
         self.model = model
         self.train_network, rf_info, infer_sz, compile_args = self.model()
         self.train_network.summary()
@@ -205,7 +205,13 @@ class FplNetwork:
         """image: (Z,Y,X) array (already normalised float, as in the reference)
         or uint8 with `normalize=(mean, std)`; or an h5 path with dataset /main.
         Returns float32 predictions of the same shape; the rf_offset border
-        shell is zero."""
+        shell is zero.
+
+        precision (default: the network's, 'auto'): 'auto' = fp32-grade results on the
+        fastest executor that delivers them - split IEEE halves for vgg_like (within
+        ~2e-6 of fp32, detections identical; 'f16s'), the fp32 MFMA kernels for every
+        other architecture ('f32'); 'f16' / 'bf16' = plain 16-bit operands (up to ~1e-3 /
+        ~8e-3 off fp32 on trained weights, 3x faster than 'f16s')."""
         if isinstance(image, str):
             from . import keras_io
             image = np.load(image) if image.endswith('.npy') else keras_io.read_main(image)

@@ -44,7 +44,12 @@ enum fpl_dtype { FPL_U8 = 0, FPL_F32 = 1, FPL_F64 = 2 };
  * three MFMAs per product: probabilities within ~2e-6 of fp32 - inside the reference's
  * 1e-3 gate with detections identical to the fp32 path's - at a third of the 16-bit
  * rate; vgg_like only, other graphs are refused) */
-enum fpl_precision { FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1, FPL_PREC_F16 = 2, FPL_PREC_F16S = 3 };
+enum fpl_precision {
+  /* fp32-GRADE, fastest executor that delivers it: FPL_PREC_F16S where it exists
+   * (vgg_like), else FPL_PREC_F32 - what FplNetwork.infer uses unless told otherwise */
+  FPL_PREC_AUTO = -1,
+  FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1, FPL_PREC_F16 = 2, FPL_PREC_F16S = 3
+};
 
 /* fused layer-program ops, produced by LayerGraph.lower_inference()
  * (flypylib_amd/program.py); layer semantics = Keras layers instantiated in

@@ -282,11 +282,11 @@ def test_f32_fused_epilogues_equal_one_kernel_per_op(ctx, name, tile):
     synth.synthetic_weights(net.train_single, 4)
     net._set_infer()
     u8 = synth.em_volume_u8(12, (tile + 40, tile + 9, tile + 22))
-    a = net.infer(u8, normalize=(128., 33.))
+    a = net.infer(u8, normalize=(128., 33.), precision='f32')
     assert ctx.last_path() == 'mfma_f32'
     os.environ['FPL_F32_UNFUSED'] = '1'
     try:
-        b = net.infer(u8, normalize=(128., 33.))
+        b = net.infer(u8, normalize=(128., 33.), precision='f32')
     finally:
         del os.environ['FPL_F32_UNFUSED']
     assert a.std() > 0 and np.array_equal(a, b)

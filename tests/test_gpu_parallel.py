@@ -93,7 +93,8 @@ def test_infer_reports_the_executor(ctx):
     """fpl_last_path names the executor instead of leaving it to the timing names"""
     net = _vgg_net()
     u8 = synth.em_volume_u8(5, (46, 40, 38))
-    for prec, name in (('f32', 'mfma_f32'), ('f16', 'vgg_fused_f16'), ('bf16', 'vgg_fused_bf16')):
+    for prec, name in (('f32', 'mfma_f32'), ('f16', 'vgg_fused_f16'), ('bf16', 'vgg_fused_bf16'),
+                       ('f16s', 'vgg_split_f16'), ('auto', 'vgg_split_f16'), (None, 'vgg_split_f16')):
         net.infer(u8, normalize=(128., 33.), precision=prec)
         assert ctx.last_path() == name
     unet = FplNetwork(fplmodels.unet_like2)
