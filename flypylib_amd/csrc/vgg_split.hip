@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   int xb, yb, zb;
-  if (!block_coords(a.bg, xb, yb, zb)) return;
+  if (!brick_coords(a.bg, xb, yb, zb)) return;
   const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 2;
   if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
 
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   int xb, yb, zb;
-  if (!block_coords(a.bg, xb, yb, zb)) return;
+  if (!brick_coords(a.bg, xb, yb, zb)) return;
   const int cx0 = xb * 16, cy0 = yb * 4, cz0 = zb * 4;
   if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
 
@@ -972,7 +972,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
       a.p2 = (unsigned char *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
       a.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 2)};
       TimedLaunch tl(ctx, "vggs_mid_pool");
-      vggs_mid_pool<<<block_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+      vggs_mid_pool<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
     }
     {
       TailSArgs a;
@@ -985,7 +985,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
       a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = 7;
       a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
       TimedLaunch tl(ctx, "vggs_c5_tail");
-      vggs_c5_tail<<<block_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+      vggs_c5_tail<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
     }
     FPL_HIP(ctx, hipGetLastError());
   }

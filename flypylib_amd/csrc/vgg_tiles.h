@@ -31,6 +31,35 @@ __device__ __forceinline__ bool block_coords(const BlockGrid &g, int &xb, int &y
   return zb < g.nbz;
 }
 
+// Brick order (the split-operand kernels, whose concurrent tiles are twice the L2s' size):
+// the 64 workgroups an XCD runs at a time take 64 consecutive indices of the order
+// (z / 4, y / 4, x, y % 4, z % 4) - a 4 x 4 x 4 brick of blocks whose tiles overlap in z, y
+// and x inside ONE L2 (input footprint 1.4x its share of the tensor, against 2.5x for 64
+// separate tiles).  Ragged edges: the last z / y groups are thinner; closed-form decode.
+__host__ __device__ inline unsigned brick_grid_size(const BlockGrid &g) {
+  const int64_t n = (int64_t)g.nbx * g.nby * g.nbz;
+  return (unsigned)((n + 511) / 512 * 512);
+}
+__device__ __forceinline__ bool brick_coords(const BlockGrid &g, int &xb, int &yb, int &zb) {
+  const unsigned q = blockIdx.x, j = q >> 3;
+  const int64_t b = (int64_t)(j >> 6) * 512 + (q & 7u) * 64 + (j & 63u);
+  if (b >= (int64_t)g.nbx * g.nby * g.nbz) return false;
+  const int64_t slab = (int64_t)g.nbx * g.nby * 4;       // blocks of a full group of 4 z
+  const int zh = (int)(b / slab);
+  const int nzl = g.nbz - 4 * zh < 4 ? g.nbz - 4 * zh : 4;
+  int64_t r = b - zh * slab;
+  const int64_t col = (int64_t)g.nbx * 4 * nzl;          // blocks of a full group of 4 y
+  const int yh = (int)(r / col);
+  const int nyl = g.nby - 4 * yh < 4 ? g.nby - 4 * yh : 4;
+  r -= yh * col;
+  const int cell = nyl * nzl;
+  xb = (int)(r / cell);
+  const int r3 = (int)(r - (int64_t)xb * cell);
+  yb = 4 * yh + r3 / nzl;
+  zb = 4 * zh + r3 % nzl;
+  return true;
+}
+
 // Fill an activation tile by LDS-DMA: the tile is TZ*TY rows of TX voxels of 96 B (six
 // 16-B pieces); the source is a (AZ, AY, AX) channels-last tensor whose voxels are
 // SRC_VOX bytes apart, `act` pointing at the 96 B of voxel (0,0,0) the tile takes (the

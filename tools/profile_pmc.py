@@ -35,6 +35,10 @@ GROUPS = {
     'rdreq': ['TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum'],
     'l2hit': ['TCC_HIT_sum', 'TCC_MISS_sum'],
     'write': ['WRITE_SIZE', 'TCC_EA0_WRREQ_sum'],
+    # vector-memory path of a CU: L1 (TCP) accesses / misses to L2, address unit busy
+    'tcp': ['TCP_TOTAL_CACHE_ACCESSES_sum', 'TCP_TCC_READ_REQ_sum', 'TCP_PENDING_STALL_CYCLES_sum',
+            'TCP_TCC_READ_REQ_LATENCY_sum'],
+    'ta': ['TA_TA_BUSY_sum', 'TA_BUSY_avr', 'TD_TD_BUSY_sum', 'TCP_GATE_EN1_sum'],
 }
 
 
