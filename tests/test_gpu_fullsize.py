@@ -149,3 +149,88 @@ def test_pipeline_1024_cubed_is_idempotent_and_order_independent(ctx, tmp_path):
     assert len(a['conf']) > 0
     # every detection lies inside its substack (buffer detections are dropped)
     assert a['locs'].min() >= 0 and a['locs'].max() < 1024
+
+
+def test_configs2_rank_share_equals_the_whole_volume_rows(ctx):
+    """configs[2] at its stated size: unet_like2 (trained fixture) over the 1024 x 2048 x 2048
+    volume is 13 tile rows of pitch 82 along z; 8 ranks take 2,2,2,2,2,1,1,1 of them.  Rank
+    0's slab (2 rows + halo = 182 z rows) run as a standalone volume - what a torchrun rank
+    of bench.py / multi_gpu does - equals, bit for bit, the same rows of a run over the
+    WHOLE volume on this one GPU; so does rank 7's (the ragged last row)."""
+    import torch
+    from tests.trained_fixture import trained_weights
+    Z, Y, X = 1024, 2048, 2048
+    tile, off, world = 100, 9, 8
+    g = fplmodels.unet_like2(tile)[0]
+    g.set_weights(trained_weights('unet_like2'))
+    prog = _capi.Program(ctx, g, (1, 1, 1))
+    n_rows = multi_gpu.n_tile_rows(Z, tile, off)
+    parts = multi_gpu.slab_partition(n_rows, world)
+    assert n_rows == 13 and [e - b for b, e in parts] == [2, 2, 2, 2, 2, 1, 1, 1]
+    pitch = tile - 2 * off
+    whole_src = torch.empty((Z, Y, X), dtype=torch.uint8, device='cuda')
+    ctx.synth_volume_u8(3, (Z, Y, X), out=whole_src)
+    whole_dst = torch.empty((Z, Y, X), dtype=torch.float32, device='cuda')
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F16)
+    prog.infer_volume(whole_src, (tile,) * 3, (off,) * 3, dst=whole_dst, dims=(Z, Y, X), **kw)
+    assert ctx.last_path() == 'unet_mfma_f16'
+    assert float(whole_dst[off:-off, off:-off, off:-off].std()) > 0
+    for rank in (0, 7):
+        zb, ze = parts[rank]
+        z_lo, z_hi = zb * pitch, min(ze * pitch + 2 * off, Z)
+        slab_src = whole_src[z_lo:z_hi].contiguous()
+        slab_dst = torch.empty((z_hi - z_lo, Y, X), dtype=torch.float32, device='cuda')
+        prog.infer_volume(slab_src, (tile,) * 3, (off,) * 3, dst=slab_dst,
+                          dims=(z_hi - z_lo, Y, X), **kw)
+        lo, hi = multi_gpu.slab_rows((zb, ze), Z, tile, off)       # rows the rank owns
+        # its interior rows (the whole-volume run zeroes the outer shell, the slab run its own)
+        a, b = max(lo, off), min(hi, Z - off)
+        assert torch.equal(slab_dst[a - z_lo:b - z_lo], whole_dst[a:b]), rank
+        del slab_src, slab_dst
+    del whole_src, whole_dst
+    prog.close()
+
+
+def test_configs4_rank_share_of_a_4096_cubed_roi(ctx, tmp_path):
+    """configs[4] at its stated size, a rank's share: the 4096^3 synthetic ROI is 512
+    substacks of 512^3 (+ 35 buffer: 582^3 cubes); of 8 ranks rank 3 takes every 8th.
+    Its first 8 substacks run through full_roi_inference at the DEFAULT precision
+    (split halves: fp32-grade) with the trained vgg_like fixture; the substack with the
+    most detections is recomputed stage by stage and its point list compared with the CPU
+    oracle's voxel2obj on the same device prediction - identical."""
+    import os
+    import pickle
+    import warnings
+    from flypylib_amd import fplpipeline
+    from tests.trained_fixture import trained_network
+    n = 4096
+    net = trained_network('vgg_like', tile=102)
+    wd = str(tmp_path)
+    src = 'synth://5,%d,%d,%d' % (n, n, n)
+    fplobjdetect.gen_full_tab_roi(wd + '/roi', src, None, step_size=512)
+    roi = fplobjdetect.roi_from_txt(wd + '/roi_00.txt')[0]
+    assert len(roi) == 512
+    mine = roi[3::8][:8]
+    norm = [128., 33., 0.5]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out = fplobjdetect.full_roi_inference(src, None, mine, net, 0.1, wd + '/work', norm)
+    assert ctx.last_path() == 'vgg_split_f16'
+    counts = [len(pickle.load(open(fplobjdetect.fri_filename(wd + '/work', s_), 'rb'))['conf'])
+              for s_ in mine]
+    assert len(out['conf']) == sum(counts)
+    ss = mine[int(np.argmax(counts))]
+    print('detections per substack', counts)
+    sz = ss.size + 70
+    cube = ctx.malloc((sz,) * 3, np.uint8)
+    pred = ctx.malloc((sz,) * 3, np.float32)
+    ctx.synth_substack_u8(5, (n, n, n), (sz,) * 3, [ss.z - 35, ss.y - 35, ss.x - 35], cube)
+    st = fplpipeline.normalisation_from_histogram(ctx.histogram_u8(cube), norm)
+    net.infer_network.program.infer_volume(cube, net.infer_sz, net.rf_offset, mean=st['mn_use'],
+                                           std=norm[1], precision=_capi.PREC_AUTO, dst=pred,
+                                           dims=(sz,) * 3)
+    ref = voxel2obj_oracle.voxel2obj(pred.to_host(), 27, 5, (ss.x - 35, ss.y - 35, ss.z - 35), 35, 0.1)
+    got = pickle.load(open(fplobjdetect.fri_filename(wd + '/work', ss), 'rb'))
+    assert np.array_equal(ref['locs'], got['locs']) and np.array_equal(ref['conf'], got['conf'])
+    cube.free()
+    pred.free()

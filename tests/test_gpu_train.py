@@ -25,9 +25,10 @@ def _oracle_step(graph, shape, data_seed, loss='binary_crossentropy', labels=Non
     differ at fp32 rounding level (the MFMA and the direct fp32 convolutions
     themselves differ by ~2e-6 relative) can be routed differently by two correct
     fp32 implementations, which moves every gradient UPSTREAM of that pool (observed:
-    one flipped window of unet_like2's 3^3 pool -> 5 % on the encoder gradients).  A
-    few seeds are tried for an input without such windows; the returned flag says
-    whether one was found."""
+    one flipped window of unet_like2's 3^3 pool -> 5 % on the encoder gradients).  The
+    seeds data_seed, data_seed + 1000, ... are tried in order for an input without such
+    windows - a deterministic, CPU-side search (every call of this file finds one within
+    four seeds); not finding one FAILS the test: there is no loose fallback bound."""
     best = None
     for k in range(tries):
         rng = np.random.default_rng(data_seed + 1000 * k)
@@ -41,40 +42,27 @@ def _oracle_step(graph, shape, data_seed, loss='binary_crossentropy', labels=Non
         if gap > FLIP_GAP:
             break
     gap, data, rl, rm, rg = best
-    return data, rl, rm, rg, gap > FLIP_GAP
+    assert gap > FLIP_GAP, ('no input among %d seeds whose max-pool windows are separated by more '
+                            'than %g (best %g): pick another data_seed' % (tries, FLIP_GAP, gap))
+    return data, rl, rm, rg
 
 
-def _check_grads(graph, grads, rg, separated, tol_flip):
-    """tight (2e-4) on every gradient when no pool window is flip-prone, and always
-    on the layers after the last pool (no pool backward upstream of them);
-    `tol_flip` on the rest otherwise"""
-    if not separated:
-        # never silent: the run's warning summary names every test that took the loose bound
-        import warnings
-        warnings.warn('gradient check fell back to tol_flip = %g upstream of the last pool: no '
-                      'seed gave an input whose max-pool windows are separated by more than '
-                      '%g' % (tol_flip, FLIP_GAP))
-    last_pool = max([n.idx for n in graph.nodes if n.kind == 'pool'] or [-1])
-    after = set()
-    for n in graph.nodes:
-        if n.idx > last_pool:
-            after.update(n.weight_slots)
+def _check_grads(graph, grads, rg):
+    """every gradient tensor within 2e-4 (relative to its largest entry) of the oracle's"""
     for i, (g, r) in enumerate(zip(grads, rg)):
         if np.max(np.abs(r)) < 1e-12:
             assert np.max(np.abs(g)) < 1e-7, graph.weight_names[i]
             continue
-        tol = 2e-4 if (separated or i in after) else tol_flip
-        assert _rel(g, r) < tol, '%s: rel err %g (tol %g)' % (graph.weight_names[i], _rel(g, r), tol)
+        assert _rel(g, r) < 2e-4, '%s: rel err %g' % (graph.weight_names[i], _rel(g, r))
 
 
-def _check_step(ctx, graph, shape, labels, seed=5, tol_flip=2e-3, data_seed=0):
-    data, rl, rm, rg, separated = _oracle_step(graph, shape, data_seed, labels=labels,
-                                               step_seed=seed)
+def _check_step(ctx, graph, shape, labels, seed=5, data_seed=0):
+    data, rl, rm, rg = _oracle_step(graph, shape, data_seed, labels=labels, step_seed=seed)
     tr = _capi.Trainer(ctx, graph)
     loss, acc = tr.step(data, labels, seed=seed)
     assert abs(loss - rl) < 1e-5 * max(1.0, abs(rl)), (loss, rl)
     assert abs(acc - rm['acc']) < 1e-6
-    _check_grads(graph, tr.get_grads(), rg, separated, tol_flip)
+    _check_grads(graph, tr.get_grads(), rg)
     return tr, rg
 
 
@@ -127,12 +115,58 @@ def test_fused_and_separate_bn_relu_pool_agree(ctx, monkeypatch):
         assert _rel(a, b) < 2e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
 
 
+def test_c3_shape_32_patches_of_64(ctx, monkeypatch):
+    """configs[3]'s stated shape - batch 32 of 64^3 patches, 12^3 outputs each.  The float64
+    oracle needs minutes for that batch, so (a) the whole batch through properties: the
+    fused BN + ReLU + pool layers and the separate kernels (FPL_TRAIN_UNFUSED) give the
+    same finite loss, accuracy and gradients; the step is repeatable up to the float
+    atomics of the weight gradients; (b) ONE 64^3 patch against the oracle: loss, accuracy
+    and the gradients of every layer after the last pool (the layers upstream see max-pool
+    routing, which two correct fp32 convolutions may decide differently on some of the
+    1.4 M windows of this shape - they are held to the oracle at 18^3 / 24^3 / 30^3 above)"""
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 8)
+    rng = np.random.default_rng(0)
+    data = rng.standard_normal((32, 64, 64, 64, 1)).astype(np.float32)
+    labels = (rng.random((32, 12, 12, 12, 1)) > 0.9).astype(np.uint8)
+    tr = _capi.Trainer(ctx, g)
+    loss_f, acc_f = tr.step(data, labels, seed=3)
+    grads_f = [x.copy() for x in tr.get_grads()]
+    loss_r, acc_r = tr.step(data, labels, seed=3)
+    grads_r = tr.get_grads()
+    assert np.isfinite(loss_f) and 0.0 < loss_f < 5.0 and abs(loss_f - loss_r) < 1e-6
+    assert acc_f == acc_r
+    for i, (a, b) in enumerate(zip(grads_f, grads_r)):
+        assert _rel(a, b) < 1e-5, g.weight_names[i]
+    monkeypatch.setenv('FPL_TRAIN_UNFUSED', '1')
+    tr2 = _capi.Trainer(ctx, g)
+    loss_u, acc_u = tr2.step(data, labels, seed=3)
+    assert abs(loss_f - loss_u) < 1e-6 and acc_f == acc_u
+    for i, (a, b) in enumerate(zip(grads_f, tr2.get_grads())):
+        assert _rel(a, b) < 2e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
+    monkeypatch.delenv('FPL_TRAIN_UNFUSED')
+    tr2.close()
+    # (b) one patch against the oracle
+    d1, l1 = data[:1], labels[:1]
+    rl, rm, rg = train_oracle.train_step(g, g.weights, d1, l1, 5, return_metrics=True)
+    loss1, acc1 = tr.step(d1, l1, seed=5)
+    assert abs(loss1 - rl) < 1e-5 * max(1.0, abs(rl)) and abs(acc1 - rm['acc']) < 1e-6
+    last_pool = max(n.idx for n in g.nodes if n.kind == 'pool')
+    after = {s for n in g.nodes if n.idx > last_pool for s in n.weight_slots}
+    assert len(after) >= 14
+    grads1 = tr.get_grads()
+    for i in sorted(after):
+        assert _rel(grads1[i], rg[i]) < 2e-4, '%s: rel err %g' % (g.weight_names[i],
+                                                                   _rel(grads1[i], rg[i]))
+    tr.close()
+
+
 def test_unet_like2_step(ctx):
     g = fplmodels.unet_like2()[0]
     synth.synthetic_weights(g, 5)
     rng = np.random.default_rng(2)
     labels = (rng.random((2, 6, 6, 6, 1)) > 0.5).astype(np.uint8)
-    _check_step(ctx, g, (2, 24, 24, 24, 1), labels, data_seed=2, tol_flip=1e-1)
+    _check_step(ctx, g, (2, 24, 24, 24, 1), labels, data_seed=2)
 
 
 @pytest.mark.parametrize('loss', ['masked_focal_loss', 'masked_binary_crossentropy',
@@ -144,8 +178,7 @@ def test_masked_losses_and_metrics(ctx, loss):
     synth.synthetic_weights(g, 6)
     rng = np.random.default_rng(8)
     labels = rng.integers(0, 3, (2, 6, 6, 6, 1)).astype(np.uint8)      # {0, 1, 2}
-    data, rl, rm, rg, separated = _oracle_step(g, (2, 24, 24, 24, 1), 8, loss=loss,
-                                               labels=labels)
+    data, rl, rm, rg = _oracle_step(g, (2, 24, 24, 24, 1), 8, loss=loss, labels=labels)
     tr = _capi.Trainer(ctx, g, loss=loss)
     lv, _ = tr.step(data, labels, seed=5)
     assert abs(lv - rl) < 1e-5 * max(1.0, abs(rl)), (lv, rl)
@@ -153,7 +186,7 @@ def test_masked_losses_and_metrics(ctx, loss):
     assert abs(m['loss'] - rl) < 1e-5 * max(1.0, abs(rl))
     for k, v in rm.items():
         assert abs(m[k] - v) < 1e-5, (k, m[k], v)
-    _check_grads(g, tr.get_grads(), rg, separated, 1e-1)
+    _check_grads(g, tr.get_grads(), rg)
     tr.close()
 
 
