@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREC_AUTO, PREC_F32, PREC_BF16, PREC_F16, PREC_F16S = -1, 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 COMM_ID_BYTES = 128
 
 
@@ -69,6 +69,10 @@ SIGNATURES = {
     'fpl_v2o_nms': (C.c_int, [_vp, _f64, _vp, _i64, _pi64, _pi32]),
     'fpl_v2o_set_seg': (C.c_int, [_vp, _vp, _i32, C.c_int, _pi64, _i64]),
     'fpl_v2o_select': (C.c_int, [_vp, _pi64, _i32, _vp]),
+    'fpl_v2o_smooth_f64': (C.c_int, [_vp, _vp, C.c_int, _pi64, _i32, _vp, _i32]),
+    'fpl_v2o_select_f64': (C.c_int, [_vp, _pi64, _i32, _vp]),
+    'fpl_v2o_rank_f64': (C.c_int, [_vp, C.c_double, _pi64]),
+    'fpl_v2o_values_f64': (C.c_int, [_vp, _pi64, _i64, _vp]),
     'fpl_v2o_nms_seg': (C.c_int, [_vp, C.c_double, _i32, _i32, _vp, _i64, _pi64, _pi32]),
     'fpl_v2o_copy_smoothed': (C.c_int, [_vp, _vp, C.c_int]),
     'fpl_trainer_create': (C.c_int, [_vp, C.POINTER(fpl_layer), _i32, _i32, _i32,
@@ -335,6 +339,32 @@ class Context:
         self.check(self.lib.fpl_v2o_select(self.h, ranks.ctypes.data_as(_pi64),
                                            int(ranks.size), _ptr(vals)))
         return vals[:ranks.size]
+
+    # float64 predictions (include/fplhip.h: fpl_v2o_smooth_f64 ...)
+    def v2o_smooth_f64(self, pred, dims, r, weights):
+        w = np.ascontiguousarray(weights, np.float64)
+        self.check(self.lib.fpl_v2o_smooth_f64(self.h, _ptr(pred), _mem_of(pred),
+                                               _arr(dims, C.c_int64), int(r), _ptr(w),
+                                               int((w.size - 1) // 2)))
+
+    def v2o_select_f64(self, ranks):
+        ranks = np.ascontiguousarray(ranks, np.int64)
+        vals = np.zeros(max(ranks.size, 1), np.float64)
+        self.check(self.lib.fpl_v2o_select_f64(self.h, ranks.ctypes.data_as(_pi64),
+                                               int(ranks.size), _ptr(vals)))
+        return vals[:ranks.size]
+
+    def v2o_rank_f64(self, thresh):
+        n = C.c_int64()
+        self.check(self.lib.fpl_v2o_rank_f64(self.h, float(thresh), C.byref(n)))
+        return n.value
+
+    def v2o_values_f64(self, flat):
+        flat = np.ascontiguousarray(flat, np.int64)
+        out = np.zeros(max(flat.size, 1), np.float64)
+        self.check(self.lib.fpl_v2o_values_f64(self.h, flat.ctypes.data_as(_pi64), int(flat.size),
+                                               _ptr(out)))
+        return out[:flat.size]
 
     def v2o_nms_seg(self, thresh, seg_dilate, seg_force, cap=1 << 20):
         out = np.zeros((cap, 4), np.float64)

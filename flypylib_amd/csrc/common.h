@@ -44,6 +44,15 @@ struct V2oState {
   bool cellmax_valid = false;
   float floor = 0.f;            // fpl_v2o_set_floor: the NMS threshold will be >= this
   float cellmax_floor = 0.f;    // the floor the keys in `cellmax` were taken with
+  // float64 predictions (v2o_f64.hip): the smoothed volume in double, its voxels sorted
+  // by value (order statistics, dense ranks); `smoothed` then holds rank surrogates
+  bool f64 = false;
+  double *smoothed64 = nullptr;
+  size_t cap64_bytes = 0;
+  unsigned long long *sort_keys = nullptr;     // ascending monotone keys of smoothed64
+  unsigned int *sort_idx = nullptr;            // their flat indices
+  size_t sort_cap = 0;                         // elements
+  bool sorted = false;
 };
 
 struct fpl_ctx {

@@ -64,6 +64,9 @@ int fpl_ctx_destroy(fpl_ctx *ctx) {
   if (ctx->v2o.smoothed) fpl_dev_release(ctx, ctx->v2o.smoothed);
   if (ctx->v2o.seg) fpl_dev_release(ctx, ctx->v2o.seg);
   if (ctx->v2o.cellmax) fpl_dev_release(ctx, ctx->v2o.cellmax);
+  if (ctx->v2o.smoothed64) fpl_dev_release(ctx, ctx->v2o.smoothed64);
+  if (ctx->v2o.sort_keys) fpl_dev_release(ctx, ctx->v2o.sort_keys);
+  if (ctx->v2o.sort_idx) fpl_dev_release(ctx, ctx->v2o.sort_idx);
   fpl_dev_trim(ctx);
   for (auto &kv : ctx->live_blocks) hipFree(kv.first);
   hipStreamDestroy(ctx->own_stream);

@@ -1162,16 +1162,17 @@ __global__ void seg_count(const unsigned long long *__restrict__ seg, int64_t n,
 }
 
 // smoothed = 0 where the voxel's segment has fewer than sz_thd voxels
+template <typename T>
 __global__ void seg_zero_small(const unsigned long long *__restrict__ seg, int64_t n,
                                const unsigned long long *__restrict__ keys,
                                const unsigned int *__restrict__ counts, uint64_t mask,
-                               long long sz_thd, float *__restrict__ smoothed) {
+                               long long sz_thd, T *__restrict__ smoothed) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long k = seg[i];
   uint64_t h = seg_hash(k) & mask;
   while (keys[h] != k + 1ull) h = (h + 1) & mask;      // every label was inserted
-  if ((long long)counts[h] < sz_thd) smoothed[i] = 0.f;
+  if ((long long)counts[h] < sz_thd) smoothed[i] = (T)0;
 }
 
 // one workgroup per winner: the part of its r-ball that lies in its own segment (mask
@@ -1442,6 +1443,8 @@ int fpl_v2o_smooth(fpl_ctx *ctx, const float *pred, int pred_mem,
   V2oState &S = ctx->v2o;
   S.valid = false;
   S.seg_valid = false;            // a segmentation belongs to one smoothed volume
+  S.f64 = false;
+  S.sorted = false;
   const size_t vol_bytes = (size_t)n_pad * sizeof(float);
   if (S.cap_bytes < vol_bytes) {
     if (S.smoothed) fpl_dev_release(ctx, S.smoothed);
@@ -1819,8 +1822,14 @@ int fpl_v2o_set_seg(fpl_ctx *ctx, const void *seg, int32_t seg_bytes, int seg_me
                 (unsigned long long)cap);
     {
       TimedLaunch tl(ctx, "v2o_seg_zero_small");
-      seg_zero_small<<<grid, 256, 0, st>>>(S.seg, n_pad, keys, counts, cap - 1,
-                                           (long long)sz_thd, S.smoothed);
+      if (S.f64) {               // float64 prediction: the volume of record is the double one
+        seg_zero_small<double><<<grid, 256, 0, st>>>(S.seg, n_pad, keys, counts, cap - 1,
+                                                     (long long)sz_thd, S.smoothed64);
+        S.sorted = false;
+      } else {
+        seg_zero_small<float><<<grid, 256, 0, st>>>(S.seg, n_pad, keys, counts, cap - 1,
+                                                    (long long)sz_thd, S.smoothed);
+      }
     }
     FPL_HIP(ctx, hipGetLastError());
   }

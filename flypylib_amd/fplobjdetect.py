@@ -57,7 +57,11 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
               device=None, return_info=False, _ctx=None):
     """convert voxel-wise predictions to object (point) predictions.
 
-    pred: (Z,Y,X) float32 numpy array, or a float32 device tensor of that shape.
+    pred: (Z,Y,X) float32 numpy array, or a float32 device tensor of that shape; a float64
+    numpy array is smoothed, thresholded and compared in float64, as the reference does
+    for its input's own dtype (the results differ from the float32 ones: no rounding
+    between the smoothing passes).  Other dtypes raise, as scipy's filter does for
+    float16 in the reference.
     Smoothing + percentile(97)-or-`thd` threshold + greedy non-maxima suppression
     with minimum distance `obj_min_dist`; detections inside `buffer_sz` of the
     volume faces are dropped; `volume_offset` (x,y,z) is added.
@@ -73,11 +77,15 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     if isinstance(pred, str):
         pred = _load_main(pred)
     r = int(obj_min_dist)
+    f64 = False
     if isinstance(pred, np.ndarray):
-        if pred.dtype != np.float32:
-            # the reference smooths in the array's own dtype; only float32 (what
-            # FplNetwork.infer returns) is bit-matched on the device
-            raise TypeError('voxel2obj: pred must be float32, got %s' % pred.dtype)
+        if pred.dtype == np.float64:
+            f64 = True
+        elif pred.dtype != np.float32:
+            # the reference smooths in the array's own dtype: float32 (what
+            # FplNetwork.infer returns) and float64 exist on the device; scipy itself
+            # refuses float16, and integer volumes would be smoothed in integers
+            raise TypeError('voxel2obj: pred must be float32 or float64, got %s' % pred.dtype)
         pred = np.ascontiguousarray(pred)
     pred_sz = tuple(int(s) for s in pred.shape)
     assert len(pred_sz) == 3, 'pred must be (Z,Y,X)'
@@ -85,9 +93,30 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     ctx = _ctx or runtime.get_context(runtime.default_device() if device is None
                                       else device)
     n_pad = int(np.prod([s + 2 * r for s in pred_sz]))
-    lo_rank, hi_rank, gamma = percentile_plan(n_pad, 97, np.float32)
+    lo_rank, hi_rank, gamma = percentile_plan(n_pad, 97, np.float64 if f64 else np.float32)
     weights = gaussian_kernel1d(smoothing_sigma, truncate=2.0)
-    if seg is None:
+    if f64:
+        # float64: the volume of record is the double one; the NMS runs on float32 rank
+        # surrogates of the candidates (same order, same ties) and the picked voxels'
+        # float64 values are fetched afterwards
+        if seg is None and seg_sz_thd is not None:
+            raise ValueError('seg_sz_thd needs a segmentation')
+        ctx.v2o_smooth_f64(pred, pred_sz, r, weights)
+        if seg is not None:
+            if isinstance(seg, str):
+                seg = _load_main(seg)
+            assert tuple(int(v) for v in seg.shape) == pred_sz, 'seg must have pred\'s shape'
+            ctx.v2o_set_seg(seg, pred_sz, seg_sz_thd)
+        lo_v, hi_v = ctx.v2o_select_f64([lo_rank, hi_rank])
+        thresh = np.maximum(percentile_lerp(lo_v, hi_v, gamma), thd)
+        ctx.v2o_rank_f64(float(thresh))
+        pts, rounds = (ctx.v2o_nms(0.5) if seg is None
+                       else ctx.v2o_nms_seg(0.5, seg_dilate, seg_force))
+        pdims = [s + 2 * r for s in pred_sz]
+        flat = ((pts[:, 0].astype(np.int64) * pdims[1] + pts[:, 1].astype(np.int64)) * pdims[2]
+                + pts[:, 2].astype(np.int64))
+        pts[:, 3] = ctx.v2o_values_f64(flat)
+    elif seg is None:
         if seg_sz_thd is not None:
             raise ValueError('seg_sz_thd needs a segmentation')
         if thd > 0:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 6
+#define FPL_ABI_VERSION 7
 
 typedef struct fpl_ctx fpl_ctx;
 typedef struct fpl_program fpl_program;
@@ -193,6 +193,21 @@ int fpl_v2o_set_seg(fpl_ctx *ctx, const void *seg, int32_t seg_bytes, int seg_me
 int fpl_v2o_select(fpl_ctx *ctx, const int64_t *ranks, int32_t n_ranks, float *rank_values);
 int fpl_v2o_nms_seg(fpl_ctx *ctx, double thresh, int32_t seg_dilate, int32_t seg_force,
                     double *out_zyxv, int64_t cap, int64_t *n_out, int32_t *n_rounds);
+/* float64 predictions.  The reference pads, smooths (scipy: float64 output for a float64
+ * input, no rounding between the axes), takes the percentile and compares in the array's
+ * own dtype (fplobjdetect.py:158-231); its results then differ from the float32
+ * pipeline's.  Call order: fpl_v2o_smooth_f64 [-> fpl_v2o_set_seg] -> fpl_v2o_select_f64
+ * (sorts all padded voxels; exact float64 order statistics) -> host: thresh =
+ * max(percentile, thd) -> fpl_v2o_rank_f64 (every voxel > max(thresh, 0) gets its dense
+ * rank among those values as a float32 surrogate - exact below 2^24 distinct values, else
+ * an error) -> fpl_v2o_nms / fpl_v2o_nms_seg with thresh 0.5 (unchanged: the NMS only
+ * needs the order) -> fpl_v2o_values_f64 (the float64 values at the picked voxels' padded
+ * flat indices). */
+int fpl_v2o_smooth_f64(fpl_ctx *ctx, const double *pred, int pred_mem, const int64_t dims[3],
+                       int32_t r, const double *weights, int32_t wr);
+int fpl_v2o_select_f64(fpl_ctx *ctx, const int64_t *ranks, int32_t n_ranks, double *rank_values);
+int fpl_v2o_rank_f64(fpl_ctx *ctx, double thresh, int64_t *n_candidates);
+int fpl_v2o_values_f64(fpl_ctx *ctx, const int64_t *flat, int64_t n, double *out);
 /* smoothed padded volume of the last fpl_v2o_smooth call (tests) */
 int fpl_v2o_copy_smoothed(fpl_ctx *ctx, float *dst, int dst_mem);
 

@@ -128,6 +128,30 @@ def gen_voxel2obj_seg():
     np.savez_compressed(os.path.join(HERE, 'voxel2obj_seg.npz'), **out)
 
 
+def gen_voxel2obj_f64():
+    """float64 predictions through the reference's voxel2obj (it pads, smooths and
+    compares in the input's dtype): point lists + the float64 percentile"""
+    from tests.helpers import V2O_F64_CASES, make_pred_f64
+    out = {'names': np.array([c[0] for c in V2O_F64_CASES])}
+    for name, kind, seed, shape, r, sigma, thd, buf, off, segp in V2O_F64_CASES:
+        pred = make_pred_f64(kind, seed, shape)
+        assert pred.dtype == np.float64 and not np.array_equal(pred, pred.astype(np.float32))
+        kw = {}
+        if segp is not None:
+            sseed, n_sites, tiny, dil, szt, force = segp
+            kw = dict(seg=synth.voronoi_segmentation(sseed, shape, n_sites, tiny), seg_dilate=dil,
+                      seg_sz_thd=szt, seg_force=force)
+        res = fplobjdetect.voxel2obj(pred.copy(), r, sigma, tuple(off), buf, thd, **kw)
+        f32 = fplobjdetect.voxel2obj(pred.astype(np.float32), r, sigma, tuple(off), buf, thd, **kw)
+        out[name + '_locs'], out[name + '_conf'] = res['locs'], res['conf']
+        out[name + '_pred_sha'] = np.array(sha(pred))
+        same = (res['locs'].shape == f32['locs'].shape and np.array_equal(res['locs'], f32['locs'])
+                and np.array_equal(res['conf'], f32['conf']))
+        print('%-12s %4d detections (float32 input: %d, identical: %s)'
+              % (name, len(res['conf']), len(f32['conf']), same))
+    np.savez_compressed(os.path.join(HERE, 'voxel2obj_f64.npz'), **out)
+
+
 class _FakeNet:
     """crop-identity stand-in for the Keras inference network"""
 
@@ -366,6 +390,7 @@ if __name__ == '__main__':
         sys.exit(0)
     gen_keras_tiny()
     gen_voxel2obj_seg()
+    gen_voxel2obj_f64()
     gen_synapses()
     gen_fri_get_image()
     gen_set_filter()

@@ -77,3 +77,22 @@ V2O_SEG_CASES = [
     ('seg_r70', 'uniform', 48, (150, 40, 44), 70, 2.0, 0.1, 0, 10, 6, 0, None, None, 3),
 ]
 
+
+
+# float64 predictions (tests/golden/voxel2obj_f64.npz): the reference smooths, thresholds
+# and compares in the array's own dtype.
+# (name, kind, seed, shape, r, sigma, thd, buffer, offset, seg: None | (seed, n_sites, tiny,
+#  seg_dilate, seg_sz_thd, seg_force))
+V2O_F64_CASES = [
+    ('f64_blobs', 'blobs', 61, (64, 60, 56), 9, 3.0, 0.05, 2, (0, 0, 0), None),
+    ('f64_uniform', 'uniform', 62, (40, 44, 48), 6, 1.5, 0.1, (1, 2, 3), (10, 20, 30), None),
+    ('f64_pct', 'uniform', 63, (36, 36, 36), 5, 2.0, 0, 0, (0, 0, 0), None),
+    ('f64_seg', 'blobs', 64, (56, 48, 52), 9, 2.0, 0.05, 0, (0, 0, 0), (6, 8, 30, 1, 60, 3)),
+]
+
+
+def make_pred_f64(kind, seed, shape):
+    """a float64 volume that is NOT float32-representable: the float32 generator's values
+    plus a hashed perturbation of relative size 1e-9"""
+    base = make_pred(kind, seed, shape).astype(np.float64)
+    return base * (1.0 + 1e-9 * synth.hash_uniform_f32(seed + 7000, shape).astype(np.float64))

@@ -190,8 +190,9 @@ def test_negative_and_empty_inputs(ctx):
     # a segmentation of all-negative predictions changes nothing: still no points
     got = fplobjdetect.voxel2obj(pred, 5, 2.0, seg=np.zeros((30, 30, 30), np.uint64), seg_dilate=2)
     assert got['locs'].shape == (0, 3)
-    with pytest.raises(TypeError):
-        fplobjdetect.voxel2obj(pred.astype(np.float64), 5, 2.0)
+    # ... and in float64 (no candidate above max(percentile, 0))
+    got = fplobjdetect.voxel2obj(pred.astype(np.float64), 5, 2.0)
+    assert got['locs'].shape == (0, 3)
 
 
 @pytest.mark.parametrize('case', helpers.V2O_SEG_CASES, ids=[c[0] for c in helpers.V2O_SEG_CASES])
@@ -222,3 +223,33 @@ def test_segmentation_aware_matches_oracle_at_pipeline_parameters(ctx):
     assert np.array_equal(got['locs'], ref['locs']) and np.array_equal(got['conf'], ref['conf'])
     with pytest.raises(ValueError):
         fplobjdetect.voxel2obj(pred, 27, 5.0, seg_sz_thd=10)
+
+
+@pytest.mark.parametrize('case', helpers.V2O_F64_CASES, ids=[c[0] for c in helpers.V2O_F64_CASES])
+def test_float64_predictions_match_the_reference_bit_for_bit(ctx, golden, case):
+    """a float64 `pred` is padded, smoothed (no rounding between the axes), thresholded and
+    compared in float64, as the reference does for its input's dtype
+    (fplobjdetect.py:158-231): the reference's own point lists and float64 confidences,
+    with and without a segmentation"""
+    g = golden('voxel2obj_f64.npz')
+    name, kind, seed, shape, r, sigma, thd, buf, off, segp = case
+    pred = helpers.make_pred_f64(kind, seed, shape)
+    kw = {}
+    if segp is not None:
+        sseed, n_sites, tiny, dil, szt, force = segp
+        kw = dict(seg=synth.voronoi_segmentation(sseed, shape, n_sites, tiny), seg_dilate=dil,
+                  seg_sz_thd=szt, seg_force=force)
+    res = fplobjdetect.voxel2obj(pred, r, sigma, tuple(off), buf, thd, **kw)
+    assert res['conf'].dtype == np.float64
+    assert np.array_equal(res['locs'], g[name + '_locs']), name
+    assert np.array_equal(res['conf'], g[name + '_conf']), name
+    # the float32 pipeline still works afterwards (the context leaves float64 mode)
+    again = fplobjdetect.voxel2obj(pred.astype(np.float32), r, sigma, tuple(off), buf, thd, **kw)
+    assert len(again['conf']) == len(res['conf']) and not np.array_equal(again['conf'], res['conf'])
+
+
+def test_other_dtypes_are_refused_as_in_the_reference(ctx):
+    """scipy's gaussian_filter raises on float16 (the reference would fail there too);
+    integer volumes would be smoothed in integer arithmetic - neither is offered"""
+    with pytest.raises(TypeError, match='float32 or float64'):
+        fplobjdetect.voxel2obj(np.zeros((20, 20, 20), np.float16), 5, 2.0)

@@ -117,3 +117,24 @@ def test_segmentation_aware_voxel2obj_oracle_matches_reference(golden, case):
                                      seg_dilate=dil, seg_sz_thd=szt, seg_force=force)
     assert np.array_equal(res['locs'], g[name + '_locs'])
     assert np.array_equal(res['conf'], g[name + '_conf'])
+
+
+@pytest.mark.parametrize('case', helpers.V2O_F64_CASES, ids=[c[0] for c in helpers.V2O_F64_CASES])
+def test_float64_voxel2obj_oracle_matches_reference(golden, case):
+    """float64 predictions: the reference pads, smooths, thresholds and compares in the
+    input's own dtype - the oracle (numpy / scipy on the float64 array) gives the reference's
+    point lists, which differ from those of the float32-rounded input"""
+    g = golden('voxel2obj_f64.npz')
+    name, kind, seed, shape, r, sigma, thd, buf, off, segp = case
+    pred = helpers.make_pred_f64(kind, seed, shape)
+    assert helpers.sha(pred) == str(g[name + '_pred_sha'])
+    kw = {}
+    if segp is not None:
+        sseed, n_sites, tiny, dil, szt, force = segp
+        kw = dict(seg=synth.voronoi_segmentation(sseed, shape, n_sites, tiny), seg_dilate=dil,
+                  seg_sz_thd=szt, seg_force=force)
+    res = voxel2obj_oracle.voxel2obj(pred, r, sigma, tuple(off), buf, thd, **kw)
+    assert np.array_equal(res['locs'], g[name + '_locs'])
+    assert np.array_equal(res['conf'], g[name + '_conf'])
+    f32 = voxel2obj_oracle.voxel2obj(pred.astype(np.float32), r, sigma, tuple(off), buf, thd, **kw)
+    assert not np.array_equal(f32['conf'], res['conf'])
