@@ -34,6 +34,9 @@ CXXFLAGS += os.environ.get('FPL_EXTRA_CXXFLAGS', '').split()
 # translation units built a second time with -DFPL_F16 (IEEE-half operands instead of
 # bfloat16; mfma_util.h)
 DUAL_PRECISION = ('vgg_fused.hip', 'conv_mfma.hip')
+# ... and a third time on SPLIT IEEE-half operands (hi + lo per value; -DFPL_SPLIT):
+# the U-Net executor (vgg_like's split kernels are a file of their own, vgg_split.hip)
+SPLIT_BUILD = ('conv_mfma.hip',)
 
 
 def _sources():
@@ -44,6 +47,8 @@ def _sources():
             out.append((f, f[:-4], []))
             if f in DUAL_PRECISION:
                 out.append((f, f[:-4] + '_f16', ['-DFPL_F16=1']))
+            if f in SPLIT_BUILD:
+                out.append((f, f[:-4] + '_f16s', ['-DFPL_F16=1', '-DFPL_SPLIT=1']))
     return out
 
 

@@ -24,7 +24,21 @@
 
 namespace {
 
-constexpr int CC = 32;                    // channels per staged chunk = one K-step per tap
+// Split build (-DFPL_SPLIT, precision f16s): every tensor carries, per 16 REAL channels,
+// [hi 16 | lo 16] halves (v = hi + lo, mfma_util.h) - 2 C "physical" channels per voxel.
+// A staged chunk of 32 physical channels is then ONE group of 16 real channels, its
+// K-step B fragment [a_hi | a_lo], multiplied by [w_hi | w_hi] and by [w_lo | w_lo]: all
+// four products of (a_hi + a_lo)(w_hi + w_lo) in two MFMAs per 16 channels and tap.  The
+// kernels below are the 16-bit ones; what changes is the weight set (two fragments per
+// M-block and K-step), the epilogues (hi / lo stores, pooling in fp32) and the stem.
+#ifdef FPL_SPLIT
+constexpr bool SPLIT = true;
+#else
+constexpr bool SPLIT = false;
+#endif
+constexpr int PM = SPLIT ? 2 : 1;         // physical halves per real channel
+constexpr int CC = 32;                    // PHYSICAL channels per staged chunk = one K-step per tap
+constexpr int RCH = CC / PM;              // real channels per staged chunk
 constexpr int TZ = 6, TY = 6, TX = 18;    // input tile of a 4 x 4 x 16 output block
 // LDS tile layout: four planes, plane q = channels 8q..8q+7 of every tile voxel at a
 // 16-B pitch.  A lane (c, g) reads plane g, voxel v0 + c: the 16-lane groups of a
@@ -60,6 +74,28 @@ struct Src {             // one CC-channel chunk of the (virtual) concatenated i
 template <int MB, bool RELU_ALWAYS>
 __device__ __forceinline__ void store_il(h16_t *vox_out, int g, const f32x4 (&acc)[MB], int relu) {
   static_assert(MB % 2 == 0, "16-B pieces");
+  if (SPLIT) {
+    // the lane's 4*MB real channels start at 4*MB*g; per 8 of them one 16-B piece of hi
+    // halves and, 16 halves behind it, one of lo halves, inside their group of 16
+#pragma unroll
+    for (int h = 0; h < MB / 2; ++h) {
+      const int ch = 4 * MB * g + 8 * h;
+      h16_t *d = vox_out + (ch / 16) * 32 + ch % 16;
+      u32x4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 &v = acc[2 * h + q];
+        const bool rl = RELU_ALWAYS || relu;
+        const Pair2 p0 = rl ? split_pk_relu(v[0], v[1]) : split_pk(v[0], v[1]);
+        const Pair2 p1 = rl ? split_pk_relu(v[2], v[3]) : split_pk(v[2], v[3]);
+        hi[2 * q] = p0.hi; hi[2 * q + 1] = p1.hi;
+        lo[2 * q] = p0.lo; lo[2 * q + 1] = p1.lo;
+      }
+      *reinterpret_cast<u32x4 *>(d) = hi;
+      *reinterpret_cast<u32x4 *>(d + 16) = lo;
+    }
+    return;
+  }
   h16_t *dst = vox_out + 4 * MB * g;
 #pragma unroll
   for (int h = 0; h < MB / 2; ++h) {
@@ -78,7 +114,7 @@ __device__ __forceinline__ void store_il(h16_t *vox_out, int g, const f32x4 (&ac
 }
 
 struct Conv3Args {
-  Src src[6];
+  Src src[12];                   // (split build: chunks of 16 real channels - up to 192 / 16)
   int ncc;                       // channel chunks
   int ntab;                      // offset tables in use
   int tabH[MAXTAB], tabW[MAXTAB], tabC[MAXTAB], tabU[MAXTAB];
@@ -92,7 +128,7 @@ struct Conv3Args {
   // STEM variant: the (single) source is conv3 1->32 + shift + ReLU of this raw
   // (n, T, T, T) f32 volume, computed into the tile instead of being read
   const float *raw; int T;
-  const h16x8 *wstem;           // 2 fragments (SLOT_STEM, interleaved rows)
+  const h16x8 *wstem;           // 2 fragments (SLOT_STEM, interleaved rows); split: [chunk][part]
   const float *shstem;
   // optional fused MaxPooling3D(2) of the (ReLU) output: (n, OD/2, OH/2, OW/2, 16*MB)
   h16_t *pool_out;
@@ -107,7 +143,7 @@ struct Conv3Args {
   // registers and stores the probability of every valid voxel into the prediction
   // volume - no 32-channel tensor, no separate head kernel, no stitch pass.
   FplTileIO io;
-  const h16x8 *w8, *w9;          // HEAD: 2 fragments (SLOT_SPATIAL), 1 fragment (SLOT_CHAIN)
+  const h16x8 *w8, *w9;          // HEAD: 2 fragments (SLOT_SPATIAL), 1 fragment (SLOT_CHAIN); split: [part][b]
   const float *sh8;
   float bias9;
 };
@@ -138,7 +174,7 @@ constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
 constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
 template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false>
-__global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a) {
+__global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(Conv3Args a) {
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
   static_assert(!HEAD || (MB == 2 && !POOL), "the head variant is conv3 ->32");
   static_assert(NRAW % 256 == 0, "raw tile pieces per thread");
@@ -148,7 +184,7 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
   unsigned char *tile = smem;
   unsigned *offtab = reinterpret_cast<unsigned *>(smem + TILE_BYTES);
   // STEM: [0, TABN) = raw-tile offset of tile voxel v; then the bf16 raw tile
-  unsigned short *rawt = reinterpret_cast<unsigned short *>(offtab + TABN);
+  unsigned short *rawt = reinterpret_cast<unsigned short *>(offtab + TABN);   // split: hi, then lo
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int G = (int)gridDim.x;                     // multiple of 8 (host)
@@ -222,14 +258,52 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
       const int t = 8 * g + j;
       toff[j] = t < 27 ? ((t / 9) * RY + (t / 3) % 3) * RX + t % 3 : 0;
     }
+    if (!SPLIT) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      wsf[b] = a.wstem[b * 64 + lane];
+      for (int b = 0; b < 2; ++b) {
+        wsf[b] = a.wstem[b * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) shs[b][r] = a.shstem[8 * g + 4 * b + r];
+        for (int r = 0; r < 4; ++r) shs[b][r] = a.shstem[8 * g + 4 * b + r];
+      }
     }
   }
-  auto put = [&]() {
+  auto put = [&](int cc) {
+    if (STEM && SPLIT) {
+      // conv3 1->32 of the raw tile for the chunk's 16 real channels [16 cc, 16 cc + 16):
+      // input and weights as hi + lo, three products; plain rows, so lane (c, g) holds
+      // channels 4g .. 4g+3 of its voxel: 8 B of plane g / 2 (hi) and of plane 2 + g / 2 (lo)
+#pragma unroll
+      for (int j = 0; j < NRAW / 256; ++j) {
+        const float x = rawv[j];
+        const h16_t h = (h16_t)x;
+        rawt[tid + 256 * j] = h16_bits(x);
+        rawt[NRAW + tid + 256 * j] = h16_bits(x - (float)h);
+      }
+      const h16x8 wh = a.wstem[(cc * 2 + 0) * 64 + lane], wl = a.wstem[(cc * 2 + 1) * 64 + lane];
+      f32x4 sh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sh[r] = a.shstem[16 * cc + 4 * g + r];
+      __syncthreads();                              // raw tiles visible
+      constexpr int NGRP = (TZ * TY * TX + 15) / 16;
+      for (int grp = wave; grp < NGRP; grp += 4) {
+        const int v = 16 * grp + c;
+        const unsigned ro = offtab[v];              // TABN >= 16 * NGRP, tail clamped
+        u16x8 rh, rl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rh[j] = rawt[ro + toff[j]]; rl[j] = rawt[NRAW + ro + toff[j]]; }
+        Frag2 bf;
+        bf.hi = __builtin_bit_cast(h16x8, rh);
+        bf.lo = __builtin_bit_cast(h16x8, rl);
+        const f32x4 a0 = mfma3(wh, wl, bf, sh);
+        const Pair2 p0 = split_pk_relu(a0[0], a0[1]), p1 = split_pk_relu(a0[2], a0[3]);
+        if (v < TZ * TY * TX) {
+          unsigned char *d = tile + (g >> 1) * PLANE + v * PITCH + 8 * (g & 1);
+          *reinterpret_cast<u32x2 *>(d) = u32x2{p0.hi, p1.hi};
+          *reinterpret_cast<u32x2 *>(d + 2 * PLANE) = u32x2{p0.lo, p1.lo};
+        }
+      }
+      return;
+    }
     if (STEM) {
 #pragma unroll
       for (int j = 0; j < NRAW / 256; ++j) rawt[tid + 256 * j] = h16_bits(rawv[j]);
@@ -278,12 +352,13 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
   // from L2 into registers, WQ K-steps ahead of their use and across tile / block
   // boundaries: no LDS ring and no barrier inside the K loop.
   const unsigned char *wl = a.w + lane * 16;
-  h16x8 wq[WQ][MB];
+  constexpr int WMB = PM * MB;      // fragments per K-step: split carries [w_hi | w_hi] and [w_lo | w_lo]
+  h16x8 wq[WQ][WMB];
 #pragma unroll
   for (int d = 0; d < WQ; ++d)
 #pragma unroll
-    for (int b = 0; b < MB; ++b)
-      wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * MB + b) * 1024);
+    for (int b = 0; b < WMB; ++b)
+      wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * WMB + b) * 1024);
 
   for (;;) {
     for (int cc = 0; cc < a.ncc; ++cc) {
@@ -295,7 +370,7 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
       }
       __syncthreads();            // every wave has left the previous tile
       if (!PF) fetch(blk, cc);
-      put();
+      put(cc);
       if (PF) {
         const bool last_cc = cc + 1 == a.ncc;
         int64_t nb = last_cc ? blk + G : blk;
@@ -328,14 +403,21 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
 #pragma unroll
             for (int b = 0; b < MB; ++b)
               acc[sub][b] = mfma16(wq[st % WQ][b], brow[ck & 1][sub + dy], acc[sub][b]);
+          if (SPLIT) {
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+              for (int b = 0; b < MB; ++b)
+                acc[sub][b] = mfma16(wq[st % WQ][MB + b], brow[ck & 1][sub + dy], acc[sub][b]);
+          }
           __builtin_amdgcn_s_setprio(0);
           {
             int nxt = cc * (NCH * KC) + st + WQ;
             nxt = nxt < total_steps ? nxt : nxt - total_steps;   // next block starts over
 #pragma unroll
-            for (int b = 0; b < MB; ++b)
+            for (int b = 0; b < WMB; ++b)
               wq[st % WQ][b] =
-                  *reinterpret_cast<const h16x8 *>(wl + ((size_t)nxt * MB + b) * 1024);
+                  *reinterpret_cast<const h16x8 *>(wl + ((size_t)nxt * WMB + b) * 1024);
           }
         }
       }
@@ -353,16 +435,29 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
         if (HEAD) {
           // with interleaved rows lane (c,g) holds channels 8g..8g+7 of voxel c: the
           // packed pair IS the K-step of conv1 32->32 in SLOT_SPATIAL order
-          const h16x8 h7 = pack_relu(acc[sub][0], acc[sub][1]);
-          f32x4 a8[2];
+          f32x4 a8[2], t9;
+          if (SPLIT) {
+            const Frag2 h7 = pack_relu_split(acc[sub][0], acc[sub][1]);
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            f32x4 sh;
+            for (int b = 0; b < 2; ++b) {
+              f32x4 sh;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sh[r] = a.sh8[16 * b + 4 * g + r];
-            a8[b] = mfma16(a.w8[b * 64 + lane], h7, sh);
+              for (int r = 0; r < 4; ++r) sh[r] = a.sh8[16 * b + 4 * g + r];
+              a8[b] = mfma3(a.w8[b * 64 + lane], a.w8[(2 + b) * 64 + lane], h7, sh);
+            }
+            t9 = mfma3(a.w9[lane], a.w9[64 + lane], pack_relu_split(a8[0], a8[1]),
+                       f32x4{0.f, 0.f, 0.f, 0.f});
+          } else {
+            const h16x8 h7 = pack_relu(acc[sub][0], acc[sub][1]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              f32x4 sh;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sh[r] = a.sh8[16 * b + 4 * g + r];
+              a8[b] = mfma16(a.w8[b * 64 + lane], h7, sh);
+            }
+            t9 = mfma16(a.w9[lane], pack_relu(a8[0], a8[1]), f32x4{0.f, 0.f, 0.f, 0.f});
           }
-          const f32x4 t9 = mfma16(a.w9[lane], pack_relu(a8[0], a8[1]), f32x4{0.f, 0.f, 0.f, 0.f});
           const float logit = __shfl(t9[0], c) + a.bias9;     // lane (c, g=0) register 0
           const FplTileDesc td = a.io.tiles[n];
           if (g == 0 && oz < td.ext[0] - 2 * a.io.off && oy < td.ext[1] - 2 * a.io.off &&
@@ -379,7 +474,53 @@ __global__ __launch_bounds__(256, MB == 2 ? 3 : 2) void FPLK(conv3)(Conv3Args a)
     // sub-steps of a lane, x pairs neighbouring lanes, z pairs neighbouring waves
     // (through the tile's LDS, free until the next put).  ReLU output is >= 0, so
     // the bf16 order is the int16 order.
-    if (POOL) {
+    if (POOL && SPLIT) {
+      // the same pool in fp32 (the split representation is monotonic: the split of the
+      // maximum is the maximum of the splits); ReLU and the hi / lo store at the end
+      f32x4 pm[2][MB];
+#pragma unroll
+      for (int yh = 0; yh < 2; ++yh)
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = __builtin_fmaxf(acc[2 * yh][b][r], acc[2 * yh + 1][b][r]);
+            pm[yh][b][r] = __builtin_fmaxf(v, __shfl_xor(v, 1));             // x pair (c ^ 1)
+          }
+      f32x4 *xch = reinterpret_cast<f32x4 *>(tile);          // [wave pair][yh][b][lane]
+      __syncthreads();                              // every wave is done with the tile
+      if (wave & 1) {
+#pragma unroll
+        for (int yh = 0; yh < 2; ++yh)
+#pragma unroll
+          for (int b = 0; b < MB; ++b)
+            xch[(((wave >> 1) * 2 + yh) * MB + b) * 64 + lane] = pm[yh][b];
+      }
+      __syncthreads();
+      if (!(wave & 1) && !(c & 1)) {
+        const int bx = (int)(blk % a.nbx), by = (int)((blk / a.nbx) % a.nby);
+        const int bz = (int)(blk / ((int64_t)a.nbx * a.nby));
+        const int n = bz / a.zblocks;
+        const int PD = a.OD / 2, PH = a.OH / 2, PW = a.OW / 2;
+        const int pz = (bz % a.zblocks) * 2 + (wave >> 1), px = bx * 8 + (c >> 1);
+#pragma unroll
+        for (int yh = 0; yh < 2; ++yh) {
+          const int py = by * 2 + yh;
+          if (pz < PD && py < PH && px < PW) {
+            f32x4 m[MB];
+#pragma unroll
+            for (int b = 0; b < MB; ++b) {
+              const f32x4 o = xch[(((wave >> 1) * 2 + yh) * MB + b) * 64 + lane];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) m[b][r] = __builtin_fmaxf(pm[yh][b][r], o[r]);
+            }
+            store_il<MB, true>(a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (16 * MB * PM),
+                               g, m, 1);
+          }
+        }
+      }
+    }
+    if (POOL && !SPLIT) {
       u32x4 pm[2][MB / 2];                          // [y half][16-B piece]
 #pragma unroll
       for (int yh = 0; yh < 2; ++yh)
@@ -446,8 +587,10 @@ struct Conv1Args {
 
 template <int CIN, int MB, int TAIL>
 __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
-  constexpr int KS = CIN / 32;
-  constexpr int NF = KS * MB;
+  static_assert(!SPLIT || TAIL == 0, "the split build writes through the fused head only");
+  constexpr int KS = CIN / RCH;                 // K-steps: chunks of 32 physical channels
+  constexpr int WMB = PM * MB;                  // split: [w_hi | w_hi] and [w_lo | w_lo] sets
+  constexpr int NF = KS * WMB;
   unsigned char *wl = smem;                         // NF KiB of fragments
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -468,18 +611,22 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
     h16x8 bf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      bf[s] = *reinterpret_cast<const h16x8 *>(a.in + m * CIN + 32 * s + 8 * g);
+      bf[s] = *reinterpret_cast<const h16x8 *>(a.in + m * (CIN * PM) + 32 * s + 8 * g);
     f32x4 acc[MB];
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
       acc[b] = sh[b];
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wl + ((s * MB + b) * 64 + lane) * 16),
+      for (int s = 0; s < KS; ++s) {
+        acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wl + ((s * WMB + b) * 64 + lane) * 16),
                         bf[s], acc[b]);
+        if (SPLIT)
+          acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wl + ((s * WMB + MB + b) * 64 + lane) * 16),
+                          bf[s], acc[b]);
+      }
     }
     if (TAIL == 0) {
-      if (ok) store_il<MB, true>(a.out + m * (16 * MB), g, acc, 1);
+      if (ok) store_il<MB, true>(a.out + m * (16 * MB * PM), g, acc, 1);
     } else {
       // chained 16*MB -> 1 conv (k-slots bound to the accumulator layout), sigmoid
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -717,9 +864,12 @@ bool match_unet(const fpl_program *prog, UnetDesc *d) {
 
 // conv3 fragments: per CC-channel chunk, K-step order (dz, dx, dy) (or (dz, dy, dx) for
 // the transposed edge strip); output channels [co0, co0 + ncout) as one M-block set
+// Split build: a chunk is 16 real channels as 32 physical k-slots [hi | lo]; both halves
+// of the K-step carry the SAME real channel's weight - the hi parts in the first fragment
+// set, the lo parts in the second: [chunk][K-step][set][mb].
 void pack_conv3(const float *A, const fpl_op &op, int co0, int ncout, bool transposed,
                 std::vector<uint16_t> *f) {
-  const int ncc = op.cin / CC, mb = (ncout + 15) / 16;
+  const int ncc = op.cin / RCH, mb = (ncout + 15) / 16;
   std::vector<float> sub((size_t)27 * CC * ncout), scale(A + op.scale_off + co0, A + op.scale_off + co0 + ncout);
   f->clear();
   for (int cc = 0; cc < ncc; ++cc) {
@@ -728,12 +878,34 @@ void pack_conv3(const float *A, const fpl_op &op, int co0, int ncout, bool trans
       const int tap = transposed ? dz * 9 + d1 * 3 + d2 : dz * 9 + d2 * 3 + d1;
       for (int ch = 0; ch < CC; ++ch)
         memcpy(&sub[((size_t)ks * CC + ch) * ncout],
-               A + op.w_off + ((size_t)tap * op.cin + cc * CC + ch) * op.cout + co0, ncout * sizeof(float));
+               A + op.w_off + ((size_t)tap * op.cin + cc * RCH + ch % RCH) * op.cout + co0,
+               ncout * sizeof(float));
     }
-    std::vector<uint16_t> fc;
-    fpl_pack_frags(sub.data(), scale.data(), 27, CC, ncout, mb, 27, SLOT_SPATIAL, &fc, true);
-    f->insert(f->end(), fc.begin(), fc.end());
+    std::vector<uint16_t> fc[2];
+    for (int part = 0; part < PM; ++part)
+      fpl_pack_frags(sub.data(), scale.data(), 27, CC, ncout, mb, 27, SLOT_SPATIAL, &fc[part], true, part);
+    for (int ks = 0; ks < 27; ++ks)
+      for (int part = 0; part < PM; ++part)
+        f->insert(f->end(), fc[part].begin() + (size_t)ks * mb * 512,
+                  fc[part].begin() + (size_t)(ks + 1) * mb * 512);
   }
+}
+
+// 1x1x1 conv on a (physical) channels-last row: K-steps over chunks of 32 physical
+// channels; split: [K-step][set][mb] as pack_conv3
+void pack_conv1(const float *A, const fpl_op &op, bool il, std::vector<uint16_t> *f) {
+  const int ks = op.cin / RCH, mb = (op.cout + 15) / 16;
+  std::vector<float> w((size_t)ks * CC * op.cout), scale(A + op.scale_off, A + op.scale_off + op.cout);
+  for (int k = 0; k < ks * CC; ++k)
+    memcpy(&w[(size_t)k * op.cout], A + op.w_off + (size_t)((k / CC) * RCH + (k % CC) % RCH) * op.cout,
+           op.cout * sizeof(float));
+  std::vector<uint16_t> fc[2];
+  for (int part = 0; part < PM; ++part)
+    fpl_pack_frags(w.data(), scale.data(), 1, ks * CC, op.cout, mb, ks, SLOT_SPATIAL, &fc[part], il, part);
+  f->clear();
+  for (int s = 0; s < ks; ++s)
+    for (int part = 0; part < PM; ++part)
+      f->insert(f->end(), fc[part].begin() + (size_t)s * mb * 512, fc[part].begin() + (size_t)(s + 1) * mb * 512);
 }
 
 int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState **out) {
@@ -755,7 +927,19 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
     std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
     std::vector<uint16_t> f;
     const int mb = (op.cout + 15) / 16;
-    if (l == 0) {
+    if (l == 0 && SPLIT) {
+      // conv3 1->32 per chunk of 16 output channels, plain rows: [chunk][part]
+      for (int cc = 0; cc < op.cout / 16; ++cc) {
+        std::vector<float> wc((size_t)27 * 16);
+        for (int t = 0; t < 27; ++t)
+          memcpy(&wc[(size_t)t * 16], A + op.w_off + (size_t)t * op.cout + 16 * cc, 16 * sizeof(float));
+        for (int part = 0; part < 2; ++part) {
+          std::vector<uint16_t> fp;
+          fpl_pack_frags(wc.data(), scale.data() + 16 * cc, 27, 1, 16, 1, 1, SLOT_STEM, &fp, false, part);
+          f.insert(f.end(), fp.begin(), fp.end());
+        }
+      }
+    } else if (l == 0) {
       fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, mb, 1, SLOT_STEM, &f, true);
     } else if (op.k == 3 && op.cout > 64) {
       // 128 output channels: two 64-channel launches, their fragment sets back to back
@@ -775,7 +959,22 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
         all.insert(all.end(), ft.begin(), ft.end());
       }
     } else if (l == l_last) {
-      fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, 1, 1, SLOT_CHAIN, &f);
+      for (int part = 0; part < PM; ++part) {          // split: [part]
+        std::vector<uint16_t> fp;
+        fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, 1, 1, SLOT_CHAIN, &fp, false, part);
+        f.insert(f.end(), fp.begin(), fp.end());
+      }
+    } else if (SPLIT && l == l_last - 1) {
+      // conv1 32->32 in the head epilogue: its B fragments are built in registers from the
+      // accumulators (hi and lo), REAL channels as k-slots: [part][b], three products
+      for (int part = 0; part < 2; ++part) {
+        std::vector<uint16_t> fp;
+        fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL,
+                       &fp, false, part);
+        f.insert(f.end(), fp.begin(), fp.end());
+      }
+    } else if (SPLIT) {
+      pack_conv1(A, op, true, &f);
     } else {
       // the conv1 before the head feeds the register-chained tail: plain row order there
       fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL, &f,
@@ -809,7 +1008,7 @@ template <int MB, bool STEM = false, bool POOL = false, bool HEAD = false>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   constexpr bool PF = true;
   // STEM keeps the bf16 raw tile behind the (single) offset table
-  constexpr int SMEM = TILE_BYTES + (STEM ? TABN * 4 + NRAW * 2 : TAB_BYTES);
+  constexpr int SMEM = TILE_BYTES + (STEM ? TABN * 4 + NRAW * 2 * PM : TAB_BYTES);
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   // function attributes belong to the current device: one flag per device (a process may
   // drive several GPUs, one context each; setting it twice is harmless)
@@ -819,7 +1018,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
-  if (a.cpitch == 0) a.cpitch = 16 * MB;
+  if (a.cpitch == 0) a.cpitch = 16 * MB * PM;
   // offset tables: one per distinct source geometry
   a.ntab = 0;
   for (int i = 0; i < (STEM ? 0 : a.ncc); ++i) {
@@ -845,7 +1044,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   a.nbz = n * a.zblocks;
   const int64_t total = (int64_t)a.nbx * a.nby * a.nbz;
   // two workgroups per CU, rounded to a multiple of the 8 XCDs
-  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * (MB == 2 ? 3 : 2), (total + 7) / 8 * 8);
+  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * ((MB == 2 && !SPLIT) ? 3 : 2), (total + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
   FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
@@ -864,7 +1063,9 @@ Src make_src(const h16_t *p, int dim, int C, int ch0, int up, int crop) {
 
 bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
   UnetDesc d;
-  return precision == FPL_THIS_PREC && match_unet(prog, &d);
+  if (precision != FPL_THIS_PREC || !match_unet(prog, &d)) return false;
+  // split build: the unet_like2 skeleton (3x3x3 second convs, one 1x1x1 bottom conv)
+  return !SPLIT || (!d.first1 && !d.second1 && d.nbottom == 1);
 }
 
 // in: (n, T,T,T) f32 normalised tiles on the device; out: (n, O,O,O) f32, O = T - 2 * rf_offset
@@ -874,6 +1075,8 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   UnetDesc D;
   FPL_REQUIRE(ctx, match_unet(prog, &D), "not a unet_like / unet_like2 / unet_like3 / unet_like4 program");
   FPL_REQUIRE(ctx, in && (io || out), "fpl_unet_forward: no input tiles / no output");
+  FPL_REQUIRE(ctx, !SPLIT || (io && !D.first1 && !D.second1 && D.nbottom == 1),
+              "fpl_unet_forward: the split-half build runs unet_like2 into a prediction volume");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
   DevTemp tmp(ctx);
@@ -889,12 +1092,17 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
               "U-Net tile edge %d does not fit this architecture (pools need even sizes, skips must meet)", T);
   auto cube = [](int d) { return (int64_t)d * d * d; };
   // conv3 tiles read up to 5 planes + 5 rows + 17 voxels past a source's last voxel
+  // (C real channels = C * PM halves per voxel)
   auto balloc = [&](int64_t elems, int dim, int C, h16_t **p) -> int {
     void *q;
-    const size_t slack = ((size_t)5 * dim * dim + 5 * dim + 18) * C * 2;
-    int rc = tmp.alloc((size_t)elems * 2 + slack + 64, &q);
+    const size_t slack = ((size_t)5 * dim * dim + 5 * dim + 18) * C * PM * 2;
+    int rc = tmp.alloc((size_t)elems * PM * 2 + slack + 64, &q);
     *p = (h16_t *)q;
     return rc;
+  };
+  // chunk `cc` of a source with C real channels: 32 physical channels from 32 * cc
+  auto src_of = [&](const h16_t *p, int dim, int C, int cc, int up, int crop) {
+    return make_src(p, dim, C * PM, CC * cc, up, crop);
   };
   h16_t *c1, *p1, *c2a, *c2, *p2, *c3a = nullptr, *c3, *c4a, *c4, *c5a;
   FPL_TRY(balloc(n * cube(d1) * 32, d1, 32, &c1));
@@ -928,7 +1136,8 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     FPLK(unet_stem_c1)<<<(unsigned)((int64_t)a.nbx * a.nby * n * a.zblocks), 256, 0, stm>>>(a);
   } else {  // conv3 1->32 computed into the tile of conv3 32->32
     Conv3Args a = conv3_args(1, c1, d1);
-    a.ncc = 1; a.src[0] = make_src(nullptr, d1a, 32, 0, 1, 0);
+    a.ncc = 32 / RCH;
+    for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = src_of(nullptr, d1a, 32, cc, 1, 0);
     a.raw = in; a.T = T;
     a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
     a.pool_out = p1;                               // MaxPooling3D(2) in the epilogue
@@ -936,13 +1145,14 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   }
   {  // conv3 32->64
     Conv3Args a = conv3_args(2, c2a, d2a);
-    a.ncc = 1; a.src[0] = make_src(p1, dp1, 32, 0, 1, 0);
+    a.ncc = 32 / RCH;
+    for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = src_of(p1, dp1, 32, cc, 1, 0);
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_32_64")));
   }
   if (!D.second1) {  // conv3 64->64
     Conv3Args a = conv3_args(3, c2, d2);
-    a.ncc = 2;
-    for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c2a, d2a, 64, 32 * cc, 1, 0);
+    a.ncc = 64 / RCH;
+    for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = src_of(c2a, d2a, 64, cc, 1, 0);
     a.pool_out = p2;
     FPL_TRY((launch_conv3<4, false, true>(ctx, a, n, "unet_conv3_64_64_pool")));
   }
@@ -953,7 +1163,10 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.out = y; a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, name);
-    kern<<<grid, 256, smem_frags * 1024, stm>>>(a);
+    // (split: two fragment sets per K-step and twice the K-steps; up to 64 KiB of LDS)
+    hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        smem_frags * PM * PM * 1024);
+    kern<<<grid, 256, smem_frags * PM * PM * 1024, stm>>>(a);
   };
   if (D.second1) {  // unet_like: conv1 64->64, then the pool as its own (HBM-bound) pass
     conv1(FPLK(conv1)<64, 4, 0>, 8, c2a, (int64_t)n * cube(d2a), 3, c2, "unet_conv1_64_64");
@@ -964,12 +1177,12 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   // conv3 -> 128 channels: two 64-channel launches into the halves of one tensor
   auto conv3_to128 = [&](int l, const h16_t *x, int xd, int xc, h16_t *y, int yd, const char *name) -> int {
     for (int h = 0; h < 2; ++h) {
-      Conv3Args a = conv3_args(l, y + 64 * h, yd);
+      Conv3Args a = conv3_args(l, y + 64 * PM * h, yd);
       a.w = F + st->off_w[l] + (h ? st->half_bytes[l] : 0);
       a.shift = S + st->off_s[l] + 64 * h;
-      a.cpitch = 128;
-      a.ncc = xc / 32;
-      for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = make_src(x, xd, xc, 32 * cc, 1, 0);
+      a.cpitch = 128 * PM;
+      a.ncc = xc / RCH;
+      for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = src_of(x, xd, xc, cc, 1, 0);
       FPL_TRY((launch_conv3<4>(ctx, a, n, name)));
     }
     return 0;
@@ -986,9 +1199,10 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   const int lu1 = D.l_up1(), lu2 = D.l_up2();
   {  // conv3 (up2(c3) 128 | crop(c2) 64) -> 64
     Conv3Args a = conv3_args(lu1, c4a, d4a);
-    a.ncc = 6;
-    for (int cc = 0; cc < 4; ++cc) a.src[cc] = make_src(c3, db, 128, 32 * cc, 2, 0);
-    for (int cc = 0; cc < 2; ++cc) a.src[4 + cc] = make_src(c2, d2, 64, 32 * cc, 1, D.crop2);
+    const int n3 = 128 / RCH, n2 = 64 / RCH;
+    a.ncc = n3 + n2;
+    for (int cc = 0; cc < n3; ++cc) a.src[cc] = src_of(c3, db, 128, cc, 2, 0);
+    for (int cc = 0; cc < n2; ++cc) a.src[n3 + cc] = src_of(c2, d2, 64, cc, 1, D.crop2);
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
   }
   conv1(FPLK(conv1)<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), lu1 + 1, c4, "unet_conv1_64_64");
@@ -996,9 +1210,10 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
      // the last two columns go through the transposed edge strip instead of a sixth block
      // column that would use 2 of its 16 lanes
     Conv3Args a = conv3_args(lu2, c5a, d5a);
-    a.ncc = 3;
-    for (int cc = 0; cc < 2; ++cc) a.src[cc] = make_src(c4, d4a, 64, 32 * cc, 2, 0);
-    a.src[2] = make_src(c1, d1, 32, 0, 1, D.crop1);
+    const int n4 = 64 / RCH, n1 = 32 / RCH;
+    a.ncc = n4 + n1;
+    for (int cc = 0; cc < n4; ++cc) a.src[cc] = src_of(c4, d4a, 64, cc, 2, 0);
+    for (int cc = 0; cc < n1; ++cc) a.src[n4 + cc] = src_of(c1, d1, 32, cc, 1, D.crop1);
     const int rem = d5a % 16;
     const bool strip = rem > 0 && rem <= 4 && d5a > 16 && st->off_w7t != 0;
     if (strip) a.main_w = d5a - rem;
@@ -1019,6 +1234,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
       else FPL_TRY((launch_conv3<2>(ctx, e, n, "unet_conv3_96_32_edge")));
     }
   }
+#ifndef FPL_SPLIT
   if (!io) {  // conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
     Conv1Args a;
     a.in = c5a; a.M = (int64_t)n * cube(d5a); a.w = F + st->off_w[lu2 + 1]; a.shift = S + st->off_s[lu2 + 1];
@@ -1028,6 +1244,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     TimedLaunch tl(ctx, "unet_head_" FPL_PREC_STR);
     FPLK(conv1)<32, 2, 1><<<grid, 256, 2 * 1024, stm>>>(a);
   }
+#endif
   FPL_HIP(ctx, hipGetLastError());
   return 0;
 }

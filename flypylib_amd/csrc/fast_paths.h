@@ -76,6 +76,8 @@ struct FplTileIO {
                              int T, float *out, const FplTileIO *io);
 FPL_DECLARE_H16_PATHS(bf16)
 FPL_DECLARE_H16_PATHS(f16)
+// split IEEE halves (conv_mfma.hip built with -DFPL_SPLIT): only the fpl_unet_* pair exists
+FPL_DECLARE_H16_PATHS(f16s)
 
 // fp32 MFMA executor over any lowered program without ADD (conv_mfma_f32.hip):
 // cubic tiles (n, T,T,T) f32 -> network output (n, d,d,d, c) f32

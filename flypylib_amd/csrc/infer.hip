@@ -230,13 +230,15 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   }
   // the fused fast path writes every valid voxel itself: only the border shell
   // needs clearing there; the per-op path stitches tiles into a zeroed volume
+  const bool cubic = tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2];
+  const bool unet_split_ok = cubic && fpl_unet_fast_available_f16s(prog, FPL_PREC_F16S);
   if (precision == FPL_PREC_AUTO)
-    precision = fpl_split_path_available(prog, FPL_PREC_F16S, offset, out_sz) ? FPL_PREC_F16S
-                                                                              : FPL_PREC_F32;
+    precision = (fpl_split_path_available(prog, FPL_PREC_F16S, offset, out_sz) || unet_split_ok)
+                    ? FPL_PREC_F16S : FPL_PREC_F32;
   const bool split = fpl_split_path_available(prog, precision, offset, out_sz);
-  FPL_REQUIRE(ctx, precision != FPL_PREC_F16S || split,
-              "fpl_infer_volume: the split-half kernels exist for vgg_like on its stride-4 "
-              "lattice only; use precision f32 (or f16) for this architecture");
+  FPL_REQUIRE(ctx, precision != FPL_PREC_F16S || split || unet_split_ok,
+              "fpl_infer_volume: the split-half kernels exist for vgg_like (stride-4 lattice) and "
+              "unet_like2 (cubic tiles) only; use precision f32 (or f16) for this architecture");
   const bool fast = zb < ze && (split || fpl_fast_path_available_bf16(prog, precision, offset, out_sz) ||
                                 fpl_fast_path_available_f16(prog, precision, offset, out_sz));
   if (wr_hi > wr_lo) {
@@ -290,7 +292,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   }
   if (!handled) {
     const bool unet_bf16 = (fpl_unet_fast_available_bf16(prog, precision) ||
-                            fpl_unet_fast_available_f16(prog, precision)) &&
+                            fpl_unet_fast_available_f16(prog, precision) ||
+                            fpl_unet_fast_available_f16s(prog, precision)) &&
                            tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2];
     const bool f32_mfma = precision == FPL_PREC_F32 && fpl_mfma_f32_supported(prog) &&
                           tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2] &&
@@ -298,7 +301,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || unet_bf16,
                 "fpl_infer_volume: no 16-bit MFMA kernels for this architecture yet; "
                 "use precision f32");
-    set_last_path(ctx, unet_bf16 ? (precision == FPL_PREC_F16 ? "unet_mfma_f16" : "unet_mfma_bf16")
+    set_last_path(ctx, unet_bf16 ? (precision == FPL_PREC_F16S ? "unet_split_f16"
+                                    : precision == FPL_PREC_F16 ? "unet_mfma_f16" : "unet_mfma_bf16")
                        : f32_mfma ? "mfma_f32" : "perop_f32");
     // tile list in the reference's order (z outer, x inner)
     std::vector<TileDesc> tiles;
@@ -356,7 +360,8 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
         FplTileIO io;
         io.Y = Y; io.X = X; io.tiles = tiles_dev + t0; io.dst = dst_dev;
         io.dst_z_base = dst_base; io.off = offset[0];
-        FPL_TRY((precision == FPL_PREC_F16 ? fpl_unet_forward_f16 : fpl_unet_forward_bf16)(
+        FPL_TRY((precision == FPL_PREC_F16S ? fpl_unet_forward_f16s
+                 : precision == FPL_PREC_F16 ? fpl_unet_forward_f16 : fpl_unet_forward_bf16)(
             ctx, prog, (const float *)in_batch, (int)nb, tile_in[0], nullptr, &io));
         continue;
       }

@@ -20,7 +20,16 @@
 // (probabilities within ~1e-4 of fp32 instead of ~1e-3) at a 65504 range, which the
 // weight packer checks.  FPLK(name) = name_bf16 / name_f16 keeps the two builds'
 // kernels and entry points apart.
-#ifdef FPL_F16
+// A third build of conv_mfma.hip (-DFPL_F16 -DFPL_SPLIT, csrc/build.py) runs the U-Net
+// executor on SPLIT operands (FPL_PREC_F16S): v = hi + lo, two IEEE halves; kernels and
+// entry points carry the suffix _f16s.
+#if defined(FPL_F16) && defined(FPL_SPLIT)
+typedef _Float16 h16_t;
+#define FPLK(name) name##_f16s
+#define FPL_PREC_STR "f16s"
+#define FPL_THIS_PREC FPL_PREC_F16S
+#define FPL_H16_SLOT 2
+#elif defined(FPL_F16)
 typedef _Float16 h16_t;
 #define FPLK(name) name##_f16
 #define FPL_PREC_STR "f16"
@@ -148,4 +157,62 @@ __device__ __forceinline__ void pool_relu_h16(u32x2 &pooled, const f32x4 &acc) {
 __device__ __forceinline__ unsigned short h16_bits(float f) {
   h16_t b = (h16_t)f;
   return __builtin_bit_cast(unsigned short, b);
+}
+
+// ---- split operands (FPL_PREC_F16S): v ~ hi + lo, hi = half(v), lo = half(v - hi) -------
+// ~22 significant bits between the two halves (v - hi is exact in fp32; lo may be a
+// subnormal half, which v_mfma_f32_16x16x32_f16 keeps: tools/micro/mfma_denorm.hip).
+struct Pair2 { unsigned hi, lo; };          // two values as packed halves
+struct Frag2 { h16x8 hi, lo; };             // a B fragment
+
+#ifdef FPL_F16
+// (a, b) -> packed hi halves and packed lo halves.  lo = half(v - hi) is one
+// v_fma_mix{lo,hi}_f16 per value: fma(hi as f16, -1, v) is exact in fp32, rounded once to
+// the half it writes (hipcc emits two conversions back, a packed subtract and a packed
+// conversion for the same arithmetic - 4 instructions instead of 2 in kernels whose VALU
+// issue is what the MFMAs wait for).
+__device__ __forceinline__ Pair2 split_pk(float a, float b) {
+  Pair2 r;
+  r.hi = cvt_pk_h16(a, b);
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r.lo)
+      : "v"(r.hi), "v"(a), "v"(b));
+  return r;
+}
+#else
+__device__ __forceinline__ Pair2 split_pk(float a, float b) {   // no split form on bfloat16
+  return Pair2{cvt_pk_h16(a, b), 0u};
+}
+#endif
+// ReLU as an integer max with 0 (negative floats are negative integers; -0.0 included):
+// one v_max_i32, where fmaxf costs a canonicalising v_max_f32 more per value
+__device__ __forceinline__ float relu_f32(float a) {
+  const int i = __builtin_bit_cast(int, a);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+__device__ __forceinline__ Pair2 split_pk_relu(float a, float b) {
+  return split_pk(relu_f32(a), relu_f32(b));
+}
+
+// two accumulator tiles -> the hi and lo B fragments of a K-step of the next layer, ReLU
+// applied (chain / spatial maps as pack_relu)
+__device__ __forceinline__ Frag2 pack_relu_split(const f32x4 &lo_blk, const f32x4 &hi_blk) {
+  u32x4 h, l;
+  Pair2 p;
+  p = split_pk_relu(lo_blk[0], lo_blk[1]); h[0] = p.hi; l[0] = p.lo;
+  p = split_pk_relu(lo_blk[2], lo_blk[3]); h[1] = p.hi; l[1] = p.lo;
+  p = split_pk_relu(hi_blk[0], hi_blk[1]); h[2] = p.hi; l[2] = p.lo;
+  p = split_pk_relu(hi_blk[2], hi_blk[3]); h[3] = p.hi; l[3] = p.lo;
+  Frag2 f;
+  f.hi = __builtin_bit_cast(h16x8, h);
+  f.lo = __builtin_bit_cast(h16x8, l);
+  return f;
+}
+
+// acc += (w_hi + w_lo)(b_hi + b_lo) without the lo x lo product
+__device__ __forceinline__ f32x4 mfma3(h16x8 wh, h16x8 wl, const Frag2 &b, f32x4 acc) {
+  acc = mfma16(wl, b.hi, acc);
+  acc = mfma16(wh, b.lo, acc);
+  return mfma16(wh, b.hi, acc);
 }

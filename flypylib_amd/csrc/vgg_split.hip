@@ -43,47 +43,6 @@ static_assert(CHP % 8 == 0, "a lane's 8 k-slots stay inside one tap");
 // byte offset, inside a voxel, of the hi halves of channels ch .. ch+3 (ch % 4 == 0)
 __host__ __device__ constexpr int chan_off(int ch) { return (ch / CHP) * PASS_BYTES + (ch % CHP) * 2; }
 
-struct Pair2 { unsigned hi, lo; };          // two values as packed halves
-struct Frag2 { h16x8 hi, lo; };             // a B fragment
-
-// (a, b) -> packed hi halves and packed lo halves.  lo = half(v - hi) is one
-// v_fma_mix{lo,hi}_f16 per value: fma(hi as f16, -1, v) is exact in fp32, rounded once to
-// the half it writes (hipcc emits two conversions back, a packed subtract and a packed
-// conversion for the same arithmetic - 4 instructions instead of 2 in kernels whose VALU
-// issue is what the MFMAs wait for).
-__device__ __forceinline__ Pair2 split_pk(float a, float b) {
-  Pair2 r;
-  r.hi = cvt_pk_h16(a, b);
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(r.lo)
-      : "v"(r.hi), "v"(a), "v"(b));
-  return r;
-}
-// ReLU as an integer max with 0 (negative floats are negative integers; -0.0 included):
-// one v_max_i32, where fmaxf costs a canonicalising v_max_f32 more per value
-__device__ __forceinline__ float relu_f32(float a) {
-  const int i = __builtin_bit_cast(int, a);
-  return __builtin_bit_cast(float, i > 0 ? i : 0);
-}
-__device__ __forceinline__ Pair2 split_pk_relu(float a, float b) {
-  return split_pk(relu_f32(a), relu_f32(b));
-}
-
-// two accumulator tiles (M-blocks 2s and 2s+1 of the previous layer) -> the B fragments
-// of K-step s of the next layer, ReLU applied (chain map of mfma_util.h)
-__device__ __forceinline__ Frag2 pack_relu_split(const f32x4 &lo_blk, const f32x4 &hi_blk) {
-  u32x4 h, l;
-  Pair2 p;
-  p = split_pk_relu(lo_blk[0], lo_blk[1]); h[0] = p.hi; l[0] = p.lo;
-  p = split_pk_relu(lo_blk[2], lo_blk[3]); h[1] = p.hi; l[1] = p.lo;
-  p = split_pk_relu(hi_blk[0], hi_blk[1]); h[2] = p.hi; l[2] = p.lo;
-  p = split_pk_relu(hi_blk[2], hi_blk[3]); h[3] = p.hi; l[3] = p.lo;
-  Frag2 f;
-  f.hi = __builtin_bit_cast(h16x8, h);
-  f.lo = __builtin_bit_cast(h16x8, l);
-  return f;
-}
 // The third M-block of a 48-channel layer fills only half a K-step: its hi and lo halves
 // share ONE fragment [hi | lo] (k-slots j < 4: hi, j >= 4: lo).  Against the weight step
 // [w_lo | w_hi] it yields both cross products in one MFMA, against [w_hi | w_lo] the
@@ -105,13 +64,6 @@ __device__ __forceinline__ f32x4 chain48(const h16x8 (&w)[4], const Frag2 &h01, 
   acc = mfma16(w[2], hx, acc);
   acc = mfma16(w[3], hx, acc);
   return mfma16(w[0], h01.hi, acc);
-}
-
-// acc += (w_hi + w_lo)(b_hi + b_lo) without the lo x lo product
-__device__ __forceinline__ f32x4 mfma3(h16x8 wh, h16x8 wl, const Frag2 &b, f32x4 acc) {
-  acc = mfma16(wl, b.hi, acc);
-  acc = mfma16(wh, b.lo, acc);
-  return mfma16(wh, b.hi, acc);
 }
 
 // four channels (one accumulator tile row group) of one voxel -> HBM, hi and lo halves

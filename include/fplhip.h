@@ -140,7 +140,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                      int32_t z_begin, int32_t z_end, float *dst, int dst_mem);
 
 /* name of the executor the last fpl_infer_volume / fpl_program_forward of this
- * context ran on: "vgg_fused_f16" | "vgg_fused_bf16" | "vgg_split_f16" | "unet_mfma_f16" |
+ * context ran on: "vgg_fused_f16" | "vgg_fused_bf16" | "vgg_split_f16" | "unet_split_f16" | "unet_mfma_f16" |
  * "unet_mfma_bf16" | "mfma_f32" | "perop_f32" | "none" (empty slab).  The 16-bit
  * fused kernels are keyed on the architectures of flypylib/fplmodels.py; any other
  * graph runs on the fp32 executors - this says which, instead of leaving the caller

@@ -1,0 +1,72 @@
+"""GPU parity for unet_like2 on split IEEE-half operands (csrc/conv_mfma.hip built with
+-DFPL_SPLIT, precision 'f16s'): every tensor as [hi 16 | lo 16] halves per 16 channels,
+(a_hi + a_lo)(w_hi + w_lo) in two MFMAs per 16 channels and tap.  Held to fp32-grade
+agreement (1e-5) with the emulation oracle of the same rounding points and with the fp32
+MFMA path, on the reference tile lattice."""
+import numpy as np
+import pytest
+
+from flypylib_amd import _capi, fplmodels, multi_gpu, synth
+from oracle import cnn_oracle, infer_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize('shape,tile', [((45, 38, 31), 28), ((60, 52, 70), 36),
+                                        ((110, 100, 104), 100)])
+def test_unet_split_matches_emulation_and_fp32(ctx, shape, tile):
+    g = fplmodels.unet_like2(tile)[0]
+    synth.synthetic_weights(g, 41)
+    prog = _capi.Program(ctx, g, (1, 1, 1))
+    u8 = synth.em_volume_u8(13, shape)
+    img = (u8.astype(np.float32) - np.float32(128)) / np.float32(33)
+    kw = dict(mean=128.0, std=33.0)
+    got = prog.infer_volume(u8, (tile,) * 3, (9,) * 3, precision=_capi.PREC_F16S, **kw)
+    assert ctx.last_path() == 'unet_split_f16'
+    f32gpu = prog.infer_volume(u8, (tile,) * 3, (9,) * 3, precision=_capi.PREC_F32, **kw)
+    if tile <= 36:
+        emu = infer_oracle.infer_lattice(
+            img, (tile,) * 3, (9,) * 3,
+            lambda b: cnn_oracle.unet_like2_forward_bf16emu(b.astype(np.float32), g.weights,
+                                                            kind='split'))
+        d = np.abs(got - emu)
+        print('split vs emulation %.2e' % d.max())
+        assert d.max() < TOL, 'vs split emulation: max %g' % d.max()
+    d = np.abs(got - f32gpu)
+    print('split vs fp32 %.2e' % d.max())
+    assert d.max() < TOL, 'split vs fp32: max %g' % d.max()
+    assert not got[:9].any() and not got[:, :, -9:].any()
+    assert f32gpu[9:-9, 9:-9, 9:-9].std() > 1e-3
+    # the default precision of the API takes this path
+    auto = prog.infer_volume(u8, (tile,) * 3, (9,) * 3, precision=_capi.PREC_AUTO, **kw)
+    assert ctx.last_path() == 'unet_split_f16' and np.array_equal(auto, got)
+
+
+def test_unet_split_slabs_equal_whole(ctx):
+    tile = 36
+    g = fplmodels.unet_like2(tile)[0]
+    synth.synthetic_weights(g, 42)
+    prog = _capi.Program(ctx, g, (1, 1, 1))
+    u8 = synth.em_volume_u8(14, (98, 60, 47))
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F16S)
+    whole = prog.infer_volume(u8, (tile,) * 3, (9,) * 3, **kw)
+    out = np.zeros_like(whole)
+    nz = multi_gpu.n_tile_rows(98, tile, 9)
+    for lo, hi in multi_gpu.slab_partition(nz, 3):
+        prog.infer_volume(u8, (tile,) * 3, (9,) * 3, z_range=(lo, hi), dst=out, **kw)
+    assert np.array_equal(out, whole)
+
+
+def test_unet_split_is_refused_for_the_other_unets(ctx):
+    """unet_like (1x1 second convs) has no split form: 'auto' gives it fp32, 'f16s' says no"""
+    from flypylib_amd import fplutils
+    off = fplutils.to3d(fplmodels.unet_like()[1][1])[0]
+    g = fplmodels.unet_like(30)[0]
+    synth.synthetic_weights(g, 3)
+    prog = _capi.Program(ctx, g, (1, 1, 1))
+    u8 = synth.em_volume_u8(1, (50, 41, 64))
+    prog.infer_volume(u8, (30,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
+    assert ctx.last_path() == 'mfma_f32'
+    with pytest.raises(_capi.FplHipError, match='split-half kernels'):
+        prog.infer_volume(u8, (30,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_F16S)

@@ -57,9 +57,8 @@ def main():
         src = torch.empty((n, n, n), dtype=torch.uint8, device='cuda')
         dst = torch.empty((n, n, n), dtype=torch.float32, device='cuda')
         ctx.synth_volume_u8(3, (n, n, n), out=src)
-        for pname, prec in (('bf16_mfma', _capi.PREC_BF16), ('f32_perop', _capi.PREC_F32)):
-            if pname == 'f32_perop' and n > 300:
-                continue
+        for pname, prec in (('bf16_mfma', _capi.PREC_BF16), ('f16_mfma', _capi.PREC_F16),
+                            ('f16s_split', _capi.PREC_F16S), ('f32_mfma', _capi.PREC_F32)):
             kw = dict(mean=128.0, std=33.0, precision=prec, dst=dst, dims=(n, n, n))
             prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
             ctx.synchronize()
