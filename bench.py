@@ -156,19 +156,21 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
     vgg_leg('configs0_520_f16s', 520, _capi.PREC_F16S, 'f16s', k)
     vgg_leg('configs0_520_f16', 520, _capi.PREC_F16, 'f16', k)
 
-    # configs[2]: unet_like2 on the reference lattice (tile 100, pitch 82), 510^3 sample
+    # configs[2]: unet_like2 on the reference lattice (tile 100, pitch 82), 510^3 sample:
+    # split halves (fp32-grade, what 'auto' runs) and plain f16
     g = fplmodels.unet_like2(100)[0]
     synth.synthetic_weights(g, 7)
     uprog = _capi.Program(ctx, g, (1, 1, 1))
     n = 510
-    dt, kern, path = _infer_pass(ctx, uprog, torch, n, 100, 9, _capi.PREC_F16, 2, 1, seed=3)
-    vox = (n - 18) ** 3
-    tf = vox * UNET2_FLOP / dt / 1e12
-    legs['configs2_unet_like2_510_f16'] = dict(
-        workload='unet_like2 inference %d^3 uint8 (216 reference tiles 100^3), f16' % n,
-        executor=path, ms=round(dt * 1e3, 3), mvox_s=round(vox / dt / 1e6, 1), bound='mfma',
-        achieved_tflops=round(tf, 2), peak_tflops=2500.0, frac=round(tf / 2500.0, 4),
-        kernel_ms=kern)
+    for pname, prec in (('f16s', _capi.PREC_F16S), ('f16', _capi.PREC_F16)):
+        dt, kern, path = _infer_pass(ctx, uprog, torch, n, 100, 9, prec, 2, 1, seed=3)
+        vox = (n - 18) ** 3
+        tf = vox * UNET2_FLOP / dt / 1e12
+        legs['configs2_unet_like2_510_%s' % pname] = dict(
+            workload='unet_like2 inference %d^3 uint8 (216 reference tiles 100^3), %s' % (n, pname),
+            executor=path, ms=round(dt * 1e3, 3), mvox_s=round(vox / dt / 1e6, 1), bound='mfma',
+            achieved_tflops=round(tf, 2), peak_tflops=2500.0, frac=round(tf / 2500.0, 4),
+            kernel_ms=kern)
     uprog.close()
 
     # configs[4] post-process: voxel2obj of one 512 + 2 x 35 substack (r 27, sigma 5)

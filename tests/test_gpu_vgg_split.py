@@ -89,11 +89,15 @@ def test_split_slabs_chunks_and_tilings_are_bit_identical(ctx, monkeypatch):
     assert np.array_equal(prog.infer_volume(u8, (46,) * 3, (7,) * 3, **kw), whole)
 
 
-def test_split_is_refused_for_other_graphs(ctx):
-    g = fplmodels.unet_like2(52)[0]
+def test_split_is_refused_for_graphs_without_split_kernels(ctx):
+    """split kernels exist for vgg_like and unet_like2 (tests/test_gpu_unet_split.py);
+    vgg_like2 has none: 'f16s' says so, 'auto' runs it on fp32 MFMAs"""
+    g = fplmodels.vgg_like2(36)[0]
     synth.synthetic_weights(g, 3)
-    prog = _capi.Program(ctx, g, (1, 1, 1))
-    u8 = synth.em_volume_u8(1, (60, 60, 60))
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(1, (60, 41, 48))
     with pytest.raises(_capi.FplHipError, match='split-half kernels'):
-        prog.infer_volume(u8, (52,) * 3, (9,) * 3, mean=128.0, std=33.0,
+        prog.infer_volume(u8, (36,) * 3, (10,) * 3, mean=128.0, std=33.0,
                           precision=_capi.PREC_F16S)
+    prog.infer_volume(u8, (36,) * 3, (10,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
+    assert ctx.last_path() == 'mfma_f32'
