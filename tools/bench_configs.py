@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--what', default='unet,train,v2o,pipeline')
     ap.add_argument('--unet-size', type=int, default=264)
+    ap.add_argument('--roi-precision', default='auto')
     ap.add_argument('--vgg2-size', type=int, default=1024)
     ap.add_argument('--sub', type=int, default=582)
     ap.add_argument('--roi-size', type=int, default=1536)
@@ -205,7 +206,8 @@ def main():
         from flypylib_amd import FplNetwork
         from oracle import voxel2obj_oracle
         n = a.roi_size
-        net = FplNetwork(fplmodels.vgg_like, precision='bf16')
+        # --roi-precision: 'auto' = the package's default (split halves for vgg_like)
+        net = FplNetwork(fplmodels.vgg_like, precision=a.roi_precision)
         synth.synthetic_weights(net.train_single, 9)
         net._set_infer()
         wd = tempfile.mkdtemp(prefix='fri_')
@@ -235,14 +237,16 @@ def main():
         from flypylib_amd import fplpipeline
         st = fplpipeline.normalisation_from_histogram(ctx.histogram_u8(cube), norm)
         net.infer_network.program.infer_volume(cube, net.infer_sz, net.rf_offset, mean=st['mn_use'],
-                                               std=norm[1], precision=_capi.PREC_BF16, dst=pred,
-                                               dims=(sz,) * 3)
+                                               std=norm[1],
+                                               precision=fplpipeline.fplobjdetect_precision(net, None),
+                                               dst=pred, dims=(sz,) * 3)
         t0 = time.perf_counter()
         ref = voxel2obj_oracle.voxel2obj(pred.to_host(), 27, 5, (ss.x - 35, ss.y - 35, ss.z - 35), 35, 0.1)
         t_cpu = time.perf_counter() - t0
         got = pickle.load(open(fplobjdetect.fri_filename(wd + '/work', ss), 'rb'))
         same = np.array_equal(ref['locs'], got['locs']) and np.array_equal(ref['conf'], got['conf'])
         res['full_roi_inference_%d' % n] = dict(
+            precision=a.roi_precision, executor=ctx.last_path(),
             substacks=len(roi), seconds=dt, mvox_s=n ** 3 / dt / 1e6,
             detections=int(len(out['conf'])), checked_substack=list(ss),
             checked_substack_detections=int(len(got['conf'])),

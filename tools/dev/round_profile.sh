@@ -14,10 +14,10 @@ case $w in
 tests)
   python -m pytest tests -m gpu -q > $out/${tag}_tests_gpu.log 2>&1; tail -2 $out/${tag}_tests_gpu.log ;;
 bench)
-  python bench.py > $out/${tag}_bench1024_f16.json 2> $out/bench_f16.err
-  cut -c1-200 $out/${tag}_bench1024_f16.json
+  python bench.py > $out/${tag}_bench1024_f16s.json 2> $out/bench_f16s.err
+  cut -c1-200 $out/${tag}_bench1024_f16s.json
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --no-legs --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.err
-  find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_bench1024_f16_kernel_stats.csv \;
+  find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_bench1024_f16s_kernel_stats.csv \;
   rm -rf $out/trace
   python tools/bench_v2o.py --reps 10 --out $out/${tag}_v2o582_bench.json > $out/v2o.log 2>&1; tail -1 $out/v2o.log
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o v2o -- python3 tools/bench_v2o.py --reps 10 > $out/trace_v2o.json 2> $out/trace_v2o.err
@@ -25,14 +25,18 @@ bench)
   rm -rf $out/trace
   echo bench done ;;
 pmc)
-  python tools/profile_pmc.py --size 1024 --precision f16 --out $out/pmc > $out/pmc.log 2>&1 && \
-    cp $out/pmc/summary.json $out/${tag}_pmc_hbm_1024_f16.json && cp $out/pmc/summary.md $out/${tag}_pmc_hbm_1024_f16.md
+  python tools/profile_pmc.py --size 1024 --precision f16s --out $out/pmc > $out/pmc.log 2>&1 && \
+    cp $out/pmc/summary.json $out/${tag}_pmc_hbm_1024_f16s.json && cp $out/pmc/summary.md $out/${tag}_pmc_hbm_1024_f16s.md
+  python tools/profile_pmc.py --size 1024 --precision f16 --out $out/pmc16 > $out/pmc16.log 2>&1 && \
+    cp $out/pmc16/summary.json $out/${tag}_pmc_hbm_1024_f16.json && cp $out/pmc16/summary.md $out/${tag}_pmc_hbm_1024_f16.md
+  rm -rf $out/pmc16
   python tools/profile_pmc.py --target v2o --size 582 --out $out/pmc_v2o > $out/pmc_v2o.log 2>&1 && \
     cp $out/pmc_v2o/summary.json $out/${tag}_v2o582_pmc.json
   rm -rf $out/pmc $out/pmc_v2o
   echo pmc done ;;
 other)
   python tools/bench_configs.py --out $out/${tag}_other_configs.json > $out/other.log 2>&1; tail -2 $out/other.log
-  python tools/bench_configs.py --what roi --out $out/${tag}_roi1536.json > $out/roi.log 2>&1; tail -1 $out/roi.log ;;
+  python tools/bench_configs.py --what roi --out $out/${tag}_roi1536.json > $out/roi.log 2>&1; tail -1 $out/roi.log
+  python tools/bench_configs.py --what roi --roi-precision f16 --out $out/${tag}_roi1536_f16.json > $out/roi16.log 2>&1; tail -1 $out/roi16.log ;;
 esac
 done
