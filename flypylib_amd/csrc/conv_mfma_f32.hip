@@ -8,8 +8,10 @@
 // k-slot (j, g) of a block is bound to k = 4g + j, so a lane's operands for the
 // whole block are ONE 16-byte read (4 consecutive channels of a tap / 4 floats of
 // a fragment).  conv3_f32 mirrors conv3_bf16 (conv_mfma.hip): LDS tile of 16
-// channels x (6 x 6 x 18) voxels at 96 B pitch, weight fragments through a 2-slot
-// LDS ring staged through registers, two workgroups per CU.
+// channels x (6 x 6 x 18) voxels at 96 B pitch; the weight fragments (MB x 1 KiB per
+// tap, the same for every wave) go from L2 straight into each wave's registers, three
+// taps ahead of their use - no LDS ring and no barrier inside the tap loop (round 3; the
+// ring cost a barrier every three taps); two workgroups per CU.
 #include <algorithm>
 
 #include "fast_paths.h"
@@ -22,9 +24,8 @@ constexpr int TZ = 6, TY = 6, TX = 18;
 constexpr int TILE_BYTES = TZ * TY * TX * PITCH;
 constexpr int CC = 16;                    // channels per LDS tile chunk
 constexpr int KB = 27;                    // K-blocks (taps) per channel chunk
-constexpr int KC = 3;                     // K-blocks per weight ring slot
-constexpr int NCH = KB / KC;              // 9 ring slots per channel chunk
-constexpr int WDEPTH = 3;
+constexpr int WQF = 3;                    // taps of weight fragments in flight per wave
+static_assert(KB % WQF == 0, "the fragment queue's phase is static inside a channel chunk");
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -103,29 +104,6 @@ struct Chain1F {
 #pragma unroll
           for (int sub = 0; sub < NSUB; ++sub)
             acc1[sub][m] = mfma4(w[q][m][j], bq[sub][j], acc1[sub][m]);
-    }
-  }
-};
-
-template <int RING> struct WRegF {
-  static constexpr int PIECES = RING / 16;
-  static constexpr int PER = (PIECES + 255) / 256;
-  u32x4 r[PER];
-  __device__ __forceinline__ void load(const unsigned char *w, int64_t chunk, int tid) {
-    const unsigned char *srcp = w + chunk * RING;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int piece = tid + 256 * k;
-      piece = piece < PIECES ? piece : PIECES - 1;
-      r[k] = *reinterpret_cast<const u32x4 *>(srcp + (size_t)piece * 16);
-    }
-  }
-  __device__ __forceinline__ void store(unsigned char *slot, int tid) const {
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int piece = tid + 256 * k;
-      piece = piece < PIECES ? piece : PIECES - 1;
-      *reinterpret_cast<u32x4 *>(slot + (size_t)piece * 16) = r[k];
     }
   }
 };
@@ -211,11 +189,9 @@ __device__ __forceinline__ f32x4 act4(const f32x4 &v, int act) {
 
 template <int MB, int MB1 = 0, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
-  constexpr int RING = KC * MB * 1024;
   constexpr int PIECES = TZ * TY * TX * 4;          // 4 x 16 B per voxel (16 ch)
   constexpr int NT = (PIECES + 255) / 256;
   unsigned char *tile = smem;
-  unsigned char *ring = smem + TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int x0 = blockIdx.x * 16, y0 = blockIdx.y * 4;
@@ -233,13 +209,14 @@ __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
   }
-  const int64_t total_chunks = (int64_t)a.ncc * NCH;
-  const unsigned char *wg = reinterpret_cast<const unsigned char *>(a.w);
-  WRegF<RING> wst[WDEPTH];
+  const int64_t total_steps = (int64_t)a.ncc * KB;
+  const unsigned char *wl = reinterpret_cast<const unsigned char *>(a.w) + lane * 16;
+  f32x4 wq[WQF][MB];
 #pragma unroll
-  for (int d = 0; d < WDEPTH; ++d) wst[d].load(wg, d < total_chunks ? d : 0, tid);
-  wst[0].store(ring, tid);
-  wst[0].load(wg, WDEPTH < total_chunks ? WDEPTH : 0, tid);
+  for (int d = 0; d < WQF; ++d)
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      wq[d][b] = *reinterpret_cast<const f32x4 *>(wl + (size_t)(d * MB + b) * 1024);
 
   for (int cc = 0; cc < a.ncc; ++cc) {
     const SrcF s = a.src[cc];
@@ -281,38 +258,29 @@ __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
       }
     }
     __syncthreads();
-    const int64_t gc0 = (int64_t)cc * NCH;
+    const int64_t gs0 = (int64_t)cc * KB;
 #pragma unroll
-    for (int ck = 0; ck < NCH; ++ck) {
-      const int64_t gc = gc0 + ck;
-      if (ck > 0) __syncthreads();
-      {
-        int64_t nxt = gc + 1 + WDEPTH;
-        nxt = nxt < total_chunks ? nxt : 0;
-        wst[(ck + 1) % WDEPTH].store(ring + ((gc + 1) & 1) * RING, tid);
-        wst[(ck + 1) % WDEPTH].load(wg, nxt, tid);
-      }
-      const unsigned char *wslot = ring + (gc & 1) * RING + lane * 16;
+    for (int tap = 0; tap < KB; ++tap) {
+      const unsigned toff = (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PITCH);
+      f32x4 bf[4];
 #pragma unroll
-      for (int ks = 0; ks < KC; ++ks) {
-        const int tap = ck * KC + ks;
-        const unsigned toff = (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PITCH);
-        f32x4 wf[MB], bf[4];
+      for (int sub = 0; sub < 4; ++sub)
+        bf[sub] = *reinterpret_cast<const f32x4 *>(tile + vbase + toff + sub * TX * PITCH);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int b = 0; b < MB; ++b)
-          wf[b] = *reinterpret_cast<const f32x4 *>(wslot + (ks * MB + b) * 1024);
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
-          bf[sub] = *reinterpret_cast<const f32x4 *>(tile + vbase + toff + sub * TX * PITCH);
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+          for (int b = 0; b < MB; ++b)
+            acc[sub][b] = mfma4(wq[tap % WQF][b][j], bf[sub][j], acc[sub][b]);
+      __builtin_amdgcn_s_setprio(0);
+      {
+        int64_t nxt = gs0 + tap + WQF;
+        nxt = nxt < total_steps ? nxt : 0;             // past the end: a harmless reload
 #pragma unroll
-          for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-            for (int b = 0; b < MB; ++b)
-              acc[sub][b] = mfma4(wf[b][j], bf[sub][j], acc[sub][b]);
-        __builtin_amdgcn_s_setprio(0);
+        for (int b = 0; b < MB; ++b)
+          wq[tap % WQF][b] = *reinterpret_cast<const f32x4 *>(wl + ((size_t)nxt * MB + b) * 1024);
       }
     }
   }
@@ -758,7 +726,7 @@ struct View {
 
 template <int MB>
 int launch3(fpl_ctx *ctx, Conv3F &a, int n) {
-  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024;
+  constexpr int SMEM = TILE_BYTES;
   // function attributes belong to the current device: one flag per device (a process may
   // drive several GPUs, one context each; setting it twice is harmless)
   static bool attr_set[FPL_MAX_DEVICES] = {false};
@@ -777,7 +745,7 @@ int launch3(fpl_ctx *ctx, Conv3F &a, int n) {
 // conv3 + chained conv1 (+ pool): the (MB, MB1) pairs the reference's architectures need
 template <int MB, int MB1, bool POOL>
 int launch3_fused(fpl_ctx *ctx, Conv3F &a, int n) {
-  constexpr int SMEM = TILE_BYTES + 2 * KC * MB * 1024;
+  constexpr int SMEM = TILE_BYTES;
   static bool attr_set[FPL_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
     FPL_HIP(ctx, hipFuncSetAttribute((const void *)conv3_f32<MB, MB1, POOL>,

@@ -187,6 +187,31 @@ def test_infer_volume_slabs_equal_whole(ctx):
     assert np.array_equal(out, whole)
 
 
+@pytest.mark.parametrize('shape', [(90, 40, 36), (131, 120, 97)])
+def test_f32_super_tiles_equal_the_reference_tiles_bit_for_bit(ctx, shape, monkeypatch):
+    """the fp32 MFMA path computes m^3 neighbouring reference tiles as one larger tile
+    (infer.hip, tiles_mergeable); the arithmetic per voxel is the same, so the volume is
+    bit-identical to the one-tile-at-a-time lattice - whole volume and rank slabs"""
+    from flypylib_amd import multi_gpu
+    g = fplmodels.vgg_like(30)[0]
+    synth.synthetic_weights(g, 19)
+    prog = _prog(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(23, shape)
+    kw = dict(mean=128.0, std=33.0)
+    merged = prog.infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
+    n = multi_gpu.n_tile_rows(shape[0], 30, 7)
+    parts = [(zr, prog.infer_volume(u8, (30,) * 3, (7,) * 3, z_range=zr, **kw))
+             for zr in multi_gpu.slab_partition(n, 2)]
+    monkeypatch.setenv('FPL_NO_TILE_MERGE', '1')
+    plain = prog.infer_volume(u8, (30,) * 3, (7,) * 3, **kw)
+    assert ctx.last_path() == 'mfma_f32'
+    assert plain[7:-7, 7:-7, 7:-7].std() > 1e-3
+    assert np.array_equal(merged, plain)
+    for zr, part in parts:
+        lo, hi = multi_gpu.slab_rows(zr, shape[0], 30, 7)
+        assert np.array_equal(part[lo:hi], plain[lo:hi])
+
+
 def test_fplnetwork_infer_api(ctx):
     net = FplNetwork(fplmodels.vgg_like)
     assert net.rf_size == (18, 18, 18) and net.rf_offset == (7, 7, 7)
