@@ -122,6 +122,15 @@ def load_library(path=None):
             'libfplhip.so not found at %s - build it with '
             '`python -m flypylib_amd.csrc.build` (there is no CPU fallback)'
             % path)
+    # One HIP runtime per process: PyTorch-ROCm carries its own libamdhip64, and whichever
+    # copy is loaded second finds "no HIP GPUs".  With torch imported first, libfplhip.so's
+    # NEEDED libamdhip64 resolves to the copy torch already loaded, and device tensors,
+    # streams and this library's contexts share one runtime (train._DeviceStager,
+    # pipeline buffers, torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
@@ -573,16 +582,23 @@ class Trainer:
     def step(self, data, labels, seed=0):
         """forward + loss + backward; data (B,D,H,W[,1]) f32, labels
         (B,d,h,w[,1]) u8.  Returns (loss, accuracy); gradients stay on device."""
-        x = np.ascontiguousarray(data, np.float32)
-        if x.ndim == 5:
-            x = x[..., 0]
-        y = np.ascontiguousarray(labels, np.uint8)
-        if y.ndim == 5:
-            y = y[..., 0]
+        if isinstance(data, np.ndarray) or not hasattr(data, 'data_ptr'):
+            x = np.ascontiguousarray(data, np.float32)
+            y = np.ascontiguousarray(labels, np.uint8)
+        else:
+            # batch already resident on this trainer's GPU (train._DeviceStager: uploaded on
+            # a side stream while the previous step ran); contiguous f32 / u8 tensors
+            x, y = data, labels
+            if 'float32' not in str(x.dtype) or 'uint8' not in str(y.dtype) or \
+                    not x.is_contiguous() or not y.is_contiguous():
+                raise TypeError('device batches must be contiguous float32 data / uint8 labels')
+        shape = tuple(int(v) for v in x.shape)
+        if len(shape) == 5:
+            shape = shape[:4]                     # trailing channel axis of 1
         loss, acc = C.c_float(), C.c_float()
         self.ctx.check(self.ctx.lib.fpl_trainer_step(
-            self.h, _ptr(x), MEM_HOST, _ptr(y), MEM_HOST, x.shape[0],
-            _arr(x.shape[1:], C.c_int32), C.c_uint64(int(seed)),
+            self.h, _ptr(x), _mem_of(x), _ptr(y), _mem_of(y), shape[0],
+            _arr(shape[1:], C.c_int32), C.c_uint64(int(seed)),
             C.byref(loss), C.byref(acc)))
         return loss.value, acc.value
 

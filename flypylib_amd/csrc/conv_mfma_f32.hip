@@ -429,6 +429,74 @@ __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
   if (STATS) cs.finish(red, a.stats, a.cout);
 }
 
+// The same GEMM when cin is exactly 16 * NKB and the fragments fit the register file: the
+// weights are loaded once per wave instead of once per 16 voxels (the generic kernel pulls
+// 3 x its input bytes through the vector-memory path as weight fragments), and the next
+// group's voxels are in flight while this one is multiplied.  Same group order, same K
+// order: bit-identical outputs and statistics.
+template <int MB, int NKB, bool STATS>
+__global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
+  __shared__ double red[STATS ? 4 * 2 * 16 * MB : 1];
+  ChanStats<STATS ? MB : 1> cs;
+  if (STATS) cs.clear();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  f32x4 sh[MB], wr[NKB][MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * b + 4 * g + r;
+      sh[b][r] = co < a.cout ? a.shift[co] : 0.f;
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      wr[kb][b] = *reinterpret_cast<const f32x4 *>(a.w + ((int64_t)(kb * MB + b) * 64 + lane) * 4);
+  }
+  const int64_t groups = (a.M + 15) / 16, stride = (int64_t)gridDim.x * 4;
+  int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+  f32x4 nx[NKB];
+  {
+    const int64_t m = min(grp * 16 + c, a.M - 1);
+    if (grp < groups)
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+        nx[kb] = *reinterpret_cast<const f32x4 *>(a.in + m * (16 * NKB) + 16 * kb + 4 * g);
+  }
+  for (; grp < groups; grp += stride) {
+    const int64_t m = grp * 16 + c;
+    const bool ok = m < a.M;
+    f32x4 bf[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) bf[kb] = nx[kb];
+    if (grp + stride < groups) {
+      const int64_t m2 = min((grp + stride) * 16 + c, a.M - 1);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+        nx[kb] = *reinterpret_cast<const f32x4 *>(a.in + m2 * (16 * NKB) + 16 * kb + 4 * g);
+    }
+    f32x4 acc[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = sh[b];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[b] = mfma4(wr[kb][b][j], bf[kb][j], acc[b]);
+    if (ok) {
+      float *dst = a.out + m * a.cout;
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        const f32x4 o = act4(acc[b], a.act);
+        store_quad(dst, 16 * b + 4 * g, a.cout, o, FPL_ACT_NONE);
+        if (STATS) cs.add(b, o);
+      }
+    }
+  }
+  if (STATS) cs.finish(red, a.stats, a.cout);
+}
+
 // ---- conv3 1 -> cout (fp32): 27 taps = 2 K-blocks (k-slot (j,g) of block q = tap
 // 16q + 4g + j), gathered straight from an f32 LDS tile ------------------------------
 constexpr int ST_Z = 4, ST_Y = 8, ST_X = 64;
@@ -772,6 +840,14 @@ template <int MB>
 int launch1(fpl_ctx *ctx, Conv1F &a) {
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
   TimedLaunch tl(ctx, "mfma_conv1_f32");
+  // weights-in-registers form for the 48- and 96-channel inputs of the vgg / U-Net blocks
+  if constexpr (MB <= 3) {
+    if (a.cin == 48 && !getenv("FPL_CONV1_GENERIC")) {
+      if (a.stats) conv1_f32_wreg<MB, 3, true><<<grid, 256, 0, ctx->stream>>>(a);
+      else conv1_f32_wreg<MB, 3, false><<<grid, 256, 0, ctx->stream>>>(a);
+      return 0;
+    }
+  }
   if (a.stats) conv1_f32<MB, true><<<grid, 256, 0, ctx->stream>>>(a);
   else conv1_f32<MB, false><<<grid, 256, 0, ctx->stream>>>(a);
   return 0;
@@ -1279,6 +1355,89 @@ __global__ __launch_bounds__(256) void conv3_wgrad_cin1_f32(WgradArgs a, int64_t
       }
 }
 
+// The same product without LDS or barriers (round 3): a wave walks rows of 16 output voxels;
+// lane (c, g) of K-step j reads its dY scalars (voxel 4j + g, channels 16b + c: 64
+// contiguous bytes per 16 lanes) and its two shifted input scalars (taps c and 16 + c; the
+// input volume stays in L2) straight from global memory, one row ahead of the MFMAs.  The
+// LDS form above ran load -> barrier -> multiply -> barrier and reached a quarter of the
+// dY stream's HBM rate.
+__global__ __launch_bounds__(256) void conv3_wgrad_cin1_direct_f32(WgradArgs a, int64_t rows, int nbx) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int64_t toff[2];
+  bool tap_ok[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int t = 16 * mb + c;
+    tap_ok[mb] = t < 27;
+    toff[mb] = tap_ok[mb] ? ((int64_t)(t / 9) * a.H + (t / 3) % 3) * a.W + t % 3 : 0;
+  }
+  f32x4 acc[2][3];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[mb][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float an[4][2], bn[4][3];
+  auto fetch = [&](int64_t row) {
+    const int x0 = (int)(row % nbx) * 16;
+    int64_t t = row / nbx;
+    const int y = (int)(t % a.oh); t /= a.oh;
+    const int z = (int)(t % a.od);
+    const int64_t n = t / a.od;
+    const float *xr = a.x + (((int64_t)n * a.D + z) * a.H + y) * a.W;
+    const float *yr = a.dy + ((((int64_t)n * a.od + z) * a.oh + y) * a.ow) * a.cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xv = x0 + 4 * j + g;
+      const bool ok = xv < a.ow;
+      const int xs = ok ? xv : 0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int co = 16 * b + c;
+        bn[j][b] = (ok && co < a.cout) ? yr[(int64_t)xs * a.cout + co] : 0.f;
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) an[j][mb] = (ok && tap_ok[mb]) ? xr[xs + toff[mb]] : 0.f;
+    }
+  };
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row < rows) fetch(row);
+  for (; row < rows; row += stride) {
+    float av[4][2], bv[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) av[j][mb] = an[j][mb];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) bv[j][b] = bn[j][b];
+    }
+    if (row + stride < rows) fetch(row + stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[mb][b] = mfma4(av[j][mb], bv[j][b], acc[mb][b]);
+  }
+  // one sum per workgroup, then one atomic per element
+  __shared__ float red[4][2 * 3 * 256];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][((mb * 3 + b) * 4 + r) * 64 + lane] = acc[mb][b][r];
+  __syncthreads();
+  for (int i = tid; i < 2 * 3 * 256; i += 256) {
+    const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    const int ln = i & 63, r = (i >> 6) & 3, mbb = i >> 8;
+    const int mb = mbb / 3, b = mbb % 3;
+    const int tap = 16 * mb + 4 * (ln >> 4) + r, co = 16 * b + (ln & 15);
+    if (tap < 27 && co < a.cout && v != 0.f) atomicAdd(&a.dw[(int64_t)tap * a.cout + co], v);
+  }
+}
+
 // ---- weight gradient, 1x1x1: dW[ci][co] += sum_m X[m][ci] * dY[m][co]; one workgroup
 // = 1024 voxels (256 per wave) x one 16-channel input chunk x up to 48 output channels
 struct Wgrad1Args {
@@ -1344,27 +1503,33 @@ __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict
     for (int b = 0; b < 3; ++b) acc[q][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int64_t groups = (M + 15) / 16;
   const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += 2 * stride) {
-    f32x3 av[2][4], bv[2][4];
+  // the next group's rows are in flight while this one is multiplied (same group order as
+  // the two-groups-per-iteration form it replaces: same sums)
+  f32x3 an[4], bn[4];
+  auto fetch = [&](int64_t grp) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = grp * 16 + 4 * g + j;                    // k-slot (g, j) = voxel
+      const bool ok = m < M;
+      const int64_t mm = ok ? m : 0;
+      an[j] = *reinterpret_cast<const f32x3 *>(x + mm * 48 + 3 * c);
+      bn[j] = *reinterpret_cast<const f32x3 *>(dy + mm * 48 + 3 * c);
+      if (!ok) an[j] = f32x3{0.f, 0.f, 0.f};
+    }
+  };
+  int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+  if (grp < groups) fetch(grp);
+  for (; grp < groups; grp += stride) {
+    f32x3 av[4], bv[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t m = (grp + u * stride) * 16 + 4 * g + j;   // k-slot (g, j) = voxel
-        const bool ok = m < M;
-        const int64_t mm = ok ? m : 0;
-        av[u][j] = *reinterpret_cast<const f32x3 *>(x + mm * 48 + 3 * c);
-        bv[u][j] = *reinterpret_cast<const f32x3 *>(dy + mm * 48 + 3 * c);
-        if (!ok) av[u][j] = f32x3{0.f, 0.f, 0.f};
-      }
+    for (int j = 0; j < 4; ++j) { av[j] = an[j]; bv[j] = bn[j]; }
+    if (grp + stride < groups) fetch(grp + stride);
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) acc[q][b] = mfma4(av[u][j][q], bv[u][j][b], acc[q][b]);
+        for (int b = 0; b < 3; ++b) acc[q][b] = mfma4(av[j][q], bv[j][b], acc[q][b]);
   }
   // D row 4g + r of block (q, b) is ci = 3 (4g + r) + q, column c is co = 3c + b
 #pragma unroll
@@ -1577,7 +1742,13 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
     const int64_t total = (int64_t)nbx * nby * n * a.zblocks;
     const unsigned grid1 = (unsigned)std::min<int64_t>(total, (int64_t)ctx->n_cu * 3);
     TimedLaunch tl(ctx, "mfma_wgrad3_f32_cin1");
-    conv3_wgrad_cin1_f32<<<grid1, 256, SMEM1, ctx->stream>>>(a, total, nbx, nby);
+    if (getenv("FPL_WGRAD_CIN1_LDS")) {
+      conv3_wgrad_cin1_f32<<<grid1, 256, SMEM1, ctx->stream>>>(a, total, nbx, nby);
+      return 0;
+    }
+    const int64_t rows = (int64_t)n * od * oh * nbx;
+    const unsigned gridd = (unsigned)std::min<int64_t>(ceil_div64(rows, 4), (int64_t)ctx->n_cu * 8);
+    conv3_wgrad_cin1_direct_f32<<<gridd, 256, 0, ctx->stream>>>(a, rows, nbx);
     return 0;
   }
   constexpr int SMEM = TILE_BYTES + 256 * WG_YP;

@@ -212,6 +212,19 @@ def test_f32_super_tiles_equal_the_reference_tiles_bit_for_bit(ctx, shape, monke
         assert np.array_equal(part[lo:hi], plain[lo:hi])
 
 
+def test_conv1_weights_in_registers_equals_the_generic_kernel(ctx, monkeypatch):
+    """conv1_f32_wreg (cin 48: fragments loaded once per wave, next voxels prefetched)
+    keeps the generic kernel's group and K order: same bits"""
+    g = fplmodels.vgg_like(30)[0]
+    synth.synthetic_weights(g, 21)
+    prog = _prog(ctx, g, (4, 4, 4))
+    x = (synth.hash_uniform_f32(6, (3, 30, 30, 30)) - np.float32(0.5))
+    fast = prog.forward(x)
+    monkeypatch.setenv('FPL_CONV1_GENERIC', '1')
+    slow = prog.forward(x)
+    assert fast.std() > 1e-3 and np.array_equal(fast, slow)
+
+
 def test_fplnetwork_infer_api(ctx):
     net = FplNetwork(fplmodels.vgg_like)
     assert net.rf_size == (18, 18, 18) and net.rf_offset == (7, 7, 7)
