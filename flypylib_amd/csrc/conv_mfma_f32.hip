@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
     }
     __syncthreads();
     const int64_t gs0 = (int64_t)cc * KB;
+    // a z plane past the output extent (ragged last block): nothing to multiply - the
+    // SIMD goes to the CU's other workgroup
+    if (z0 + wave >= a.OD) continue;
 #pragma unroll
     for (int tap = 0; tap < KB; ++tap) {
       const unsigned toff = (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PITCH);
@@ -1235,6 +1238,7 @@ __global__ __launch_bounds__(512) void conv3_wgrad_f32(WgradArgs a, int64_t tota
   __syncthreads();
   for (int row = 0; row < 16; ++row) {             // (z,y) rows of 16 x
     const int vz = row >> 2, vy = row & 3;
+    if (z0 + vz >= a.od || y0 + vy >= a.oh) continue;   // a row of zeros (ragged extent)
     float bv[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
