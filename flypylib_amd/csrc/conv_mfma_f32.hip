@@ -375,7 +375,14 @@ struct Conv1F {
   int act;
   float *out; int cout;
   double *stats;                           // STATS: part[grid][2][cout]
+  FplBnView bn = {nullptr, nullptr, nullptr, nullptr};   // conv1_f32_wreg<.., BN>: in -> relu(bn(in))
 };
+
+// train.hip's bn_affine: the forward value and every recomputation of the ReLU mask in the
+// backward passes use this one rounding sequence
+__device__ __forceinline__ float bn_relu_f(float v, float m, float s, float g, float b) {
+  return fmaxf(__fmaf_rn(__fmul_rn(__fsub_rn(v, m), s), g, b), 0.f);
+}
 
 template <int MB, bool STATS>
 __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
@@ -437,9 +444,17 @@ __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
 // 3 x its input bytes through the vector-memory path as weight fragments), and the next
 // group's voxels are in flight while this one is multiplied.  Same group order, same K
 // order: bit-identical outputs and statistics.
-template <int MB, int NKB, bool STATS>
+template <int MB, int NKB, bool STATS, bool BN = false>
 __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
   __shared__ double red[STATS ? 4 * 2 * 16 * MB : 1];
+  // BN: the four per-channel vectors, read back as 16-B pieces of a lane's four channels
+  __shared__ f32x4 prm[BN ? 4 * NKB * 4 : 1];
+  if (BN) {
+    const float *src[4] = {a.bn.mean, a.bn.invstd, a.bn.gamma, a.bn.beta};
+    for (int i = threadIdx.x; i < 4 * NKB * 16; i += 256)
+      reinterpret_cast<float *>(prm)[i] = src[i / (NKB * 16)][i % (NKB * 16)];
+    __syncthreads();
+  }
   ChanStats<STATS ? MB : 1> cs;
   if (STATS) cs.clear();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -472,6 +487,15 @@ __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
     f32x4 bf[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) bf[kb] = nx[kb];
+    if (BN) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const f32x4 pm = prm[(0 * NKB + kb) * 4 + g], ps = prm[(1 * NKB + kb) * 4 + g],
+                    pg = prm[(2 * NKB + kb) * 4 + g], pb = prm[(3 * NKB + kb) * 4 + g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bf[kb][q] = bn_relu_f(bf[kb][q], pm[q], ps[q], pg[q], pb[q]);
+      }
+    }
     if (grp + stride < groups) {
       const int64_t m2 = min((grp + stride) * 16 + c, a.M - 1);
 #pragma unroll
@@ -845,12 +869,18 @@ int launch1(fpl_ctx *ctx, Conv1F &a) {
   TimedLaunch tl(ctx, "mfma_conv1_f32");
   // weights-in-registers form for the 48- and 96-channel inputs of the vgg / U-Net blocks
   if constexpr (MB <= 3) {
+    if (a.cin == 48 && a.bn.mean) {
+      if (a.stats) conv1_f32_wreg<MB, 3, true, true><<<grid, 256, 0, ctx->stream>>>(a);
+      else conv1_f32_wreg<MB, 3, false, true><<<grid, 256, 0, ctx->stream>>>(a);
+      return 0;
+    }
     if (a.cin == 48 && !getenv("FPL_CONV1_GENERIC")) {
       if (a.stats) conv1_f32_wreg<MB, 3, true><<<grid, 256, 0, ctx->stream>>>(a);
       else conv1_f32_wreg<MB, 3, false><<<grid, 256, 0, ctx->stream>>>(a);
       return 0;
     }
   }
+  if (a.bn.mean) return fpl_fail(ctx, "conv1: no BatchNorm-view kernel for %d -> %d", a.cin, a.cout);
   if (a.stats) conv1_f32<MB, true><<<grid, 256, 0, ctx->stream>>>(a);
   else conv1_f32<MB, false><<<grid, 256, 0, ctx->stream>>>(a);
   return 0;
@@ -1494,12 +1524,21 @@ __global__ __launch_bounds__(256) void conv1_wgrad_f32(Wgrad1Args a) {
 // Partials per workgroup, then a deterministic sum (no float atomics).
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
+template <bool BN>
 __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict__ x,
                                                          const float *__restrict__ dy,
-                                                         int64_t M, float *__restrict__ part) {
+                                                         int64_t M, float *__restrict__ part,
+                                                         FplBnView bn) {
   __shared__ float red[4][2304];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
+  f32x3 pm = {0.f, 0.f, 0.f}, ps = pm, pg = pm, pb = pm;     // BN: x -> relu(bn(x))
+  if (BN) {
+    pm = *reinterpret_cast<const f32x3 *>(bn.mean + 3 * c);
+    ps = *reinterpret_cast<const f32x3 *>(bn.invstd + 3 * c);
+    pg = *reinterpret_cast<const f32x3 *>(bn.gamma + 3 * c);
+    pb = *reinterpret_cast<const f32x3 *>(bn.beta + 3 * c);
+  }
   f32x4 acc[3][3];
 #pragma unroll
   for (int q = 0; q < 3; ++q)
@@ -1509,7 +1548,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict
   const int64_t stride = (int64_t)gridDim.x * 4;
   // the next group's rows are in flight while this one is multiplied (same group order as
   // the two-groups-per-iteration form it replaces: same sums)
-  f32x3 an[4], bn[4];
+  f32x3 an[4], bn_[4];
   auto fetch = [&](int64_t grp) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1517,7 +1556,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict
       const bool ok = m < M;
       const int64_t mm = ok ? m : 0;
       an[j] = *reinterpret_cast<const f32x3 *>(x + mm * 48 + 3 * c);
-      bn[j] = *reinterpret_cast<const f32x3 *>(dy + mm * 48 + 3 * c);
+      bn_[j] = *reinterpret_cast<const f32x3 *>(dy + mm * 48 + 3 * c);
       if (!ok) an[j] = f32x3{0.f, 0.f, 0.f};
     }
   };
@@ -1526,7 +1565,18 @@ __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict
   for (; grp < groups; grp += stride) {
     f32x3 av[4], bv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { av[j] = an[j]; bv[j] = bn[j]; }
+    for (int j = 0; j < 4; ++j) { av[j] = an[j]; bv[j] = bn_[j]; }
+    if (BN) {
+      // rows past M were zeroed by fetch(); relu(bn(0)) is not 0, but their dY rows are
+      // loaded from voxel 0 - zero THOSE instead
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = grp * 16 + 4 * g + j < M;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          av[j][q] = ok ? bn_relu_f(av[j][q], pm[q], ps[q], pg[q], pb[q]) : 0.f;
+      }
+    }
     if (grp + stride < groups) fetch(grp + stride);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -1592,9 +1642,14 @@ int64_t fpl_tm_conv_stats_rows(fpl_ctx *ctx, int n, int D, int H, int W_, int ci
   return 0;
 }
 
+// both the forward and the weight-gradient kernel must take the view
+bool fpl_tm_bn_view_supported(int k, int cin, int cout) { return k == 1 && cin == 48 && cout == 48; }
+
 int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int k,
                     int cout, const float *Wd, const float *bias, int act, float *y,
-                    double *stats) {
+                    double *stats, const FplBnView *bn) {
+  FPL_REQUIRE(ctx, !bn || fpl_tm_bn_view_supported(k, cin, cout),
+              "conv fwd: no BatchNorm-view kernel for k %d, %d -> %d", k, cin, cout);
   DevTemp tmp(ctx);
   const int mb = (cout + 15) / 16;
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
@@ -1622,6 +1677,7 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
     Conv1F c;
     c.in = x; c.M = (int64_t)n * D * H * W_; c.cin = cin; c.w = (const float *)fr; c.shift = bias;
     c.act = act; c.out = y; c.cout = cout; c.stats = stats;
+    if (bn) c.bn = *bn;
     switch (mb) {
       case 1: return launch1<1>(ctx, c);
       case 2: return launch1<2>(ctx, c);
@@ -1715,7 +1771,9 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
 
 // dw [k^3][cin][cout] += weight gradient (float atomics)
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
-                      const float *dy, int k, int cout, float *dw) {
+                      const float *dy, int k, int cout, float *dw, const FplBnView *bn) {
+  FPL_REQUIRE(ctx, !bn || fpl_tm_bn_view_supported(k, cin, cout),
+              "conv wgrad: no BatchNorm-view kernel for k %d, %d -> %d", k, cin, cout);
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
   const int ncc = (cin + 15) / 16, nco = (cout + 47) / 48;
   DevTemp tmp(ctx);
@@ -1728,7 +1786,8 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
       void *part;
       FPL_TRY(tmp.alloc((size_t)nblk * 2304 * 4, &part));
       TimedLaunch tl(ctx, "mfma_wgrad1_f32");
-      conv1_wgrad48_f32<<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part);
+      if (bn) conv1_wgrad48_f32<true><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, *bn);
+      else conv1_wgrad48_f32<false><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, FplBnView{});
       wgrad_partials_add<<<36, 256, 0, ctx->stream>>>((const float *)part, nblk, 2304, dw);
       return 0;
     }

@@ -91,13 +91,19 @@ bool fpl_tm_bwd_supported(int k, int cin, int cout);   // dgrad + wgrad of that 
 // `stats` (optional): per-channel (sum, sum of squares) partials of y for a following
 // BatchNorm, fpl_tm_conv_stats_rows(...) rows x 2 x cout doubles (0 rows = not offered)
 int64_t fpl_tm_conv_stats_rows(fpl_ctx *ctx, int n, int D, int H, int W_, int cin, int k, int cout);
+// `bn` (optional, fpl_tm_bn_view_supported): x is the INPUT of a BatchNorm + ReLU whose
+// output is this convolution's real operand; the kernel applies relu(bn(x)) (the fixed
+// rounding sequence of train.hip's bn_affine) while loading, so that output tensor never
+// exists in HBM.  Per-channel device vectors.
+struct FplBnView { const float *mean, *invstd, *gamma, *beta; };
+bool fpl_tm_bn_view_supported(int k, int cin, int cout);
 int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int k,
                     int cout, const float *Wd, const float *bias, int act, float *y,
-                    double *stats = nullptr);
+                    double *stats = nullptr, const FplBnView *bn = nullptr);
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
                       int k, int cin, const float *Wd, const float *zeros, float *dx);
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
-                      const float *dy, int k, int cout, float *dw);
+                      const float *dy, int k, int cout, float *dw, const FplBnView *bn = nullptr);
 
 // Split-operand IEEE-half path for vgg_like (vgg_split.hip, FPL_PREC_F16S): every
 // activation and folded weight is carried as hi + lo (two halves, ~22 significant bits)

@@ -1105,6 +1105,32 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
     }
   }
 
+  // ... and when it is a 1x1x1 convolution with a kernel for it, the convolution (and
+  // its weight gradient) apply BN + ReLU while loading: that tensor is never written
+  // (vgg_like's first block: 1.46 GB of a 32 x 64^3 step written and read back)
+  std::vector<int> bn_view(nt, -1);            // tensor -> BN layer whose relu output it is
+  for (int li = 0; li + 2 < nl; ++li) {
+    if (!bn_fused[li] || pool_fused[li] || !use_mfma || !use_mfma_bwd) continue;
+    const fpl_layer &B = t->layers[li], &R = t->layers[li + 1];
+    const bool v4 = shp[B.src0].c % 4 == 0 && B.w_off[0] % 4 == 0 && B.w_off[1] % 4 == 0;
+    if (!v4 || n_cons[R.dst] != 1 || R.dst == t->out_tensor) continue;
+    for (int lc = li + 2; lc < nl; ++lc) {
+      const fpl_layer &Cv = t->layers[lc];
+      if (Cv.src0 != R.dst) continue;
+      if (Cv.kind == FPL_L_CONV && fpl_tm_bn_view_supported(Cv.k, Cv.cin, Cv.cout) &&
+          fpl_tm_supported(Cv.k, Cv.cin, Cv.cout) && fpl_tm_bwd_supported(Cv.k, Cv.cin, Cv.cout))
+        bn_view[R.dst] = li;
+      break;
+    }
+  }
+  auto view_of = [&](int tensor, FplBnView *v) -> const float * {
+    const int li = bn_view[tensor];
+    const fpl_layer &B = t->layers[li];
+    v->mean = bn_mean[li]; v->invstd = bn_invstd[li];
+    v->gamma = t->w + B.w_off[0]; v->beta = t->w + B.w_off[1];
+    return val[B.src0];
+  };
+
   // ------------------------------ forward ------------------------------------
   for (int li = 0; li < nl; ++li) {
     const fpl_layer &L = t->layers[li];
@@ -1137,8 +1163,12 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
               conv_stats_rows[L.dst] = (int)rows;
             }
           }
-          FPL_TRY(fpl_tm_conv_fwd(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, L.k, L.cout,
-                                  t->w + L.w_off[0], bias, L.act, val[L.dst], st_part));
+          FplBnView bv;
+          const bool viewed = bn_view[L.src0] >= 0;
+          const float *xin = viewed ? view_of(L.src0, &bv) : val[L.src0];
+          FPL_TRY(fpl_tm_conv_fwd(ctx, xin, batch, a.d, a.h, a.w, a.c, L.k, L.cout,
+                                  t->w + L.w_off[0], bias, L.act, val[L.dst], st_part,
+                                  viewed ? &bv : nullptr));
           break;
         }
         TimedLaunch tl(ctx, "train_conv_fwd");
@@ -1190,6 +1220,8 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
           bn_relu_pool4<<<g1(np4), 256, 0, st>>>((cf4)val[L.src0], (cf4)bn_mean[li],
               (cf4)bn_invstd[li], (cf4)(t->w + L.w_off[0]), (cf4)(t->w + L.w_off[1]),
               (float4 *)val[pdst], (uint32_t *)arg[pl], np4, C / 4, geo);
+        } else if (bn_fused[li] && bn_view[t->layers[li + 1].dst] == li) {
+          // applied by the consuming convolution's loader
         } else if (v4) {
           typedef const float4 *cf4;
           if (bn_fused[li])
@@ -1325,8 +1357,11 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         const int64_t n_vox = (int64_t)batch * o.vox();
         const int taps = L.k * L.k * L.k;
         if (use_mfma_bwd && fpl_tm_bwd_supported(L.k, L.cin, L.cout)) {
-          FPL_TRY(fpl_tm_conv_wgrad(ctx, val[L.src0], batch, a.d, a.h, a.w, a.c, dy, L.k,
-                                    L.cout, t->g + L.w_off[0]));
+          FplBnView bv;
+          const bool viewed = bn_view[L.src0] >= 0;
+          const float *xin = viewed ? view_of(L.src0, &bv) : val[L.src0];
+          FPL_TRY(fpl_tm_conv_wgrad(ctx, xin, batch, a.d, a.h, a.w, a.c, dy, L.k,
+                                    L.cout, t->g + L.w_off[0], viewed ? &bv : nullptr));
           if (L.use_bias) {
             const int rr = red_rows(n_vox), nb = (int)ceil_div64(n_vox, rr);
             const int R = std::max(1, 256 / L.cout);
