@@ -27,10 +27,15 @@ namespace {
 // Split build (-DFPL_SPLIT, precision f16s): every tensor carries, per 16 REAL channels,
 // [hi 16 | lo 16] halves (v = hi + lo, mfma_util.h) - 2 C "physical" channels per voxel.
 // A staged chunk of 32 physical channels is then ONE group of 16 real channels, its
-// K-step B fragment [a_hi | a_lo], multiplied by [w_hi | w_hi] and by [w_lo | w_lo]: all
-// four products of (a_hi + a_lo)(w_hi + w_lo) in two MFMAs per 16 channels and tap.  The
-// kernels below are the 16-bit ones; what changes is the weight set (two fragments per
-// M-block and K-step), the epilogues (hi / lo stores, pooling in fp32) and the stem.
+// K-step B fragment [a_hi | a_lo], multiplied by [w_hi | w_hi]: a_hi w_hi + a_lo w_hi in
+// one MFMA per 16 channels and tap.  The third product a_hi w_lo needs only the hi halves,
+// half a K-step: in conv3 TWO taps share one - lanes g < 2 read the hi planes at row group
+// k, lanes g >= 2 the hi planes at row group k' (a per-lane LDS address, no lane movement),
+// against [w_lo(k) | w_lo(k')] - so a chunk is 27 + 15 K-steps (9 row groups + 5 paired
+// ones) instead of 2 x 27: 3.1 MFMAs per product, not 4.  The 1x1x1 kernels keep the
+// [w_lo | w_lo] second set (a_lo w_lo rides along unused).  The kernels below are the
+// 16-bit ones; what changes is the K-step sequence and weight set, the epilogues (hi / lo
+// stores, pooling in fp32) and the stem.
 #ifdef FPL_SPLIT
 constexpr bool SPLIT = true;
 #else
@@ -57,6 +62,16 @@ constexpr int TAB_BYTES = MAXTAB * TABN * 4;
 static_assert(NPIECE % 32 == 0, "tile pieces come in groups of 32");
 constexpr int NCH = 9;                    // row groups per channel chunk: (dz, dx)
 constexpr int KC = 3;                     // K-steps per row group: dy
+// Row-group sequence of a chunk.  16-bit builds: the 9 (dz, dx) groups.  Split build:
+// M0 M1 P(0,1) M2 M3 P(2,3) M4 M5 P(4,5) M6 M7 P(6,7) M8 P(8,-): M = [a_hi | a_lo] of one
+// group against [w_hi | w_hi], P = [a_hi(k) | a_hi(k')] against [w_lo(k) | w_lo(k')].
+constexpr int NG = SPLIT ? 14 : NCH;
+constexpr bool grp_pair(int gi) { return SPLIT && (gi == 13 || (gi < 12 && gi % 3 == 2)); }
+constexpr int grp_k0(int gi) {
+  return !SPLIT ? gi : gi >= 12 ? 8 : gi % 3 == 2 ? 2 * (gi / 3) : 2 * (gi / 3) + gi % 3;
+}
+constexpr int grp_k1(int gi) { return gi >= 12 ? 8 : 2 * (gi / 3) + 1; }   // pairs only
+constexpr unsigned grp_off(int k) { return (unsigned)(((k / 3) * TY * TX + k % 3) * PITCH); }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -341,7 +356,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
 #pragma unroll
     for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[4 * MB * g + 4 * b + r];
   f32x4 acc[4][MB];
-  const int total_steps = a.ncc * NCH * KC;
+  const int total_steps = a.ncc * NG * KC;
   __syncthreads();                                  // offset tables visible
   // The tile loads go out BEFORE the weight loads, as in the steady state of the
   // loop below: vmcnt retires in order, and with this order the waits hipcc derives
@@ -352,13 +367,20 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
   // from L2 into registers, WQ K-steps ahead of their use and across tile / block
   // boundaries: no LDS ring and no barrier inside the K loop.
   const unsigned char *wl = a.w + lane * 16;
-  constexpr int WMB = PM * MB;      // fragments per K-step: split carries [w_hi | w_hi] and [w_lo | w_lo]
-  h16x8 wq[WQ][WMB];
+  static_assert((NG * KC) % WQ == 0, "the fragment queue's phase is static inside a chunk");
+  h16x8 wq[WQ][MB];
 #pragma unroll
   for (int d = 0; d < WQ; ++d)
 #pragma unroll
-    for (int b = 0; b < WMB; ++b)
-      wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * WMB + b) * 1024);
+    for (int b = 0; b < MB; ++b)
+      wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * MB + b) * 1024);
+  // split: a paired group's rows - hi planes only, lanes g >= 2 at the second group
+  const unsigned pbase = (unsigned)(((wave * TY) * TX + c) * PITCH + (g & 1) * PLANE);
+  auto row_addr = [&](int gi, int r) -> const unsigned char * {
+    if (grp_pair(gi))
+      return tile + pbase + (g >= 2 ? grp_off(grp_k1(gi)) : grp_off(grp_k0(gi))) + r * ROW;
+    return tile + vbase + grp_off(grp_k0(gi)) + r * ROW;
+  };
 
   for (;;) {
     for (int cc = 0; cc < a.ncc; ++cc) {
@@ -382,42 +404,32 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
       h16x8 brow[2][6];
 #pragma unroll
       for (int r = 0; r < 6; ++r)
-        brow[0][r] = *reinterpret_cast<const h16x8 *>(tile + vbase + r * ROW);
+        brow[0][r] = *reinterpret_cast<const h16x8 *>(row_addr(0, r));
 #pragma unroll
-      for (int ck = 0; ck < NCH; ++ck) {
-        // next row group: (dz, dx) of ck+1 (wraps to the tile origin; the wrapped
-        // read of the last group is unused)
-        const int nk = ck + 1 < NCH ? ck + 1 : 0;
-        const unsigned noff = (unsigned)(((nk / 3) * TY * TX + nk % 3) * PITCH);
+      for (int gi = 0; gi < NG; ++gi) {
+        // next row group (wraps to the first; the wrapped read of the last group is unused)
+        const int ng = gi + 1 < NG ? gi + 1 : 0;
 #pragma unroll
         for (int dy = 0; dy < KC; ++dy) {
-          const int st = ck * KC + dy;              // K-step inside the channel chunk
+          const int st = gi * KC + dy;              // K-step inside the channel chunk
           // spread the six prefetch reads over the three K-steps
 #pragma unroll
           for (int r = 2 * dy; r < 2 * dy + 2; ++r)
-            brow[(ck + 1) & 1][r] =
-                *reinterpret_cast<const h16x8 *>(tile + vbase + noff + r * ROW);
+            brow[(gi + 1) & 1][r] = *reinterpret_cast<const h16x8 *>(row_addr(ng, r));
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
             for (int b = 0; b < MB; ++b)
-              acc[sub][b] = mfma16(wq[st % WQ][b], brow[ck & 1][sub + dy], acc[sub][b]);
-          if (SPLIT) {
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-              for (int b = 0; b < MB; ++b)
-                acc[sub][b] = mfma16(wq[st % WQ][MB + b], brow[ck & 1][sub + dy], acc[sub][b]);
-          }
+              acc[sub][b] = mfma16(wq[st % WQ][b], brow[gi & 1][sub + dy], acc[sub][b]);
           __builtin_amdgcn_s_setprio(0);
           {
-            int nxt = cc * (NCH * KC) + st + WQ;
+            int nxt = cc * (NG * KC) + st + WQ;
             nxt = nxt < total_steps ? nxt : nxt - total_steps;   // next block starts over
 #pragma unroll
-            for (int b = 0; b < WMB; ++b)
+            for (int b = 0; b < MB; ++b)
               wq[st % WQ][b] =
-                  *reinterpret_cast<const h16x8 *>(wl + ((size_t)nxt * WMB + b) * 1024);
+                  *reinterpret_cast<const h16x8 *>(wl + ((size_t)nxt * MB + b) * 1024);
           }
         }
       }
@@ -864,30 +876,44 @@ bool match_unet(const fpl_program *prog, UnetDesc *d) {
 
 // conv3 fragments: per CC-channel chunk, K-step order (dz, dx, dy) (or (dz, dy, dx) for
 // the transposed edge strip); output channels [co0, co0 + ncout) as one M-block set
-// Split build: a chunk is 16 real channels as 32 physical k-slots [hi | lo]; both halves
-// of the K-step carry the SAME real channel's weight - the hi parts in the first fragment
-// set, the lo parts in the second: [chunk][K-step][set][mb].
+// Split build: a chunk is 16 real channels as 32 physical k-slots [hi | lo]; the K-steps of
+// a main row group carry the SAME real channel's w_hi in both halves, those of a paired
+// group the w_lo of group k in the lower and of group k' in the upper half (NG above):
+// [chunk][K-step of the 42][mb].
 void pack_conv3(const float *A, const fpl_op &op, int co0, int ncout, bool transposed,
                 std::vector<uint16_t> *f) {
   const int ncc = op.cin / RCH, mb = (ncout + 15) / 16;
-  std::vector<float> sub((size_t)27 * CC * ncout), scale(A + op.scale_off + co0, A + op.scale_off + co0 + ncout);
+  const int nst = NG * KC;
+  std::vector<float> sub((size_t)nst * CC * ncout), scale(A + op.scale_off + co0, A + op.scale_off + co0 + ncout);
   f->clear();
+  auto tap_of = [&](int k, int dy) {               // row group k = (dz, dx)
+    const int dz = k / 3, d1 = k % 3;
+    return transposed ? dz * 9 + d1 * 3 + dy : dz * 9 + dy * 3 + d1;
+  };
   for (int cc = 0; cc < ncc; ++cc) {
-    for (int ks = 0; ks < 27; ++ks) {
-      const int dz = ks / 9, d1 = (ks / 3) % 3, d2 = ks % 3;     // d1 = dx, d2 = dy
-      const int tap = transposed ? dz * 9 + d1 * 3 + d2 : dz * 9 + d2 * 3 + d1;
-      for (int ch = 0; ch < CC; ++ch)
-        memcpy(&sub[((size_t)ks * CC + ch) * ncout],
-               A + op.w_off + ((size_t)tap * op.cin + cc * RCH + ch % RCH) * op.cout + co0,
-               ncout * sizeof(float));
-    }
+    std::fill(sub.begin(), sub.end(), 0.f);
+    for (int gi = 0; gi < NG; ++gi)
+      for (int dy = 0; dy < KC; ++dy)
+        for (int ch = 0; ch < CC; ++ch) {
+          // k-slot ch of this K-step: which tap's weight of which real channel
+          int k = grp_k0(gi);
+          if (grp_pair(gi) && ch >= RCH) {
+            if (gi == NG - 1) continue;            // the unpaired ninth group: upper half 0
+            k = grp_k1(gi);
+          }
+          memcpy(&sub[((size_t)(gi * KC + dy) * CC + ch) * ncout],
+                 A + op.w_off + ((size_t)tap_of(k, dy) * op.cin + cc * RCH + ch % RCH) * op.cout + co0,
+                 ncout * sizeof(float));
+        }
     std::vector<uint16_t> fc[2];
     for (int part = 0; part < PM; ++part)
-      fpl_pack_frags(sub.data(), scale.data(), 27, CC, ncout, mb, 27, SLOT_SPATIAL, &fc[part], true, part);
-    for (int ks = 0; ks < 27; ++ks)
-      for (int part = 0; part < PM; ++part)
+      fpl_pack_frags(sub.data(), scale.data(), nst, CC, ncout, mb, nst, SLOT_SPATIAL, &fc[part], true, part);
+    for (int gi = 0; gi < NG; ++gi)
+      for (int dy = 0; dy < KC; ++dy) {
+        const int ks = gi * KC + dy, part = grp_pair(gi) ? 1 : 0;     // pairs carry the lo parts
         f->insert(f->end(), fc[part].begin() + (size_t)ks * mb * 512,
                   fc[part].begin() + (size_t)(ks + 1) * mb * 512);
+      }
   }
 }
 
