@@ -80,6 +80,17 @@ __device__ __forceinline__ void store_split4(unsigned char *vox, int ch, const f
 // block's 64 tasks (16 pooled x of one (pz,py) row), 8 sub-steps per task walk the
 // 2x2x2 pooling window.  Persistent and software-pipelined like the 16-bit stem: the
 // next block's tile rows are loaded, split and stored inside the task loop.
+//
+// uint8 volumes (round 3): conv(w, (u - mean) / sd) = conv(w / sd, u - c0) + (c0 - mean) / sd
+// * sum(w) with c0 = round(mean) clamped to [0, 255].  u - c0 is an integer of at most 8
+// bits - EXACT in a half, no lo half - so conv3 1->48 is two MFMAs per M-block (w_hi a,
+// w_lo a) on ONE gathered fragment, and the weights are re-split per (mean, sd) on the host
+// (12 KiB).  The constant rides in the accumulators' initial value, which also takes care of
+// the zero padding past the volume's end (normalised 0 - not an integer in this operand):
+// padding voxels are stored as 0 and the initial value of an output whose window has
+// (pz, py, px) planes of padding leaves those taps' share of the constant out - a 64-entry
+// table of 48-channel vectors in LDS, indexed per lane and sub-step (entry 0 everywhere
+// inside the volume), three 16-B LDS reads per sub-step and no branch.
 // -------------------------------------------------------------------------------
 constexpr int S_PZ = 4, S_PY = 8, S_PX = 32;
 constexpr int S_TZ = 2 * S_PZ + 2, S_TY = 2 * S_PY + 2, S_TX = 2 * S_PX + 2;
@@ -91,13 +102,16 @@ constexpr int S_WROWS = (S_ROWS + S_WAVES - 1) / S_WAVES;   // 23 per wave (the 
 constexpr int S_TASKS = S_PZ * S_PY * 2 / S_WAVES;          // 8 tasks per wave and block
 constexpr int S_RPT = 3;                       // rows per task iteration
 static_assert(S_RPT * S_TASKS >= S_WROWS && S_WROWS <= 64, "stem fill schedule");
-constexpr int S_SMEM = 4 * S_TILE * 2 + 256 * 4;
+constexpr int S_SHTAB = 64 * 48;                // u8 path: floats of the initial-value table
+constexpr int S_SMEM = 4 * S_TILE * 2 + 256 * 4 + S_SHTAB * 4;
 
 struct StemSArgs {
   const void *src;
   int64_t SZ, SY, SX;      // volume dims
   int64_t z_hi;            // rows >= z_hi are not needed (and may not be resident)
   float mean, sd;
+  float c0;                // u8 path: the integer the operand is centred on
+  const float *shtab;      // u8 path: [pz 4][py 4][px 4][48] initial accumulator values
   int64_t p1z0;            // global P1 row of chunk-local row 0
   const h16x8 *w1, *w2;    // fragments [part][e][b][lane]; chain48 steps [4][b][lane]
   const float *shift1, *shift2;
@@ -178,7 +192,7 @@ __device__ __forceinline__ unsigned stem_norm(const StemSArgs &a, const unsigned
                                               bool ok) {
   unsigned t;
   if (sizeof(SRC) == 1) {
-    t = lut[(unsigned)v & 255u];
+    t = lut[(unsigned)v & 255u];              // u - c0: exact, lo half 0; padding 0
   } else {
     const float x = ((float)v - a.mean) / a.sd;
     const h16_t h = (h16_t)x;
@@ -197,14 +211,15 @@ __device__ __forceinline__ void stem_convert_rows(const StemSArgs &a, const Stem
   for (int k = 0; k < S_RPT; ++k) o.b[k] = stem_norm<SRC>(a, lut, r.v[k], r.ok[k] && b.x_ok);
 }
 
-// tile = hi tile, tile + S_TILE = lo tile
+// tile = hi tile, tile + S_TILE = lo tile (LO = false: u8 volumes, no lo tile)
+template <bool LO>
 __device__ __forceinline__ void stem_write_rows(unsigned short *tile, int wrow0, int idx0, int lane,
                                                 const StemBits &o) {
 #pragma unroll
   for (int k = 0; k < S_RPT; ++k) {
     const int e = stem_row_of(wrow0, idx0 + k) * S_TP + lane;
     tile[e] = (unsigned short)o.b[k];
-    tile[S_TILE + e] = (unsigned short)(o.b[k] >> 16);
+    if (LO) tile[S_TILE + e] = (unsigned short)(o.b[k] >> 16);
   }
 }
 
@@ -236,7 +251,8 @@ __device__ __forceinline__ void stem_store_edge(const StemSArgs &a, unsigned sho
   const unsigned v0 = stem_norm<SRC>(a, lut, e.v[0], e.ok[0]);
   const unsigned v1 = stem_norm<SRC>(a, lut, e.v[1], e.ok[1]);
   *reinterpret_cast<unsigned *>(&tile[row * S_TP + 64]) = (v0 & 0xFFFFu) | (v1 << 16);
-  *reinterpret_cast<unsigned *>(&tile[S_TILE + row * S_TP + 64]) = (v0 >> 16) | (v1 & 0xFFFF0000u);
+  if (sizeof(SRC) != 1)
+    *reinterpret_cast<unsigned *>(&tile[S_TILE + row * S_TP + 64]) = (v0 >> 16) | (v1 & 0xFFFF0000u);
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -251,11 +267,12 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
   const int nblocks = a.nbx * a.nby * a.nbz;
   int q = blockIdx.x;
   if (q >= nblocks) return;
-  if (sizeof(SRC) == 1 && tid < 256) {
-    const float x = ((float)tid - a.mean) / a.sd;
-    const h16_t h = (h16_t)x;
-    lut[tid] = (unsigned)h16_bits(x) | ((unsigned)h16_bits(x - (float)h) << 16);
-  }
+  constexpr bool INT = sizeof(SRC) == 1;            // integer operand, no lo tile
+  if (INT && tid < 256) lut[tid] = (unsigned)h16_bits((float)tid - a.c0);
+  const unsigned char *shtab = smem + 4 * S_TILE * 2 + 256 * 4;
+  if (INT)
+    for (int i = tid; i < S_SHTAB; i += 64 * S_WAVES)
+      reinterpret_cast<float *>(smem + 4 * S_TILE * 2 + 256 * 4)[i] = a.shtab[i];
 
   // per-lane byte offsets of the 3 pair reads and 2 single reads for sub-step parity
   // e = dx (k-slot layout: pack_weights.h::fpl_stem_slot_tap)
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       StemBits hb;
       stem_load_rows<SRC>(base0, tab0, blk.xc, i0, rr);
       stem_convert_rows<SRC>(a, blk, lut, rr, hb);
-      stem_write_rows(tiles, wrow0, i0, lane, hb);
+      stem_write_rows<!INT>(tiles, wrow0, i0, lane, hb);
     }
     StemEdge<SRC> ee;
     stem_load_edge<SRC>(a, blk, wrow0, lane, ee);
@@ -354,15 +371,19 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       // max-pool in fp32 (the split of the maximum is the maximum of the splits: the
       // representation is monotonic); the initial 0 is the ReLU
       f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      // INT: planes of padding in the 3 x 3 x 3 window of this lane's outputs (0 inside)
+      const int xrel = (int)(blk.gx0 + 2 * (16 * xh + c) + 3 - a.SX);
+      const int yrel = (int)(blk.gy0 + 2 * pyl + 3 - a.SY), zrel = (int)(blk.gz0 + 2 * pzl + 3 - a.z_hi);
 #pragma unroll
       for (int sp = 0; sp < 4; ++sp) {
         f32x4 a2[2][3];
+        const int pzy = 4 * min(max(zrel + (sp >> 1), 0), 3) + min(max(yrel + (sp & 1), 0), 3);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {                 // sub = 2 sp + e: x parity e
           const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
           Frag2 bf;
 #pragma unroll
-          for (int part = 0; part < 2; ++part) {
+          for (int part = 0; part < (INT ? 1 : 2); ++part) {
             const unsigned char *tp = tb + part * (S_TILE * 2) + base + so;
             u32x4 raw;
 #pragma unroll
@@ -374,10 +395,17 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
             else bf.lo = __builtin_bit_cast(h16x8, raw);
           }
           f32x4 a1[3];
+          if (INT) {
+            const unsigned char *tp = shtab + ((4 * pzy + min(max(xrel + e, 0), 3)) * 48 + 4 * g) * 4;
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, sh1[b]);
+            for (int b = 0; b < 3; ++b)
+              a1[b] = mfma16(w1[1][e][b], bf.hi, *reinterpret_cast<const f32x4 *>(tp + 64 * b));
+          } else {
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.lo, a1[b]);
+            for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, sh1[b]);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.lo, a1[b]);
+          }
 #pragma unroll
           for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.hi, a1[b]);
           const Frag2 h0 = pack_relu_split(a1[0], a1[1]);
@@ -400,7 +428,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
           for (int r = 0; r < 4; ++r)
             poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
         if (sp == 1) {
-          stem_write_rows(tnext, wrow0, S_RPT * ti, lane, hb);
+          stem_write_rows<!INT>(tnext, wrow0, S_RPT * ti, lane, hb);
           stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
         }
       }
@@ -742,12 +770,22 @@ struct SplitState {
   size_t off_w[8] = {0};              // byte offsets of L1..L8 fragment sets
   size_t off_s[8] = {0};              // float offsets of shift1..shift8
   float bias8 = 0.f;
+  // u8 volumes: conv3 1->48 on the operand u - c0, fragments of w / sd and the shift with the
+  // constant folded in, rebuilt when (mean, sd) change
+  unsigned char *w1_int = nullptr;    // [part][e][b][lane] as off_w[0]
+  float *shift1_int = nullptr;
+  float int_mean = 0.f, int_sd = 0.f, int_c0 = 0.f;
+  bool int_valid = false;
+  std::vector<uint16_t> w1_int_host;
+  std::vector<float> shift1_int_host;       // the table [pz][py][px][48]
 };
 
 void split_state_free(fpl_ctx *ctx, void *p) {
   SplitState *s = (SplitState *)p;
   if (s->frags) hipFree(s->frags);
   if (s->shifts) hipFree(s->shifts);
+  if (s->w1_int) hipFree(s->w1_int);
+  if (s->shift1_int) hipFree(s->shift1_int);
   delete s;
 }
 
@@ -838,6 +876,55 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_c5_tail,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   st->version = prog->arena_version;
+  st->int_valid = false;
+  return 0;
+}
+
+// the stem's conv3 for uint8 volumes normalised with (mean, sd): operand u - c0
+int split_prepare_int(fpl_ctx *ctx, fpl_program *prog, SplitState *st, float mean, float sd) {
+  if (st->int_valid && st->int_mean == mean && st->int_sd == sd) return 0;
+  const fpl_op &op = prog->ops[0];
+  const float *A = prog->arena_host.data();
+  const double c0 = std::min(255.0, std::max(0.0, std::nearbyint((double)mean)));
+  std::vector<float> scale(op.cout);
+  st->shift1_int_host.assign(S_SHTAB, 0.f);
+  const double k = (c0 - (double)mean) / (double)sd;
+  for (int co = 0; co < op.cout; ++co) {
+    scale[co] = (float)((double)A[op.scale_off + co] / (double)sd);
+    // entry (pz, py, px): the constant over the taps that are NOT padding, i.e. with
+    // dz < 3 - pz, dy < 3 - py, dx < 3 - px
+    for (int pz = 0; pz < 4; ++pz)
+      for (int py = 0; py < 4; ++py)
+        for (int px = 0; px < 4; ++px) {
+          double sum = 0.0;
+          for (int dz = 0; dz < 3 - pz; ++dz)
+            for (int dy = 0; dy < 3 - py; ++dy)
+              for (int dx = 0; dx < 3 - px; ++dx)
+                sum += (double)A[op.w_off + (size_t)((dz * 3 + dy) * 3 + dx) * op.cout + co];
+          st->shift1_int_host[(size_t)((pz * 4 + py) * 4 + px) * 48 + co] =
+              (float)((double)A[op.shift_off + co] + k * sum * (double)A[op.scale_off + co]);
+        }
+  }
+  st->w1_int_host.clear();
+  for (int part = 0; part < 2; ++part) {         // [part][e][b]
+    std::vector<uint16_t> f;
+    fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f, part);
+    st->w1_int_host.insert(st->w1_int_host.end(), f.begin(), f.end());
+  }
+  for (uint16_t h : st->w1_int_host)
+    FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
+                "a first-layer weight divided by std %g exceeds the IEEE-half range; use "
+                "precision f32 for this normalisation", (double)sd);
+  const size_t wb = st->w1_int_host.size() * sizeof(uint16_t);
+  if (!st->w1_int) FPL_HIP(ctx, hipMalloc((void **)&st->w1_int, wb));
+  if (!st->shift1_int) FPL_HIP(ctx, hipMalloc((void **)&st->shift1_int, S_SHTAB * sizeof(float)));
+  // stream-ordered behind any launch that still reads the previous set
+  FPL_HIP(ctx, hipMemcpyAsync(st->w1_int, st->w1_int_host.data(), wb, hipMemcpyHostToDevice, ctx->stream));
+  FPL_HIP(ctx, hipMemcpyAsync(st->shift1_int, st->shift1_int_host.data(), S_SHTAB * sizeof(float),
+                              hipMemcpyHostToDevice, ctx->stream));
+  st->int_c0 = (float)c0;
+  st->int_mean = mean; st->int_sd = sd;
+  st->int_valid = true;
   return 0;
 }
 
@@ -860,6 +947,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
                            int32_t zb, int32_t ze, float *dst) {
   SplitState *st;
   FPL_TRY(split_prepare(ctx, prog, &st));
+  if (src_dtype == FPL_U8) FPL_TRY(split_prepare_int(ctx, prog, st, mean, sd));
   hipStream_t stream = ctx->stream;
   const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];
   const int64_t VZ = SZ - 14, VY = SY - 14, VX = SX - 14;
@@ -903,6 +991,11 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
       a.w1 = (const h16x8 *)(F + st->off_w[0]);
       a.w2 = (const h16x8 *)(F + st->off_w[1]);
       a.shift1 = S + st->off_s[0]; a.shift2 = S + st->off_s[1];
+      a.c0 = 0.f; a.shtab = nullptr;
+      if (src_dtype == FPL_U8) {
+        a.w1 = (const h16x8 *)st->w1_int; a.shtab = st->shift1_int;
+        a.c0 = st->int_c0;
+      }
       a.p1 = (unsigned char *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
       a.nbx = (int)ceil_div64(P1X, S_PX); a.nby = (int)ceil_div64(P1Y, S_PY);
       a.nbz = (int)ceil_div64(P1Z, S_PZ);

@@ -68,6 +68,23 @@ def test_split_float_input_and_other_normalisation(ctx):
     assert np.abs(a - b).max() < 1e-6
 
 
+@pytest.mark.parametrize('mean,std', [(127.37, 31.9), (300.5, 40.0), (-20.25, 17.0), (100.0, -25.0)])
+def test_split_u8_operand_is_centred_on_an_integer(ctx, mean, std):
+    """uint8 volumes run conv3 1->48 on the exact operand u - round(mean) with 1 / std and the
+    constant folded into weights and shift (vgg_split.hip, K1); the zero padding past the
+    volume's end is the one non-integer value.  Ragged volume (padding on every axis), means
+    inside and outside [0, 255], and the per-(mean, std) weight set rebuilt between calls."""
+    g = _net(24, 30)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(12, (50, 47, 41))
+    for m, s in ((128.0, 33.0), (mean, std)):
+        img = (u8.astype(np.float32) - np.float32(m)) / np.float32(s)
+        got = prog.infer_volume(u8, (30,) * 3, (7,) * 3, mean=m, std=s, precision=_capi.PREC_F16S)
+        _, f32 = _refs(g, img, 30)
+        assert f32[7:-7, 7:-7, 7:-7].std() > 1e-4
+        assert np.abs(got - f32).max() < TOL, (m, s, np.abs(got - f32).max())
+
+
 def test_split_slabs_chunks_and_tilings_are_bit_identical(ctx, monkeypatch):
     g = _net(23, 46)
     prog = _capi.Program(ctx, g, (4, 4, 4))
