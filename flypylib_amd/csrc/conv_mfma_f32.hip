@@ -376,6 +376,7 @@ struct Conv1F {
   float *out; int cout;
   double *stats;                           // STATS: part[grid][2][cout]
   FplBnView bn = {nullptr, nullptr, nullptr, nullptr};   // conv1_f32_wreg<.., BN>: in -> relu(bn(in))
+  const float *bsx = nullptr;    // conv1_f32_wreg<.., BSTAT>: BN input at the OUTPUT positions; stats = BN backward sums
 };
 
 // train.hip's bn_affine: the forward value and every recomputation of the ReLU mask in the
@@ -444,8 +445,12 @@ __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
 // 3 x its input bytes through the vector-memory path as weight fragments), and the next
 // group's voxels are in flight while this one is multiplied.  Same group order, same K
 // order: bit-identical outputs and statistics.
-template <int MB, int NKB, bool STATS, bool BN = false>
+// BSTAT (an input-gradient launch): the outputs are the gradient of relu(bn(x)); `stats`
+// then receives the BN backward sums (sum g, sum g * xhat; g = output where bn(x) > 0)
+// instead of the outputs' moments - x is read at the output positions (cout = 16 * NKB)
+template <int MB, int NKB, bool STATS, bool BN = false, bool BSTAT = false>
 __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
+  static_assert(!BSTAT || (STATS && BN && MB == NKB), "BSTAT: statistics of a BN view, cout = cin");
   __shared__ double red[STATS ? 4 * 2 * 16 * MB : 1];
   // BN: the four per-channel vectors, read back as 16-B pieces of a lane's four channels
   __shared__ f32x4 prm[BN ? 4 * NKB * 4 : 1];
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
     f32x4 bf[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) bf[kb] = nx[kb];
-    if (BN) {
+    if (BN && !BSTAT) {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         const f32x4 pm = prm[(0 * NKB + kb) * 4 + g], ps = prm[(1 * NKB + kb) * 4 + g],
@@ -517,7 +522,20 @@ __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
       for (int b = 0; b < MB; ++b) {
         const f32x4 o = act4(acc[b], a.act);
         store_quad(dst, 16 * b + 4 * g, a.cout, o, FPL_ACT_NONE);
-        if (STATS) cs.add(b, o);
+        if (BSTAT) {
+          const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.bsx + m * a.cout + 16 * b + 4 * g);
+          const f32x4 pm = prm[(0 * NKB + b) * 4 + g], ps = prm[(1 * NKB + b) * 4 + g],
+                      pg = prm[(2 * NKB + b) * 4 + g], pb = prm[(3 * NKB + b) * 4 + g];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gq = bn_relu_f(xv[r], pm[r], ps[r], pg[r], pb[r]) > 0.f ? o[r] : 0.f;
+            const float xh = (xv[r] - pm[r]) * ps[r];
+            cs.s0[b][r] += gq;
+            cs.s1[b][r] += (double)gq * xh;
+          }
+        } else if (STATS) {
+          cs.add(b, o);
+        }
       }
     }
   }
@@ -868,6 +886,13 @@ int launch1(fpl_ctx *ctx, Conv1F &a) {
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
   TimedLaunch tl(ctx, "mfma_conv1_f32");
   // weights-in-registers form for the 48- and 96-channel inputs of the vgg / U-Net blocks
+  if constexpr (MB == 3) {
+    if (a.cin == 48 && a.bsx) {
+      conv1_f32_wreg<3, 3, true, true, true><<<grid, 256, 0, ctx->stream>>>(a);
+      return 0;
+    }
+  }
+  if (a.bsx) return fpl_fail(ctx, "conv1: no BatchNorm-statistics epilogue for %d -> %d", a.cin, a.cout);
   if constexpr (MB <= 3) {
     if (a.cin == 48 && a.bn.mean) {
       if (a.stats) conv1_f32_wreg<MB, 3, true, true><<<grid, 256, 0, ctx->stream>>>(a);
@@ -1716,7 +1741,10 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
 // dx (n,D,H,W,cin) = input gradient of the valid conv for dy (n,od,oh,ow,cout);
 // dx is OVERWRITTEN (the caller accumulates when a tensor has several consumers)
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
-                      int k, int cin, const float *Wd, const float *zeros, float *dx) {
+                      int k, int cin, const float *Wd, const float *zeros, float *dx,
+                      const FplBnStat *bstat) {
+  FPL_REQUIRE(ctx, !bstat || fpl_tm_bn_view_supported(k, cin, cout),
+              "conv dgrad: no BatchNorm-statistics epilogue for k %d, %d -> %d", k, cin, cout);
   DevTemp tmp(ctx);
   const int ncc = (cout + 15) / 16, k3 = k * k * k;
   if (k == 1) {
@@ -1728,6 +1756,7 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
     Conv1F c;
     c.in = dy; c.M = (int64_t)n * od * oh * ow; c.cin = cout; c.w = (const float *)fr;
     c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin; c.stats = nullptr;
+    if (bstat) { c.bsx = bstat->x; c.bn = bstat->bn; c.stats = bstat->part; }
     switch (mb) {
       case 1: return launch1<1>(ctx, c);
       case 2: return launch1<2>(ctx, c);

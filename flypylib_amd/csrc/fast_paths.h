@@ -100,8 +100,14 @@ bool fpl_tm_bn_view_supported(int k, int cin, int cout);
 int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int k,
                     int cout, const float *Wd, const float *bias, int act, float *y,
                     double *stats = nullptr, const FplBnView *bn = nullptr);
+// `bstat` (optional, fpl_tm_bn_view_supported(k, cin, cout)): dx is the gradient of a
+// BatchNorm + ReLU output whose BN input is bstat->x; the epilogue also accumulates that
+// BN's backward sums (sum g, sum g * xhat with g = dx where bn(x) > 0) into
+// part[fpl_tm_conv_stats_rows(.., k = 1, ..)][2][cin] - the BN backward's first pass
+struct FplBnStat { const float *x; FplBnView bn; double *part; };
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
-                      int k, int cin, const float *Wd, const float *zeros, float *dx);
+                      int k, int cin, const float *Wd, const float *zeros, float *dx,
+                      const FplBnStat *bstat = nullptr);
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
                       const float *dy, int k, int cout, float *dw, const FplBnView *bn = nullptr);
 

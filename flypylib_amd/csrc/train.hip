@@ -1109,6 +1109,8 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   // its weight gradient) apply BN + ReLU while loading: that tensor is never written
   // (vgg_like's first block: 1.46 GB of a 32 x 64^3 step written and read back)
   std::vector<int> bn_view(nt, -1);            // tensor -> BN layer whose relu output it is
+  std::vector<double *> bn_bstat(nl, nullptr); // BN layer -> backward sums made by its consumer
+  std::vector<int> bn_bstat_rows(nl, 0);
   for (int li = 0; li + 2 < nl; ++li) {
     if (!bn_fused[li] || pool_fused[li] || !use_mfma || !use_mfma_bwd) continue;
     const fpl_layer &B = t->layers[li], &R = t->layers[li + 1];
@@ -1371,7 +1373,20 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
             finish_sums<<<L.cout, 256, 0, st>>>(part, nb, L.cout, t->g + L.w_off[1],
                                                            nullptr, 1.f);
           }
-          if (dx && assign[L.src0]) {
+          if (dx && assign[L.src0] && viewed && !getenv("FPL_TRAIN_BNSTAT_SEPARATE")) {
+            // ... and the input-gradient kernel's epilogue makes that BatchNorm's backward
+            // sums while the gradient is in registers (the separate pass read it back)
+            const int bl = bn_view[L.src0];
+            const int64_t rows = fpl_tm_conv_stats_rows(ctx, batch, a.d, a.h, a.w, a.c, 1, L.cin);
+            void *q;
+            FPL_TRY(tmp.alloc((size_t)rows * 2 * L.cin * sizeof(double), &q));
+            FplBnStat bs;
+            bs.x = xin; bs.bn = bv; bs.part = (double *)q;
+            bn_bstat[bl] = (double *)q;
+            bn_bstat_rows[bl] = (int)rows;
+            FPL_TRY(fpl_tm_conv_dgrad(ctx, dy, batch, o.d, o.h, o.w, o.c, L.k, L.cin,
+                                      t->w + L.w_off[0], t->zeros, dx, &bs));
+          } else if (dx && assign[L.src0]) {
             FPL_TRY(fpl_tm_conv_dgrad(ctx, dy, batch, o.d, o.h, o.w, o.c, L.k, L.cin,
                                       t->w + L.w_off[0], t->zeros, dx));
           } else if (dx) {
@@ -1456,7 +1471,12 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
           }
           break;
         }
-        if (v4 && bn_fused[li])
+        const double *bpart = part;
+        int bnb = nb;
+        if (bn_bstat[li]) {                      // made by the consumer's input-gradient kernel
+          bpart = bn_bstat[li];
+          bnb = bn_bstat_rows[li];
+        } else if (v4 && bn_fused[li])
           chan_reduce_partial4<3><<<nb, dim3(C / 4, R4), (size_t)C * R4 * 2 * sizeof(double), st>>>(
               dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, rr, part, t->w + L.w_off[0],
               t->w + L.w_off[1]);
@@ -1469,7 +1489,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         else
           chan_reduce_partial<1><<<nb, dim3(C, R), (size_t)C * R * 2 * sizeof(double), st>>>(
               dy, val[L.src0], bn_mean[li], bn_invstd[li], M, C, rr, part);
-        finish_sums<<<C, 256, 0, st>>>(part, nb, C, sdy, sdyx, 1.f);
+        finish_sums<<<C, 256, 0, st>>>(bpart, bnb, C, sdy, sdyx, 1.f);
         // dbeta = sum dy, dgamma = sum dy*xhat
         accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
         accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);

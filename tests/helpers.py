@@ -96,3 +96,20 @@ def make_pred_f64(kind, seed, shape):
     plus a hashed perturbation of relative size 1e-9"""
     base = make_pred(kind, seed, shape).astype(np.float64)
     return base * (1.0 + 1e-9 * synth.hash_uniform_f32(seed + 7000, shape).astype(np.float64))
+
+
+def same_detections(a, b, conf_tol, tie=2e-6):
+    """Two `voxel2obj` / pipeline results name the same point SET (the north star's gate) with
+    confidences within conf_tol, in the same descending-confidence order wherever that order
+    is decided by more than `tie`: two peaks whose fp32 confidences differ by a few 1e-8 may
+    swap places between two correct implementations of the CNN (seen on the 582^3 trained
+    substack: 0.11498727 / 0.11498725)."""
+    assert len(a['conf']) == len(b['conf']), (len(a['conf']), len(b['conf']))
+    la, lb = np.asarray(a['locs']), np.asarray(b['locs'])
+    ia, ib = np.lexsort(la.T[::-1]), np.lexsort(lb.T[::-1])
+    assert np.array_equal(la[ia], lb[ib]), 'different point sets'
+    np.testing.assert_allclose(np.asarray(a['conf'])[ia], np.asarray(b['conf'])[ib], rtol=0, atol=conf_tol)
+    moved = np.where((la != lb).any(axis=1))[0]
+    for i in moved:
+        assert abs(a['conf'][i] - b['conf'][i]) < tie, (i, a['conf'][i], b['conf'][i])
+    return len(moved)

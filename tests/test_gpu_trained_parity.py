@@ -15,6 +15,8 @@ What is held, per precision, against the fp32 path of the same library (itself h
   bf16  bounded at what 8 significant bits deliver.
 """
 import numpy as np
+
+from tests import helpers
 import pytest
 
 from flypylib_amd import fplobjdetect
@@ -24,19 +26,9 @@ from tests.trained_fixture import RECIPES, blob_region, blob_region_u8, trained_
 pytestmark = pytest.mark.gpu
 
 
-def _same_detections(a, b, conf_tol, tie=1e-6):
-    """the same point SET (the north star's gate) with confidences within conf_tol, and the
-    same descending-confidence order wherever the order is decided by more than `tie`: two
-    peaks whose fp32 confidences differ by a few 1e-8 may swap places between two correct
-    implementations (seen once on the 582^3 substack: 0.11498727 / 0.11498725)"""
-    assert len(a['conf']) == len(b['conf']), (len(a['conf']), len(b['conf']))
-    ia = np.lexsort(a['locs'].T[::-1]); ib = np.lexsort(b['locs'].T[::-1])
-    assert np.array_equal(a['locs'][ia], b['locs'][ib])
-    np.testing.assert_allclose(a['conf'][ia], b['conf'][ib], rtol=0, atol=conf_tol)
-    moved = np.where((a['locs'] != b['locs']).any(axis=1))[0]
-    assert len(moved) <= max(2, len(a['conf']) // 100), len(moved)
-    for i in moved:
-        assert abs(a['conf'][i] - b['conf'][i]) < tie, (i, a['conf'][i], b['conf'][i])
+def _same_detections(a, b, conf_tol):
+    moved = helpers.same_detections(a, b, conf_tol, tie=1e-6)
+    assert moved <= max(2, len(a['conf']) // 100), moved
 
 
 @pytest.mark.parametrize('name', ['vgg_like', 'unet_like2'])
