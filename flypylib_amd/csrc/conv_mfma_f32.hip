@@ -607,15 +607,19 @@ __global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
     const int oz = z0 + zl, oy = y0 + yl, ox = x0 + 16 * xg + c;
     const bool ok = oz < a.OD && oy < a.OH && ox < a.OW;
     float *dst = a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.cout;
+    f32x4 accb[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) accb[b] = sh[b];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < MB; ++b) accb[b] = mfma4(w[q][b][j], bv[4 * q + j], accb[b]);   // MB independent chains
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
-      f32x4 acc = sh[b];
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = mfma4(w[q][b][j], bv[4 * q + j], acc);
       if (ok) {
-        const f32x4 o = act4(acc, a.act);
+        const f32x4 o = act4(accb[b], a.act);
         store_quad(dst, 16 * b + 4 * g, a.cout, o, FPL_ACT_NONE);
         if (STATS) cs.add(b, o);
       }
@@ -678,31 +682,38 @@ __global__ __launch_bounds__(256) void stem_conv1_pool_f32(StemF a) {
   for (int task = wave; task < (ST_Z / 2) * (ST_Y / 2) * (ST_X / 16); task += 4) {
     const int xg = task % (ST_X / 16), pyl = (task / (ST_X / 16)) % (ST_Y / 2),
               pzl = task / (ST_X / 16 * (ST_Y / 2));
+    // the four window positions side by side: 4 * MB independent accumulators, so no MFMA
+    // waits for the one before it; every accumulator still sums in the same order.  (Measured
+    // against one position at a time - MB chains of 8 dependent MFMAs: the same 119 ms at
+    // 1024^3, so dependent issue was not what holds this kernel at half the fp32 MFMA rate.)
     f32x4 pm[MB1];
+    float bv[4][8];
+    f32x4 acc[4][MB];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
       const int zl = 2 * pzl + (sub >> 1), yl = 2 * pyl + (sub & 1);
       const int base = (zl * ST_TY + yl) * ST_TX + 16 * xg + c;
-      float bv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = tile[base + toff[j]];
-      f32x4 acc[1][MB];
+      for (int j = 0; j < 8; ++j) bv[sub][j] = tile[base + toff[j]];
 #pragma unroll
-      for (int b = 0; b < MB; ++b) {
-        acc[0][b] = sh[b];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[0][b] = mfma4(w[q][b][j], bv[4 * q + j], acc[0][b]);
-      }
-      f32x4 acc1[1][MB1];
-      ch.template apply<1>(acc, a.act, acc1);
-#pragma unroll
-      for (int m = 0; m < MB1; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          pm[m][r] = sub == 0 ? acc1[0][m][r] : fmaxf(pm[m][r], acc1[0][m][r]);
+      for (int b = 0; b < MB; ++b) acc[sub][b] = sh[b];
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int b = 0; b < MB; ++b)
+            acc[sub][b] = mfma4(w[q][b][j], bv[sub][4 * q + j], acc[sub][b]);
+    f32x4 acc1[4][MB1];
+    ch.template apply<4>(acc, a.act, acc1);
+#pragma unroll
+    for (int m = 0; m < MB1; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pm[m][r] = fmaxf(fmaxf(acc1[0][m][r], acc1[1][m][r]), fmaxf(acc1[2][m][r], acc1[3][m][r]));
 #pragma unroll
     for (int m = 0; m < MB1; ++m)
 #pragma unroll
