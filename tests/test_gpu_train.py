@@ -115,6 +115,62 @@ def test_fused_and_separate_bn_relu_pool_agree(ctx, monkeypatch):
         assert _rel(a, b) < 2e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
 
 
+def test_bn_in_the_conv_loader_and_sums_in_the_dgrad_epilogue(ctx, monkeypatch):
+    """round 3's fusions around the first block's 1x1x1 convolution - BatchNorm + ReLU applied
+    by its loader (forward and weight gradient), the BN backward sums made in its input-
+    gradient epilogue - against the same step with the sums in their own pass
+    (FPL_TRAIN_BNSTAT_SEPARATE) and with every layer as its own kernel (FPL_TRAIN_UNFUSED):
+    identical up to the order of fp64 partial sums and the float atomics of the weight
+    gradients.  (The oracle holds the default, fused, step in the tests above.)"""
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 17)
+    rng = np.random.default_rng(2)
+    data = rng.standard_normal((3, 30, 30, 30, 1)).astype(np.float32)
+    lab = (rng.random((3, 4, 4, 4, 1)) > 0.7).astype(np.uint8)
+    tr = _capi.Trainer(ctx, g)
+    loss_f, acc_f = tr.step(data, lab, seed=5)
+    grads_f = [x.copy() for x in tr.get_grads()]
+    tr.close()
+    for env in ('FPL_TRAIN_BNSTAT_SEPARATE', 'FPL_TRAIN_UNFUSED'):
+        monkeypatch.setenv(env, '1')
+        tr2 = _capi.Trainer(ctx, g)
+        loss_s, acc_s = tr2.step(data, lab, seed=5)
+        assert abs(loss_f - loss_s) < 1e-6 and acc_f == acc_s, env
+        for i, (a, b) in enumerate(zip(grads_f, tr2.get_grads())):
+            assert _rel(a, b) < 2e-5, '%s %s: %g' % (env, g.weight_names[i], _rel(a, b))
+        tr2.close()
+        monkeypatch.delenv(env)
+
+
+def test_device_batches_equal_host_batches(ctx):
+    """train._DeviceStager (the prefetch worker uploads the next batch on a side stream):
+    a step fed device tensors is the step fed the same host arrays, bit for bit"""
+    from flypylib_amd import train
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 18)
+    rng = np.random.default_rng(4)
+    data = rng.standard_normal((4, 30, 30, 30, 1)).astype(np.float32)
+    lab = (rng.random((4, 4, 4, 4, 1)) > 0.7).astype(np.uint8)
+    stage = train._DeviceStager(ctx.device)
+    xd, yd = stage(data, lab)
+    assert xd.is_cuda and tuple(xd.shape) == data.shape and yd.dtype.is_floating_point is False
+    tr = _capi.Trainer(ctx, g)
+    la, aa = tr.step(data, lab, seed=3)
+    ga = [x.copy() for x in tr.get_grads()]
+    tr2 = _capi.Trainer(ctx, g)
+    lb, ab = tr2.step(xd, yd, seed=3)
+    assert la == lb and aa == ab
+    for i, (a, b) in enumerate(zip(ga, tr2.get_grads())):
+        assert _rel(a, b) < 1e-5, g.weight_names[i]          # float atomics in the weight gradients
+    # rank rows: the stager slices this rank's examples and checks the batch size
+    part = train._DeviceStager(ctx.device, slice(2, 4), 4, 'need 4, got %d')
+    xs, ys = part(data, lab)
+    assert tuple(xs.shape) == (2, 30, 30, 30, 1) and np.array_equal(xs.cpu().numpy(), data[2:4])
+    with pytest.raises(ValueError, match='need 4, got 3'):
+        part(data[:3], lab[:3])
+    tr.close(); tr2.close()
+
+
 def test_c3_shape_32_patches_of_64(ctx, monkeypatch):
     """configs[3]'s stated shape - batch 32 of 64^3 patches, 12^3 outputs each.  The float64
     oracle needs minutes for that batch, so (a) the whole batch through properties: the
