@@ -71,7 +71,29 @@ constexpr int grp_k0(int gi) {
   return !SPLIT ? gi : gi >= 12 ? 8 : gi % 3 == 2 ? 2 * (gi / 3) : 2 * (gi / 3) + gi % 3;
 }
 constexpr int grp_k1(int gi) { return gi >= 12 ? 8 : 2 * (gi / 3) + 1; }   // pairs only
-constexpr unsigned grp_off(int k) { return (unsigned)(((k / 3) * TY * TX + k % 3) * PITCH); }
+constexpr unsigned grp_off(int k, int ty) { return (unsigned)(((k / 3) * ty * TX + k % 3) * PITCH); }
+// Geometry of a block of 4 (z: one plane per wave) x R (y: rows per wave) x 16 (x: lanes)
+// outputs.  R = 4 everywhere but the 32-output-channel kernels (unet_like2's stem: R = 8, 96
+// rows = 12 blocks; its head: R = 6, 82 rows = 14 blocks): a weight fragment then feeds 8 / 6
+// MFMAs instead of 4 - these kernels' vector-memory return path is ~90 % busy with the
+// per-wave weight stream (profiles/r03_pmc_unet264.json) - and the tile carries 2.1 / 2.25
+// instead of 2.53 input voxels per output.  Measured (27 tiles of 100^3, f16 / split): stem
+// 1.50 -> 1.38 / 4.3 -> 3.8 ms, head 2.47 -> 2.32 / 6.65 -> 5.96 ms (R = 8 for the head:
+// 2.35 / 6.1, it pads 82 rows to 88 and spills).  The 64-channel kernels stay at R = 4: 8
+// rows of 4 M-blocks do not fit 256 registers.
+template <int R> struct Geo {
+  static constexpr int TY = R + 2;
+  static constexpr int PLANE = (TZ * TY * TX * PITCH + 255) / 256 * 256;
+  static constexpr int TILE_BYTES = 4 * PLANE;
+  static constexpr int NPIECE = TZ * TY * TX * 4;
+  static constexpr int NT = (NPIECE + 255) / 256;
+  static constexpr int TABN = NT * 64;
+  static constexpr int TAB_BYTES = MAXTAB * TABN * 4;
+  static constexpr int RY = TY + 2;
+  static constexpr int NRAW = (TZ + 2) * RY * (TX + 2);
+  static constexpr int NRAWT = (NRAW + 255) / 256;       // raw values per thread
+  static_assert(NPIECE % 32 == 0, "tile pieces come in groups of 32");
+};
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -188,11 +210,15 @@ struct Conv3Args {
 constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
 constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
-template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false>
-__global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(Conv3Args a) {
+template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false, int R = 4>
+__global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FPLK(conv3)(Conv3Args a) {
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
   static_assert(!HEAD || (MB == 2 && !POOL), "the head variant is conv3 ->32");
-  static_assert(NRAW % 256 == 0, "raw tile pieces per thread");
+  static_assert(R % 2 == 0, "pool pairs");
+  // this instantiation's geometry (the names shadow the R = 4 constants above)
+  constexpr int TY = Geo<R>::TY, PLANE = Geo<R>::PLANE, TILE_BYTES = Geo<R>::TILE_BYTES;
+  constexpr int NT = Geo<R>::NT, TABN = Geo<R>::TABN, RY = Geo<R>::RY, NRAW = Geo<R>::NRAW;
+  constexpr int NRAWT = Geo<R>::NRAWT;
   // K-steps of weight fragments in flight (27 % WQ == 0)
   constexpr int WQ = 3;
   constexpr int ROW = TX * PITCH;
@@ -233,17 +259,17 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
   const int vox0 = (tid >> 5) * 8 + (tid & 7);
   const unsigned pc = (unsigned)((tid >> 3) & 3);
   u32x4 nt[STEM ? 1 : NT];
-  float rawv[STEM ? NRAW / 256 : 1];
+  float rawv[STEM ? NRAWT : 1];
   auto fetch = [&](int64_t fb, int cc) {
     const int bx = (int)(fb % a.nbx), by = (int)((fb / a.nbx) % a.nby);
     const int bz = (int)(fb / ((int64_t)a.nbx * a.nby));
     const int n = bz / a.zblocks;
     if (STEM) {
-      const int z0 = (bz % a.zblocks) * 4, y0 = by * 4, x0 = bx * 16;
+      const int z0 = (bz % a.zblocks) * 4, y0 = by * R, x0 = bx * 16;
       const float *base = a.raw + (int64_t)n * a.T * a.T * a.T;
 #pragma unroll
-      for (int j = 0; j < NRAW / 256; ++j) {
-        const int p = tid + 256 * j;
+      for (int j = 0; j < NRAWT; ++j) {
+        const int p = min(tid + 256 * j, NRAW - 1);
         int z = z0 + p / (RY * RX), y = y0 + (p / RX) % RY, x = x0 + p % RX;
         z = z < a.T ? z : a.T - 1;                 // clamped reads only feed masked
         y = y < a.T ? y : a.T - 1;                 // outputs
@@ -254,8 +280,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
     }
     const Src s = a.src[cc];
     const int z0 = ((bz % a.zblocks) * 4 + s.crop) >> s.ups;
-    const int y0 = ((a.transposed ? bx * 16 : by * 4) + s.crop) >> s.ups;
-    const int x0 = ((a.transposed ? a.xorg + by * 4 : bx * 16) + s.crop) >> s.ups;
+    const int y0 = ((a.transposed ? bx * 16 : by * R) + s.crop) >> s.ups;
+    const int x0 = ((a.transposed ? a.xorg + by * R : bx * 16) + s.crop) >> s.ups;
     const unsigned char *base = reinterpret_cast<const unsigned char *>(
         s.p + ((((int64_t)n * s.D + z0) * s.H + y0) * s.W + x0) * s.C + s.ch0);
     const unsigned *tab = offtab + s.tab * TABN + vox0;
@@ -288,11 +314,13 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
       // input and weights as hi + lo, three products; plain rows, so lane (c, g) holds
       // channels 4g .. 4g+3 of its voxel: 8 B of plane g / 2 (hi) and of plane 2 + g / 2 (lo)
 #pragma unroll
-      for (int j = 0; j < NRAW / 256; ++j) {
+      for (int j = 0; j < NRAWT; ++j) {
         const float x = rawv[j];
         const h16_t h = (h16_t)x;
-        rawt[tid + 256 * j] = h16_bits(x);
-        rawt[NRAW + tid + 256 * j] = h16_bits(x - (float)h);
+        if (tid + 256 * j < NRAW) {
+          rawt[tid + 256 * j] = h16_bits(x);
+          rawt[NRAW + tid + 256 * j] = h16_bits(x - (float)h);
+        }
       }
       const h16x8 wh = a.wstem[(cc * 2 + 0) * 64 + lane], wl = a.wstem[(cc * 2 + 1) * 64 + lane];
       f32x4 sh;
@@ -321,7 +349,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
     }
     if (STEM) {
 #pragma unroll
-      for (int j = 0; j < NRAW / 256; ++j) rawt[tid + 256 * j] = h16_bits(rawv[j]);
+      for (int j = 0; j < NRAWT; ++j)
+        if (tid + 256 * j < NRAW) rawt[tid + 256 * j] = h16_bits(rawv[j]);
       __syncthreads();                              // raw tile visible
       constexpr int NGRP = (TZ * TY * TX + 15) / 16;
       for (int grp = wave; grp < NGRP; grp += 4) {
@@ -355,7 +384,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
   for (int b = 0; b < MB; ++b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[4 * MB * g + 4 * b + r];
-  f32x4 acc[4][MB];
+  f32x4 acc[R][MB];
   const int total_steps = a.ncc * NG * KC;
   __syncthreads();                                  // offset tables visible
   // The tile loads go out BEFORE the weight loads, as in the steady state of the
@@ -378,8 +407,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
   const unsigned pbase = (unsigned)(((wave * TY) * TX + c) * PITCH + (g & 1) * PLANE);
   auto row_addr = [&](int gi, int r) -> const unsigned char * {
     if (grp_pair(gi))
-      return tile + pbase + (g >= 2 ? grp_off(grp_k1(gi)) : grp_off(grp_k0(gi))) + r * ROW;
-    return tile + vbase + grp_off(grp_k0(gi)) + r * ROW;
+      return tile + pbase + (g >= 2 ? grp_off(grp_k1(gi), TY) : grp_off(grp_k0(gi), TY)) + r * ROW;
+    return tile + vbase + grp_off(grp_k0(gi), TY) + r * ROW;
   };
 
   for (;;) {
@@ -388,7 +417,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
 #pragma unroll
         for (int b = 0; b < MB; ++b)
 #pragma unroll
-          for (int sub = 0; sub < 4; ++sub) acc[sub][b] = shv[b];
+          for (int sub = 0; sub < R; ++sub) acc[sub][b] = shv[b];
       }
       __syncthreads();            // every wave has left the previous tile
       if (!PF) fetch(blk, cc);
@@ -401,9 +430,9 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();            // tile visible
-      h16x8 brow[2][6];
+      h16x8 brow[2][R + 2];
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+      for (int r = 0; r < R + 2; ++r)
         brow[0][r] = *reinterpret_cast<const h16x8 *>(row_addr(0, r));
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
@@ -412,13 +441,13 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
 #pragma unroll
         for (int dy = 0; dy < KC; ++dy) {
           const int st = gi * KC + dy;              // K-step inside the channel chunk
-          // spread the six prefetch reads over the three K-steps
+          // spread the R + 2 prefetch reads over the three K-steps
 #pragma unroll
-          for (int r = 2 * dy; r < 2 * dy + 2; ++r)
+          for (int r = (R + 2) * dy / 3; r < (R + 2) * (dy + 1) / 3; ++r)
             brow[(gi + 1) & 1][r] = *reinterpret_cast<const h16x8 *>(row_addr(ng, r));
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int sub = 0; sub < 4; ++sub)
+          for (int sub = 0; sub < R; ++sub)
 #pragma unroll
             for (int b = 0; b < MB; ++b)
               acc[sub][b] = mfma16(wq[st % WQ][b], brow[gi & 1][sub + dy], acc[sub][b]);
@@ -441,9 +470,9 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
       const int n = bz / a.zblocks;
       const int oz = (bz % a.zblocks) * 4 + wave;
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
-        const int oy = a.transposed ? bx * 16 + c : by * 4 + sub;
-        const int ox = a.transposed ? a.xorg + by * 4 + sub : bx * 16 + c;
+      for (int sub = 0; sub < R; ++sub) {
+        const int oy = a.transposed ? bx * 16 + c : by * R + sub;
+        const int ox = a.transposed ? a.xorg + by * R + sub : bx * 16 + c;
         if (HEAD) {
           // with interleaved rows lane (c,g) holds channels 8g..8g+7 of voxel c: the
           // packed pair IS the K-step of conv1 32->32 in SLOT_SPATIAL order
@@ -489,9 +518,9 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
     if (POOL && SPLIT) {
       // the same pool in fp32 (the split representation is monotonic: the split of the
       // maximum is the maximum of the splits); ReLU and the hi / lo store at the end
-      f32x4 pm[2][MB];
+      f32x4 pm[R / 2][MB];
 #pragma unroll
-      for (int yh = 0; yh < 2; ++yh)
+      for (int yh = 0; yh < R / 2; ++yh)
 #pragma unroll
         for (int b = 0; b < MB; ++b)
 #pragma unroll
@@ -503,10 +532,10 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
       __syncthreads();                              // every wave is done with the tile
       if (wave & 1) {
 #pragma unroll
-        for (int yh = 0; yh < 2; ++yh)
+        for (int yh = 0; yh < R / 2; ++yh)
 #pragma unroll
           for (int b = 0; b < MB; ++b)
-            xch[(((wave >> 1) * 2 + yh) * MB + b) * 64 + lane] = pm[yh][b];
+            xch[(((wave >> 1) * (R / 2) + yh) * MB + b) * 64 + lane] = pm[yh][b];
       }
       __syncthreads();
       if (!(wave & 1) && !(c & 1)) {
@@ -516,13 +545,13 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
         const int PD = a.OD / 2, PH = a.OH / 2, PW = a.OW / 2;
         const int pz = (bz % a.zblocks) * 2 + (wave >> 1), px = bx * 8 + (c >> 1);
 #pragma unroll
-        for (int yh = 0; yh < 2; ++yh) {
-          const int py = by * 2 + yh;
+        for (int yh = 0; yh < R / 2; ++yh) {
+          const int py = by * (R / 2) + yh;
           if (pz < PD && py < PH && px < PW) {
             f32x4 m[MB];
 #pragma unroll
             for (int b = 0; b < MB; ++b) {
-              const f32x4 o = xch[(((wave >> 1) * 2 + yh) * MB + b) * 64 + lane];
+              const f32x4 o = xch[(((wave >> 1) * (R / 2) + yh) * MB + b) * 64 + lane];
 #pragma unroll
               for (int r = 0; r < 4; ++r) m[b][r] = __builtin_fmaxf(pm[yh][b][r], o[r]);
             }
@@ -533,9 +562,9 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
       }
     }
     if (POOL && !SPLIT) {
-      u32x4 pm[2][MB / 2];                          // [y half][16-B piece]
+      u32x4 pm[R / 2][MB / 2];                      // [y pair][16-B piece]
 #pragma unroll
-      for (int yh = 0; yh < 2; ++yh)
+      for (int yh = 0; yh < R / 2; ++yh)
 #pragma unroll
         for (int h = 0; h < MB / 2; ++h) {
 #pragma unroll
@@ -552,10 +581,10 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
       __syncthreads();                              // every wave is done with the tile
       if (wave & 1) {
 #pragma unroll
-        for (int yh = 0; yh < 2; ++yh)
+        for (int yh = 0; yh < R / 2; ++yh)
 #pragma unroll
           for (int h = 0; h < MB / 2; ++h)
-            xch[(((wave >> 1) * 2 + yh) * (MB / 2) + h) * 64 + lane] = pm[yh][h];
+            xch[(((wave >> 1) * (R / 2) + yh) * (MB / 2) + h) * 64 + lane] = pm[yh][h];
       }
       __syncthreads();
       if (!(wave & 1) && !(c & 1)) {
@@ -565,13 +594,13 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT) ? 3 : 2) void FPLK(conv3)(
         const int PD = a.OD / 2, PH = a.OH / 2, PW = a.OW / 2;
         const int pz = (bz % a.zblocks) * 2 + (wave >> 1), px = bx * 8 + (c >> 1);
 #pragma unroll
-        for (int yh = 0; yh < 2; ++yh) {
-          const int py = by * 2 + yh;
+        for (int yh = 0; yh < R / 2; ++yh) {
+          const int py = by * (R / 2) + yh;
           if (pz < PD && py < PH && px < PW) {
             h16_t *dst = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (16 * MB) + 4 * MB * g;
 #pragma unroll
             for (int h = 0; h < MB / 2; ++h) {
-              const u32x4 o = xch[(((wave >> 1) * 2 + yh) * (MB / 2) + h) * 64 + lane];
+              const u32x4 o = xch[(((wave >> 1) * (R / 2) + yh) * (MB / 2) + h) * 64 + lane];
               u32x4 m;
 #pragma unroll
               for (int q = 0; q < 4; ++q) m[q] = pk_max_i16(pm[yh][h][q], o[q]);
@@ -1030,17 +1059,18 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
   return 0;
 }
 
-template <int MB, bool STEM = false, bool POOL = false, bool HEAD = false>
+template <int MB, bool STEM = false, bool POOL = false, bool HEAD = false, int R = 4>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   constexpr bool PF = true;
+  typedef Geo<R> GE;
   // STEM keeps the bf16 raw tile behind the (single) offset table
-  constexpr int SMEM = TILE_BYTES + (STEM ? TABN * 4 + NRAW * 2 * PM : TAB_BYTES);
+  constexpr int SMEM = GE::TILE_BYTES + (STEM ? GE::TABN * 4 + GE::NRAW * 2 * PM : GE::TAB_BYTES);
   static_assert(2 * SMEM <= 160 * 1024, "two conv3 workgroups must fit one CU");
   // function attributes belong to the current device: one flag per device (a process may
   // drive several GPUs, one context each; setting it twice is harmless)
   static bool attr_set[FPL_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL, HEAD>,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL, HEAD, R>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
@@ -1063,19 +1093,19 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   }
   a.zblocks = (int)ceil_div64(a.OD, 4);
   if (a.transposed) {            // lanes walk y, sub-steps walk x in [xorg, OW)
-    a.nbx = (int)ceil_div64(a.OH, 16); a.nby = (int)ceil_div64(a.OW - a.xorg, 4);
+    a.nbx = (int)ceil_div64(a.OH, 16); a.nby = (int)ceil_div64(a.OW - a.xorg, R);
   } else {
-    a.nbx = (int)ceil_div64(a.main_w ? a.main_w : a.OW, 16); a.nby = (int)ceil_div64(a.OH, 4);
+    a.nbx = (int)ceil_div64(a.main_w ? a.main_w : a.OW, 16); a.nby = (int)ceil_div64(a.OH, R);
   }
   a.nbz = n * a.zblocks;
   const int64_t total = (int64_t)a.nbx * a.nby * a.nbz;
   // two workgroups per CU, rounded to a multiple of the 8 XCDs
-  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * ((MB == 2 && !SPLIT) ? 3 : 2), (total + 7) / 8 * 8);
+  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu * ((MB == 2 && !SPLIT && R == 4) ? 3 : 2), (total + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   TimedLaunch tl(ctx, name);
   FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
               "conv3: pool output / template mismatch");
-  FPLK(conv3)<MB, PF, STEM, POOL, HEAD><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
+  FPLK(conv3)<MB, PF, STEM, POOL, HEAD, R><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
 
@@ -1121,7 +1151,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   // (C real channels = C * PM halves per voxel)
   auto balloc = [&](int64_t elems, int dim, int C, h16_t **p) -> int {
     void *q;
-    const size_t slack = ((size_t)5 * dim * dim + 5 * dim + 18) * C * PM * 2;
+    const size_t slack = ((size_t)5 * dim * dim + 9 * dim + 18) * C * PM * 2;   // rows: up to R + 1 = 7 (R = 6)
     int rc = tmp.alloc((size_t)elems * PM * 2 + slack + 64, &q);
     *p = (h16_t *)q;
     return rc;
@@ -1167,7 +1197,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.raw = in; a.T = T;
     a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
     a.pool_out = p1;                               // MaxPooling3D(2) in the epilogue
-    FPL_TRY((launch_conv3<2, true, true>(ctx, a, n, "unet_stem_conv3_32_32_pool")));
+    FPL_TRY((launch_conv3<2, true, true, false, 8>(ctx, a, n, "unet_stem_conv3_32_32_pool")));
   }
   {  // conv3 32->64
     Conv3Args a = conv3_args(2, c2a, d2a);
@@ -1248,9 +1278,9 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
       a.w8 = (const h16x8 *)(F + st->off_w[lu2 + 1]); a.sh8 = S + st->off_s[lu2 + 1];
       a.w9 = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias9 = st->bias_tail;
       a.out = nullptr;
-      FPL_TRY((launch_conv3<2, false, false, true>(ctx, a, n, "unet_conv3_96_32_head")));
+      FPL_TRY((launch_conv3<2, false, false, true, 6>(ctx, a, n, "unet_conv3_96_32_head")));
     } else {
-      FPL_TRY((launch_conv3<2>(ctx, a, n, "unet_conv3_96_32")));
+      FPL_TRY((launch_conv3<2, false, false, false, 6>(ctx, a, n, "unet_conv3_96_32")));
     }
     if (strip) {
       Conv3Args e = a;
