@@ -326,7 +326,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     // reference lattice's pitch (tile - 2*off) is a multiple of that stride when every pool
     // sees even extents - so m x m x m neighbouring reference tiles computed as ONE tile of
     // m*pitch + 2*off give, voxel for voxel, the same arithmetic in the same order as the m^3
-    // small ones (bit-identical: tests/test_gpu_fullsize.py), while the halo that every tile
+    // small ones (bit-identical: tests/test_gpu_cnn.py), while the halo that every tile
     // recomputes shrinks from (102/88)^3 = 1.56x to (542/528)^3 = 1.08x of the work
     // (vgg_like, m = 6).  m minimises the voxels computed under a per-tile memory cap.
     int32_t m = 1;
