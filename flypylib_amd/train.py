@@ -416,7 +416,7 @@ class _DeviceStager:
     a side stream and waits for that copy, so the training thread receives device tensors
     and fpl_trainer_step starts without the 33 MB host-to-device copy in front of it (about
     0.8 ms of a 12.4 ms vgg_like step, configs[3]).  The reference's generators yield host
-    arrays (flypylib/fplnetwork.py:gen_batches); where they live afterwards is plumbing."""
+    arrays (`gen_batches`, flypylib/fplobjdetect.py:27-130); where they live afterwards is plumbing."""
 
     def __init__(self, device, rows=None, need=None, need_msg=None):
         import torch
