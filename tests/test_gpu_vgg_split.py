@@ -85,11 +85,12 @@ def test_split_u8_operand_is_centred_on_an_integer(ctx, mean, std):
         assert np.abs(got - f32).max() < TOL, (m, s, np.abs(got - f32).max())
 
 
-def test_split_slabs_chunks_and_tilings_are_bit_identical(ctx, monkeypatch):
+@pytest.mark.parametrize('mean,std', [(128.0, 33.0), (126.63, 29.7)])
+def test_split_slabs_chunks_and_tilings_are_bit_identical(ctx, monkeypatch, mean, std):
     g = _net(23, 46)
     prog = _capi.Program(ctx, g, (4, 4, 4))
     u8 = synth.em_volume_u8(11, (131, 70, 121))
-    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F16S)
+    kw = dict(mean=mean, std=std, precision=_capi.PREC_F16S)
     whole = prog.infer_volume(u8, (46,) * 3, (7,) * 3, **kw)
     # Z slabs of the tile lattice (multi-GPU sharding), each written into its rows
     out = np.zeros_like(whole)
