@@ -34,14 +34,17 @@ constexpr int CH = 48;
 constexpr int CHP = 24, NPASS = CH / CHP;
 constexpr int LO_OFF = CHP * 2;            // lo halves of a pass sit 48 B behind the hi halves
 constexpr int PASS_BYTES = 2 * LO_OFF;     // 96
-constexpr int VOX = NPASS * PASS_BYTES;    // 192 B per voxel in HBM
+constexpr int VOX = NPASS * PASS_BYTES;    // 192 B per voxel in HBM, as NPASS planes [pass][z][y][x][96 B]:
+                                           // a pass's tile rows are then contiguous (interleaved per voxel,
+                                           // a row fill touched twice the cache lines it used)
 constexpr int KS = (27 * CHP + 31) / 32;   // 21 K-steps per pass (27 * 24 = 648 = 20.25)
 constexpr int KTAB = (KS + 4) / 4 * 4;     // table entries per lane group
 constexpr int KTAB_BYTES = 4 * KTAB * 4;
 static_assert(CHP % 8 == 0, "a lane's 8 k-slots stay inside one tap");
 
-// byte offset, inside a voxel, of the hi halves of channels ch .. ch+3 (ch % 4 == 0)
-__host__ __device__ constexpr int chan_off(int ch) { return (ch / CHP) * PASS_BYTES + (ch % CHP) * 2; }
+// byte offset of the hi halves of channels ch .. ch+3 (ch % 4 == 0) from a voxel's position
+// in plane 0; `plane` = bytes of one pass plane of the tensor
+__host__ __device__ constexpr int64_t chan_off(int ch, int64_t plane) { return (ch / CHP) * plane + (ch % CHP) * 2; }
 
 // The third M-block of a 48-channel layer fills only half a K-step: its hi and lo halves
 // share ONE fragment [hi | lo] (k-slots j < 4: hi, j >= 4: lo).  Against the weight step
@@ -67,9 +70,9 @@ __device__ __forceinline__ f32x4 chain48(const h16x8 (&w)[4], const Frag2 &h01, 
 }
 
 // four channels (one accumulator tile row group) of one voxel -> HBM, hi and lo halves
-__device__ __forceinline__ void store_split4(unsigned char *vox, int ch, const f32x4 &v) {
+__device__ __forceinline__ void store_split4(unsigned char *vox, int64_t plane, int ch, const f32x4 &v) {
   const Pair2 p0 = split_pk(v[0], v[1]), p1 = split_pk(v[2], v[3]);
-  unsigned char *d = vox + chan_off(ch);
+  unsigned char *d = vox + chan_off(ch, plane);
   *reinterpret_cast<u32x2 *>(d) = u32x2{p0.hi, p1.hi};
   *reinterpret_cast<u32x2 *>(d + LO_OFF) = u32x2{p0.lo, p1.lo};
 }
@@ -434,9 +437,10 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       }
       const int pz = blk.pz0 + pzl, py = blk.py0 + pyl, px = blk.px0 + 16 * xh + c;
       if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
-        unsigned char *vox = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * VOX;
+        unsigned char *vox = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * PASS_BYTES;
+        const int64_t plane = (int64_t)a.P1Z * a.P1Y * a.P1X * PASS_BYTES;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) store_split4(vox, 16 * b + 4 * g, poolf[b]);
+        for (int b = 0; b < 3; ++b) store_split4(vox, plane, 16 * b + 4 * g, poolf[b]);
       }
     }
     if (!has_next) break;
@@ -480,7 +484,8 @@ __device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, i
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     if (pass) __syncthreads();                       // every wave has left the previous pass's tile
-    stage_tile<TZ, TY, TX, VOX>(act + pass * PASS_BYTES, AZ, AY, AX, z0, y0, x0, tile, wave, lane);
+    stage_tile<TZ, TY, TX, PASS_BYTES>(act + (int64_t)pass * AZ * AY * AX * PASS_BYTES, AZ, AY, AX,
+                                        z0, y0, x0, tile, wave, lane);
     const unsigned char *wl = wglobal + (size_t)pass * KS * 6 * 1024 + lane * 16;
     h16x8 wq[WQ][6];                                 // [..][0..2] hi, [3..5] lo
 #pragma unroll
@@ -612,9 +617,10 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
       pooled[b][r] = __builtin_fmaxf(pooled[b][r], __shfl_xor(pooled[b][r], 1));
   const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + (c >> 1);
   if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
-    unsigned char *vox = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * VOX;
+    unsigned char *vox = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * PASS_BYTES;
+    const int64_t plane = (int64_t)a.P2Z * a.P2Y * a.P2X * PASS_BYTES;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) store_split4(vox, 16 * b + 4 * g, pooled[b]);
+    for (int b = 0; b < 3; ++b) store_split4(vox, plane, 16 * b + 4 * g, pooled[b]);
   }
 }
 
@@ -969,7 +975,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   FPL_REQUIRE(ctx, (int64_t)S_TZ * SY * SX < ((int64_t)1 << 31),
               "vgg split path: a %lld x %lld plane is too large for the stem's 31-bit row "
               "offsets", (long long)SY, (long long)SX);
-  FPL_REQUIRE(ctx, (int64_t)P1Y * P1X * VOX * 8 < ((int64_t)1 << 32),
+  FPL_REQUIRE(ctx, (int64_t)P1Y * P1X * PASS_BYTES * 8 < ((int64_t)1 << 32),
               "vgg split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
               "offsets", (long long)SY, (long long)SX);
   DevTemp tmp(ctx);
