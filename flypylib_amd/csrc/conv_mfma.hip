@@ -106,18 +106,25 @@ struct Src {             // one CC-channel chunk of the (virtual) concatenated i
   int tab;               // which offset table (geometry H, W, C, ups) this source uses
 };
 
+// Activation tensors are stored as planes of CC = 32 physical channels: [chunk][n][z][y][x][32]
+// (round 3).  A tile loader reads ONE chunk at a time, and with the chunks interleaved per
+// voxel (64 of every 128 / 256 / 512 B) each fill touched two to eight times the cache
+// lines it used; a chunk plane makes a tile row one contiguous run.  `plane` = elements of
+// one chunk plane of the tensor being written.
+//
 // Epilogue store for interleaved output channels (pack_weights.h, fpl_out_channel):
-// lane (c, g) writes the 4*MB contiguous channels [4*MB*g, ...) of its voxel.
+// lane (c, g) writes the 4*MB contiguous channels [4*MB*g, ...) of its voxel; `vox0` is the
+// voxel's position in chunk plane 0.
 template <int MB, bool RELU_ALWAYS>
-__device__ __forceinline__ void store_il(h16_t *vox_out, int g, const f32x4 (&acc)[MB], int relu) {
+__device__ __forceinline__ void store_il(h16_t *vox0, int64_t plane, int g, const f32x4 (&acc)[MB], int relu) {
   static_assert(MB % 2 == 0, "16-B pieces");
   if (SPLIT) {
     // the lane's 4*MB real channels start at 4*MB*g; per 8 of them one 16-B piece of hi
-    // halves and, 16 halves behind it, one of lo halves, inside their group of 16
+    // halves and, 16 halves behind it, one of lo halves, inside their chunk of 16 real
 #pragma unroll
     for (int h = 0; h < MB / 2; ++h) {
       const int ch = 4 * MB * g + 8 * h;
-      h16_t *d = vox_out + (ch / 16) * 32 + ch % 16;
+      h16_t *d = vox0 + (ch / 16) * plane + ch % 16;
       u32x4 hi, lo;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -133,9 +140,9 @@ __device__ __forceinline__ void store_il(h16_t *vox_out, int g, const f32x4 (&ac
     }
     return;
   }
-  h16_t *dst = vox_out + 4 * MB * g;
 #pragma unroll
   for (int h = 0; h < MB / 2; ++h) {
+    const int ch = 4 * MB * g + 8 * h;
     u32x4 o;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -146,7 +153,7 @@ __device__ __forceinline__ void store_il(h16_t *vox_out, int g, const f32x4 (&ac
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = pk_max_i16(o[q], 0u);
     }
-    *reinterpret_cast<u32x4 *>(dst + 8 * h) = o;
+    *reinterpret_cast<u32x4 *>(vox0 + (ch / CC) * plane + ch % CC) = o;
   }
 }
 
@@ -158,8 +165,8 @@ struct Conv3Args {
   const unsigned char *w;        // fragments [cc][dz][dx][dy][mb], 1 KiB each
   const float *shift;
   int relu;
-  h16_t *out;                   // (n, OD, OH, OW, cpitch): channels [0, 16*MB) of each voxel
-  int cpitch;                    // channel pitch of `out` (0 = 16*MB; 128 when two launches fill the halves)
+  h16_t *out;                   // chunk plane 0 of the output's channels [0, 16*MB): (n, OD, OH, OW, 32)
+  int64_t oplane;                // elements of one chunk plane of `out` (n * OD * OH * OW * 32)
   int OD, OH, OW, zblocks;       // zblocks = ceil(OD/4)
   int nbx, nby, nbz;             // blocks: ceil(OW/16), ceil(OH/4), n * zblocks
   // STEM variant: the (single) source is conv3 1->32 + shift + ReLU of this raw
@@ -169,6 +176,7 @@ struct Conv3Args {
   const float *shstem;
   // optional fused MaxPooling3D(2) of the (ReLU) output: (n, OD/2, OH/2, OW/2, 16*MB)
   h16_t *pool_out;
+  int64_t pplane;                // elements of one chunk plane of `pool_out`
   // Edge strip (transposed view).  An output width that is not a multiple of 16
   // wastes lanes in the last x block (OW = 82: 14 of 16).  The strip x in [xorg, OW)
   // is then run with the block's axes swapped: lanes walk y, the four sub-steps walk
@@ -507,8 +515,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
                       td.start[1] + a.io.off + oy) * a.io.X + td.start[2] + a.io.off + ox] =
                 1.f / (1.f + __expf(-logit));
         } else if (oz < a.OD && oy < a.OH && ox < a.OW)
-          store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.cpitch,
-                              g, acc[sub], a.relu);
+          store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * CC,
+                              a.oplane, g, acc[sub], a.relu);
       }
     }
     // ---- fused 2x2x2 max pool of the block (4 x 4 x 16 -> 2 x 2 x 8): y pairs are
@@ -555,8 +563,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
 #pragma unroll
               for (int r = 0; r < 4; ++r) m[b][r] = __builtin_fmaxf(pm[yh][b][r], o[r]);
             }
-            store_il<MB, true>(a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (16 * MB * PM),
-                               g, m, 1);
+            store_il<MB, true>(a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * CC,
+                               a.pplane, g, m, 1);
           }
         }
       }
@@ -597,14 +605,15 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
         for (int yh = 0; yh < R / 2; ++yh) {
           const int py = by * (R / 2) + yh;
           if (pz < PD && py < PH && px < PW) {
-            h16_t *dst = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (16 * MB) + 4 * MB * g;
+            h16_t *vox0 = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * CC;
 #pragma unroll
             for (int h = 0; h < MB / 2; ++h) {
               const u32x4 o = xch[(((wave >> 1) * (R / 2) + yh) * (MB / 2) + h) * 64 + lane];
               u32x4 m;
 #pragma unroll
               for (int q = 0; q < 4; ++q) m[q] = pk_max_i16(pm[yh][h][q], o[q]);
-              *reinterpret_cast<u32x4 *>(dst + 8 * h) = m;
+              const int ch = 4 * MB * g + 8 * h;
+              *reinterpret_cast<u32x4 *>(vox0 + (ch / CC) * a.pplane + ch % CC) = m;
             }
           }
         }
@@ -617,7 +626,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
 
 // ---- 1x1x1 conv as a voxel GEMM ---------------------------------------------------
 struct Conv1Args {
-  const h16_t *in; int64_t M;   // voxels (n*D*H*W), CIN channels each
+  const h16_t *in; int64_t M;   // voxels (n*D*H*W), CIN channels each, in chunk planes of M * 32
+  int64_t plane;                 // = M * 32: elements of one chunk plane of `in` and of `out`
   const unsigned char *w;        // [kstep][mb] fragments (SLOT_SPATIAL, 1 tap)
   const float *shift;
   h16_t *out;                   // (M, 16*MB) bf16            (TAIL == 0)
@@ -652,7 +662,7 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
     h16x8 bf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      bf[s] = *reinterpret_cast<const h16x8 *>(a.in + m * (CIN * PM) + 32 * s + 8 * g);
+      bf[s] = *reinterpret_cast<const h16x8 *>(a.in + s * a.plane + m * CC + 8 * g);
     f32x4 acc[MB];
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
@@ -667,7 +677,7 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
       }
     }
     if (TAIL == 0) {
-      if (ok) store_il<MB, true>(a.out + m * (16 * MB * PM), g, acc, 1);
+      if (ok) store_il<MB, true>(a.out + m * CC, a.plane, g, acc, 1);
     } else {
       // chained 16*MB -> 1 conv (k-slots bound to the accumulator layout), sigmoid
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
     acc[sub][1] = mfma16(w1[1], h0, sh1[1]);
     const int oz = z0 + wave, oy = y0 + sub, ox = x0 + c;
     if (oz < a.D && oy < a.D && ox < a.D)
-      store_il<2, true>(a.c1 + ((((int64_t)n * a.D + oz) * a.D + oy) * a.D + ox) * 32, g, acc[sub], 1);
+      store_il<2, true>(a.c1 + ((((int64_t)n * a.D + oz) * a.D + oy) * a.D + ox) * 32, 0, g, acc[sub], 1);
   }
   // 2x2x2 max pool of the block, as the POOL epilogue of conv3
   u32x4 pm[2];
@@ -1074,7 +1084,8 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
-  if (a.cpitch == 0) a.cpitch = 16 * MB * PM;
+  a.oplane = (int64_t)n * a.OD * a.OH * a.OW * CC;
+  a.pplane = (int64_t)n * (a.OD / 2) * (a.OH / 2) * (a.OW / 2) * CC;
   // offset tables: one per distinct source geometry
   a.ntab = 0;
   for (int i = 0; i < (STEM ? 0 : a.ncc); ++i) {
@@ -1156,9 +1167,9 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     *p = (h16_t *)q;
     return rc;
   };
-  // chunk `cc` of a source with C real channels: 32 physical channels from 32 * cc
+  // chunk `cc` of a source: its plane of 32 physical channels
   auto src_of = [&](const h16_t *p, int dim, int C, int cc, int up, int crop) {
-    return make_src(p, dim, C * PM, CC * cc, up, crop);
+    return make_src(p ? p + cc * (n * cube(dim) * CC) : p, dim, CC, 0, up, crop);
   };
   h16_t *c1, *p1, *c2a, *c2, *p2, *c3a = nullptr, *c3, *c4a, *c4, *c5a;
   FPL_TRY(balloc(n * cube(d1) * 32, d1, 32, &c1));
@@ -1175,7 +1186,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   auto conv3_args = [&](int l, h16_t *outp, int od) {
     Conv3Args a;
     a.w = F + st->off_w[l]; a.shift = S + st->off_s[l]; a.relu = 1;
-    a.out = outp; a.cpitch = 0; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
+    a.out = outp; a.oplane = a.pplane = 0; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
     a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr; a.pool_out = nullptr;
     a.transposed = 0; a.xorg = 0; a.main_w = 0;
     memset(&a.io, 0, sizeof(a.io)); a.w8 = a.w9 = nullptr; a.sh8 = nullptr; a.bias9 = 0.f;
@@ -1215,7 +1226,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   auto conv1 = [&](auto kern, int smem_frags, const h16_t *x, int64_t M, int l, h16_t *y,
                    const char *name) {
     Conv1Args a;
-    a.in = x; a.M = M; a.w = F + st->off_w[l]; a.shift = S + st->off_s[l];
+    a.in = x; a.M = M; a.plane = M * CC; a.w = F + st->off_w[l]; a.shift = S + st->off_s[l];
     a.out = y; a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, name);
@@ -1226,17 +1237,19 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   };
   if (D.second1) {  // unet_like: conv1 64->64, then the pool as its own (HBM-bound) pass
     conv1(FPLK(conv1)<64, 4, 0>, 8, c2a, (int64_t)n * cube(d2a), 3, c2, "unet_conv1_64_64");
-    const int64_t no = (int64_t)n * cube(dp2) * 8;
+    // one launch per chunk plane (32 channels = 4 pieces of 16 B per voxel)
+    const int64_t no = (int64_t)n * cube(dp2) * 4;
     TimedLaunch tl(ctx, "unet_pool_64");
-    FPLK(pool2_h16)<<<(unsigned)ceil_div64(no, 256), 256, 0, stm>>>((const u32x4 *)c2, (u32x4 *)p2, no, d2, 8, dp2);
+    for (int ck = 0; ck < 64 * PM / CC; ++ck)
+      FPLK(pool2_h16)<<<(unsigned)ceil_div64(no, 256), 256, 0, stm>>>(
+          (const u32x4 *)(c2 + ck * (n * cube(d2) * CC)), (u32x4 *)(p2 + ck * (n * cube(dp2) * CC)), no, d2, 4, dp2);
   }
   // conv3 -> 128 channels: two 64-channel launches into the halves of one tensor
   auto conv3_to128 = [&](int l, const h16_t *x, int xd, int xc, h16_t *y, int yd, const char *name) -> int {
     for (int h = 0; h < 2; ++h) {
-      Conv3Args a = conv3_args(l, y + 64 * PM * h, yd);
+      Conv3Args a = conv3_args(l, y + (64 * PM / CC) * h * (n * cube(yd) * CC), yd);   // its chunk planes
       a.w = F + st->off_w[l] + (h ? st->half_bytes[l] : 0);
       a.shift = S + st->off_s[l] + 64 * h;
-      a.cpitch = 128 * PM;
       a.ncc = xc / RCH;
       for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = src_of(x, xd, xc, cc, 1, 0);
       FPL_TRY((launch_conv3<4>(ctx, a, n, name)));
@@ -1293,7 +1306,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
 #ifndef FPL_SPLIT
   if (!io) {  // conv1 32->32 (+ReLU) chained into conv1 32->1, sigmoid
     Conv1Args a;
-    a.in = c5a; a.M = (int64_t)n * cube(d5a); a.w = F + st->off_w[lu2 + 1]; a.shift = S + st->off_s[lu2 + 1];
+    a.in = c5a; a.M = (int64_t)n * cube(d5a); a.plane = a.M * CC; a.w = F + st->off_w[lu2 + 1]; a.shift = S + st->off_s[lu2 + 1];
     a.out = nullptr; a.w_tail = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias_tail = st->bias_tail;
     a.out_f32 = out;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
