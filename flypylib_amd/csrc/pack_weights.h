@@ -96,12 +96,12 @@ static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
 // hi x hi (and, for free, lo x lo) product.  Appends n_mblocks fragments to *out.
 static inline void fpl_pack_chain_step(const float *W, const float *scale, int cin, int cout,
                                        int n_mblocks, const int blk[2], const int part[2],
-                                       std::vector<uint16_t> *out) {
+                                       std::vector<uint16_t> *out, bool il = false) {
   const size_t base = out->size();
   out->resize(base + (size_t)n_mblocks * 512, 0);
   for (int b = 0; b < n_mblocks; ++b)
     for (int lane = 0; lane < 64; ++lane) {
-      const int m = lane & 15, g = lane >> 4, co = 16 * b + m;
+      const int m = lane & 15, g = lane >> 4, co = fpl_out_channel(b, m, n_mblocks, il);
       if (co >= cout) continue;
       for (int j = 0; j < 8; ++j) {
         const int c = 16 * blk[j >> 2] + 4 * g + (j & 3);

@@ -69,6 +69,26 @@ __device__ __forceinline__ f32x4 chain48(const h16x8 (&w)[4], const Frag2 &h01, 
   return mfma16(w[0], h01.hi, acc);
 }
 
+// The 1x1x1 convolutions that write P1 / P2 use interleaved rows (pack_weights.h,
+// fpl_out_channel): lane (c, g) then holds the 12 CONTIGUOUS channels [12 g, 12 g + 12) of
+// its voxel - half a pass - and writes 24 B of hi halves and 24 B of lo halves instead of
+// three 8-B pieces each, 32 B apart (the stem's P1 stores cost 3.9 of its 21.5 ms).
+typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ void store_split12(unsigned char *vox, int64_t plane, int g, const f32x4 (&v)[3]) {
+  unsigned hi[6], lo[6];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const Pair2 p0 = split_pk(v[b][0], v[b][1]), p1 = split_pk(v[b][2], v[b][3]);
+    hi[2 * b] = p0.hi; hi[2 * b + 1] = p1.hi;
+    lo[2 * b] = p0.lo; lo[2 * b + 1] = p1.lo;
+  }
+  unsigned char *d = vox + (g >> 1) * plane + 24 * (g & 1);
+  *reinterpret_cast<u32x4_a8 *>(d) = u32x4_a8{hi[0], hi[1], hi[2], hi[3]};
+  *reinterpret_cast<u32x2 *>(d + 16) = u32x2{hi[4], hi[5]};
+  *reinterpret_cast<u32x4_a8 *>(d + LO_OFF) = u32x4_a8{lo[0], lo[1], lo[2], lo[3]};
+  *reinterpret_cast<u32x2 *>(d + LO_OFF + 16) = u32x2{lo[4], lo[5]};
+}
+
 // four channels (one accumulator tile row group) of one voxel -> HBM, hi and lo halves
 __device__ __forceinline__ void store_split4(unsigned char *vox, int64_t plane, int ch, const f32x4 &v) {
   const Pair2 p0 = split_pk(v[0], v[1]), p1 = split_pk(v[2], v[3]);
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sh1[b][r] = a.shift1[16 * b + 4 * g + r];
-      sh2[b][r] = a.shift2[16 * b + 4 * g + r];
+      sh2[b][r] = a.shift2[12 * g + 4 * b + r];        // interleaved rows
     }
   __syncthreads();                      // lut
 
@@ -439,8 +459,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
         unsigned char *vox = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * PASS_BYTES;
         const int64_t plane = (int64_t)a.P1Z * a.P1Y * a.P1X * PASS_BYTES;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) store_split4(vox, plane, 16 * b + 4 * g, poolf[b]);
+        store_split12(vox, plane, g, poolf);
       }
     }
     if (!has_next) break;
@@ -596,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
 #pragma unroll
   for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[16 * b + 4 * g + r];
+    for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[12 * g + 4 * b + r];   // interleaved rows
   f32x4 pooled[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
@@ -619,8 +638,7 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
   if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
     unsigned char *vox = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * PASS_BYTES;
     const int64_t plane = (int64_t)a.P2Z * a.P2Y * a.P2X * PASS_BYTES;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) store_split4(vox, plane, 16 * b + 4 * g, pooled[b]);
+    store_split12(vox, plane, g, pooled);
   }
 }
 
@@ -844,7 +862,8 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
       static const int part[4][2] = {{0, 0}, {1, 1}, {1, 0}, {0, 1}};
       std::vector<uint16_t> f;
       for (int s = 0; s < 4; ++s)
-        fpl_pack_chain_step(A + op.w_off, scale.data(), op.cin, op.cout, mblocks[l], blk[s], part[s], &f);
+        fpl_pack_chain_step(A + op.w_off, scale.data(), op.cin, op.cout, mblocks[l], blk[s], part[s], &f,
+                            /*il=*/op.cout == CH);      // L2 / L4 write P1 / P2: interleaved rows
       all.insert(all.end(), f.begin(), f.end());
     } else {
       for (int part = 0; part < 2; ++part) {       // [part][s][b]
