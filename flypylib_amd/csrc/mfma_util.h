@@ -49,6 +49,7 @@ typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 16-B store at an 8-B aligned address
 
 __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
 #ifdef FPL_F16

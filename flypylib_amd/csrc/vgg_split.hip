@@ -73,7 +73,6 @@ __device__ __forceinline__ f32x4 chain48(const h16x8 (&w)[4], const Frag2 &h01, 
 // fpl_out_channel): lane (c, g) then holds the 12 CONTIGUOUS channels [12 g, 12 g + 12) of
 // its voxel - half a pass - and writes 24 B of hi halves and 24 B of lo halves instead of
 // three 8-B pieces each, 32 B apart (the stem's P1 stores cost 3.9 of its 21.5 ms).
-typedef unsigned u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 __device__ __forceinline__ void store_split12(unsigned char *vox, int64_t plane, int g, const f32x4 (&v)[3]) {
   unsigned hi[6], lo[6];
 #pragma unroll
