@@ -489,7 +489,10 @@ __device__ __forceinline__ unsigned kslot_entry(int idx) {
   return (unsigned)((((tap / 9) * TY + (tap / 3) % 3) * TX + tap % 3) * PASS_BYTES + ch0 * 2);
 }
 
-constexpr int WQ = 3;
+// K-steps of weight fragments in flight: a split K-step is 36 MFMAs (three times the 16-bit
+// kernels'), so two steps ahead cover the same time as their six; measured mid 38.7 / 37.7 /
+// 38.2 / 38.7 ms with 1 / 2 / 3 / 4 (the U-Net split kernels, 8 - 16 MFMAs per step, keep 3)
+constexpr int WQ = 2;
 
 template <int TZ, int TY, int TX, typename SubOff>
 __device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, int AY, int AX,
