@@ -493,6 +493,9 @@ __device__ __forceinline__ unsigned kslot_entry(int idx) {
 // kernels'), so two steps ahead cover the same time as their six; measured mid 38.7 / 37.7 /
 // 38.2 / 38.7 ms with 1 / 2 / 3 / 4 (the U-Net split kernels, 8 - 16 MFMAs per step, keep 3)
 constexpr int WQ = 2;
+// (Three passes of 16 channels - 41.5 KB tiles - were measured too: mid and tail unchanged at two
+// workgroups per CU; three per CU need <= 168 VGPRs, which this loop only reaches by spilling:
+// 43 ms.)
 
 template <int TZ, int TY, int TX, typename SubOff>
 __device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, int AY, int AX,
@@ -505,7 +508,7 @@ __device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, i
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     if (pass) __syncthreads();                       // every wave has left the previous pass's tile
-    stage_tile<TZ, TY, TX, PASS_BYTES>(act + (int64_t)pass * AZ * AY * AX * PASS_BYTES, AZ, AY, AX,
+    stage_tile<TZ, TY, TX, PASS_BYTES, PASS_BYTES>(act + (int64_t)pass * AZ * AY * AX * PASS_BYTES, AZ, AY, AX,
                                         z0, y0, x0, tile, wave, lane);
     const unsigned char *wl = wglobal + (size_t)pass * KS * 6 * 1024 + lane * 16;
     h16x8 wq[WQ][6];                                 // [..][0..2] hi, [3..5] lo

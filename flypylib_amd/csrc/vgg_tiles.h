@@ -68,11 +68,12 @@ __device__ __forceinline__ bool brick_coords(const BlockGrid &g, int &xb, int &y
 // coordinates are divided out once and then advanced by constant steps, and the edge
 // clamp is a min against per-block bounds: ~10 VALU per piece (the flat index
 // arithmetic this replaces, with its divisions, made the fill VALU-bound).
-template <int TZ, int TY, int TX, int SRC_VOX = 96>
+template <int TZ, int TY, int TX, int SRC_VOX = 96, int VB = 96>
 __device__ __forceinline__ void stage_tile(const void *act, int AZ, int AY, int AX,
                                            int z0, int y0, int x0,
                                            unsigned char *tile, int wave, int lane) {
-  constexpr int RC = TX * 6;                               // 16-B pieces per row
+  constexpr int PV = VB / 16;                              // 16-B pieces per tile voxel
+  constexpr int RC = TX * PV;                              // 16-B pieces per row
   constexpr int TOTAL = TZ * TY * RC;
   constexpr int PIECES = (TOTAL + 63) / 64;
   constexpr int DR = 256 / RC, DC = 256 % RC;              // advance per iteration
@@ -88,7 +89,7 @@ __device__ __forceinline__ void stage_tile(const void *act, int AZ, int AY, int 
   for (int p = wave; p < PIECES; p += 4) {
     const bool past = rz >= TZ;                            // tail lanes re-read the last piece
     const int rzc = past ? TZ - 1 : rz, ryc = past ? TY - 1 : ry, cwc = past ? RC - 1 : cw;
-    const int vx = cwc / 6, pc = cwc - 6 * vx;
+    const int vx = cwc / PV, pc = cwc - PV * vx;
     const int zc = rzc < zmax ? rzc : zmax, yc = ryc < ymax ? ryc : ymax, xc = vx < xmax ? vx : xmax;
     const unsigned off = (unsigned)zc * SZ + (unsigned)yc * SY + (unsigned)(xc * SRC_VOX + pc * 16);
     glds16(base + off, tile + (size_t)p * 1024);
