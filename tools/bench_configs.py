@@ -111,20 +111,40 @@ def main():
         rng = np.random.default_rng(0)
         data = rng.standard_normal((32, 64, 64, 64)).astype(np.float32)
         labels = (rng.random((32, 12, 12, 12)) > 0.9).astype(np.uint8)
-        tr.step(data, labels, 0); tr.apply(1.0)
+        # the loop of train.fit_generator (bench.py's leg): the prefetch worker uploads the next
+        # batch while the step runs; 20 steps without per-kernel events, then 5 with
+        from flypylib_amd import train as fpl_train
+
+        def forever():
+            while True:
+                yield data, labels
+        batches = fpl_train._Prefetch(forever(), stage=fpl_train._DeviceStager(ctx.device))
+        tr.step(*next(batches), 0); tr.apply(1.0)
         ctx.synchronize()
-        ctx.timing(True); ctx.timing_reset()
         t0 = time.perf_counter()
-        steps = 3
+        steps = 20
         for s in range(steps):
-            tr.step(data, labels, s + 1); tr.apply(1.0)
+            tr.step(*next(batches), s + 1); tr.apply(1.0)
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        res['vgg_train_b32_64cubed_f32'] = dict(
-            seconds_per_step=dt, steps_per_s=1 / dt,
-            tflops_algorithmic=492e9 / dt / 1e12, note='includes H2D of the batch',
-            kernels={k: round(v['ms'] / steps, 2) for k, v in ctx.timing_get().items()})
+        ctx.timing(True); ctx.timing_reset()
+        for s in range(5):
+            tr.step(*next(batches), steps + s + 1); tr.apply(1.0)
+        ctx.synchronize()
+        kern = ctx.timing_get()
         ctx.timing(False)
+        batches.close()
+        t0 = time.perf_counter()
+        for s in range(5):
+            tr.step(data, labels, s + 1); tr.apply(1.0)
+        ctx.synchronize()
+        dt_host = (time.perf_counter() - t0) / 5
+        res['vgg_train_b32_64cubed_f32'] = dict(
+            seconds_per_step=dt, steps_per_s=1 / dt, steps_per_s_host_arrays=1 / dt_host,
+            tflops_algorithmic=492e9 / dt / 1e12,
+            note='fit_generator loop (upload of the next batch overlaps the step); '
+                 'steps_per_s_host_arrays = the step fed host arrays directly, H2D inside',
+            kernels={k: round(v['ms'] / 5, 2) for k, v in kern.items()})
         print(json.dumps(res['vgg_train_b32_64cubed_f32']), flush=True)
 
     if 'train_unet' in what:
