@@ -571,12 +571,24 @@ __global__ __launch_bounds__(256) void stem_cin1_f32(StemF a) {
   const int c = lane & 15, g = lane >> 4;
   const int x0 = blockIdx.x * ST_X, y0 = blockIdx.y * ST_Y;
   const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * ST_Z;
-  for (int i = tid; i < ST_TZ * ST_TY * ST_TX; i += 256) {
-    const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
-    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-    float v = 0.f;
-    if (z < a.D && y < a.H && x < a.W) v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
-    tile[i] = v;
+  {
+    // all of a thread's tile loads in flight before the first LDS store (the rolled loop ran
+    // load -> wait -> store 16 times in a row)
+    constexpr int NLD = (ST_TZ * ST_TY * ST_TX + 255) / 256;
+    float tv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + 256 * k;
+      const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
+      const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+      float v = 0.f;
+      if (i < ST_TZ * ST_TY * ST_TX && z < a.D && y < a.H && x < a.W)
+        v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
+      tv[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (tid + 256 * k < ST_TZ * ST_TY * ST_TX) tile[tid + 256 * k] = tv[k];
   }
   int toff[8];
 #pragma unroll
@@ -647,12 +659,24 @@ __global__ __launch_bounds__(256) void stem_conv1_pool_f32(StemF a) {
   const int c = lane & 15, g = lane >> 4;
   const int x0 = blockIdx.x * ST_X, y0 = blockIdx.y * ST_Y;
   const int n = blockIdx.z / a.zblocks, z0 = (blockIdx.z % a.zblocks) * ST_Z;
-  for (int i = tid; i < ST_TZ * ST_TY * ST_TX; i += 256) {
-    const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
-    const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-    float v = 0.f;
-    if (z < a.D && y < a.H && x < a.W) v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
-    tile[i] = v;
+  {
+    // all of a thread's tile loads in flight before the first LDS store (the rolled loop ran
+    // load -> wait -> store 16 times in a row)
+    constexpr int NLD = (ST_TZ * ST_TY * ST_TX + 255) / 256;
+    float tv[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + 256 * k;
+      const int tx = i % ST_TX, ty = (i / ST_TX) % ST_TY, tz = i / (ST_TX * ST_TY);
+      const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+      float v = 0.f;
+      if (i < ST_TZ * ST_TY * ST_TX && z < a.D && y < a.H && x < a.W)
+        v = a.in[(((int64_t)n * a.D + z) * a.H + y) * a.W + x];
+      tv[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+      if (tid + 256 * k < ST_TZ * ST_TY * ST_TX) tile[tid + 256 * k] = tv[k];
   }
   int toff[8];
 #pragma unroll
