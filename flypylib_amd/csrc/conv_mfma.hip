@@ -1131,8 +1131,9 @@ Src make_src(const h16_t *p, int dim, int C, int ch0, int up, int crop) {
 bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
   UnetDesc d;
   if (precision != FPL_THIS_PREC || !match_unet(prog, &d)) return false;
-  // split build: the unet_like2 skeleton (3x3x3 second convs, one 1x1x1 bottom conv)
-  return !SPLIT || (!d.first1 && !d.second1 && d.nbottom == 1);
+  // split build: 3x3x3 second convs (unet_like2, unet_like3, unet_like4); unet_like's 1x1x1
+  // second convs run through unet_stem_c1 / pool2_h16, which have no split form
+  return !SPLIT || (!d.first1 && !d.second1);
 }
 
 // in: (n, T,T,T) f32 normalised tiles on the device; out: (n, O,O,O) f32, O = T - 2 * rf_offset
@@ -1142,8 +1143,8 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   UnetDesc D;
   FPL_REQUIRE(ctx, match_unet(prog, &D), "not a unet_like / unet_like2 / unet_like3 / unet_like4 program");
   FPL_REQUIRE(ctx, in && (io || out), "fpl_unet_forward: no input tiles / no output");
-  FPL_REQUIRE(ctx, !SPLIT || (io && !D.first1 && !D.second1 && D.nbottom == 1),
-              "fpl_unet_forward: the split-half build runs unet_like2 into a prediction volume");
+  FPL_REQUIRE(ctx, !SPLIT || (io && !D.first1 && !D.second1),
+              "fpl_unet_forward: the split-half build runs unet_like2 / 3 / 4 into a prediction volume");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
   DevTemp tmp(ctx);

@@ -12,8 +12,8 @@ from flypylib_amd import _capi, fplmodels, fplutils, synth
 from oracle import cnn_oracle, infer_oracle
 
 pytestmark = pytest.mark.gpu
-TOL = {'bf16': 1.5e-2, 'f16': 1e-3}
-PREC = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16}
+TOL = {'bf16': 1.5e-2, 'f16': 1e-3, 'f16s': 1e-5}
+PREC = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16, 'f16s': _capi.PREC_F16S}
 
 
 @pytest.mark.parametrize('kind', ['bf16', 'f16'])
@@ -22,6 +22,19 @@ PREC = {'bf16': _capi.PREC_BF16, 'f16': _capi.PREC_F16}
     ('unet_like3', 44, (60, 50, 75)), ('unet_like3', 100, (110, 100, 124)),
     ('unet_like4', 52, (70, 52, 90)), ('unet_like4', 100, (100, 130, 104))])
 def test_unet_siblings_fused_match_fp32_oracle(ctx, name, tile, shape, kind):
+    _check_sibling(ctx, name, tile, shape, kind)
+
+
+@pytest.mark.parametrize('name,tile,shape', [
+    ('unet_like3', 44, (60, 50, 75)), ('unet_like3', 100, (110, 100, 124)),
+    ('unet_like4', 52, (70, 52, 90)), ('unet_like4', 100, (100, 130, 104))])
+def test_unet_siblings_split_halves_are_fp32_grade(ctx, name, tile, shape):
+    """the split-half build (precision 'f16s', what 'auto' picks) on the skeletons with 3x3x3
+    second convs: within 1e-5 of the fp32 oracle"""
+    _check_sibling(ctx, name, tile, shape, 'f16s')
+
+
+def _check_sibling(ctx, name, tile, shape, kind):
     factory = getattr(fplmodels, name)
     _, rf, _, _ = factory()
     off = fplutils.to3d(rf[1])[0]
