@@ -497,19 +497,19 @@ constexpr int WQ = 2;
 // workgroups per CU; three per CU need <= 168 VGPRs, which this loop only reaches by spilling:
 // 43 ms.)
 
-template <int TZ, int TY, int TX, typename SubOff>
-__device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, int AY, int AX,
-                                             int z0, int y0, int x0, unsigned char *tile,
-                                             const unsigned *kofftab, const unsigned char *wglobal,
-                                             unsigned vbase, SubOff sub_off, f32x4 (&acc)[4][3],
-                                             int tid) {
+// `fill(pass)` puts the pass's 6 x 6 x 18 x 96 B tile into LDS (stage_tile, or vgg_like2's
+// stem, which computes it); the barrier after it makes it visible.
+template <typename Fill, typename SubOff>
+__device__ __forceinline__ void conv3s_kloop_f(Fill fill, unsigned char *tile,
+                                               const unsigned *kofftab, const unsigned char *wglobal,
+                                               unsigned vbase, SubOff sub_off, f32x4 (&acc)[4][3],
+                                               int tid) {
   const int lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const unsigned *ktab = kofftab + g * KTAB;
 #pragma unroll 1
   for (int pass = 0; pass < NPASS; ++pass) {
     if (pass) __syncthreads();                       // every wave has left the previous pass's tile
-    stage_tile<TZ, TY, TX, PASS_BYTES, PASS_BYTES>(act + (int64_t)pass * AZ * AY * AX * PASS_BYTES, AZ, AY, AX,
-                                        z0, y0, x0, tile, wave, lane);
+    fill(pass);
     const unsigned char *wl = wglobal + (size_t)pass * KS * 6 * 1024 + lane * 16;
     h16x8 wq[WQ][6];                                 // [..][0..2] hi, [3..5] lo
 #pragma unroll
@@ -560,6 +560,20 @@ __device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, i
       for (int sub = 0; sub < 4; ++sub) bcur[sub] = bnxt[sub];
     }
   }
+}
+
+template <int TZ, int TY, int TX, typename SubOff>
+__device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, int AY, int AX,
+                                             int z0, int y0, int x0, unsigned char *tile,
+                                             const unsigned *kofftab, const unsigned char *wglobal,
+                                             unsigned vbase, SubOff sub_off, f32x4 (&acc)[4][3],
+                                             int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  auto fill = [&](int pass) {
+    stage_tile<TZ, TY, TX, PASS_BYTES, PASS_BYTES>(act + (int64_t)pass * AZ * AY * AX * PASS_BYTES, AZ, AY, AX,
+                                                   z0, y0, x0, tile, wave, lane);
+  };
+  conv3s_kloop_f(fill, tile, kofftab, wglobal, vbase, sub_off, acc, tid);
 }
 
 // -------------------------------------------------------------------------------
@@ -790,6 +804,184 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
 }
 
 // -------------------------------------------------------------------------------
+// vgg_like2 on split halves (flypylib/fplmodels.py:138-172; the model of the reference's
+// scripts/fpl_cx1_0_vgg_4ss.py): [conv3 1->48, conv3 48->48, pool] [conv3, conv3, pool] conv3,
+// head.  As in vgg_fused.hip::vgg2_conv3 one kernel template covers the three 48->48
+// convolutions before the tail (vggs_c5_tail is the fifth and the head): block 4 x 4 x 16
+// outputs, the K loop of K2 / K3, and
+//   STEM  each pass's 6 x 6 x 18 tile (24 channels, hi | lo) is COMPUTED from the raw 8 x 8 x 20
+//         input tile: conv3 1->48 + BN + ReLU as 41 groups of 16 tile voxels x two M-blocks
+//         (the pass's 24 channels + 8 zero rows) x three MFMAs on hi / lo operands;
+//   POOL  ReLU + 2x2x2 max pool in fp32, then the split (wave = pooled (z,y) row as in K2),
+//         otherwise ReLU, split and a plain store (wave = z as in K3).
+// The 48->48 weight rows are interleaved (12 contiguous channels per lane: store_split12).
+// -------------------------------------------------------------------------------
+constexpr int V2_RZ = M_TZ + 2, V2_RY = M_TY + 2, V2_RX = M_TX + 2;     // raw tile 8 x 8 x 20
+constexpr int V2_NRAW = V2_RZ * V2_RY * V2_RX;
+static_assert(V2_NRAW % 256 == 0, "raw tile pieces per thread");
+constexpr int V2_SMEM = M_TILE_BYTES + KTAB_BYTES + V2_NRAW * 4 + 256 * 4;
+static_assert(2 * V2_SMEM <= 160 * 1024, "two vgg_like2 workgroups must fit one CU");
+
+struct V2SArgs {
+  // STEM: the raw volume
+  const void *src;
+  int64_t SZ, SY, SX;
+  float mean, sd;
+  int64_t gz0;                   // raw z of chunk-local conv row 0
+  const h16x8 *wstem;            // [pass][part][blk] fragments, k-slot (g,j) = tap 8g + j
+  const float *shstem;           // [48]
+  // otherwise: a split tensor in pass planes
+  const unsigned char *in;
+  int IZ, IY, IX;
+  const unsigned char *w;        // [pass][KS][part][b], interleaved rows
+  const float *shift;
+  unsigned char *out;
+  int OZ, OY, OX;                // output dims (pooled dims with POOL)
+  BlockGrid bg;
+};
+
+template <bool STEM, bool POOL, typename SRC>
+__global__ __launch_bounds__(256, 2) void vggs2_conv3(V2SArgs a) {
+  unsigned char *tile = smem;
+  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
+  unsigned *rawt = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES + KTAB_BYTES);   // hi | lo << 16
+  unsigned *lut = rawt + V2_NRAW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  int xb, yb, zb;
+  if (!brick_coords(a.bg, xb, yb, zb)) return;
+  // origin of the block's 4 x 4 x 16 conv outputs (= of its input tile)
+  const int x0 = xb * 16, y0 = yb * 4, z0 = zb * 4;
+  if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
+  int toff[8];
+  if (STEM) {
+    auto norm_bits = [&](float raw) -> unsigned {
+      const float x = (raw - a.mean) / a.sd;
+      const h16_t h = (h16_t)x;
+      return (unsigned)h16_bits(x) | ((unsigned)h16_bits(x - (float)h) << 16);
+    };
+    const SRC *src = (const SRC *)a.src;
+    if (sizeof(SRC) == 1) {
+      lut[tid] = norm_bits((float)tid);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < V2_NRAW / 256; ++j) {
+      const int p = tid + 256 * j;
+      const int64_t z = a.gz0 + z0 + p / (V2_RY * V2_RX), y = y0 + (p / V2_RX) % V2_RY, x = x0 + p % V2_RX;
+      unsigned b = 0u;                                   // zero past the volume end
+      if (z < a.SZ && y < a.SY && x < a.SX) {
+        const SRC v = src[(z * a.SY + y) * a.SX + x];
+        b = sizeof(SRC) == 1 ? lut[(int)v] : norm_bits((float)v);
+      }
+      rawt[p] = b;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 8 * g + j;
+      toff[j] = t < 27 ? ((t / 9) * V2_RY + (t / 3) % 3) * V2_RX + t % 3 : 0;
+    }
+    __syncthreads();                                    // raw tile visible
+  }
+  auto fill = [&](int pass) {
+    if (STEM) {
+      h16x8 wst[2][2];                                  // [part][blk]
+      f32x4 shs[2];
+#pragma unroll
+      for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) wst[part][blk] = a.wstem[((pass * 2 + part) * 2 + blk) * 64 + lane];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lc = 16 * blk + 4 * g + r;          // channel inside the pass
+          shs[blk][r] = lc < CHP ? a.shstem[CHP * pass + lc] : 0.f;
+        }
+      constexpr int NVOX = M_TZ * M_TY * M_TX, NGRP = (NVOX + 15) / 16;
+      for (int grp = wave; grp < NGRP; grp += 4) {
+        const int v = 16 * grp + c, vv = v < NVOX ? v : NVOX - 1;
+        const int tz = vv / (M_TY * M_TX), ty = (vv / M_TX) % M_TY, tx = vv % M_TX;
+        const int ro = (tz * V2_RY + ty) * V2_RX + tx;
+        u16x8 rh, rl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned t = rawt[ro + toff[j]];
+          rh[j] = (unsigned short)t; rl[j] = (unsigned short)(t >> 16);
+        }
+        Frag2 bf;
+        bf.hi = __builtin_bit_cast(h16x8, rh);
+        bf.lo = __builtin_bit_cast(h16x8, rl);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const f32x4 a1 = mfma3(wst[0][blk], wst[1][blk], bf, shs[blk]);
+          const Pair2 p0 = split_pk_relu(a1[0], a1[1]), p1 = split_pk_relu(a1[2], a1[3]);
+          if (v < NVOX && 16 * blk + 4 * g < CHP) {
+            unsigned char *d = tile + v * PASS_BYTES + (16 * blk + 4 * g) * 2;
+            *reinterpret_cast<u32x2 *>(d) = u32x2{p0.hi, p1.hi};
+            *reinterpret_cast<u32x2 *>(d + LO_OFF) = u32x2{p0.lo, p1.lo};
+          }
+        }
+      }
+    } else {
+      stage_tile<M_TZ, M_TY, M_TX, PASS_BYTES, PASS_BYTES>(
+          a.in + (int64_t)pass * a.IZ * a.IY * a.IX * PASS_BYTES, a.IZ, a.IY, a.IX, z0, y0, x0, tile, wave, lane);
+    }
+  };
+
+  // POOL: wave = pooled (z,y) row, sub-steps = the (dz,dy) window; else wave = z, subs = y
+  const int pzl = wave >> 1, pyl = wave & 1;
+  const unsigned vbase = POOL ? (unsigned)((((2 * pzl) * M_TY + 2 * pyl) * M_TX + c) * PASS_BYTES)
+                              : (unsigned)(((wave * M_TY) * M_TX + c) * PASS_BYTES);
+  f32x4 acc[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    f32x4 sh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sh[r] = a.shift[12 * g + 4 * b + r];      // interleaved rows
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
+  }
+  auto sub_off = [](int sub) -> unsigned {
+    return POOL ? (unsigned)(((((sub >> 1) & 1) * M_TY + (sub & 1)) * M_TX) * PASS_BYTES)
+                : (unsigned)(sub * M_TX * PASS_BYTES);
+  };
+  conv3s_kloop_f(fill, tile, kofftab, a.w, vbase, sub_off, acc, tid);
+
+  const int64_t plane = (int64_t)a.OZ * a.OY * a.OX * PASS_BYTES;
+  if (POOL) {
+    f32x4 pooled[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // 0 = the ReLU
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pooled[b][r] = __builtin_fmaxf(pooled[b][r], acc[sub][b][r]);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pooled[b][r] = __builtin_fmaxf(pooled[b][r], __shfl_xor(pooled[b][r], 1));     // the x pair
+    const int pz = zb * 2 + pzl, py = yb * 2 + pyl, px = xb * 8 + (c >> 1);
+    if ((c & 1) == 0 && pz < a.OZ && py < a.OY && px < a.OX)
+      store_split12(a.out + (((int64_t)pz * a.OY + py) * a.OX + px) * PASS_BYTES, plane, g, pooled);
+  } else {
+    const int oz = z0 + wave, ox = x0 + c;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int oy = y0 + sub;
+      f32x4 o[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[b][r] = __builtin_fmaxf(acc[sub][b][r], 0.f);
+      if (oz < a.OZ && oy < a.OY && ox < a.OX)
+        store_split12(a.out + (((int64_t)oz * a.OY + oy) * a.OX + ox) * PASS_BYTES, plane, g, o);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------
 // host side: weight packing, slab orchestration
 // -------------------------------------------------------------------------------
 struct SplitState {
@@ -830,6 +1022,7 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
   static const int conv_ops[8] = {0, 1, 3, 4, 6, 7, 8, 9};
   static const int mblocks[8] = {3, 3, 3, 3, 3, 6, 6, 1};
   static const int ksteps[8] = {1, 2, KS, 2, KS, 2, 3, 3};
+  const bool v2 = fpl_vgg_variant(prog) == 2;        // vgg_like2: L2 and L4 are 3x3x3 as well
   std::vector<uint16_t> all;
   std::vector<float> shifts;
   const float *A = prog->arena_host.data();
@@ -837,7 +1030,22 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
     const fpl_op &op = prog->ops[conv_ops[l]];
     std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
     st->off_w[l] = all.size() * sizeof(uint16_t);
-    if (l == 0) {
+    if (l == 0 && v2) {
+      // vggs2_conv3<STEM>: per pass the 24 channels of that pass as two M-blocks (8 zero
+      // rows), one K-step of 27 taps, k-slot (g, j) = tap 8g + j: [pass][part][blk]
+      for (int pass = 0; pass < NPASS; ++pass) {
+        std::vector<float> wp((size_t)27 * 32, 0.f), sp(32, 0.f);
+        for (int tap = 0; tap < 27; ++tap)
+          for (int ch = 0; ch < CHP; ++ch)
+            wp[(size_t)tap * 32 + ch] = A[op.w_off + (size_t)tap * op.cout + pass * CHP + ch];
+        for (int ch = 0; ch < CHP; ++ch) sp[ch] = scale[pass * CHP + ch];
+        for (int part = 0; part < 2; ++part) {
+          std::vector<uint16_t> f;
+          fpl_pack_frags(wp.data(), sp.data(), 27, 1, 32, 2, 1, SLOT_SPATIAL, &f, false, part);
+          all.insert(all.end(), f.begin(), f.end());
+        }
+      }
+    } else if (l == 0) {
       for (int part = 0; part < 2; ++part) {       // [part][e][b]
         std::vector<uint16_t> f;
         fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f, part);
@@ -855,7 +1063,7 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
         std::vector<uint16_t> f[2];
         for (int part = 0; part < 2; ++part)
           fpl_pack_frags(wp.data(), scale.data(), 27, CHP, op.cout, 3, KS, SLOT_SPATIAL, &f[part],
-                         false, part);
+                         /*il=*/v2 && l >= 1 && l <= 3, part);     // vggs2_conv3 stores 12-channel runs
         for (int s = 0; s < KS; ++s)
           for (int part = 0; part < 2; ++part)
             all.insert(all.end(), f[part].begin() + (size_t)s * 3 * 512,
@@ -905,6 +1113,14 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_c5_tail,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs2_conv3<true, true, uint8_t>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs2_conv3<true, true, float>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs2_conv3<false, false, uint8_t>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs2_conv3<false, true, uint8_t>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
   st->version = prog->arena_version;
   st->int_valid = false;
   return 0;
@@ -962,11 +1178,105 @@ int split_prepare_int(fpl_ctx *ctx, fpl_program *prog, SplitState *st, float mea
 
 bool fpl_split_path_available(const fpl_program *prog, int precision, const int32_t offset[3],
                               const int32_t out_sz[3]) {
-  if (precision != FPL_PREC_F16S || fpl_vgg_variant(prog) != 1) return false;
+  const int variant = fpl_vgg_variant(prog);           // 1: vgg_like (offset 7), 2: vgg_like2 (10)
+  if (precision != FPL_PREC_F16S || variant == 0) return false;
   for (int a = 0; a < 3; ++a)
-    if (offset[a] != 7 || out_sz[a] % 4 != 0) return false;
+    if (offset[a] != (variant == 1 ? 7 : 10) || out_sz[a] % 4 != 0) return false;
   return true;
 }
+
+namespace {
+
+// vgg_like2 over the coarse rows of a slab, as vgg_fused.hip::vgg2_infer (where the lattice
+// argument is made): four launches per chunk, the three intermediate tensors in pass planes
+//   H1 = pool(conv3(conv3(volume)))   vggs2_conv3<STEM, POOL>   (half resolution)
+//   L3 = conv3(H1)                    vggs2_conv3<>
+//   Q  = pool(conv3(L3))              vggs2_conv3<POOL>         (quarter resolution)
+//   prediction = head(conv3(Q))       vggs_c5_tail
+int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, float mean, float sd,
+                 const int64_t dims[3], const std::vector<int32_t> origins[3],
+                 const int32_t out_sz[3], int32_t zb, int32_t ze, float *dst) {
+  hipStream_t stream = ctx->stream;
+  constexpr int OFF = 10;
+  const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];
+  const int64_t VZ = SZ - 2 * OFF, VY = SY - 2 * OFF, VX = SX - 2 * OFF;
+  if (VZ <= 0 || VY <= 0 || VX <= 0 || zb >= ze) return 0;
+  const int64_t fz_lo = (int64_t)origins[0][zb] - OFF;
+  const int64_t fz_hi = std::min<int64_t>((int64_t)origins[0][ze - 1] - OFF + out_sz[0], VZ);
+  const int64_t cz_lo = fz_lo / 4, cz_hi = ceil_div64(fz_hi, 4);
+  const int CY = (int)ceil_div64(VY, 4), CX = (int)ceil_div64(VX, 4);
+  const int QY = CY + 2, QX = CX + 2, T3Y = 2 * QY + 2, T3X = 2 * QX + 2, HY = T3Y + 2, HX = T3X + 2;
+  const int64_t h_row = (int64_t)HY * HX * VOX, t_row = (int64_t)T3Y * T3X * VOX;
+  const char *budget_env = getenv("FPL_VGG_SCRATCH_MB");
+  const int64_t budget = budget_env ? (int64_t)atoll(budget_env) << 20 : (int64_t)64 << 30;
+  // H1 has 2 (cz + 2) + 4 rows, L3 two fewer
+  int64_t cz_chunk = std::max<int64_t>(4, (budget / (h_row + t_row) - 8) / 2);
+  cz_chunk = std::min<int64_t>(cz_chunk, cz_hi - cz_lo);
+  cz_chunk = (cz_chunk + 3) / 4 * 4;
+  FPL_REQUIRE(ctx, (int64_t)HY * HX * PASS_BYTES * 8 < ((int64_t)1 << 32),
+              "vgg_like2 split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
+              "offsets", (long long)SY, (long long)SX);
+  DevTemp tmp(ctx);
+  void *h1v, *l3v, *qv;
+  FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 8) * h_row, &h1v));
+  FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 6) * t_row, &l3v));
+  FPL_TRY(tmp.alloc((size_t)(cz_chunk + 2) * QY * QX * VOX, &qv));
+  const unsigned char *F = st->frags;
+  const float *S = st->shifts;
+  for (int64_t c0 = cz_lo; c0 < cz_hi; c0 += cz_chunk) {
+    const int CZ = (int)std::min<int64_t>(cz_chunk, cz_hi - c0);
+    const int QZ = CZ + 2, T3Z = 2 * QZ + 2, HZ = T3Z + 2;
+    {
+      V2SArgs a = {};
+      a.src = src; a.SZ = SZ; a.SY = SY; a.SX = SX; a.mean = mean; a.sd = sd;
+      a.gz0 = 4 * c0;
+      a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
+      a.w = F + st->off_w[1]; a.shift = S + st->off_s[1];
+      a.out = (unsigned char *)h1v; a.OZ = HZ; a.OY = HY; a.OX = HX;
+      a.bg = BlockGrid{(int)ceil_div64(HX, 8), (int)ceil_div64(HY, 2), (int)ceil_div64(HZ, 2)};
+      TimedLaunch tl(ctx, "vggs2_stem_conv3_pool");
+      if (src_dtype == FPL_U8)
+        vggs2_conv3<true, true, uint8_t><<<brick_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+      else
+        vggs2_conv3<true, true, float><<<brick_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+    }
+    {
+      V2SArgs a = {};
+      a.in = (const unsigned char *)h1v; a.IZ = HZ; a.IY = HY; a.IX = HX;
+      a.w = F + st->off_w[2]; a.shift = S + st->off_s[2];
+      a.out = (unsigned char *)l3v; a.OZ = T3Z; a.OY = T3Y; a.OX = T3X;
+      a.bg = BlockGrid{(int)ceil_div64(T3X, 16), (int)ceil_div64(T3Y, 4), (int)ceil_div64(T3Z, 4)};
+      TimedLaunch tl(ctx, "vggs2_conv3");
+      vggs2_conv3<false, false, uint8_t><<<brick_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+    }
+    {
+      V2SArgs a = {};
+      a.in = (const unsigned char *)l3v; a.IZ = T3Z; a.IY = T3Y; a.IX = T3X;
+      a.w = F + st->off_w[3]; a.shift = S + st->off_s[3];
+      a.out = (unsigned char *)qv; a.OZ = QZ; a.OY = QY; a.OX = QX;
+      a.bg = BlockGrid{(int)ceil_div64(QX, 8), (int)ceil_div64(QY, 2), (int)ceil_div64(QZ, 2)};
+      TimedLaunch tl(ctx, "vggs2_conv3_pool");
+      vggs2_conv3<false, true, uint8_t><<<brick_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
+    }
+    {
+      TailSArgs a;
+      a.p2 = (const unsigned char *)qv; a.P2Z = QZ; a.P2Y = QY; a.P2X = QX;
+      a.w5 = F + st->off_w[4]; a.shift5 = S + st->off_s[4];
+      a.CZ = CZ; a.CY = CY; a.CX = CX;
+      a.w6 = F + st->off_w[5]; a.w7 = F + st->off_w[6]; a.w8 = F + st->off_w[7];
+      a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
+      a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
+      a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = OFF;
+      a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
+      TimedLaunch tl(ctx, "vggs_c5_tail");
+      vggs_c5_tail<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+    }
+    FPL_HIP(ctx, hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace
 
 // Slab orchestration: as the vgg_like branch of fpl_fast_infer_volume_* (vgg_fused.hip;
 // the lattice equivalence with FplNetwork.infer, flypylib/fplnetwork.py:146-187, is
@@ -977,6 +1287,8 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
                            int32_t zb, int32_t ze, float *dst) {
   SplitState *st;
   FPL_TRY(split_prepare(ctx, prog, &st));
+  if (fpl_vgg_variant(prog) == 2)
+    return split2_infer(ctx, st, src, src_dtype, mean, sd, dims, origins, out_sz, zb, ze, dst);
   if (src_dtype == FPL_U8) FPL_TRY(split_prepare_int(ctx, prog, st, mean, sd));
   hipStream_t stream = ctx->stream;
   const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];

@@ -86,3 +86,42 @@ def test_fplnetwork_vgg_like2_f16(ctx):
     got = net.infer(img)
     ref = _oracle(net.train_single, img, 36)
     assert np.abs(got - ref).max() < TOL['f16']
+
+
+# ---- the split-half build (precision 'f16s', what 'auto' picks): fp32-grade ---------------
+@pytest.mark.parametrize('shape,tile', [
+    ((52, 47, 61), 36), ((44, 44, 44), 36), ((37, 36, 70), 36), ((110, 64, 90), 100)])
+def test_vgg_like2_split_halves_match_fp32_oracle(ctx, shape, tile):
+    g = _net(31, tile)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(11, shape)
+    for mean, std in ((128.0, 33.0), (121.4, 29.3)):
+        img = (u8.astype(np.float32) - np.float32(mean)) / np.float32(std)
+        ctx.timing(True)
+        ctx.timing_reset()
+        got = prog.infer_volume(u8, (tile,) * 3, (OFF,) * 3, mean=mean, std=std, precision=_capi.PREC_AUTO)
+        names = set(ctx.timing_get())
+        ctx.timing(False)
+        assert ctx.last_path() == 'vgg_split_f16' and 'vggs2_stem_conv3_pool' in names, names
+        ref = _oracle(g, img, tile)
+        assert not got[:OFF].any() and not got[-OFF:].any() and not got[:, :, -OFF:].any()
+        d = np.abs(got - ref)
+        assert d.max() < 1e-5, 'split halves vs fp32 oracle: max %g' % d.max()
+        assert ref[OFF:-OFF, OFF:-OFF, OFF:-OFF].std() > 1e-3
+
+
+def test_vgg_like2_split_float_input_chunks_and_slabs(ctx, monkeypatch):
+    g = _net(32, 36)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    img = synth.hash_uniform_f32(5, (95, 50, 58)) * np.float32(4) - np.float32(2)
+    kw = dict(precision=_capi.PREC_F16S)
+    whole = prog.infer_volume(img, (36,) * 3, (OFF,) * 3, **kw)
+    assert np.abs(whole - _oracle(g, img, 36)).max() < 1e-5
+    monkeypatch.setenv('FPL_VGG_SCRATCH_MB', '2')
+    assert np.array_equal(prog.infer_volume(img, (36,) * 3, (OFF,) * 3, **kw), whole)
+    monkeypatch.delenv('FPL_VGG_SCRATCH_MB')
+    n_rows = multi_gpu.n_tile_rows(95, 36, OFF)
+    parts = np.zeros_like(whole)
+    for zb, ze in multi_gpu.slab_partition(n_rows, 3):
+        prog.infer_volume(img, (36,) * 3, (OFF,) * 3, z_range=(zb, ze), dst=parts, **kw)
+    assert np.array_equal(parts, whole)

@@ -108,14 +108,18 @@ def test_split_slabs_chunks_and_tilings_are_bit_identical(ctx, monkeypatch, mean
 
 
 def test_split_is_refused_for_graphs_without_split_kernels(ctx):
-    """split kernels exist for vgg_like and unet_like2 (tests/test_gpu_unet_split.py);
-    vgg_like2 has none: 'f16s' says so, 'auto' runs it on fp32 MFMAs"""
-    g = fplmodels.vgg_like2(36)[0]
+    """split kernels exist for vgg_like, vgg_like2 (tests/test_gpu_vgg2_fused.py) and
+    unet_like2 / 3 / 4 (tests/test_gpu_unet_split.py, test_gpu_unet_family.py); the baseline
+    model has none: 'f16s' says so, 'auto' runs it on fp32 MFMAs"""
+    from flypylib_amd import fplutils
+    g, rf, _, _ = fplmodels.baseline_model(22)
+    off = fplutils.to3d(rf[1])[0]
+    stride = fplutils.to3d(rf[2])
     synth.synthetic_weights(g, 3)
-    prog = _capi.Program(ctx, g, (4, 4, 4))
+    prog = _capi.Program(ctx, g, stride)
     u8 = synth.em_volume_u8(1, (60, 41, 48))
     with pytest.raises(_capi.FplHipError, match='split-half kernels'):
-        prog.infer_volume(u8, (36,) * 3, (10,) * 3, mean=128.0, std=33.0,
+        prog.infer_volume(u8, (22,) * 3, (off,) * 3, mean=128.0, std=33.0,
                           precision=_capi.PREC_F16S)
-    prog.infer_volume(u8, (36,) * 3, (10,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
+    prog.infer_volume(u8, (22,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
     assert ctx.last_path() == 'mfma_f32'

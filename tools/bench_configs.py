@@ -86,9 +86,8 @@ def main():
         dst = torch.empty((n, n, n), dtype=torch.float32, device='cuda')
         ctx.synth_volume_u8(4, (n, n, n), out=src)
         flop = 2 * (27 * 48 + 27 * 48 * 48 + (2 * 27 * 48 * 48) / 8 + (27 * 48 * 48 + 48 * 96 + 96 * 96 + 96) / 64)
-        for pname, prec in (('f16', _capi.PREC_F16), ('bf16', _capi.PREC_BF16), ('f32', _capi.PREC_F32)):
-            if pname == 'f32' and n > 420:
-                continue
+        for pname, prec in (('f16s', _capi.PREC_F16S), ('f16', _capi.PREC_F16), ('bf16', _capi.PREC_BF16),
+                            ('f32', _capi.PREC_F32)):
             kw = dict(mean=128.0, std=33.0, precision=prec, dst=dst, dims=(n, n, n))
             prog.infer_volume(src, (100,) * 3, (10,) * 3, **kw)
             ctx.synchronize()
