@@ -517,7 +517,12 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
     step_no = getattr(network, '_train_steps_done', 0)
     history = []
     stage = None
-    if towers is None and not os.environ.get('FPL_TRAIN_HOST_BATCHES'):
+    try:
+        import torch  # noqa: F401   (the stager moves batches with torch; without it: host batches)
+        have_torch = True
+    except ImportError:
+        have_torch = False
+    if towers is None and have_torch and not os.environ.get('FPL_TRAIN_HOST_BATCHES'):
         if world > 1 and par is not None:
             need = par.batch_size * world
             stage = _DeviceStager(
