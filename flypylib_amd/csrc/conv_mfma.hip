@@ -701,13 +701,14 @@ struct StemC1Args {
   const h16x8 *w1;               // 2 fragments of conv1 32->32 (SLOT_SPATIAL, interleaved rows)
   const float *sh1;
   h16_t *c1, *p1;                // (n, D, D, D, 32), D = T - 2; (n, D/2, D/2, D/2, 32)
+  int64_t c1plane, p1plane;      // split: elements of one chunk plane of c1 / p1
   int D, zblocks, nbx, nby;
 };
 
 __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
   constexpr int RZ = 6, RY = 6, RX = 18;
-  __shared__ unsigned short rawt[RZ * RY * RX];
-  __shared__ u32x4 xch[2 * 2 * 64];                        // [wave pair][y half][lane]
+  __shared__ unsigned short rawt[PM * RZ * RY * RX];        // split: hi, then lo
+  __shared__ u32x4 xch[(SPLIT ? 2 : 1) * 2 * 2 * 64];      // [wave pair][y half]([b])[lane]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int bx = blockIdx.x % a.nbx, by = (blockIdx.x / a.nbx) % a.nby, bz = blockIdx.x / (a.nbx * a.nby);
@@ -718,7 +719,9 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
     z = z < a.T ? z : a.T - 1;                             // clamped reads only feed masked
     y = y < a.T ? y : a.T - 1;                             // outputs
     x = x < a.T ? x : a.T - 1;
-    rawt[p] = h16_bits(base[((int64_t)z * a.T + y) * a.T + x]);
+    const float v = base[((int64_t)z * a.T + y) * a.T + x];
+    rawt[p] = h16_bits(v);
+    if (SPLIT) rawt[RZ * RY * RX + p] = h16_bits(v - (float)(h16_t)v);
   }
   int toff[8];
 #pragma unroll
@@ -726,12 +729,17 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
     const int t = 8 * g + j;
     toff[j] = t < 27 ? ((t / 9) * RY + (t / 3) % 3) * RX + t % 3 : 0;
   }
-  h16x8 ws[2], w1[2];
+  // split: [part][b] fragment sets (hi parts, then lo parts)
+  h16x8 ws[2], w1[2], wsl[2], w1l[2];
   f32x4 shs[2], sh1[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     ws[b] = a.wstem[b * 64 + lane];
     w1[b] = a.w1[b * 64 + lane];
+    if (SPLIT) {
+      wsl[b] = a.wstem[(2 + b) * 64 + lane];
+      w1l[b] = a.w1[(2 + b) * 64 + lane];
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       shs[b][r] = a.shstem[8 * g + 4 * b + r];
@@ -747,12 +755,64 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) rw[j] = rawt[ro + toff[j]];
     const h16x8 bf = __builtin_bit_cast(h16x8, rw);
-    const h16x8 h0 = pack_relu(mfma16(ws[0], bf, shs[0]), mfma16(ws[1], bf, shs[1]));
-    acc[sub][0] = mfma16(w1[0], h0, sh1[0]);
-    acc[sub][1] = mfma16(w1[1], h0, sh1[1]);
+    if (SPLIT) {
+      u16x8 rl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rl[j] = rawt[RZ * RY * RX + ro + toff[j]];
+      Frag2 b2;
+      b2.hi = bf;
+      b2.lo = __builtin_bit_cast(h16x8, rl);
+      const Frag2 h0 = pack_relu_split(mfma3(ws[0], wsl[0], b2, shs[0]), mfma3(ws[1], wsl[1], b2, shs[1]));
+      acc[sub][0] = mfma3(w1[0], w1l[0], h0, sh1[0]);
+      acc[sub][1] = mfma3(w1[1], w1l[1], h0, sh1[1]);
+    } else {
+      const h16x8 h0 = pack_relu(mfma16(ws[0], bf, shs[0]), mfma16(ws[1], bf, shs[1]));
+      acc[sub][0] = mfma16(w1[0], h0, sh1[0]);
+      acc[sub][1] = mfma16(w1[1], h0, sh1[1]);
+    }
     const int oz = z0 + wave, oy = y0 + sub, ox = x0 + c;
     if (oz < a.D && oy < a.D && ox < a.D)
-      store_il<2, true>(a.c1 + ((((int64_t)n * a.D + oz) * a.D + oy) * a.D + ox) * 32, 0, g, acc[sub], 1);
+      store_il<2, true>(a.c1 + ((((int64_t)n * a.D + oz) * a.D + oy) * a.D + ox) * 32, a.c1plane, g, acc[sub], 1);
+  }
+  if (SPLIT) {
+    // the pool in fp32 (as the POOL epilogue of the split conv3), then split and store
+    f32x4 pmf[2][2];
+#pragma unroll
+    for (int yh = 0; yh < 2; ++yh)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = __builtin_fmaxf(acc[2 * yh][b][r], acc[2 * yh + 1][b][r]);
+          pmf[yh][b][r] = __builtin_fmaxf(v, __shfl_xor(v, 1));
+        }
+    f32x4 *xf = reinterpret_cast<f32x4 *>(xch);            // [wave pair][yh][b][lane]
+    if (wave & 1) {
+#pragma unroll
+      for (int yh = 0; yh < 2; ++yh)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) xf[(((wave >> 1) * 2 + yh) * 2 + b) * 64 + lane] = pmf[yh][b];
+    }
+    __syncthreads();
+    if (!(wave & 1) && !(c & 1)) {
+      const int PD = a.D / 2;
+      const int pz = (bz % a.zblocks) * 2 + (wave >> 1), px = bx * 8 + (c >> 1);
+#pragma unroll
+      for (int yh = 0; yh < 2; ++yh) {
+        const int py = by * 2 + yh;
+        if (pz < PD && py < PD && px < PD) {
+          f32x4 m[2];
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const f32x4 o = xf[(((wave >> 1) * 2 + yh) * 2 + b) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[b][r] = __builtin_fmaxf(pmf[yh][b][r], o[r]);
+          }
+          store_il<2, true>(a.p1 + ((((int64_t)n * PD + pz) * PD + py) * PD + px) * 32, a.p1plane, g, m, 1);
+        }
+      }
+    }
+    return;
   }
   // 2x2x2 max pool of the block, as the POOL epilogue of conv3
   u32x4 pm[2];
@@ -800,6 +860,32 @@ __global__ void FPLK(pool2_h16)(const u32x4 *__restrict__ x, u32x4 *__restrict__
   const int ox = (int)(t % od); t /= od;
   const int oy = (int)(t % od); t /= od;
   const int oz = (int)(t % od); t /= od;
+  if (SPLIT) {
+    // a chunk plane holds [hi 16 | lo 16] per voxel (C8 = 4): pieces 0, 1 = hi halves of real
+    // channels 0-7 / 8-15, pieces 2, 3 their lo halves.  Threads c = 0, 1 pool 8 channels each
+    // in fp32 and write the hi piece c and the lo piece c + 2; c = 2, 3 have nothing to do.
+    if (c >= 2) return;
+    float best[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) best[q] = 0.f;             // post-ReLU values are >= 0
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int64_t vox = (((t * D + 2 * oz + (p >> 2)) * D + 2 * oy + ((p >> 1) & 1)) * (int64_t)D +
+                           2 * ox + (p & 1)) * C8;
+      const h16x8 hi = __builtin_bit_cast(h16x8, x[vox + c]), lo = __builtin_bit_cast(h16x8, x[vox + 2 + c]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) best[q] = __builtin_fmaxf(best[q], (float)hi[q] + (float)lo[q]);
+    }
+    u32x4 oh, ol;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const Pair2 pr = split_pk(best[2 * q], best[2 * q + 1]);
+      oh[q] = pr.hi; ol[q] = pr.lo;
+    }
+    y[(i / C8) * C8 + c] = oh;
+    y[(i / C8) * C8 + 2 + c] = ol;
+    return;
+  }
   u32x4 m = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -992,7 +1078,16 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
     std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
     std::vector<uint16_t> f;
     const int mb = (op.cout + 15) / 16;
-    if (l == 0 && SPLIT) {
+    if (SPLIT && d.first1 && l <= 1) {
+      // unet_like's chained stem (unet_stem_c1): conv3 1->32 and conv1 32->32 with interleaved
+      // rows and REAL channels as k-slots, hi parts then lo parts: [part][b]
+      for (int part = 0; part < 2; ++part) {
+        std::vector<uint16_t> fp;
+        if (l == 0) fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, mb, 1, SLOT_STEM, &fp, true, part);
+        else fpl_pack_frags(A + op.w_off, scale.data(), 1, op.cin, op.cout, mb, op.cin / 32, SLOT_SPATIAL, &fp, true, part);
+        f.insert(f.end(), fp.begin(), fp.end());
+      }
+    } else if (l == 0 && SPLIT) {
       // conv3 1->32 per chunk of 16 output channels, plain rows: [chunk][part]
       for (int cc = 0; cc < op.cout / 16; ++cc) {
         std::vector<float> wc((size_t)27 * 16);
@@ -1131,9 +1226,8 @@ Src make_src(const h16_t *p, int dim, int C, int ch0, int up, int crop) {
 bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
   UnetDesc d;
   if (precision != FPL_THIS_PREC || !match_unet(prog, &d)) return false;
-  // split build: 3x3x3 second convs (unet_like2, unet_like3, unet_like4); unet_like's 1x1x1
-  // second convs run through unet_stem_c1 / pool2_h16, which have no split form
-  return !SPLIT || (!d.first1 && !d.second1);
+  (void)d;
+  return true;                  // every skeleton match_unet accepts, in every build
 }
 
 // in: (n, T,T,T) f32 normalised tiles on the device; out: (n, O,O,O) f32, O = T - 2 * rf_offset
@@ -1143,8 +1237,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   UnetDesc D;
   FPL_REQUIRE(ctx, match_unet(prog, &D), "not a unet_like / unet_like2 / unet_like3 / unet_like4 program");
   FPL_REQUIRE(ctx, in && (io || out), "fpl_unet_forward: no input tiles / no output");
-  FPL_REQUIRE(ctx, !SPLIT || (io && !D.first1 && !D.second1),
-              "fpl_unet_forward: the split-half build runs unet_like2 / 3 / 4 into a prediction volume");
+  FPL_REQUIRE(ctx, !SPLIT || io, "fpl_unet_forward: the split-half build writes into a prediction volume");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
   DevTemp tmp(ctx);
@@ -1199,6 +1292,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
     a.w1 = (const h16x8 *)(F + st->off_w[1]); a.sh1 = S + st->off_s[1];
     a.c1 = c1; a.p1 = p1; a.D = d1;
+    a.c1plane = (int64_t)n * cube(d1) * CC; a.p1plane = (int64_t)n * cube(dp1) * CC;
     a.zblocks = (int)ceil_div64(d1, 4); a.nbx = (int)ceil_div64(d1, 16); a.nby = (int)ceil_div64(d1, 4);
     TimedLaunch tl(ctx, "unet_stem_conv1_32_32_pool");
     FPLK(unet_stem_c1)<<<(unsigned)((int64_t)a.nbx * a.nby * n * a.zblocks), 256, 0, stm>>>(a);

@@ -58,15 +58,18 @@ def test_unet_split_slabs_equal_whole(ctx):
     assert np.array_equal(out, whole)
 
 
-def test_unet_split_is_refused_for_the_other_unets(ctx):
-    """unet_like (1x1 second convs) has no split form: 'auto' gives it fp32, 'f16s' says no"""
+def test_unet_split_is_refused_for_graphs_outside_the_skeleton(ctx):
+    """unet_like4b (48-channel bottlenecks) is not the skeleton the fused kernels know:
+    'auto' gives it fp32, 'f16s' says no"""
     from flypylib_amd import fplutils
-    off = fplutils.to3d(fplmodels.unet_like()[1][1])[0]
-    g = fplmodels.unet_like(30)[0]
+    off = fplutils.to3d(fplmodels.unet_like4b()[1][1])[0]
+    tile = fplmodels.unet_like4b()[2]
+    tile = fplutils.to3d(tile)[0]
+    g = fplmodels.unet_like4b(tile)[0]
     synth.synthetic_weights(g, 3)
     prog = _capi.Program(ctx, g, (1, 1, 1))
-    u8 = synth.em_volume_u8(1, (50, 41, 64))
-    prog.infer_volume(u8, (30,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
+    u8 = synth.em_volume_u8(1, (tile + 6, tile, tile + 9))
+    prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
     assert ctx.last_path() == 'mfma_f32'
     with pytest.raises(_capi.FplHipError, match='split-half kernels'):
-        prog.infer_volume(u8, (30,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_F16S)
+        prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_F16S)
