@@ -830,6 +830,10 @@ struct V2SArgs {
   int64_t gz0;                   // raw z of chunk-local conv row 0
   const h16x8 *wstem;            // [pass][part][blk] fragments, k-slot (g,j) = tap 8g + j
   const float *shstem;           // [48]
+  // uint8 volumes (as K1): the operand is u - c0, 1 / sd is in `wstem`, and the initial
+  // accumulator values come from shtab[(pz, py, px) planes of padding in the window][48]
+  float c0;
+  const float *shtab;
   // otherwise: a split tensor in pass planes
   const unsigned char *in;
   int IZ, IY, IX;
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void vggs2_conv3(V2SArgs a) {
     };
     const SRC *src = (const SRC *)a.src;
     if (sizeof(SRC) == 1) {
-      lut[tid] = norm_bits((float)tid);
+      lut[tid] = (unsigned)h16_bits((float)tid - a.c0);    // exact; lo half 0; padding 0
       __syncthreads();
     }
 #pragma unroll
@@ -912,9 +916,24 @@ __global__ __launch_bounds__(256, 2) void vggs2_conv3(V2SArgs a) {
         Frag2 bf;
         bf.hi = __builtin_bit_cast(h16x8, rh);
         bf.lo = __builtin_bit_cast(h16x8, rl);
+        // uint8: the window's planes of padding select the initial values (entry 0 inside)
+        const float *init = nullptr;
+        if (sizeof(SRC) == 1) {
+          const int pz = min(max((int)(a.gz0 + z0 + tz + 3 - a.SZ), 0), 3);
+          const int py = min(max((int)(y0 + ty + 3 - a.SY), 0), 3), px = min(max((int)(x0 + tx + 3 - a.SX), 0), 3);
+          init = a.shtab + ((pz * 4 + py) * 4 + px) * 48 + CHP * pass + 4 * g;
+        }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
-          const f32x4 a1 = mfma3(wst[0][blk], wst[1][blk], bf, shs[blk]);
+          f32x4 a1;
+          if (sizeof(SRC) == 1) {
+            f32x4 i0 = {0.f, 0.f, 0.f, 0.f};
+            if (16 * blk + 4 * g < CHP) i0 = *reinterpret_cast<const f32x4 *>(init + 16 * blk);
+            a1 = mfma16(wst[1][blk], bf.hi, i0);
+            a1 = mfma16(wst[0][blk], bf.hi, a1);
+          } else {
+            a1 = mfma3(wst[0][blk], wst[1][blk], bf, shs[blk]);
+          }
           const Pair2 p0 = split_pk_relu(a1[0], a1[1]), p1 = split_pk_relu(a1[2], a1[3]);
           if (v < NVOX && 16 * blk + 4 * g < CHP) {
             unsigned char *d = tile + v * PASS_BYTES + (16 * blk + 4 * g) * 2;
@@ -1152,10 +1171,27 @@ int split_prepare_int(fpl_ctx *ctx, fpl_program *prog, SplitState *st, float mea
         }
   }
   st->w1_int_host.clear();
-  for (int part = 0; part < 2; ++part) {         // [part][e][b]
-    std::vector<uint16_t> f;
-    fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f, part);
-    st->w1_int_host.insert(st->w1_int_host.end(), f.begin(), f.end());
+  if (fpl_vgg_variant(prog) == 2) {
+    // vggs2_conv3<STEM>: [pass][part][blk] as in split_prepare, with 1 / sd in the scale
+    for (int pass = 0; pass < NPASS; ++pass) {
+      std::vector<float> wp((size_t)27 * 32, 0.f), sp(32, 0.f);
+      for (int tap = 0; tap < 27; ++tap)
+        for (int ch = 0; ch < CHP; ++ch)
+          wp[(size_t)tap * 32 + ch] = A[op.w_off + (size_t)tap * op.cout + pass * CHP + ch];
+      for (int ch = 0; ch < CHP; ++ch) sp[ch] = scale[pass * CHP + ch];
+      for (int part = 0; part < 2; ++part) {
+        std::vector<uint16_t> f;
+        fpl_pack_frags(wp.data(), sp.data(), 27, 1, 32, 2, 1, SLOT_SPATIAL, &f, false, part);
+        st->w1_int_host.insert(st->w1_int_host.end(), f.begin(), f.end());
+      }
+    }
+    st->w1_int_host.resize((size_t)2 * 6 * 512, 0);          // the buffer's fixed size
+  } else {
+    for (int part = 0; part < 2; ++part) {         // [part][e][b]
+      std::vector<uint16_t> f;
+      fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f, part);
+      st->w1_int_host.insert(st->w1_int_host.end(), f.begin(), f.end());
+    }
   }
   for (uint16_t h : st->w1_int_host)
     FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
@@ -1231,6 +1267,9 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
       a.src = src; a.SZ = SZ; a.SY = SY; a.SX = SX; a.mean = mean; a.sd = sd;
       a.gz0 = 4 * c0;
       a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
+      if (src_dtype == FPL_U8) {
+        a.wstem = (const h16x8 *)st->w1_int; a.shtab = st->shift1_int; a.c0 = st->int_c0;
+      }
       a.w = F + st->off_w[1]; a.shift = S + st->off_s[1];
       a.out = (unsigned char *)h1v; a.OZ = HZ; a.OY = HY; a.OX = HX;
       a.bg = BlockGrid{(int)ceil_div64(HX, 8), (int)ceil_div64(HY, 2), (int)ceil_div64(HZ, 2)};
@@ -1287,9 +1326,9 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
                            int32_t zb, int32_t ze, float *dst) {
   SplitState *st;
   FPL_TRY(split_prepare(ctx, prog, &st));
+  if (src_dtype == FPL_U8) FPL_TRY(split_prepare_int(ctx, prog, st, mean, sd));
   if (fpl_vgg_variant(prog) == 2)
     return split2_infer(ctx, st, src, src_dtype, mean, sd, dims, origins, out_sz, zb, ze, dst);
-  if (src_dtype == FPL_U8) FPL_TRY(split_prepare_int(ctx, prog, st, mean, sd));
   hipStream_t stream = ctx->stream;
   const int64_t SZ = dims[0], SY = dims[1], SX = dims[2];
   const int64_t VZ = SZ - 14, VY = SY - 14, VX = SX - 14;
