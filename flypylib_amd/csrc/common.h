@@ -78,13 +78,31 @@ struct fpl_ctx {
   int comm_rank = 0, comm_nranks = 1;
   // executor chosen by the last fpl_infer_volume / fpl_program_forward (fpl_last_path)
   char last_path[64] = {0};
+  // half-range guard of the split-operand kernels (mfma_util.h): a device word the kernels
+  // OR into and its pinned host copy, read back at the end of fpl_infer_volume
+  unsigned *range_flag_dev = nullptr;
+  unsigned *range_flag_host = nullptr;
 };
+
+// the context's half-range flag word (allocated on first use)
+int fpl_range_flag(fpl_ctx *ctx, unsigned **dev);
 
 void fpl_comm_release(fpl_ctx *ctx);                  // comm.hip
 
 extern thread_local char g_fpl_err[FPL_MAX_ERR];
 
 int fpl_fail(fpl_ctx *ctx, const char *fmt, ...);
+// "this network / input does not fit the IEEE-half range of the split-operand kernels":
+// sets the message and returns FPL_RC_RANGE, which fpl_infer_volume turns into the fp32
+// executor under FPL_PREC_AUTO and into an ordinary failure under FPL_PREC_F16S
+#define FPL_RC_RANGE 3
+// bits of the half-range flag word: which kernel family raised it (for the message)
+#define FPL_RANGE_INPUT 1u      // a normalised input voxel beyond the stem's input limit
+#define FPL_RANGE_STEM 2u
+#define FPL_RANGE_MID 4u
+#define FPL_RANGE_TAIL 8u
+#define FPL_RANGE_UNET 16u
+int fpl_fail_range(fpl_ctx *ctx, const char *fmt, ...);
 
 #define FPL_HIP(ctx, expr)                                                     \
   do {                                                                         \

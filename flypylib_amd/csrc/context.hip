@@ -14,6 +14,28 @@ int fpl_fail(fpl_ctx *ctx, const char *fmt, ...) {
   return 1;
 }
 
+int fpl_fail_range(fpl_ctx *ctx, const char *fmt, ...) {
+  char buf[FPL_MAX_ERR];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) memcpy(ctx->err, buf, sizeof(buf));
+  memcpy(g_fpl_err, buf, sizeof(buf));
+  return FPL_RC_RANGE;
+}
+
+int fpl_range_flag(fpl_ctx *ctx, unsigned **dev) {
+  if (!ctx->range_flag_dev) {
+    FPL_HIP(ctx, hipMalloc((void **)&ctx->range_flag_dev, sizeof(unsigned)));
+    FPL_HIP(ctx, hipHostMalloc((void **)&ctx->range_flag_host, sizeof(unsigned), hipHostMallocDefault));
+    *ctx->range_flag_host = 0u;
+    FPL_HIP(ctx, hipMemsetAsync(ctx->range_flag_dev, 0, sizeof(unsigned), ctx->stream));
+  }
+  *dev = ctx->range_flag_dev;
+  return 0;
+}
+
 extern "C" {
 
 int fpl_abi_version(void) { return FPL_ABI_VERSION; }
@@ -69,6 +91,8 @@ int fpl_ctx_destroy(fpl_ctx *ctx) {
   if (ctx->v2o.sort_idx) fpl_dev_release(ctx, ctx->v2o.sort_idx);
   fpl_dev_trim(ctx);
   for (auto &kv : ctx->live_blocks) hipFree(kv.first);
+  if (ctx->range_flag_dev) hipFree(ctx->range_flag_dev);
+  if (ctx->range_flag_host) hipHostFree(ctx->range_flag_host);
   hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return 0;

@@ -17,6 +17,7 @@
 // weight fragments go from L2 straight into registers, a few K-steps ahead;
 // <= 80 KiB LDS so two workgroups share a CU.  Details at the kernel.
 #include <algorithm>
+#include <cmath>
 
 #include "fast_paths.h"
 #include "mfma_util.h"
@@ -115,8 +116,10 @@ struct Src {             // one CC-channel chunk of the (virtual) concatenated i
 // Epilogue store for interleaved output channels (pack_weights.h, fpl_out_channel):
 // lane (c, g) writes the 4*MB contiguous channels [4*MB*g, ...) of its voxel; `vox0` is the
 // voxel's position in chunk plane 0.
+// `ovf`: the split build's half-range guard (mfma_util.h)
 template <int MB, bool RELU_ALWAYS>
-__device__ __forceinline__ void store_il(h16_t *vox0, int64_t plane, int g, const f32x4 (&acc)[MB], int relu) {
+__device__ __forceinline__ void store_il(h16_t *vox0, int64_t plane, int g, const f32x4 (&acc)[MB], int relu,
+                                         unsigned &ovf) {
   static_assert(MB % 2 == 0, "16-B pieces");
   if (SPLIT) {
     // the lane's 4*MB real channels start at 4*MB*g; per 8 of them one 16-B piece of hi
@@ -130,8 +133,8 @@ __device__ __forceinline__ void store_il(h16_t *vox0, int64_t plane, int g, cons
       for (int q = 0; q < 2; ++q) {
         const f32x4 &v = acc[2 * h + q];
         const bool rl = RELU_ALWAYS || relu;
-        const Pair2 p0 = rl ? split_pk_relu(v[0], v[1]) : split_pk(v[0], v[1]);
-        const Pair2 p1 = rl ? split_pk_relu(v[2], v[3]) : split_pk(v[2], v[3]);
+        const Pair2 p0 = rl ? split_pk_relu(v[0], v[1], ovf) : split_pk_signed(v[0], v[1], ovf);
+        const Pair2 p1 = rl ? split_pk_relu(v[2], v[3], ovf) : split_pk_signed(v[2], v[3], ovf);
         hi[2 * q] = p0.hi; hi[2 * q + 1] = p1.hi;
         lo[2 * q] = p0.lo; lo[2 * q + 1] = p1.lo;
       }
@@ -191,6 +194,10 @@ struct Conv3Args {
   const h16x8 *w8, *w9;          // HEAD: 2 fragments (SLOT_SPATIAL), 1 fragment (SLOT_CHAIN); split: [part][b]
   const float *sh8;
   float bias9;
+  // split build: half-range guard (mfma_util.h).  STEM: conv3 1->32's outputs are bounded on
+  // the host for raw inputs |x| <= xlim, which the kernel checks per raw voxel
+  unsigned *flag;
+  float xlim;
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
   }
   const int vox0 = (tid >> 5) * 8 + (tid & 7);
   const unsigned pc = (unsigned)((tid >> 3) & 3);
+  unsigned ovf = 0u, xmax = 0u;                     // split build: half-range guard
   u32x4 nt[STEM ? 1 : NT];
   float rawv[STEM ? NRAWT : 1];
   auto fetch = [&](int64_t fb, int cc) {
@@ -324,6 +332,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
 #pragma unroll
       for (int j = 0; j < NRAWT; ++j) {
         const float x = rawv[j];
+        const unsigned ax = __builtin_bit_cast(unsigned, x) & 0x7FFFFFFFu;
+        xmax = ax > xmax ? ax : xmax;
         const h16_t h = (h16_t)x;
         if (tid + 256 * j < NRAW) {
           rawt[tid + 256 * j] = h16_bits(x);
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
           // packed pair IS the K-step of conv1 32->32 in SLOT_SPATIAL order
           f32x4 a8[2], t9;
           if (SPLIT) {
-            const Frag2 h7 = pack_relu_split(acc[sub][0], acc[sub][1]);
+            const Frag2 h7 = pack_relu_split(acc[sub][0], acc[sub][1], ovf);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
               f32x4 sh;
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
               for (int r = 0; r < 4; ++r) sh[r] = a.sh8[16 * b + 4 * g + r];
               a8[b] = mfma3(a.w8[b * 64 + lane], a.w8[(2 + b) * 64 + lane], h7, sh);
             }
-            t9 = mfma3(a.w9[lane], a.w9[64 + lane], pack_relu_split(a8[0], a8[1]),
+            t9 = mfma3(a.w9[lane], a.w9[64 + lane], pack_relu_split(a8[0], a8[1], ovf),
                        f32x4{0.f, 0.f, 0.f, 0.f});
           } else {
             const h16x8 h7 = pack_relu(acc[sub][0], acc[sub][1]);
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
                 1.f / (1.f + __expf(-logit));
         } else if (oz < a.OD && oy < a.OH && ox < a.OW)
           store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * CC,
-                              a.oplane, g, acc[sub], a.relu);
+                              a.oplane, g, acc[sub], a.relu, ovf);
       }
     }
     // ---- fused 2x2x2 max pool of the block (4 x 4 x 16 -> 2 x 2 x 8): y pairs are
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
               for (int r = 0; r < 4; ++r) m[b][r] = __builtin_fmaxf(pm[yh][b][r], o[r]);
             }
             store_il<MB, true>(a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * CC,
-                               a.pplane, g, m, 1);
+                               a.pplane, g, m, 1, ovf);
           }
         }
       }
@@ -622,6 +632,10 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
     blk += G;
     if (blk >= total_blocks) break;
   }
+  if (SPLIT) {
+    ovf_commit(ovf, a.flag, FPL_RANGE_UNET);
+    if (STEM && xmax > __builtin_bit_cast(unsigned, a.xlim)) atomicOr(a.flag, FPL_RANGE_INPUT);
+  }
 }
 
 // ---- 1x1x1 conv as a voxel GEMM ---------------------------------------------------
@@ -634,6 +648,7 @@ struct Conv1Args {
   const h16x8 *w_tail;          // TAIL: [kstep] fragments of the 16*MB -> 1 conv
   float bias_tail;
   float *out_f32;                // TAIL: (M) sigmoid probabilities
+  unsigned *flag;                // split build: half-range guard
 };
 
 template <int CIN, int MB, int TAIL>
@@ -655,6 +670,7 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
       sh[b][r] = a.shift[TAIL ? 16 * b + 4 * g + r : 4 * MB * g + 4 * b + r];
   __syncthreads();
   const int64_t groups = (a.M + 15) / 16;
+  unsigned ovf = 0u;
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < groups; grp += (int64_t)gridDim.x * 4) {
     int64_t m = grp * 16 + c;
     const bool ok = m < a.M;
@@ -677,7 +693,7 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
       }
     }
     if (TAIL == 0) {
-      if (ok) store_il<MB, true>(a.out + m * CC, a.plane, g, acc, 1);
+      if (ok) store_il<MB, true>(a.out + m * CC, a.plane, g, acc, 1, ovf);
     } else {
       // chained 16*MB -> 1 conv (k-slots bound to the accumulator layout), sigmoid
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -688,6 +704,7 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
       if (ok && g == 0) a.out_f32[m] = 1.f / (1.f + __expf(-logit));
     }
   }
+  if (SPLIT) ovf_commit(ovf, a.flag, FPL_RANGE_UNET);
 }
 
 // ---- unet_like's first stage (fplmodels.py:210-256): conv3 1->32 +BN+ReLU, conv1 32->32
@@ -703,6 +720,7 @@ struct StemC1Args {
   h16_t *c1, *p1;                // (n, D, D, D, 32), D = T - 2; (n, D/2, D/2, D/2, 32)
   int64_t c1plane, p1plane;      // split: elements of one chunk plane of c1 / p1
   int D, zblocks, nbx, nby;
+  unsigned *flag;                // split build: half-range guard (every split is checked here)
 };
 
 __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
@@ -714,6 +732,7 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
   const int bx = blockIdx.x % a.nbx, by = (blockIdx.x / a.nbx) % a.nby, bz = blockIdx.x / (a.nbx * a.nby);
   const int n = bz / a.zblocks, z0 = (bz % a.zblocks) * 4, y0 = by * 4, x0 = bx * 16;
   const float *base = a.raw + (int64_t)n * a.T * a.T * a.T;
+  unsigned ovf = 0u;
   for (int p = tid; p < RZ * RY * RX; p += 256) {
     int z = z0 + p / (RY * RX), y = y0 + (p / RX) % RY, x = x0 + p % RX;
     z = z < a.T ? z : a.T - 1;                             // clamped reads only feed masked
@@ -721,6 +740,7 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
     x = x < a.T ? x : a.T - 1;
     const float v = base[((int64_t)z * a.T + y) * a.T + x];
     rawt[p] = h16_bits(v);
+    if (SPLIT) ovf_note(ovf, (unsigned)h16_bits(v) & 0x7FFFu);
     if (SPLIT) rawt[RZ * RY * RX + p] = h16_bits(v - (float)(h16_t)v);
   }
   int toff[8];
@@ -762,7 +782,7 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
       Frag2 b2;
       b2.hi = bf;
       b2.lo = __builtin_bit_cast(h16x8, rl);
-      const Frag2 h0 = pack_relu_split(mfma3(ws[0], wsl[0], b2, shs[0]), mfma3(ws[1], wsl[1], b2, shs[1]));
+      const Frag2 h0 = pack_relu_split(mfma3(ws[0], wsl[0], b2, shs[0]), mfma3(ws[1], wsl[1], b2, shs[1]), ovf);
       acc[sub][0] = mfma3(w1[0], w1l[0], h0, sh1[0]);
       acc[sub][1] = mfma3(w1[1], w1l[1], h0, sh1[1]);
     } else {
@@ -772,7 +792,7 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
     }
     const int oz = z0 + wave, oy = y0 + sub, ox = x0 + c;
     if (oz < a.D && oy < a.D && ox < a.D)
-      store_il<2, true>(a.c1 + ((((int64_t)n * a.D + oz) * a.D + oy) * a.D + ox) * 32, a.c1plane, g, acc[sub], 1);
+      store_il<2, true>(a.c1 + ((((int64_t)n * a.D + oz) * a.D + oy) * a.D + ox) * 32, a.c1plane, g, acc[sub], 1, ovf);
   }
   if (SPLIT) {
     // the pool in fp32 (as the POOL epilogue of the split conv3), then split and store
@@ -808,10 +828,11 @@ __global__ __launch_bounds__(256) void FPLK(unet_stem_c1)(StemC1Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) m[b][r] = __builtin_fmaxf(pmf[yh][b][r], o[r]);
           }
-          store_il<2, true>(a.p1 + ((((int64_t)n * PD + pz) * PD + py) * PD + px) * 32, a.p1plane, g, m, 1);
+          store_il<2, true>(a.p1 + ((((int64_t)n * PD + pz) * PD + py) * PD + px) * 32, a.p1plane, g, m, 1, ovf);
         }
       }
     }
+    ovf_commit(ovf, a.flag, FPL_RANGE_UNET);
     return;
   }
   // 2x2x2 max pool of the block, as the POOL epilogue of conv3
@@ -906,6 +927,7 @@ struct UnetState {
   size_t half_bytes[12] = {0};   // conv3 with 128 outputs: bytes of the first 64-channel half
   size_t off_w7t = 0;            // conv 7 with the dy / dx taps swapped (edge strip)
   float bias_tail = 0.f;
+  float xlim = 0.f;              // split build: input limit of the stem's half-range bound
 };
 
 void unet_state_free(fpl_ctx *, void *p) {
@@ -1148,10 +1170,27 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
   }
 #ifdef FPL_F16
   for (uint16_t h : all)
-    FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
-                "a folded weight exceeds the IEEE-half range (65504); use precision "
-                "bf16 or f32 for this network");
+    if ((h & 0x7C00u) == 0x7C00u) {
+      const char *msg = "a folded weight exceeds the IEEE-half range (65504); use precision "
+                        "bf16, f32 or 'auto' for this network";
+      return SPLIT ? fpl_fail_range(ctx, "%s", msg) : fpl_fail(ctx, "%s", msg);
+    }
 #endif
+  if (SPLIT) {
+    // half-range guard of the stem computed in the tile loader: conv3 1->32's outputs stay
+    // below the limit for raw inputs |x| <= xlim (checked per raw voxel by the kernel)
+    const fpl_op &op = prog->ops[d.conv[0]];
+    double xl = 65000.0;
+    for (int co = 0; co < op.cout; ++co) {
+      double sw = 0.0;
+      for (int tap = 0; tap < 27; ++tap) sw += std::fabs((double)A[op.w_off + (size_t)tap * op.cout + co]);
+      sw *= std::fabs((double)A[op.scale_off + co]);
+      const double sh = std::fabs((double)A[op.shift_off + co]);
+      if (!(sh < 65000.0)) return fpl_fail_range(ctx, "the first layer's shift exceeds the IEEE-half range");
+      if (sw > 0.0) xl = std::min(xl, (65000.0 - sh) / sw);
+    }
+    st->xlim = (float)xl;
+  }
   st->bias_tail = A[prog->ops[d.conv[l_last]].shift_off];
   if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
   if (st->shifts) FPL_HIP(ctx, hipFree(st->shifts));
@@ -1241,6 +1280,8 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
   DevTemp tmp(ctx);
+  unsigned *flag = nullptr;
+  if (SPLIT) FPL_TRY(fpl_range_flag(ctx, &flag));
   const unsigned char *F = st->frags;
   const float *S = st->shifts;
   const bool b3[2] = {prog->ops[D.conv[4]].k == 3, D.nbottom == 2 && prog->ops[D.conv[5]].k == 3};
@@ -1284,6 +1325,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr; a.pool_out = nullptr;
     a.transposed = 0; a.xorg = 0; a.main_w = 0;
     memset(&a.io, 0, sizeof(a.io)); a.w8 = a.w9 = nullptr; a.sh8 = nullptr; a.bias9 = 0.f;
+    a.flag = flag; a.xlim = st->xlim;
     return a;
   };
   if (D.first1) {  // unet_like: conv3 1->32 and conv1 32->32 chained, c1 + pooled p1
@@ -1293,6 +1335,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.w1 = (const h16x8 *)(F + st->off_w[1]); a.sh1 = S + st->off_s[1];
     a.c1 = c1; a.p1 = p1; a.D = d1;
     a.c1plane = (int64_t)n * cube(d1) * CC; a.p1plane = (int64_t)n * cube(dp1) * CC;
+    a.flag = flag;
     a.zblocks = (int)ceil_div64(d1, 4); a.nbx = (int)ceil_div64(d1, 16); a.nby = (int)ceil_div64(d1, 4);
     TimedLaunch tl(ctx, "unet_stem_conv1_32_32_pool");
     FPLK(unet_stem_c1)<<<(unsigned)((int64_t)a.nbx * a.nby * n * a.zblocks), 256, 0, stm>>>(a);
@@ -1322,7 +1365,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
                    const char *name) {
     Conv1Args a;
     a.in = x; a.M = M; a.plane = M * CC; a.w = F + st->off_w[l]; a.shift = S + st->off_s[l];
-    a.out = y; a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr;
+    a.out = y; a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr; a.flag = flag;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, name);
     // (split: two fragment sets per K-step and twice the K-steps; up to 64 KiB of LDS)
@@ -1403,7 +1446,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     Conv1Args a;
     a.in = c5a; a.M = (int64_t)n * cube(d5a); a.plane = a.M * CC; a.w = F + st->off_w[lu2 + 1]; a.shift = S + st->off_s[lu2 + 1];
     a.out = nullptr; a.w_tail = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias_tail = st->bias_tail;
-    a.out_f32 = out;
+    a.out_f32 = out; a.flag = nullptr;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, "unet_head_" FPL_PREC_STR);
     FPLK(conv1)<32, 2, 1><<<grid, 256, 2 * 1024, stm>>>(a);

@@ -175,21 +175,16 @@ int fpl_program_forward(fpl_ctx *ctx, fpl_program *prog, const float *in,
   return 0;
 }
 
-int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
-                     int src_dtype, int src_mem, float mean, float sd,
-                     const int64_t dims[3], const int32_t tile_in[3],
-                     const int32_t offset[3], int precision, int32_t z_begin,
-                     int32_t z_end, float *dst, int dst_mem) {
-  if (!ctx || !prog || !src || !dims || !tile_in || !offset || !dst)
-    return fpl_fail(ctx, "fpl_infer_volume: NULL argument");
-  FPL_REQUIRE(ctx, src_dtype == FPL_U8 || src_dtype == FPL_F32,
-              "fpl_infer_volume: src dtype must be u8 or f32");
-  FPL_REQUIRE(ctx, sd != 0.f, "fpl_infer_volume: std is 0");
-  FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || precision == FPL_PREC_BF16 ||
-                       precision == FPL_PREC_F16 || precision == FPL_PREC_F16S ||
-                       precision == FPL_PREC_AUTO,
-              "fpl_infer_volume: unknown precision %d", precision);
-  FPL_HIP(ctx, hipSetDevice(ctx->device));
+}  // extern "C"
+
+// one pass at a fixed precision (never FPL_PREC_AUTO).  *range_bits: the half-range guard's
+// flag word after a FPL_PREC_F16S pass (mfma_util.h; 0 = every split value was finite)
+static int infer_volume_impl(fpl_ctx *ctx, fpl_program *prog, const void *src,
+                             int src_dtype, int src_mem, float mean, float sd,
+                             const int64_t dims[3], const int32_t tile_in[3],
+                             const int32_t offset[3], int precision, int32_t z_begin,
+                             int32_t z_end, float *dst, int dst_mem, unsigned *range_bits) {
+  *range_bits = 0u;
   int32_t out_sz[3];
   std::vector<int32_t> origins[3];
   for (int a = 0; a < 3; ++a) {
@@ -249,9 +244,6 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   // needs clearing there; the per-op path stitches tiles into a zeroed volume
   const bool cubic = tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2];
   const bool unet_split_ok = cubic && fpl_unet_fast_available_f16s(prog, FPL_PREC_F16S);
-  if (precision == FPL_PREC_AUTO)
-    precision = (fpl_split_path_available(prog, FPL_PREC_F16S, offset, out_sz) || unet_split_ok)
-                    ? FPL_PREC_F16S : FPL_PREC_F32;
   const bool split = fpl_split_path_available(prog, precision, offset, out_sz);
   FPL_REQUIRE(ctx, precision != FPL_PREC_F16S || split || unet_split_ok,
               "fpl_infer_volume: the split-half kernels exist for vgg_like / vgg_like2 (stride-4 lattice) and "
@@ -273,6 +265,11 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     }
   }
   set_last_path(ctx, "none");
+  unsigned *range_flag = nullptr;
+  if (precision == FPL_PREC_F16S) {
+    FPL_TRY(fpl_range_flag(ctx, &range_flag));
+    FPL_HIP(ctx, hipMemsetAsync(range_flag, 0, sizeof(unsigned), st));
+  }
   if (zb >= ze) {
     if (dst_mem == FPL_MEM_HOST && wr_hi > wr_lo)
       FPL_HIP(ctx, hipMemcpyAsync(dst + wr_lo * Y * X, dst_dev,
@@ -438,12 +435,82 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
       }
     }
   }
+  if (range_flag) {
+    // the guard's verdict first: a pass that left the half range is not worth copying out
+    FPL_HIP(ctx, hipMemcpyAsync(ctx->range_flag_host, range_flag, sizeof(unsigned),
+                                hipMemcpyDeviceToHost, st));
+    FPL_HIP(ctx, hipStreamSynchronize(st));
+    *range_bits = *ctx->range_flag_host;
+    if (*range_bits) return 0;
+  }
   if (dst_mem == FPL_MEM_HOST)
     FPL_HIP(ctx, hipMemcpyAsync(dst + wr_lo * Y * X, dst_dev,
                                 (size_t)(wr_hi - wr_lo) * Y * X * sizeof(float),
                                 hipMemcpyDeviceToHost, st));
   FPL_HIP(ctx, hipStreamSynchronize(st));
   return 0;
+}
+
+extern "C" {
+
+int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
+                     int src_dtype, int src_mem, float mean, float sd,
+                     const int64_t dims[3], const int32_t tile_in[3],
+                     const int32_t offset[3], int precision, int32_t z_begin,
+                     int32_t z_end, float *dst, int dst_mem) {
+  if (!ctx || !prog || !src || !dims || !tile_in || !offset || !dst)
+    return fpl_fail(ctx, "fpl_infer_volume: NULL argument");
+  FPL_REQUIRE(ctx, src_dtype == FPL_U8 || src_dtype == FPL_F32,
+              "fpl_infer_volume: src dtype must be u8 or f32");
+  FPL_REQUIRE(ctx, sd != 0.f, "fpl_infer_volume: std is 0");
+  FPL_REQUIRE(ctx, precision == FPL_PREC_F32 || precision == FPL_PREC_BF16 ||
+                       precision == FPL_PREC_F16 || precision == FPL_PREC_F16S ||
+                       precision == FPL_PREC_AUTO,
+              "fpl_infer_volume: unknown precision %d", precision);
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  auto run = [&](int prec, unsigned *bits) {
+    return infer_volume_impl(ctx, prog, src, src_dtype, src_mem, mean, sd, dims, tile_in, offset,
+                             prec, z_begin, z_end, dst, dst_mem, bits);
+  };
+  auto where = [](unsigned bits) {
+    return bits & FPL_RANGE_INPUT ? "a normalised input voxel (times the first layer's weights)"
+           : bits & FPL_RANGE_STEM ? "an activation of the first block"
+           : bits & FPL_RANGE_MID ? "an activation of the second block"
+           : bits & FPL_RANGE_TAIL ? "an activation of the head" : "an activation";
+  };
+  unsigned bits = 0u;
+  if (precision == FPL_PREC_AUTO) {
+    // fp32-GRADE on the fastest executor that delivers it: the split-half kernels where they
+    // exist and the values stay inside the IEEE-half range, else the fp32 MFMA executor - the
+    // reference predicts in fp32 (flypylib/fplnetwork.py:175-176), which has no range limit
+    int32_t out_sz[3];
+    for (int a = 0; a < 3; ++a) out_sz[a] = tile_in[a] - 2 * offset[a];
+    const bool cubic = tile_in[0] == tile_in[1] && tile_in[1] == tile_in[2];
+    const bool have_split = fpl_split_path_available(prog, FPL_PREC_F16S, offset, out_sz) ||
+                            (cubic && fpl_unet_fast_available_f16s(prog, FPL_PREC_F16S));
+    if (have_split && prog->half_range_bad_version != prog->arena_version) {
+      const int rc = run(FPL_PREC_F16S, &bits);
+      if (rc == 0 && !bits) return 0;
+      if (rc != 0 && rc != FPL_RC_RANGE) return rc;
+      // weights (rc) or activations (bits) beyond the half range: this network runs in fp32
+      // from now on (until its weights change); an out-of-range INPUT voxel only costs this call
+      if (rc == FPL_RC_RANGE || (bits & ~FPL_RANGE_INPUT)) prog->half_range_bad_version = prog->arena_version;
+    }
+    const int rc = run(FPL_PREC_F32, &bits);
+    if (rc == 0 && have_split) {
+      char name[64];
+      snprintf(name, sizeof(name), "%s(range)", ctx->last_path);
+      set_last_path(ctx, name);
+    }
+    return rc;
+  }
+  const int rc = run(precision, &bits);
+  if (rc == FPL_RC_RANGE) return 1;                  // message set by the packer
+  if (rc == 0 && bits)
+    return fpl_fail(ctx, "fpl_infer_volume: %s exceeds the IEEE-half range (65504) of the split-operand "
+                         "kernels (guard bits 0x%x): the result is not valid; use precision f32, or "
+                         "'auto', which falls back to it", where(bits), bits);
+  return rc;
 }
 
 const char *fpl_last_path(fpl_ctx *ctx) { return ctx ? ctx->last_path : ""; }

@@ -196,6 +196,42 @@ __device__ __forceinline__ Pair2 split_pk_relu(float a, float b) {
   return split_pk(relu_f32(a), relu_f32(b));
 }
 
+// ---- half-range guard (FPL_PREC_F16S / FPL_PREC_AUTO; the reference predicts in fp32,
+// flypylib/fplnetwork.py:175-176, which has no such limit).  A value >= 65520 becomes
+// hi = inf, lo = half(v - inf) = -inf, and the next layer's accumulators NaN or, through a
+// max-pool or a ReLU, silently wrong finite numbers.  Every value these kernels split is
+// non-negative (post-ReLU / post-pool; -0.0 is a negative int16), so "some hi half is inf or
+// NaN" is "the running int16 maximum of the packed hi halves reaches 0x7C00": one
+// v_pk_max_i16 per split pair into a per-thread word, looked at once at the end of the
+// kernel (ovf_commit: an atomic OR into the context's flag word, which the host reads
+// after the call; 'auto' then reruns the call on the fp32 executor, 'f16s' fails).
+// The layers whose splits sit in VALU-bound inner loops (the stems' conv3 1->C) are covered
+// by a host-side bound on their outputs instead (sum |w| * the input limit, checked per
+// loaded input value where the input is not uint8).
+__device__ __forceinline__ void ovf_note(unsigned &ovf, unsigned hi_pair) { ovf = pk_max_i16(ovf, hi_pair); }
+__device__ __forceinline__ bool ovf_hit(unsigned ovf) {
+  return (ovf & 0x7C00u) == 0x7C00u || (ovf & 0x7C000000u) == 0x7C000000u;
+}
+__device__ __forceinline__ void ovf_commit(unsigned ovf, unsigned *flag, unsigned bit) {
+  if (ovf_hit(ovf)) atomicOr(flag, bit);
+}
+// (flag bits FPL_RANGE_*: common.h)
+
+__device__ __forceinline__ Pair2 split_pk(float a, float b, unsigned &ovf) {
+  const Pair2 r = split_pk(a, b);
+  ovf_note(ovf, r.hi);
+  return r;
+}
+__device__ __forceinline__ Pair2 split_pk_relu(float a, float b, unsigned &ovf) {
+  return split_pk(relu_f32(a), relu_f32(b), ovf);
+}
+// signed values: the guard looks at |hi|
+__device__ __forceinline__ Pair2 split_pk_signed(float a, float b, unsigned &ovf) {
+  const Pair2 r = split_pk(a, b);
+  ovf_note(ovf, r.hi & 0x7FFF7FFFu);
+  return r;
+}
+
 // two accumulator tiles -> the hi and lo B fragments of a K-step of the next layer, ReLU
 // applied (chain / spatial maps as pack_relu)
 __device__ __forceinline__ Frag2 pack_relu_split(const f32x4 &lo_blk, const f32x4 &hi_blk) {
@@ -208,6 +244,13 @@ __device__ __forceinline__ Frag2 pack_relu_split(const f32x4 &lo_blk, const f32x
   Frag2 f;
   f.hi = __builtin_bit_cast(h16x8, h);
   f.lo = __builtin_bit_cast(h16x8, l);
+  return f;
+}
+// ... with the half-range guard: the four hi words are already packed, so four v_pk_max
+__device__ __forceinline__ Frag2 pack_relu_split(const f32x4 &lo_blk, const f32x4 &hi_blk, unsigned &ovf) {
+  const Frag2 f = pack_relu_split(lo_blk, hi_blk);
+  const u32x4 h = __builtin_bit_cast(u32x4, f.hi);
+  ovf_note(ovf, pk_max_i16(pk_max_i16(h[0], h[1]), pk_max_i16(h[2], h[3])));
   return f;
 }
 

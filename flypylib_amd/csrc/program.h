@@ -23,6 +23,9 @@ struct fpl_program {
   void *fast_state_h16[3] = {nullptr, nullptr, nullptr};
   void (*fast_state_h16_free[3])(fpl_ctx *, void *) = {nullptr, nullptr, nullptr};
   uint64_t arena_version = 0;
+  // arena version at which FPL_PREC_AUTO found weights or values beyond the IEEE-half range:
+  // that network runs on the fp32 executor until its weights change (infer.hip)
+  uint64_t half_range_bad_version = ~0ull;
   // fp32 MFMA executor state (conv_mfma_f32.hip)
   void *fast_state_f32 = nullptr;
   void (*fast_state_f32_free)(fpl_ctx *, void *) = nullptr;

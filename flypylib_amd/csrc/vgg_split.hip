@@ -58,6 +58,12 @@ __device__ __forceinline__ h16x8 pack_relu_split_x(const f32x4 &blk) {
   p = split_pk_relu(blk[2], blk[3]); v[1] = p.hi; v[3] = p.lo;
   return __builtin_bit_cast(h16x8, v);
 }
+__device__ __forceinline__ h16x8 pack_relu_split_x(const f32x4 &blk, unsigned &ovf) {   // half-range guard
+  const h16x8 r = pack_relu_split_x(blk);
+  const u32x4 v = __builtin_bit_cast(u32x4, r);
+  ovf_note(ovf, pk_max_i16(v[0], v[1]));
+  return r;
+}
 
 // A 1x1 conv on a 48-channel register-chained input, one M-block: w = the block's four
 // weight steps [blocks 0,1 hi], [blocks 0,1 lo], [blk 2: w_lo | w_hi], [blk 2: w_hi | w_lo]
@@ -73,11 +79,12 @@ __device__ __forceinline__ f32x4 chain48(const h16x8 (&w)[4], const Frag2 &h01, 
 // fpl_out_channel): lane (c, g) then holds the 12 CONTIGUOUS channels [12 g, 12 g + 12) of
 // its voxel - half a pass - and writes 24 B of hi halves and 24 B of lo halves instead of
 // three 8-B pieces each, 32 B apart (the stem's P1 stores cost 3.9 of its 21.5 ms).
-__device__ __forceinline__ void store_split12(unsigned char *vox, int64_t plane, int g, const f32x4 (&v)[3]) {
+__device__ __forceinline__ void store_split12(unsigned char *vox, int64_t plane, int g, const f32x4 (&v)[3],
+                                              unsigned &ovf) {
   unsigned hi[6], lo[6];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    const Pair2 p0 = split_pk(v[b][0], v[b][1]), p1 = split_pk(v[b][2], v[b][3]);
+    const Pair2 p0 = split_pk(v[b][0], v[b][1], ovf), p1 = split_pk(v[b][2], v[b][3], ovf);
     hi[2 * b] = p0.hi; hi[2 * b + 1] = p1.hi;
     lo[2 * b] = p0.lo; lo[2 * b + 1] = p1.lo;
   }
@@ -140,6 +147,11 @@ struct StemSArgs {
   unsigned char *p1;
   int P1Z, P1Y, P1X;       // chunk-local dims
   int nbx, nby, nbz;       // blocks of S_PX x S_PY x S_PZ pooled voxels
+  // half-range guard (mfma_util.h): conv3 1->48's outputs are bounded on the host from
+  // sum |w| and the input limit (uint8: |u - c0| <= 255; float volumes: |x| <= xlim, checked
+  // per loaded voxel), conv1's pooled outputs are checked where they are split for the store
+  unsigned *flag;
+  float xlim;
 };
 
 __device__ __forceinline__ int stem_row_off(int row) {
@@ -211,12 +223,15 @@ __device__ __forceinline__ void stem_load_rows(const SRC *base, unsigned tab, un
 // u8 sources go through a per-workgroup table of the 256 possible results.
 template <typename SRC>
 __device__ __forceinline__ unsigned stem_norm(const StemSArgs &a, const unsigned *lut, SRC v,
-                                              bool ok) {
+                                              bool ok, unsigned &xmax) {
   unsigned t;
   if (sizeof(SRC) == 1) {
     t = lut[(unsigned)v & 255u];              // u - c0: exact, lo half 0; padding 0
   } else {
     const float x = ((float)v - a.mean) / a.sd;
+    // largest |x| seen, as an integer (a NaN is larger than every finite value)
+    const unsigned ax = __builtin_bit_cast(unsigned, x) & 0x7FFFFFFFu;
+    xmax = ax > xmax ? ax : xmax;
     const h16_t h = (h16_t)x;
     t = (unsigned)h16_bits(x) | ((unsigned)h16_bits(x - (float)h) << 16);
   }
@@ -228,9 +243,9 @@ struct StemBits { unsigned b[S_RPT]; };
 template <typename SRC>
 __device__ __forceinline__ void stem_convert_rows(const StemSArgs &a, const StemBlock &b,
                                                   const unsigned *lut, const StemRows<SRC> &r,
-                                                  StemBits &o) {
+                                                  StemBits &o, unsigned &xmax) {
 #pragma unroll
-  for (int k = 0; k < S_RPT; ++k) o.b[k] = stem_norm<SRC>(a, lut, r.v[k], r.ok[k] && b.x_ok);
+  for (int k = 0; k < S_RPT; ++k) o.b[k] = stem_norm<SRC>(a, lut, r.v[k], r.ok[k] && b.x_ok, xmax);
 }
 
 // tile = hi tile, tile + S_TILE = lo tile (LO = false: u8 volumes, no lo tile)
@@ -268,10 +283,10 @@ __device__ __forceinline__ void stem_load_edge(const StemSArgs &a, const StemBlo
 template <typename SRC>
 __device__ __forceinline__ void stem_store_edge(const StemSArgs &a, unsigned short *tile,
                                                 const unsigned *lut, int wrow0, int lane,
-                                                const StemEdge<SRC> &e) {
+                                                const StemEdge<SRC> &e, unsigned &xmax) {
   const int row = stem_row_of(wrow0, lane);
-  const unsigned v0 = stem_norm<SRC>(a, lut, e.v[0], e.ok[0]);
-  const unsigned v1 = stem_norm<SRC>(a, lut, e.v[1], e.ok[1]);
+  const unsigned v0 = stem_norm<SRC>(a, lut, e.v[0], e.ok[0], xmax);
+  const unsigned v1 = stem_norm<SRC>(a, lut, e.v[1], e.ok[1], xmax);
   *reinterpret_cast<unsigned *>(&tile[row * S_TP + 64]) = (v0 & 0xFFFFu) | (v1 << 16);
   if (sizeof(SRC) != 1)
     *reinterpret_cast<unsigned *>(&tile[S_TILE + row * S_TP + 64]) = (v0 >> 16) | (v1 & 0xFFFF0000u);
@@ -330,6 +345,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
     }
   __syncthreads();                      // lut
 
+  unsigned ovf = 0u, xmax = 0u;         // half-range guard: split stores / float inputs
   // ---- the first block's tile: plain fill, once per workgroup
   const int wrow0 = wave * S_WROWS;
   StemBlock blk = stem_block(a, q, lane);
@@ -340,12 +356,12 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       StemRows<SRC> rr;
       StemBits hb;
       stem_load_rows<SRC>(base0, tab0, blk.xc, i0, rr);
-      stem_convert_rows<SRC>(a, blk, lut, rr, hb);
+      stem_convert_rows<SRC>(a, blk, lut, rr, hb, xmax);
       stem_write_rows<!INT>(tiles, wrow0, i0, lane, hb);
     }
     StemEdge<SRC> ee;
     stem_load_edge<SRC>(a, blk, wrow0, lane, ee);
-    stem_store_edge<SRC>(a, tiles, lut, wrow0, lane, ee);
+    stem_store_edge<SRC>(a, tiles, lut, wrow0, lane, ee, xmax);
   }
   __syncthreads();
 
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       // task's MFMAs, where the loads of group ti + 1 - or, in the last task, of group 0
       // of the block after next - are issued
       StemBits hb;
-      stem_convert_rows<SRC>(a, nxt, lut, rr, hb);
+      stem_convert_rows<SRC>(a, nxt, lut, rr, hb, xmax);
       const bool last = ti + 1 == S_TASKS;
       const SRC *lbase = last ? base_2 : base_n;
       const unsigned ltab = last ? tab_2 : tab_n, lxc = last ? nx2.xc : nxt.xc;
@@ -458,17 +474,19 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
         unsigned char *vox = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * PASS_BYTES;
         const int64_t plane = (int64_t)a.P1Z * a.P1Y * a.P1X * PASS_BYTES;
-        store_split12(vox, plane, g, poolf);
+        store_split12(vox, plane, g, poolf, ovf);
       }
     }
     if (!has_next) break;
-    stem_store_edge<SRC>(a, tnext, lut, wrow0, lane, ee);
+    stem_store_edge<SRC>(a, tnext, lut, wrow0, lane, ee, xmax);
     stem_load_edge<SRC>(a, nx2, wrow0, lane, ee);
     __syncthreads();        // tile[cur] consumed by every wave, tile[cur ^ 1] complete
     q = qn;
     blk = nxt;
     cur ^= 1;
   }
+  ovf_commit(ovf, a.flag, FPL_RANGE_STEM);
+  if (!INT && xmax > __builtin_bit_cast(unsigned, a.xlim)) atomicOr(a.flag, FPL_RANGE_INPUT);
 }
 
 // -------------------------------------------------------------------------------
@@ -595,6 +613,7 @@ struct MidSArgs {
   unsigned char *p2;
   int P2Z, P2Y, P2X;
   BlockGrid bg;
+  unsigned *flag;                // half-range guard (mfma_util.h)
 };
 
 __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
@@ -636,10 +655,11 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[12 * g + 4 * b + r];   // interleaved rows
   f32x4 pooled[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  unsigned ovf = 0u;
 #pragma unroll
   for (int sub = 0; sub < 4; ++sub) {
-    const Frag2 h0 = pack_relu_split(acc[sub][0], acc[sub][1]);
-    const h16x8 hx = pack_relu_split_x(acc[sub][2]);
+    const Frag2 h0 = pack_relu_split(acc[sub][0], acc[sub][1], ovf);
+    const h16x8 hx = pack_relu_split_x(acc[sub][2], ovf);
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
       const f32x4 a4 = chain48(w4[b], h0, hx, sh4[b]);
@@ -657,8 +677,9 @@ __global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
   if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
     unsigned char *vox = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * PASS_BYTES;
     const int64_t plane = (int64_t)a.P2Z * a.P2Y * a.P2X * PASS_BYTES;
-    store_split12(vox, plane, g, pooled);
+    store_split12(vox, plane, g, pooled, ovf);
   }
+  ovf_commit(ovf, a.flag, FPL_RANGE_MID);
 }
 
 // -------------------------------------------------------------------------------
@@ -685,6 +706,7 @@ struct TailSArgs {
   int64_t VZ, VY, VX;            // valid fine extents (dim - 2 * off)
   int off;                       // rf offset of the network: 7
   BlockGrid bg;
+  unsigned *flag;                // half-range guard (mfma_util.h)
 };
 
 __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
@@ -715,14 +737,15 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
     return *reinterpret_cast<const h16x8 *>(w + ((size_t)(part * nfrag + f) * 64 + lane) * 16);
   };
   float logit[4];
+  unsigned ovf = 0u;
 #pragma unroll
   for (int sp = 0; sp < 2; ++sp) {
     Frag2 h5[2];
     h16x8 h5x[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      h5[q] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1]);
-      h5x[q] = pack_relu_split_x(acc[2 * sp + q][2]);
+      h5[q] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1], ovf);
+      h5x[q] = pack_relu_split_x(acc[2 * sp + q][2], ovf);
     }
     Frag2 h6[2][3];
     {
@@ -741,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) h6[q][s] = pack_relu_split(a6[q][2 * s], a6[q][2 * s + 1]);
+        for (int s = 0; s < 3; ++s) h6[q][s] = pack_relu_split(a6[q][2 * s], a6[q][2 * s + 1], ovf);
     }
     Frag2 h7[2][3];
     {
@@ -763,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int s = 0; s < 3; ++s) h7[q][s] = pack_relu_split(a7[q][2 * s], a7[q][2 * s + 1]);
+        for (int s = 0; s < 3; ++s) h7[q][s] = pack_relu_split(a7[q][2 * s], a7[q][2 * s + 1], ovf);
     }
     f32x4 a8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -776,6 +799,7 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) logit[2 * sp + q] = __shfl(a8[q][0], c) + a.bias8;
   }
+  ovf_commit(ovf, a.flag, FPL_RANGE_TAIL);
 
   const int cz = cz0 + wave, cx = cx0 + c;
 #pragma unroll
@@ -842,6 +866,8 @@ struct V2SArgs {
   unsigned char *out;
   int OZ, OY, OX;                // output dims (pooled dims with POOL)
   BlockGrid bg;
+  unsigned *flag;                // half-range guard, as K1 / K2 (xlim: STEM on float volumes)
+  float xlim;
 };
 
 template <bool STEM, bool POOL, typename SRC>
@@ -858,9 +884,12 @@ __global__ __launch_bounds__(256, 2) void vggs2_conv3(V2SArgs a) {
   const int x0 = xb * 16, y0 = yb * 4, z0 = zb * 4;
   if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
   int toff[8];
+  unsigned ovf = 0u, xmax = 0u;
   if (STEM) {
     auto norm_bits = [&](float raw) -> unsigned {
       const float x = (raw - a.mean) / a.sd;
+      const unsigned ax = __builtin_bit_cast(unsigned, x) & 0x7FFFFFFFu;
+      xmax = ax > xmax ? ax : xmax;
       const h16_t h = (h16_t)x;
       return (unsigned)h16_bits(x) | ((unsigned)h16_bits(x - (float)h) << 16);
     };
@@ -983,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void vggs2_conv3(V2SArgs a) {
         pooled[b][r] = __builtin_fmaxf(pooled[b][r], __shfl_xor(pooled[b][r], 1));     // the x pair
     const int pz = zb * 2 + pzl, py = yb * 2 + pyl, px = xb * 8 + (c >> 1);
     if ((c & 1) == 0 && pz < a.OZ && py < a.OY && px < a.OX)
-      store_split12(a.out + (((int64_t)pz * a.OY + py) * a.OX + px) * PASS_BYTES, plane, g, pooled);
+      store_split12(a.out + (((int64_t)pz * a.OY + py) * a.OX + px) * PASS_BYTES, plane, g, pooled, ovf);
   } else {
     const int oz = z0 + wave, ox = x0 + c;
 #pragma unroll
@@ -995,9 +1024,11 @@ __global__ __launch_bounds__(256, 2) void vggs2_conv3(V2SArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[b][r] = __builtin_fmaxf(acc[sub][b][r], 0.f);
       if (oz < a.OZ && oy < a.OY && ox < a.OX)
-        store_split12(a.out + (((int64_t)oz * a.OY + oy) * a.OX + ox) * PASS_BYTES, plane, g, o);
+        store_split12(a.out + (((int64_t)oz * a.OY + oy) * a.OX + ox) * PASS_BYTES, plane, g, o, ovf);
     }
   }
+  ovf_commit(ovf, a.flag, FPL_RANGE_MID);
+  if (STEM && sizeof(SRC) != 1 && xmax > __builtin_bit_cast(unsigned, a.xlim)) atomicOr(a.flag, FPL_RANGE_INPUT);
 }
 
 // -------------------------------------------------------------------------------
@@ -1018,7 +1049,28 @@ struct SplitState {
   bool int_valid = false;
   std::vector<uint16_t> w1_int_host;
   std::vector<float> shift1_int_host;       // the table [pz][py][px][48]
+  // half-range guard: float volumes must satisfy |normalised voxel| <= xlim for conv3 1->48's
+  // outputs to stay inside the half range (kernels check every voxel they load)
+  float xlim = 0.f;
 };
+
+// Outputs of conv3 1->48 (+ BN) are bounded by |shift[c]| + |scale[c]| sum_taps |w[tap][c]| * X
+// for inputs |x| <= X.  FPL_RANGE_LIM leaves room for the rounding of the bound itself.
+constexpr double FPL_RANGE_LIM = 65000.0;
+// largest X for which every channel's bound stays below FPL_RANGE_LIM (<= 0: no such X)
+double stem_input_limit(const float *A, const fpl_op &op, const float *scale, const float *shift_tab,
+                        int n_tab) {
+  double xl = FPL_RANGE_LIM;
+  for (int co = 0; co < op.cout; ++co) {
+    double sw = 0.0, sh = 0.0;
+    for (int tap = 0; tap < 27; ++tap) sw += std::fabs((double)A[op.w_off + (size_t)tap * op.cout + co]);
+    sw *= std::fabs((double)scale[co]);
+    for (int e = 0; e < n_tab; ++e) sh = std::max(sh, std::fabs((double)shift_tab[(size_t)e * 48 + co]));
+    if (!(sh < FPL_RANGE_LIM)) return 0.0;
+    if (sw > 0.0) xl = std::min(xl, (FPL_RANGE_LIM - sh) / sw);
+  }
+  return xl;
+}
 
 void split_state_free(fpl_ctx *ctx, void *p) {
   SplitState *s = (SplitState *)p;
@@ -1110,9 +1162,18 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
     while (shifts.size() % 4) shifts.push_back(0.f);
   }
   for (uint16_t h : all)
-    FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
-                "a folded weight exceeds the IEEE-half range (65504); use precision f32 for "
-                "this network");
+    if ((h & 0x7C00u) == 0x7C00u)
+      return fpl_fail_range(ctx, "a folded weight exceeds the IEEE-half range (65504); use precision "
+                                 "f32 (or 'auto') for this network");
+  {
+    const fpl_op &op0 = prog->ops[0];
+    std::vector<float> sh48(48, 0.f);
+    memcpy(sh48.data(), A + op0.shift_off, op0.cout * sizeof(float));
+    st->xlim = (float)stem_input_limit(A, op0, A + op0.scale_off, sh48.data(), 1);
+    if (!(st->xlim > 0.f))
+      return fpl_fail_range(ctx, "the first layer's shift exceeds the IEEE-half range; use precision f32 "
+                                 "(or 'auto') for this network");
+  }
   st->bias8 = A[prog->ops[9].shift_off];
   if (st->frags) FPL_HIP(ctx, hipFree(st->frags));
   if (st->shifts) FPL_HIP(ctx, hipFree(st->shifts));
@@ -1194,9 +1255,13 @@ int split_prepare_int(fpl_ctx *ctx, fpl_program *prog, SplitState *st, float mea
     }
   }
   for (uint16_t h : st->w1_int_host)
-    FPL_REQUIRE(ctx, (h & 0x7C00u) != 0x7C00u,
-                "a first-layer weight divided by std %g exceeds the IEEE-half range; use "
-                "precision f32 for this normalisation", (double)sd);
+    if ((h & 0x7C00u) == 0x7C00u)
+      return fpl_fail_range(ctx, "a first-layer weight divided by std %g exceeds the IEEE-half range; use "
+                                 "precision f32 (or 'auto') for this normalisation", (double)sd);
+  // half-range guard: the operand is |u - c0| <= max(c0, 255 - c0)
+  if (!(stem_input_limit(A, op, scale.data(), st->shift1_int_host.data(), 64) >= std::max(c0, 255.0 - c0)))
+    return fpl_fail_range(ctx, "the first layer's outputs may exceed the IEEE-half range at mean %g, std %g; "
+                               "use precision f32 (or 'auto')", (double)mean, (double)sd);
   const size_t wb = st->w1_int_host.size() * sizeof(uint16_t);
   if (!st->w1_int) FPL_HIP(ctx, hipMalloc((void **)&st->w1_int, wb));
   if (!st->shift1_int) FPL_HIP(ctx, hipMalloc((void **)&st->shift1_int, S_SHTAB * sizeof(float)));
@@ -1253,6 +1318,8 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
               "vgg_like2 split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
               "offsets", (long long)SY, (long long)SX);
   DevTemp tmp(ctx);
+  unsigned *flag;
+  FPL_TRY(fpl_range_flag(ctx, &flag));
   void *h1v, *l3v, *qv;
   FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 8) * h_row, &h1v));
   FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 6) * t_row, &l3v));
@@ -1272,6 +1339,7 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
       }
       a.w = F + st->off_w[1]; a.shift = S + st->off_s[1];
       a.out = (unsigned char *)h1v; a.OZ = HZ; a.OY = HY; a.OX = HX;
+      a.flag = flag; a.xlim = st->xlim;
       a.bg = BlockGrid{(int)ceil_div64(HX, 8), (int)ceil_div64(HY, 2), (int)ceil_div64(HZ, 2)};
       TimedLaunch tl(ctx, "vggs2_stem_conv3_pool");
       if (src_dtype == FPL_U8)
@@ -1284,6 +1352,7 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
       a.in = (const unsigned char *)h1v; a.IZ = HZ; a.IY = HY; a.IX = HX;
       a.w = F + st->off_w[2]; a.shift = S + st->off_s[2];
       a.out = (unsigned char *)l3v; a.OZ = T3Z; a.OY = T3Y; a.OX = T3X;
+      a.flag = flag;
       a.bg = BlockGrid{(int)ceil_div64(T3X, 16), (int)ceil_div64(T3Y, 4), (int)ceil_div64(T3Z, 4)};
       TimedLaunch tl(ctx, "vggs2_conv3");
       vggs2_conv3<false, false, uint8_t><<<brick_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
@@ -1293,6 +1362,7 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
       a.in = (const unsigned char *)l3v; a.IZ = T3Z; a.IY = T3Y; a.IX = T3X;
       a.w = F + st->off_w[3]; a.shift = S + st->off_s[3];
       a.out = (unsigned char *)qv; a.OZ = QZ; a.OY = QY; a.OX = QX;
+      a.flag = flag;
       a.bg = BlockGrid{(int)ceil_div64(QX, 8), (int)ceil_div64(QY, 2), (int)ceil_div64(QZ, 2)};
       TimedLaunch tl(ctx, "vggs2_conv3_pool");
       vggs2_conv3<false, true, uint8_t><<<brick_grid_size(a.bg), 256, V2_SMEM, stream>>>(a);
@@ -1306,6 +1376,7 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
       a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
       a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
       a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = OFF;
+      a.flag = flag;
       a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
       TimedLaunch tl(ctx, "vggs_c5_tail");
       vggs_c5_tail<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
@@ -1354,6 +1425,8 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
               "vgg split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
               "offsets", (long long)SY, (long long)SX);
   DevTemp tmp(ctx);
+  unsigned *flag;
+  FPL_TRY(fpl_range_flag(ctx, &flag));
   void *p1v, *p2v;
   FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 6) * p1_row_bytes, &p1v));
   FPL_TRY(tmp.alloc((size_t)(cz_chunk + 2) * P2Y * P2X * VOX, &p2v));
@@ -1378,6 +1451,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
         a.c0 = st->int_c0;
       }
       a.p1 = (unsigned char *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
+      a.flag = flag; a.xlim = st->xlim;
       a.nbx = (int)ceil_div64(P1X, S_PX); a.nby = (int)ceil_div64(P1Y, S_PY);
       a.nbz = (int)ceil_div64(P1Z, S_PZ);
       // persistent: one workgroup of 8 waves per CU walks the blocks
@@ -1396,6 +1470,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
       a.w4 = (const h16x8 *)(F + st->off_w[3]);
       a.shift3 = S + st->off_s[2]; a.shift4 = S + st->off_s[3];
       a.p2 = (unsigned char *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
+      a.flag = flag;
       a.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 2)};
       TimedLaunch tl(ctx, "vggs_mid_pool");
       vggs_mid_pool<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
@@ -1409,6 +1484,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
       a.shift6 = S + st->off_s[5]; a.shift7 = S + st->off_s[6]; a.bias8 = st->bias8;
       a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
       a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = 7;
+      a.flag = flag;
       a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
       TimedLaunch tl(ctx, "vggs_c5_tail");
       vggs_c5_tail<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);

@@ -81,6 +81,49 @@ def test_vgg_like_1024_cubed_bf16_properties(ctx):
         b.free()
 
 
+def test_vgg_like_1024_cubed_split_halves_properties(ctx):
+    """configs[1] on the path the benchmark headlines and 'auto' picks (split IEEE halves,
+    'f16s'): (a) two Z slabs of tile rows == the whole volume, bit for bit; (b) tile 102 == tile
+    142; (c) zero shell; (d) three reference tiles (corner, interior, far edge) within 1e-5 of
+    the fp32 oracle - the reference's own arithmetic (flypylib/fplnetwork.py:175-176)."""
+    n = 1024
+    g, prog = _vgg(ctx)
+    src = ctx.malloc((n, n, n), np.uint8)
+    ctx.synth_volume_u8(1, (n, n, n), out=src)
+    dst = ctx.malloc((n, n, n), np.float32)
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_AUTO, dims=(n, n, n))
+    prog.infer_volume(src, (102,) * 3, (7,) * 3, dst=dst, **kw)
+    assert ctx.last_path() == 'vgg_split_f16'
+    whole = dst.to_host()
+    for ax in range(3):
+        lo = [slice(None)] * 3
+        hi = [slice(None)] * 3
+        lo[ax], hi[ax] = slice(0, 7), slice(n - 7, n)
+        assert not whole[tuple(lo)].any() and not whole[tuple(hi)].any()
+    assert whole[7:-7, 7:-7, 7:-7].std() > 1e-3
+    rows = multi_gpu.n_tile_rows(n, 102, 7)
+    dst2 = ctx.malloc((n, n, n), np.float32)
+    ctx.memcpy(dst2, np.zeros(16, np.uint8), 16)     # touch
+    for zr in multi_gpu.slab_partition(rows, 2):
+        prog.infer_volume(src, (102,) * 3, (7,) * 3, dst=dst2, z_range=zr, **kw)
+    assert np.array_equal(dst2.to_host()[7:n - 7], whole[7:n - 7])
+    kw['precision'] = _capi.PREC_F16S
+    prog.infer_volume(src, (142,) * 3, (7,) * 3, dst=dst2, **kw)
+    assert np.array_equal(dst2.to_host(), whole)
+    u8 = src.to_host()
+
+    def f32(batch):
+        return cnn_oracle.vgg_like_forward(batch.astype(np.float32), g.weights, 4)
+    for org in ((0, 0, 0), (440, 528, 352), (880, 880, 880)):
+        sl = tuple(slice(o, o + 102) for o in org)
+        img = (u8[sl].astype(np.float32) - np.float32(128)) / np.float32(33)
+        ref = infer_oracle.infer_lattice(img, (102,) * 3, (7,) * 3, f32)
+        d = np.abs(whole[sl][7:-7, 7:-7, 7:-7] - ref[7:-7, 7:-7, 7:-7])
+        assert d.max() < 1e-5, (org, d.max())
+    for b in (src, dst, dst2):
+        b.free()
+
+
 def test_unet_like2_512_cubed_bf16_properties(ctx):
     """configs[2] shape at 510^3 (6^3 reference tiles 100^3 -> 82^3): Z slabs ==
     whole (bit-exact), zero shell, two reference tiles vs the bf16-emulation oracle"""
@@ -171,9 +214,9 @@ def test_configs2_rank_share_equals_the_whole_volume_rows(ctx):
     whole_src = torch.empty((Z, Y, X), dtype=torch.uint8, device='cuda')
     ctx.synth_volume_u8(3, (Z, Y, X), out=whole_src)
     whole_dst = torch.empty((Z, Y, X), dtype=torch.float32, device='cuda')
-    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F16)
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_AUTO)     # the default: split halves
     prog.infer_volume(whole_src, (tile,) * 3, (off,) * 3, dst=whole_dst, dims=(Z, Y, X), **kw)
-    assert ctx.last_path() == 'unet_mfma_f16'
+    assert ctx.last_path() == 'unet_split_f16'
     assert float(whole_dst[off:-off, off:-off, off:-off].std()) > 0
     for rank in (0, 7):
         zb, ze = parts[rank]
