@@ -53,7 +53,12 @@ static inline uint16_t fpl_f32_to_h16_part(float v, int part) {
 // (il): 4*MB*(m/4) + 4b + m%4 - lane (c, g) of the accumulators (rows 4g..4g+3 of
 // every block) then owns the 4*MB CONTIGUOUS channels [4*MB*g, 4*MB*(g+1)) of its
 // voxel, so an epilogue stores 16-B pieces and a wave writes whole lines.
-static inline int fpl_out_channel(int b, int m, int n_mblocks, bool il) {
+// il = 2 (48 channels, 3 M-blocks; the x8 tensors of vgg_split_lds.h, passes of 8 channels):
+// blocks 0 and 1 of lane group g are the 8 channels of pass g, block 2 the half
+// [32 + 4 g, 32 + 4 g + 4) of pass 4 + g / 2 - a lane stores one whole 16-B pass voxel and one
+// 8-B half, the same way in every lane.
+static inline int fpl_out_channel(int b, int m, int n_mblocks, int il) {
+  if (il == 2) return b < 2 ? 8 * (m >> 2) + 4 * b + (m & 3) : 32 + m;
   return il ? 4 * n_mblocks * (m >> 2) + 4 * b + (m & 3) : 16 * b + m;
 }
 
@@ -62,7 +67,7 @@ static inline int fpl_out_channel(int b, int m, int n_mblocks, bool il) {
 static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
                                   int cin, int cout, int n_mblocks, int n_ksteps,
                                   FplSlotMap map, std::vector<uint16_t> *out,
-                                  bool il = false, int part = 0) {
+                                  int il = 0, int part = 0) {
   out->assign((size_t)n_ksteps * n_mblocks * 512, 0);
   for (int s = 0; s < n_ksteps; ++s)
     for (int b = 0; b < n_mblocks; ++b)
@@ -96,7 +101,7 @@ static inline void fpl_pack_frags(const float *W, const float *scale, int ntaps,
 // hi x hi (and, for free, lo x lo) product.  Appends n_mblocks fragments to *out.
 static inline void fpl_pack_chain_step(const float *W, const float *scale, int cin, int cout,
                                        int n_mblocks, const int blk[2], const int part[2],
-                                       std::vector<uint16_t> *out, bool il = false) {
+                                       std::vector<uint16_t> *out, int il = 0) {
   const size_t base = out->size();
   out->resize(base + (size_t)n_mblocks * 512, 0);
   for (int b = 0; b < n_mblocks; ++b)

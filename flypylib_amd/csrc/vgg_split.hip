@@ -26,6 +26,7 @@
 #include "fast_paths.h"
 #include "mfma_util.h"
 #include "pack_weights.h"
+#include "vgg_split_lds.h"
 #include "vgg_tiles.h"
 
 namespace {
@@ -144,8 +145,7 @@ struct StemSArgs {
   int64_t p1z0;            // global P1 row of chunk-local row 0
   const h16x8 *w1, *w2;    // fragments [part][e][b][lane]; chain48 steps [4][b][lane]
   const float *shift1, *shift2;
-  unsigned char *p1;
-  int P1Z, P1Y, P1X;       // chunk-local dims
+  x8::Tensor p1;           // chunk-local pool-1 tensor (planes of 8-channel passes, vgg_split_lds.h)
   int nbx, nby, nbz;       // blocks of S_PX x S_PY x S_PZ pooled voxels
   // half-range guard (mfma_util.h): conv3 1->48's outputs are bounded on the host from
   // sum |w| and the input limit (uint8: |u - c0| <= 255; float volumes: |x| <= xlim, checked
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sh1[b][r] = a.shift1[16 * b + 4 * g + r];
-      sh2[b][r] = a.shift2[12 * g + 4 * b + r];        // interleaved rows
+      sh2[b][r] = a.shift2[x8::out_channel(b, g, r)];   // rows in pass order (fpl_out_channel, il = 2)
     }
   __syncthreads();                      // lut
 
@@ -471,11 +471,8 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
         }
       }
       const int pz = blk.pz0 + pzl, py = blk.py0 + pyl, px = blk.px0 + 16 * xh + c;
-      if (pz < a.P1Z && py < a.P1Y && px < a.P1X) {
-        unsigned char *vox = a.p1 + (((int64_t)pz * a.P1Y + py) * a.P1X + px) * PASS_BYTES;
-        const int64_t plane = (int64_t)a.P1Z * a.P1Y * a.P1X * PASS_BYTES;
-        store_split12(vox, plane, g, poolf, ovf);
-      }
+      if (pz < a.p1.Z && py < a.p1.Y && px < a.p1.X)
+        x8::store12(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, poolf, ovf);
     }
     if (!has_next) break;
     stem_store_edge<SRC>(a, tnext, lut, wrow0, lane, ee, xmax);
@@ -594,92 +591,106 @@ __device__ __forceinline__ void conv3s_kloop(const unsigned char *act, int AZ, i
   conv3s_kloop_f(fill, tile, kofftab, wglobal, vbase, sub_off, acc, tid);
 }
 
-// -------------------------------------------------------------------------------
-// K2: conv3 48->48 + conv1 48->48 + maxpool2 (block, wave and sub-step geometry of
-// vgg_mid_pool: pre-pool block 4 x 4 x 16, wave = pooled (pz,py) row, 4 sub-steps =
-// the (dz,dy) window, x pairs pooled across neighbouring lanes).
-// -------------------------------------------------------------------------------
+// tile geometry of the 24-channel-pass K loop (vgg_like2's kernels and their tail below)
 constexpr int M_TZ = 6, M_TY = 6, M_TX = 18;
 constexpr int M_TILE_BYTES = ((M_TZ * M_TY * M_TX * PASS_BYTES + 1023) / 1024) * 1024;
 constexpr int M_SMEM = M_TILE_BYTES + KTAB_BYTES;
 static_assert(2 * M_SMEM <= 160 * 1024, "two workgroups must fit one CU");
 
-struct MidSArgs {
-  const unsigned char *p1;
-  int P1Z, P1Y, P1X;
-  const unsigned char *w3;       // [pass][KS][part][b] fragments
-  const h16x8 *w4;               // chain48 steps [4][b][lane]
+// -------------------------------------------------------------------------------
+// K2 (round 4): conv3 48->48 + conv1 48->48 + maxpool2 on the all-LDS K loop of
+// vgg_split_lds.h: ONE persistent workgroup of 8 waves per CU, block = 8 x 4 x 16 pre-pool
+// outputs (4 x 2 x 8 pooled), wave = pooled (pz, py) row, 4 sub-steps = its (dz, dy) window,
+// x pairs pooled across neighbouring lanes.
+// -------------------------------------------------------------------------------
+struct MidXArgs {
+  x8::Tensor p1;                 // pool-1 tensor
+  const unsigned char *w3;       // [pass 6][K-step 7][part][b] fragments
+  const h16x8 *w4;               // chain48 steps [4][b][lane], rows in pass order (il = 2)
   const float *shift3, *shift4;
-  unsigned char *p2;
-  int P2Z, P2Y, P2X;
-  BlockGrid bg;
+  x8::Tensor p2;                 // pool-2 tensor
+  x8::Walk walk;                 // blocks of 4 x 2 x 8 pooled voxels
   unsigned *flag;                // half-range guard (mfma_util.h)
 };
 
-__global__ __launch_bounds__(256, 2) void vggs_mid_pool(MidSArgs a) {
-  unsigned char *tile = smem;
-  unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_mid_pool(MidXArgs a) {
+  unsigned *ktab = reinterpret_cast<unsigned *>(smem + 2 * x8::BUF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
-  int xb, yb, zb;
-  if (!brick_coords(a.bg, xb, yb, zb)) return;
-  const int px0 = xb * 8, py0 = yb * 2, pz0 = zb * 2;
-  if (tid < 4 * KTAB) kofftab[tid] = kslot_entry<M_TY, M_TX>(tid);
-
-  const int pzl = wave >> 1, pyl = wave & 1;
-  const unsigned vbase = (unsigned)((((2 * pzl) * M_TY + 2 * pyl) * M_TX + c) * PASS_BYTES);
-  f32x4 acc[4][3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    f32x4 sh;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh[r] = a.shift3[16 * b + 4 * g + r];
-#pragma unroll
-    for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
-  }
-  auto sub_off = [](int sub) -> unsigned {
-    return (unsigned)(((((sub >> 1) & 1) * M_TY + (sub & 1)) * M_TX) * PASS_BYTES);
+  x8::ktab_init(ktab, tid);
+  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p1.Y, a.p1.X);
+  const int S = (int)gridDim.x >> 3, nbricks = a.walk.bricks();
+  const int group = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  x8::Cursor cur;
+  if (!x8::cursor_first(a.walk, nbricks, group, slot, S, cur)) return;
+  const int64_t part = a.p1.part_bytes();
+  auto origin = [&](const x8::Cursor &q) {
+    return a.p1.p + (((int64_t)(8 * q.bz) * a.p1.Y + 4 * q.by) * a.p1.X + 16 * q.bx) * 16;
   };
-  conv3s_kloop<M_TZ, M_TY, M_TX>(a.p1, a.P1Z, a.P1Y, a.P1X, 2 * pz0, 2 * py0, 2 * px0, tile,
-                                 kofftab, a.w3, vbase, sub_off, acc, tid);
-
-  // conv1 48->48 chained in registers, pooled over the 4 (dz,dy) window positions
-  h16x8 w4[3][4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) w4[b][s] = a.w4[(s * 3 + b) * 64 + lane];
-  f32x4 sh4[3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[12 * g + 4 * b + r];   // interleaved rows
-  f32x4 pooled[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  unsigned ovf = 0u;
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
-    const Frag2 h0 = pack_relu_split(acc[sub][0], acc[sub][1], ovf);
-    const h16x8 hx = pack_relu_split_x(acc[sub][2], ovf);
+  const int pzl = wave >> 1, pyl = wave & 1;
+  const unsigned vb = (unsigned)(((2 * pzl) * x8::ZS + (2 * pyl) * x8::TX + c) * 16);
+  auto sub_off = [](int sub) -> unsigned { return (unsigned)((((sub >> 1) & 1) * x8::ZS + (sub & 1) * x8::TX) * 16); };
+  unsigned ovf_all = 0u;
+  x8::prime(smem, td, origin(cur), part, a.w3, wave, lane);      // also makes the table visible
+  for (;;) {
+    x8::Cursor nxt = cur;
+    const bool has_next = x8::cursor_next(a.walk, nbricks, slot, S, nxt);
+    // (the opaque zero keeps block-invariant loads - shifts, conv1's weight fragments - INSIDE
+    // the block loop: hoisted out of it their registers live through the K loop and spill)
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    f32x4 acc[4][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-      const f32x4 a4 = chain48(w4[b], h0, hx, sh4[b]);
+      const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift3 + zero + 16 * b + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pooled[b][r] = __builtin_fmaxf(pooled[b][r], a4[r]);
+      for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
     }
-  }
-  // pool the x pair: lanes c and c^1 hold neighbouring pre-pool x
+    x8::conv_block(smem, ktab + 8 * g, td, origin(cur), origin(has_next ? nxt : cur), part, a.w3, vb,
+                   sub_off, wave, lane, acc);
+    // conv1 48->48 chained in registers, pooled over the 4 (dz, dy) window positions
+    asm volatile("" : "+s"(zero));
+    const h16x8 *w4p = a.w4 + zero;
+    f32x4 sh4[3];
 #pragma unroll
-  for (int b = 0; b < 3; ++b)
+    for (int b = 0; b < 3; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      pooled[b][r] = __builtin_fmaxf(pooled[b][r], __shfl_xor(pooled[b][r], 1));
-  const int pz = pz0 + pzl, py = py0 + pyl, px = px0 + (c >> 1);
-  if ((c & 1) == 0 && pz < a.P2Z && py < a.P2Y && px < a.P2X) {
-    unsigned char *vox = a.p2 + (((int64_t)pz * a.P2Y + py) * a.P2X + px) * PASS_BYTES;
-    const int64_t plane = (int64_t)a.P2Z * a.P2Y * a.P2X * PASS_BYTES;
-    store_split12(vox, plane, g, pooled, ovf);
+      for (int r = 0; r < 4; ++r) sh4[b][r] = a.shift4[zero + x8::out_channel(b, g, r)];
+    h16x8 w4[3][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) w4[b][s] = w4p[(s * 3 + b) * 64 + lane];
+    f32x4 pooled[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    unsigned ovf = 0u;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const Frag2 h0 = pack_relu_split(acc[sub][0], acc[sub][1], ovf);
+      const h16x8 hx = pack_relu_split_x(acc[sub][2], ovf);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const f32x4 a4 = chain48(w4[b], h0, hx, sh4[b]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pooled[b][r] = __builtin_fmaxf(pooled[b][r], a4[r]);
+      }
+    }
+    // pool the x pair: lanes c and c^1 hold neighbouring pre-pool x
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        pooled[b][r] = __builtin_fmaxf(pooled[b][r], __shfl_xor(pooled[b][r], 1));
+    const int pz = 4 * cur.bz + pzl, py = 2 * cur.by + pyl, px = 8 * cur.bx + (c >> 1);
+    const bool inside = pz < a.p2.Z && py < a.p2.Y && px < a.p2.X;
+    if ((c & 1) == 0 && inside)
+      x8::store12(a.p2, ((int64_t)pz * a.p2.Y + py) * a.p2.X + px, g, pooled, ovf);
+    // edge tiles read past the tensor (x8::Tensor): only what is stored counts for the guard
+    ovf_all = pk_max_i16(ovf_all, inside ? ovf : 0u);
+    if (!has_next) break;
+    cur = nxt;
   }
-  ovf_commit(ovf, a.flag, FPL_RANGE_MID);
+  ovf_commit(ovf_all, a.flag, FPL_RANGE_MID);
 }
 
 // -------------------------------------------------------------------------------
@@ -709,7 +720,9 @@ struct TailSArgs {
   unsigned *flag;                // half-range guard (mfma_util.h)
 };
 
-__global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
+// (this form - 24-channel passes, two 4-wave workgroups per CU - serves vgg_like2, whose
+// tensors keep the round-3 layout; vgg_like runs vggs_c5_tail below)
+__global__ __launch_bounds__(256, 2) void vggs_c5_tail_p24(TailSArgs a) {
   unsigned char *tile = smem;
   unsigned *kofftab = reinterpret_cast<unsigned *>(smem + M_TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -825,6 +838,166 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail(TailSArgs a) {
       }
     }
   }
+}
+
+// -------------------------------------------------------------------------------
+// K3 (round 4): conv3 48->48 + BN + ReLU on P2 through the all-LDS K loop (vgg_split_lds.h),
+// block 8 x 4 x 16 coarse voxels, wave = z, sub-steps = the 4 y rows; then - in registers -
+// conv1 48->96, conv1 96->96, conv1 96->1 + bias, sigmoid and the x4 nearest upsample store.
+// The 1x1 chain runs on two sub-steps at a time (all four in lockstep keep 96 registers of
+// hi / lo fragments per layer alive and spill), one output-channel PAIR at a time, conv1 96->1
+// folded into conv1 96->96's loop, so no layer's full output is ever live.
+// -------------------------------------------------------------------------------
+struct TailXArgs {
+  x8::Tensor p2;
+  const unsigned char *w5;       // [pass 6][K-step 7][part][b]
+  const float *shift5;
+  int CZ, CY, CX;                // chunk-local coarse dims
+  const unsigned char *w6, *w7, *w8;   // L6: chain48 steps [4][b]; L7, L8: [part][s][b]
+  const float *shift6, *shift7;
+  float bias8;
+  float *dst;                    // (Z,Y,X) prediction volume, row 0
+  int64_t DY, DX;                // its pitches
+  int64_t gz0;                   // global coarse z of chunk-local coarse row 0
+  int64_t VZ, VY, VX;            // valid fine extents (dim - 2 * off)
+  int off;                       // rf offset of the network: 7
+  x8::Walk walk;                 // blocks of 8 x 4 x 16 coarse voxels
+  unsigned *flag;                // half-range guard (mfma_util.h)
+};
+
+__global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_c5_tail(TailXArgs a) {
+  unsigned *ktab = reinterpret_cast<unsigned *>(smem + 2 * x8::BUF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  x8::ktab_init(ktab, tid);
+  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p2.Y, a.p2.X);
+  const int S = (int)gridDim.x >> 3, nbricks = a.walk.bricks();
+  const int group = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+  x8::Cursor cur;
+  if (!x8::cursor_first(a.walk, nbricks, group, slot, S, cur)) return;
+  const int64_t part = a.p2.part_bytes();
+  auto origin = [&](const x8::Cursor &q) {
+    return a.p2.p + (((int64_t)(8 * q.bz) * a.p2.Y + 4 * q.by) * a.p2.X + 16 * q.bx) * 16;
+  };
+  const unsigned vb = (unsigned)((wave * x8::ZS + c) * 16);
+  auto sub_off = [](int sub) -> unsigned { return (unsigned)(sub * x8::TX * 16); };
+  auto frag = [&](const unsigned char *w, int part_, int nfrag, int f) {
+    return *reinterpret_cast<const h16x8 *>(w + ((size_t)(part_ * nfrag + f) * 64 + lane) * 16);
+  };
+  unsigned ovf_all = 0u;
+  x8::prime(smem, td, origin(cur), part, a.w5, wave, lane);
+  for (;;) {
+    x8::Cursor nxt = cur;
+    const bool has_next = x8::cursor_next(a.walk, nbricks, slot, S, nxt);
+    // (the opaque zero keeps block-invariant loads - shifts, the head's 66 weight fragments -
+    // INSIDE the block loop: hoisted out of it they are live registers, i.e. spills)
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const f32x4 sh = *reinterpret_cast<const f32x4 *>(a.shift5 + zero + 16 * b + 4 * g);
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) acc[sub][b] = sh;
+    }
+    x8::conv_block(smem, ktab + 8 * g, td, origin(cur), origin(has_next ? nxt : cur), part, a.w5, vb,
+                   sub_off, wave, lane, acc);
+
+    unsigned ovf = 0u;
+    float logit[4];
+    asm volatile("" : "+s"(zero));
+    const unsigned char *w6p = a.w6 + zero, *w7p = a.w7 + zero, *w8p = a.w8 + zero;
+    const float *sh6p = a.shift6 + zero, *sh7p = a.shift7 + zero;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      Frag2 h5[2];
+      h16x8 h5x[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        h5[q] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1], ovf);
+        h5x[q] = pack_relu_split_x(acc[2 * sp + q][2], ovf);
+      }
+      // conv1 48->96 + ReLU, an output-channel pair (= one K-step of the next layer) at a time
+      Frag2 h6[2][3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        f32x4 a6[2][2];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int b = 2 * s + bb;
+          f32x4 sh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sh[r] = sh6p[16 * b + 4 * g + r];
+          h16x8 w6[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) w6[t] = frag(w6p, 0, 0, t * 6 + b);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a6[q][bb] = chain48(w6, h5[q], h5x[q], sh);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) h6[q][s] = pack_relu_split(a6[q][0], a6[q][1], ovf);
+      }
+      // conv1 96->96 + ReLU, pair by pair, each pair's split going straight into conv1 96->1
+      f32x4 a8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        f32x4 a7[2][2];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int b = 2 * s + bb;
+          f32x4 sh;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sh[r] = sh7p[16 * b + 4 * g + r];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a7[q][bb] = sh;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const h16x8 wh = frag(w7p, 0, T_W7, t * 6 + b), wl = frag(w7p, 1, T_W7, t * 6 + b);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a7[q][bb] = mfma3(wh, wl, h6[q][t], a7[q][bb]);
+          }
+        }
+        const h16x8 w8h = frag(w8p, 0, T_W8, s), w8l = frag(w8p, 1, T_W8, s);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a8[q] = mfma3(w8h, w8l, pack_relu_split(a7[q][0], a7[q][1], ovf), a8[q]);
+      }
+      // lane (c, g = 0) register 0 holds the logit of coarse voxel c
+#pragma unroll
+      for (int q = 0; q < 2; ++q) logit[2 * sp + q] = __shfl(a8[q][0], c) + a.bias8;
+      __builtin_amdgcn_sched_barrier(0);       // the second pair's weight loads stay behind the first's work
+    }
+    const int cz = 8 * cur.bz + wave, cx = 16 * cur.bx + c;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int cy = 4 * cur.by + sub;
+      const float p = 1.f / (1.f + expf(-logit[sub]));
+      // x4 upsample store: lane (c,g) writes 4 fine x of fine row (4cy+g), 4 z rows
+      if (cz < a.CZ && cy < a.CY && cx < a.CX) {
+        const int64_t fz0 = 4 * (a.gz0 + cz), fy = 4 * (int64_t)cy + g, fx0 = 4 * (int64_t)cx;
+        if (fy < a.VY && fx0 < a.VX) {
+          const int nx = (int)(a.VX - fx0 < 4 ? a.VX - fx0 : 4);
+#pragma unroll
+          for (int dz = 0; dz < 4; ++dz) {
+            const int64_t fz = fz0 + dz;
+            if (fz >= a.VZ) break;
+            float *o = a.dst + ((fz + a.off) * a.DY + fy + a.off) * a.DX + fx0 + a.off;
+            if (nx == 4) {
+              *reinterpret_cast<f32x4_a4 *>(o) = f32x4_a4{p, p, p, p};
+            } else {
+              for (int i = 0; i < nx; ++i) o[i] = p;
+            }
+          }
+        }
+      }
+    }
+    // (voxels past the coarse extent are computed from real rows of the tensor or from its
+    // zeroed slack: they cannot raise the guard on their own)
+    ovf_all = pk_max_i16(ovf_all, ovf);
+    if (!has_next) break;
+    cur = nxt;
+  }
+  ovf_commit(ovf_all, a.flag, FPL_RANGE_TAIL);
 }
 
 // -------------------------------------------------------------------------------
@@ -1122,6 +1295,24 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
         fpl_pack_stem(A + op.w_off, scale.data(), op.cout, &f, part);
         all.insert(all.end(), f.begin(), f.end());
       }
+    } else if (op.k == 3 && !v2) {
+      // vgg_like (vgg_split_lds.h): passes of 8 channels, [pass 6][K-step 7][part][b] - a pass's
+      // 42 fragments are one contiguous 42-KiB run for the LDS-DMA
+      for (int pass = 0; pass < x8::NQ; ++pass) {
+        std::vector<float> wp((size_t)27 * x8::CQ * op.cout);
+        for (int tap = 0; tap < 27; ++tap)
+          for (int ch = 0; ch < x8::CQ; ++ch)
+            memcpy(&wp[((size_t)tap * x8::CQ + ch) * op.cout],
+                   A + op.w_off + ((size_t)tap * op.cin + pass * x8::CQ + ch) * op.cout,
+                   op.cout * sizeof(float));
+        std::vector<uint16_t> f[2];
+        for (int part = 0; part < 2; ++part)
+          fpl_pack_frags(wp.data(), scale.data(), 27, x8::CQ, op.cout, 3, x8::KQ, SLOT_SPATIAL, &f[part], 0, part);
+        for (int s = 0; s < x8::KQ; ++s)
+          for (int part = 0; part < 2; ++part)
+            all.insert(all.end(), f[part].begin() + (size_t)s * 3 * 512,
+                       f[part].begin() + (size_t)(s + 1) * 3 * 512);
+      }
     } else if (op.k == 3) {
       // [pass][K-step][part][b]: per pass the (tap, channel-in-pass) sub-matrix
       for (int pass = 0; pass < NPASS; ++pass) {
@@ -1147,7 +1338,7 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
       std::vector<uint16_t> f;
       for (int s = 0; s < 4; ++s)
         fpl_pack_chain_step(A + op.w_off, scale.data(), op.cin, op.cout, mblocks[l], blk[s], part[s], &f,
-                            /*il=*/op.cout == CH);      // L2 / L4 write P1 / P2: interleaved rows
+                            /*il=*/op.cout == CH ? 2 : 0);   // L2 / L4 write P1 / P2: rows in pass order
       all.insert(all.end(), f.begin(), f.end());
     } else {
       for (int part = 0; part < 2; ++part) {       // [part][s][b]
@@ -1190,9 +1381,11 @@ int split_prepare(fpl_ctx *ctx, fpl_program *prog, SplitState **out) {
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_stem_pool<float>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, S_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_mid_pool,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, x8::SMEM));
+  FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_c5_tail_p24,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs_c5_tail,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, M_SMEM));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, x8::SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs2_conv3<true, true, uint8_t>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM));
   FPL_HIP(ctx, hipFuncSetAttribute((const void *)vggs2_conv3<true, true, float>,
@@ -1379,7 +1572,7 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
       a.flag = flag;
       a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
       TimedLaunch tl(ctx, "vggs_c5_tail");
-      vggs_c5_tail<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+      vggs_c5_tail_p24<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
     }
     FPL_HIP(ctx, hipGetLastError());
   }
@@ -1421,20 +1614,29 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   FPL_REQUIRE(ctx, (int64_t)S_TZ * SY * SX < ((int64_t)1 << 31),
               "vgg split path: a %lld x %lld plane is too large for the stem's 31-bit row "
               "offsets", (long long)SY, (long long)SX);
-  FPL_REQUIRE(ctx, (int64_t)P1Y * P1X * PASS_BYTES * 8 < ((int64_t)1 << 32),
+  FPL_REQUIRE(ctx, (int64_t)P1Y * P1X * 16 * (x8::TZ + 1) < ((int64_t)1 << 32),
               "vgg split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
               "offsets", (long long)SY, (long long)SX);
   DevTemp tmp(ctx);
   unsigned *flag;
   FPL_TRY(fpl_range_flag(ctx, &flag));
+  // P1 / P2 as planes of 8-channel passes (vgg_split_lds.h) with read slack behind them
+  x8::Tensor p1 = {nullptr, (int)(2 * cz_chunk + 6), P1Y, P1X}, p2 = {nullptr, (int)(cz_chunk + 2), P2Y, P2X};
   void *p1v, *p2v;
-  FPL_TRY(tmp.alloc((size_t)(2 * cz_chunk + 6) * p1_row_bytes, &p1v));
-  FPL_TRY(tmp.alloc((size_t)(cz_chunk + 2) * P2Y * P2X * VOX, &p2v));
+  FPL_TRY(tmp.alloc((size_t)(p1.bytes() + p1.slack_bytes()), &p1v));
+  FPL_TRY(tmp.alloc((size_t)(p2.bytes() + p2.slack_bytes()), &p2v));
+  // workgroups of the persistent kernels: one per CU, a multiple of the 8 XCDs
+  const unsigned pgrid = (unsigned)std::max(8, ctx->n_cu / 8 * 8);
   const unsigned char *F = st->frags;
   const float *S = st->shifts;
   for (int64_t c0 = cz_lo; c0 < cz_hi; c0 += cz_chunk) {
     const int CZ = (int)std::min<int64_t>(cz_chunk, cz_hi - c0);
     const int P2Z = CZ + 2, P1Z = 2 * P2Z + 2;
+    p1 = x8::Tensor{(unsigned char *)p1v, P1Z, P1Y, P1X};
+    p2 = x8::Tensor{(unsigned char *)p2v, P2Z, P2Y, P2X};
+    // edge tiles read up to TZ planes past the last pass plane: zeros, not stale scratch
+    FPL_HIP(ctx, hipMemsetAsync(p1.p + p1.bytes(), 0, (size_t)p1.slack_bytes(), stream));
+    FPL_HIP(ctx, hipMemsetAsync(p2.p + p2.bytes(), 0, (size_t)p2.slack_bytes(), stream));
     {
       StemSArgs a;
       a.src = src; a.SZ = SZ; a.SY = SY; a.SX = SX; a.mean = mean; a.sd = sd;
@@ -1450,7 +1652,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
         a.w1 = (const h16x8 *)st->w1_int; a.shtab = st->shift1_int;
         a.c0 = st->int_c0;
       }
-      a.p1 = (unsigned char *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
+      a.p1 = p1;
       a.flag = flag; a.xlim = st->xlim;
       a.nbx = (int)ceil_div64(P1X, S_PX); a.nby = (int)ceil_div64(P1Y, S_PY);
       a.nbz = (int)ceil_div64(P1Z, S_PZ);
@@ -1464,20 +1666,20 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
         vggs_stem_pool<float><<<grid, 64 * S_WAVES, S_SMEM, stream>>>(a);
     }
     {
-      MidSArgs a;
-      a.p1 = (const unsigned char *)p1v; a.P1Z = P1Z; a.P1Y = P1Y; a.P1X = P1X;
+      MidXArgs a;
+      a.p1 = p1;
       a.w3 = F + st->off_w[2];
       a.w4 = (const h16x8 *)(F + st->off_w[3]);
       a.shift3 = S + st->off_s[2]; a.shift4 = S + st->off_s[3];
-      a.p2 = (unsigned char *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
+      a.p2 = p2;
       a.flag = flag;
-      a.bg = BlockGrid{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 2)};
+      a.walk = x8::Walk{(int)ceil_div64(P2X, 8), (int)ceil_div64(P2Y, 2), (int)ceil_div64(P2Z, 4)};
       TimedLaunch tl(ctx, "vggs_mid_pool");
-      vggs_mid_pool<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+      vggs_mid_pool<<<pgrid, 64 * x8::WAVES, x8::SMEM, stream>>>(a);
     }
     {
-      TailSArgs a;
-      a.p2 = (const unsigned char *)p2v; a.P2Z = P2Z; a.P2Y = P2Y; a.P2X = P2X;
+      TailXArgs a;
+      a.p2 = p2;
       a.w5 = F + st->off_w[4]; a.shift5 = S + st->off_s[4];
       a.CZ = CZ; a.CY = CY; a.CX = CX;
       a.w6 = F + st->off_w[5]; a.w7 = F + st->off_w[6]; a.w8 = F + st->off_w[7];
@@ -1485,9 +1687,9 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
       a.dst = dst; a.DY = SY; a.DX = SX; a.gz0 = c0;
       a.VZ = std::min<int64_t>(fz_hi, VZ); a.VY = VY; a.VX = VX; a.off = 7;
       a.flag = flag;
-      a.bg = BlockGrid{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 4)};
+      a.walk = x8::Walk{(int)ceil_div64(CX, 16), (int)ceil_div64(CY, 4), (int)ceil_div64(CZ, 8)};
       TimedLaunch tl(ctx, "vggs_c5_tail");
-      vggs_c5_tail<<<brick_grid_size(a.bg), 256, M_SMEM, stream>>>(a);
+      vggs_c5_tail<<<pgrid, 64 * x8::WAVES, x8::SMEM, stream>>>(a);
     }
     FPL_HIP(ctx, hipGetLastError());
   }
