@@ -258,6 +258,59 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
     return legs
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N children of this script, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would), started before this
+    process makes any GPU call.  Rank 0's stdout (the JSON line) is relayed; the exit code is
+    non-zero if any rank's is."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed (rank, exit code): %s\n' % bad)
+    return 1 if bad else 0
+
+
+def ranks_seen(dist, backend):
+    """how many ranks the process group's collective really joined: a sum all-reduce of ones
+    (on the device under nccl = RCCL over xGMI)"""
+    import torch
+    t = torch.ones(1, dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def launcher_selftest(rank, world, backend):
+    """FPL_BENCH_SELFTEST=1: the launcher and the process group without any GPU work (the CPU
+    test of `--gpus N`); FPL_BENCH_SELFTEST=fail<r>: rank r exits non-zero instead"""
+    import torch.distributed as dist
+    mode = os.environ['FPL_BENCH_SELFTEST']
+    if mode == 'fail%d' % rank:
+        sys.exit(3)
+    n = 1
+    if world > 1 and not mode.startswith('fail'):
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        n = ranks_seen(dist, 'gloo')
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'n_ranks_seen': n}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -284,10 +337,16 @@ def main():
                     help='process-group backend (gloo only to rehearse N>1 on one GPU)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process only launches - one fresh child per
+        # GPU, before anything here touches HIP - and relays rank 0's line
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+    if os.environ.get('FPL_BENCH_SELFTEST'):
+        return launcher_selftest(rank, world, args.backend)
 
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
@@ -371,11 +430,13 @@ def main():
     timings = ctx.timing_get()
     ctx.timing(False)
     executor = ctx.last_path()
+    n_seen = 1
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64,
                          device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        n_seen = ranks_seen(dist, args.backend)
     del src, dst
 
     # HBM bytes per launch of each kernel: NOT measured in this run - read from the
@@ -423,7 +484,7 @@ def main():
                 # `achieved` counts the ALGORITHMIC flops of the convolutions; the split
                 # path issues three half-precision MFMAs per product (plus K padding), so
                 # the matrix pipe's own utilisation is ~3.4x `frac` for this kernel
-                # (profiles/r03_pmc_split_*: SQ_INSTS_MFMA x 16 384 flop per launch)
+                # (profiles/r0*_pmc_hbm_1024_f16s.json: SQ_INSTS_MFMA x 16 384 flop per launch)
                 roof['mfma_products_per_multiply'] = 3
 
     legs = None
@@ -437,6 +498,7 @@ def main():
             'metric': 'inference Mvoxels/sec, vgg_like (rf 18, 22^3 coarse -> 88^3 '
                       'per reference tile), synthetic EM uint8 volume',
             'value': round(value, 2), 'unit': 'Mvoxels/s', 'n_gpus': world,
+            'n_ranks_seen': n_seen,       # ranks that joined the max-over-ranks collective
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
             # BASELINE.json's metric string names the 520^3 volume (configs[0]'s size): the

@@ -96,14 +96,6 @@ __device__ __forceinline__ void store_split12(unsigned char *vox, int64_t plane,
   *reinterpret_cast<u32x2 *>(d + LO_OFF + 16) = u32x2{lo[4], lo[5]};
 }
 
-// four channels (one accumulator tile row group) of one voxel -> HBM, hi and lo halves
-__device__ __forceinline__ void store_split4(unsigned char *vox, int64_t plane, int ch, const f32x4 &v) {
-  const Pair2 p0 = split_pk(v[0], v[1]), p1 = split_pk(v[2], v[3]);
-  unsigned char *d = vox + chan_off(ch, plane);
-  *reinterpret_cast<u32x2 *>(d) = u32x2{p0.hi, p1.hi};
-  *reinterpret_cast<u32x2 *>(d + LO_OFF) = u32x2{p0.lo, p1.lo};
-}
-
 // -------------------------------------------------------------------------------
 // K1: stem.  ONE workgroup of 8 waves per CU (the hi and lo input tiles, double-buffered,
 // are 113 KiB); pooled block 4 x 8 x 32 as in vgg_stem_pool; a wave takes 8 of the
@@ -133,7 +125,8 @@ constexpr int S_TASKS = S_PZ * S_PY * 2 / S_WAVES;          // 8 tasks per wave 
 constexpr int S_RPT = 3;                       // rows per task iteration
 static_assert(S_RPT * S_TASKS >= S_WROWS && S_WROWS <= 64, "stem fill schedule");
 constexpr int S_SHTAB = 64 * 48;                // u8 path: floats of the initial-value table
-constexpr int S_SMEM = 4 * S_TILE * 2 + 256 * 4 + S_SHTAB * 4;
+constexpr int S_SH2 = 4 * 12;                   // conv1's shift as [g][b][r] floats (one 16-B read per M-block)
+constexpr int S_SMEM = 4 * S_TILE * 2 + 256 * 4 + S_SHTAB * 4 + S_SH2 * 4;
 
 struct StemSArgs {
   const void *src;
@@ -326,7 +319,11 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
   }
   // weight fragments in registers: [part][e or s][b]
   h16x8 w1[2][2][3], w2[4][3];
-  f32x4 sh1[3], sh2[3];
+  // conv1's shift lives in LDS (12 registers fewer across the task loop: no spills)
+  float *sh2t = reinterpret_cast<float *>(smem + 4 * S_TILE * 2 + 256 * 4 + S_SHTAB * 4);
+  if (tid < S_SH2) sh2t[tid] = a.shift2[x8::out_channel((tid % 12) / 4, tid / 12, tid % 4)];
+  const f32x4 *sh2g = reinterpret_cast<const f32x4 *>(sh2t + 12 * g);
+  f32x4 sh1[3];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -341,7 +338,6 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       sh1[b][r] = a.shift1[16 * b + 4 * g + r];
-      sh2[b][r] = a.shift2[x8::out_channel(b, g, r)];   // rows in pass order (fpl_out_channel, il = 2)
     }
   __syncthreads();                      // lut
 
@@ -450,7 +446,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
           const h16x8 hx = pack_relu_split_x(a1[2]);
           // conv1 48->48 as chain48, M-blocks interleaved (independent accumulators)
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][b], h0.hi, sh2[b]);
+          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][b], h0.hi, sh2g[b]);
 #pragma unroll
           for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.lo, a2[e][b]);
 #pragma unroll
@@ -619,7 +615,7 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_mid_pool(MidXArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   x8::ktab_init(ktab, tid);
-  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p1.Y, a.p1.X);
+  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p1.Y, a.p1.X, (unsigned)a.p1.part_bytes());
   const int S = (int)gridDim.x >> 3, nbricks = a.walk.bricks();
   const int group = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
   x8::Cursor cur;
@@ -635,7 +631,7 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_mid_pool(MidXArgs a) {
   x8::prime(smem, td, origin(cur), part, a.w3, wave, lane);      // also makes the table visible
   for (;;) {
     x8::Cursor nxt = cur;
-    const bool has_next = x8::cursor_next(a.walk, nbricks, slot, S, nxt);
+    const bool has_next = x8::cursor_next(a.walk, slot, S, nxt);
     // (the opaque zero keeps block-invariant loads - shifts, conv1's weight fragments - INSIDE
     // the block loop: hoisted out of it their registers live through the K loop and spill)
     int zero = 0;
@@ -694,14 +690,86 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_mid_pool(MidXArgs a) {
 }
 
 // -------------------------------------------------------------------------------
+// The head both tail kernels run on their conv3 accumulators, in registers: ReLU + split,
+// conv1 48->96, conv1 96->96, conv1 96->1 -> the logit of each of the wave's 4 x 16 coarse voxels
+// (returned in lanes g = 0 .. 3 alike).  Two sub-steps at a time (all four in lockstep keep 96
+// registers of hi / lo fragments per layer alive and spill), one output-channel PAIR at a time
+// (= one K-step of the next layer), conv1 96->1 folded into conv1 96->96's loop, so no layer's
+// full output is ever live.  w6: chain48 steps [4][b]; w7, w8: [part][s][b].
+// -------------------------------------------------------------------------------
+constexpr int T_W7 = 3 * 6, T_W8 = 3;   // fragments per part of L7, L8
+__device__ __forceinline__ void head_chain(const f32x4 (&acc)[4][3], const unsigned char *w6p,
+                                           const unsigned char *w7p, const unsigned char *w8p, const float *sh6p,
+                                           const float *sh7p, float bias8, int lane, unsigned &ovf, float (&logit)[4]) {
+  const int c = lane & 15, g = lane >> 4;
+  auto frag = [&](const unsigned char *w, int part_, int nfrag, int f) {
+    return *reinterpret_cast<const h16x8 *>(w + ((size_t)(part_ * nfrag + f) * 64 + lane) * 16);
+  };
+#pragma unroll
+  for (int sp = 0; sp < 2; ++sp) {
+    Frag2 h5[2];
+    h16x8 h5x[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      h5[q] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1], ovf);
+      h5x[q] = pack_relu_split_x(acc[2 * sp + q][2], ovf);
+    }
+    Frag2 h6[2][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      f32x4 a6[2][2];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int b = 2 * s + bb;
+        f32x4 sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh[r] = sh6p[16 * b + 4 * g + r];
+        h16x8 w6[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w6[t] = frag(w6p, 0, 0, t * 6 + b);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a6[q][bb] = chain48(w6, h5[q], h5x[q], sh);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) h6[q][s] = pack_relu_split(a6[q][0], a6[q][1], ovf);
+    }
+    f32x4 a8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      f32x4 a7[2][2];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int b = 2 * s + bb;
+        f32x4 sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sh[r] = sh7p[16 * b + 4 * g + r];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a7[q][bb] = sh;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const h16x8 wh = frag(w7p, 0, T_W7, t * 6 + b), wl = frag(w7p, 1, T_W7, t * 6 + b);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) a7[q][bb] = mfma3(wh, wl, h6[q][t], a7[q][bb]);
+        }
+      }
+      const h16x8 w8h = frag(w8p, 0, T_W8, s), w8l = frag(w8p, 1, T_W8, s);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a8[q] = mfma3(w8h, w8l, pack_relu_split(a7[q][0], a7[q][1], ovf), a8[q]);
+    }
+    // lane (c, g = 0) register 0 holds the logit of coarse voxel c
+#pragma unroll
+    for (int q = 0; q < 2; ++q) logit[2 * sp + q] = __shfl(a8[q][0], c) + bias8;
+    __builtin_amdgcn_sched_barrier(0);       // the second pair's weight loads stay behind the first's work
+  }
+}
+
+// -------------------------------------------------------------------------------
 // K3: conv3 48->48 + BN + ReLU on P2, then - in registers - conv1 48->96, conv1 96->96,
 // conv1 96->1 + bias, sigmoid and the x4 nearest upsample store into the (Z,Y,X) f32
 // prediction volume (vgg_c5_tail's geometry: block 4 x 4 x 16, wave = z, sub-steps = the
 // 4 y rows).  The 1x1 chain runs on two sub-steps at a time: with hi and lo fragments all
 // four in lockstep do not fit the register file.
 // -------------------------------------------------------------------------------
-constexpr int T_W7 = 3 * 6, T_W8 = 3;   // fragments per part of L7, L8
-
 struct TailSArgs {
   const unsigned char *p2;
   int P2Z, P2Y, P2X;
@@ -746,72 +814,9 @@ __global__ __launch_bounds__(256, 2) void vggs_c5_tail_p24(TailSArgs a) {
   conv3s_kloop<M_TZ, M_TY, M_TX>(a.p2, a.P2Z, a.P2Y, a.P2X, cz0, cy0, cx0, tile, kofftab, a.w5,
                                  vbase, sub_off, acc, tid);
 
-  auto frag = [&](const unsigned char *w, int part, int nfrag, int f) {
-    return *reinterpret_cast<const h16x8 *>(w + ((size_t)(part * nfrag + f) * 64 + lane) * 16);
-  };
   float logit[4];
   unsigned ovf = 0u;
-#pragma unroll
-  for (int sp = 0; sp < 2; ++sp) {
-    Frag2 h5[2];
-    h16x8 h5x[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      h5[q] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1], ovf);
-      h5x[q] = pack_relu_split_x(acc[2 * sp + q][2], ovf);
-    }
-    Frag2 h6[2][3];
-    {
-      f32x4 a6[2][6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        f32x4 sh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sh[r] = a.shift6[16 * b + 4 * g + r];
-        h16x8 w6[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) w6[s] = frag(a.w6, 0, 0, s * 6 + b);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) a6[q][b] = chain48(w6, h5[q], h5x[q], sh);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) h6[q][s] = pack_relu_split(a6[q][2 * s], a6[q][2 * s + 1], ovf);
-    }
-    Frag2 h7[2][3];
-    {
-      f32x4 a7[2][6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        f32x4 sh;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sh[r] = a.shift7[16 * b + 4 * g + r];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) a7[q][b] = sh;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const h16x8 wh = frag(a.w7, 0, T_W7, s * 6 + b), wl = frag(a.w7, 1, T_W7, s * 6 + b);
-#pragma unroll
-          for (int q = 0; q < 2; ++q) a7[q][b] = mfma3(wh, wl, h6[q][s], a7[q][b]);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) h7[q][s] = pack_relu_split(a7[q][2 * s], a7[q][2 * s + 1], ovf);
-    }
-    f32x4 a8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const h16x8 wh = frag(a.w8, 0, T_W8, s), wl = frag(a.w8, 1, T_W8, s);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) a8[q] = mfma3(wh, wl, h7[q][s], a8[q]);
-    }
-    // lane (c, g=0) register 0 holds the logit of coarse voxel c
-#pragma unroll
-    for (int q = 0; q < 2; ++q) logit[2 * sp + q] = __shfl(a8[q][0], c) + a.bias8;
-  }
+  head_chain(acc, a.w6, a.w7, a.w8, a.shift6, a.shift7, a.bias8, lane, ovf, logit);
   ovf_commit(ovf, a.flag, FPL_RANGE_TAIL);
 
   const int cz = cz0 + wave, cx = cx0 + c;
@@ -871,7 +876,7 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_c5_tail(TailXArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   x8::ktab_init(ktab, tid);
-  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p2.Y, a.p2.X);
+  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p2.Y, a.p2.X, (unsigned)a.p2.part_bytes());
   const int S = (int)gridDim.x >> 3, nbricks = a.walk.bricks();
   const int group = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
   x8::Cursor cur;
@@ -882,14 +887,11 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_c5_tail(TailXArgs a) {
   };
   const unsigned vb = (unsigned)((wave * x8::ZS + c) * 16);
   auto sub_off = [](int sub) -> unsigned { return (unsigned)(sub * x8::TX * 16); };
-  auto frag = [&](const unsigned char *w, int part_, int nfrag, int f) {
-    return *reinterpret_cast<const h16x8 *>(w + ((size_t)(part_ * nfrag + f) * 64 + lane) * 16);
-  };
   unsigned ovf_all = 0u;
   x8::prime(smem, td, origin(cur), part, a.w5, wave, lane);
   for (;;) {
     x8::Cursor nxt = cur;
-    const bool has_next = x8::cursor_next(a.walk, nbricks, slot, S, nxt);
+    const bool has_next = x8::cursor_next(a.walk, slot, S, nxt);
     // (the opaque zero keeps block-invariant loads - shifts, the head's 66 weight fragments -
     // INSIDE the block loop: hoisted out of it they are live registers, i.e. spills)
     int zero = 0;
@@ -907,66 +909,8 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_c5_tail(TailXArgs a) {
     unsigned ovf = 0u;
     float logit[4];
     asm volatile("" : "+s"(zero));
-    const unsigned char *w6p = a.w6 + zero, *w7p = a.w7 + zero, *w8p = a.w8 + zero;
-    const float *sh6p = a.shift6 + zero, *sh7p = a.shift7 + zero;
-#pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {
-      Frag2 h5[2];
-      h16x8 h5x[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        h5[q] = pack_relu_split(acc[2 * sp + q][0], acc[2 * sp + q][1], ovf);
-        h5x[q] = pack_relu_split_x(acc[2 * sp + q][2], ovf);
-      }
-      // conv1 48->96 + ReLU, an output-channel pair (= one K-step of the next layer) at a time
-      Frag2 h6[2][3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        f32x4 a6[2][2];
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int b = 2 * s + bb;
-          f32x4 sh;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sh[r] = sh6p[16 * b + 4 * g + r];
-          h16x8 w6[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) w6[t] = frag(w6p, 0, 0, t * 6 + b);
-#pragma unroll
-          for (int q = 0; q < 2; ++q) a6[q][bb] = chain48(w6, h5[q], h5x[q], sh);
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) h6[q][s] = pack_relu_split(a6[q][0], a6[q][1], ovf);
-      }
-      // conv1 96->96 + ReLU, pair by pair, each pair's split going straight into conv1 96->1
-      f32x4 a8[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        f32x4 a7[2][2];
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int b = 2 * s + bb;
-          f32x4 sh;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sh[r] = sh7p[16 * b + 4 * g + r];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) a7[q][bb] = sh;
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            const h16x8 wh = frag(w7p, 0, T_W7, t * 6 + b), wl = frag(w7p, 1, T_W7, t * 6 + b);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) a7[q][bb] = mfma3(wh, wl, h6[q][t], a7[q][bb]);
-          }
-        }
-        const h16x8 w8h = frag(w8p, 0, T_W8, s), w8l = frag(w8p, 1, T_W8, s);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) a8[q] = mfma3(w8h, w8l, pack_relu_split(a7[q][0], a7[q][1], ovf), a8[q]);
-      }
-      // lane (c, g = 0) register 0 holds the logit of coarse voxel c
-#pragma unroll
-      for (int q = 0; q < 2; ++q) logit[2 * sp + q] = __shfl(a8[q][0], c) + a.bias8;
-      __builtin_amdgcn_sched_barrier(0);       // the second pair's weight loads stay behind the first's work
-    }
+    head_chain(acc, a.w6 + zero, a.w7 + zero, a.w8 + zero, a.shift6 + zero, a.shift7 + zero, a.bias8, lane, ovf,
+               logit);
     const int cz = 8 * cur.bz + wave, cx = 16 * cur.bx + c;
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
@@ -1614,9 +1558,15 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   FPL_REQUIRE(ctx, (int64_t)S_TZ * SY * SX < ((int64_t)1 << 31),
               "vgg split path: a %lld x %lld plane is too large for the stem's 31-bit row "
               "offsets", (long long)SY, (long long)SX);
-  FPL_REQUIRE(ctx, (int64_t)P1Y * P1X * 16 * (x8::TZ + 1) < ((int64_t)1 << 32),
-              "vgg split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
-              "offsets", (long long)SY, (long long)SX);
+  // the tile loads address a pass's hi AND lo plane from one scalar base with 32-bit lane
+  // offsets: two part planes of the chunk plus the tile's reach stay below 4 GiB
+  {
+    const int64_t max_rows = (((int64_t)1 << 32) / 16 / ((int64_t)P1Y * P1X) - (x8::TZ + 2));
+    FPL_REQUIRE(ctx, max_rows >= 14,
+                "vgg split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
+                "offsets", (long long)SY, (long long)SX);
+    cz_chunk = std::min<int64_t>(cz_chunk, std::max<int64_t>(4, ((max_rows - 6) / 2) / 4 * 4));
+  }
   DevTemp tmp(ctx);
   unsigned *flag;
   FPL_TRY(fpl_range_flag(ctx, &flag));

@@ -87,15 +87,16 @@ __device__ __forceinline__ bool walk_block(const Walk &w, int k, int slot, int &
   return bx < w.nbx && by < w.nby && bz < w.nbz;
 }
 
-// per-lane constants of a wave's share of the tile DMA: chunk j = wave + 8 i holds slots
-// 64 j .. 64 j + 63 of [hi plane | lo plane]
+// per-lane constants of a wave's share of the tile: chunk j = wave + 8 i holds slots
+// 64 j .. 64 j + 63 of [hi plane | lo plane]; off[i] = byte offset of the slot's voxel from the
+// block's origin voxel in the hi plane (the lo plane is part_bytes behind it: the host keeps a
+// pass's two planes plus the tile's reach below 4 GiB, so the loads are scalar base + 32-bit
+// lane offset)
 struct TileDma {
-  unsigned off[TCH];         // byte offset of the slot's voxel from the block's origin voxel, inside a part plane
-  unsigned lo_mask;          // bit i: this lane's slot of chunk i belongs to the lo plane
+  unsigned off[TCH];
 };
-__device__ __forceinline__ TileDma tile_dma_init(int wave, int lane, int SY, int SX) {
+__device__ __forceinline__ TileDma tile_dma_init(int wave, int lane, int SY, int SX, unsigned part_bytes) {
   TileDma d;
-  d.lo_mask = 0u;
 #pragma unroll
   for (int i = 0; i < TCH; ++i) {
     int slot = 64 * (wave + WAVES * i) + lane;
@@ -106,32 +107,44 @@ __device__ __forceinline__ TileDma tile_dma_init(int wave, int lane, int SY, int
     int rem = s - tz * ZS;
     rem = rem < TY * TX ? rem : TY * TX - 1;                 // padding slots: any valid voxel
     const int ty = rem / TX, tx = rem - ty * TX;
-    d.off[i] = (unsigned)(((tz * SY + ty) * SX + tx) * 16);
-    d.lo_mask |= (unsigned)part << i;
+    d.off[i] = (unsigned)(((tz * SY + ty) * SX + tx) * 16) + (part ? part_bytes : 0u);
   }
   return d;
 }
 
-// LDS-DMA of one pass into a buffer: 79 chunks of 1 KiB - the 37 tile chunks, then the 42
-// weight fragments, contiguous in the buffer - dealt round-robin to the 8 waves: chunk
-// j = wave + 8 i, i = 0 .. 9.  i <= 3 is always a tile chunk, i >= 5 always a weight fragment,
-// i = 4 a tile chunk for waves 0 - 4; the one index past the end (wave 7, i = 9) repeats chunk
-// 78.  No branches: the issue sits between MFMAs.  `org` = the hi plane's origin voxel of the
-// pass's tile, `wpass` = the pass's weight fragments.  Nothing is waited for here.
+// Filling a buffer by LDS-DMA: 79 chunks of 1 KiB - the 37 tile chunks, then the 42 weight
+// fragments, contiguous in the buffer - dealt round-robin to the 8 waves: chunk j = wave + 8 i,
+// i = 0 .. 9.  i <= 3 is always a tile chunk, i >= 5 always a weight fragment, i = 4 a tile chunk
+// for waves 0 - 4; the one index past the end (wave 7, i = 9) repeats chunk 78.  No branches.
+// `org` = the hi plane's origin voxel of the pass's tile, `wpass` = the pass's weight fragments.
+// Nothing is waited for here.
+//
+// What the fill costs (timing builds, profiles/r04_mid_proxies.txt; mid kernel, 1024^3): 27.0 ms
+// without it (the MFMA pipe then 100 % busy), 34.5 with it - 2.5 ms for the 42 weight chunks,
+// 4.9 for the 37 tile chunks (gathers of 288-B rows).  NOT the price of waiting (barriers without
+// the vmcnt wait: the same time), of barriers (none: the same), of the bytes landing in LDS (79
+// ds_write_b128 of registers instead: free) or of where the data comes from (79 DMAs of one
+// L1-resident KiB: 33.8 ms): it is the LDS-DMA instruction itself, ~24 CU-cycles of stalled
+// matrix pipe each.  The same bytes through registers (global_load_dwordx4, ds_write_b128 three
+// or six K-steps later) cost MORE (35.3 / 37.8 ms).  Staggering the issue between SIMD partners,
+// non-temporal loads, contiguous brick ranges per XCD: no change.
 constexpr int NCH = CHUNKS + WFRAGS;                     // 79
 constexpr int DCH = (NCH + WAVES - 1) / WAVES;           // 10 per wave
+constexpr int HCH = DCH / 2;                             // issued five at a time
 static_assert(TCH == 5 && 8 * 4 + 4 < CHUNKS && 8 * 4 + 5 >= CHUNKS, "chunk deal: i = 4 splits at wave 5");
-__device__ __forceinline__ void dma_chunk(const TileDma &d, int i, int wave, int lane, const unsigned char *org,
-                                          int64_t part_bytes, const unsigned char *wpass, unsigned char *buf) {
-  int j = wave + WAVES * i;
-  j = j < NCH ? j : NCH - 1;
-  const unsigned char *wsrc = wpass + (j - CHUNKS) * 1024 + lane * 16;
-  const unsigned char *src = wsrc;
-  if (i < TCH) {
-    const unsigned char *tsrc = org + ((d.lo_mask >> i) & 1u ? part_bytes : (int64_t)0) + d.off[i];
-    src = (i < TCH - 1 || j < CHUNKS) ? tsrc : wsrc;
+static_assert(DCH % 2 == 0, "two batches");
+__device__ __forceinline__ void dma_batch(const TileDma &d, int half, int wave, int lane, const unsigned char *org,
+                                          const unsigned char *wpass, unsigned char *buf) {
+#pragma unroll
+  for (int k = 0; k < HCH; ++k) {
+    const int i = HCH * half + k;
+    int j = wave + WAVES * i;
+    j = j < NCH ? j : NCH - 1;
+    const bool tile = i < TCH - 1 || (i < TCH && j < CHUNKS);
+    const unsigned char *base = tile ? org : wpass + (j - CHUNKS) * 1024;
+    const unsigned off = tile ? d.off[i < TCH ? i : 0] : (unsigned)lane * 16u;
+    glds16(base + off, buf + j * 1024);
   }
-  glds16(src, buf + j * 1024);
 }
 
 // tap offset table: entry [g][s] = byte offset of tap 4 s + g inside a part plane of the tile
@@ -233,10 +246,12 @@ __device__ __forceinline__ void conv_block(unsigned char *smem, const unsigned *
       const unsigned char *torg = more ? org_cur + (int64_t)(pass + 1) * 2 * part_bytes : org_nxt;
       const unsigned char *tw = wglobal + (size_t)(more ? pass + 1 : 0) * WBYTES;
       auto issue = [&](int s) {
-        // the next pass's DMA goes out with the first two K-steps: five K-steps for it to land
-        if (s < 2) {
-#pragma unroll
-          for (int i = 0; i < DCH / 2; ++i) dma_chunk(td, (DCH / 2) * s + i, wave, lane, torg, part_bytes, tw, other);
+        // the next pass's DMA goes out in two batches, at K-steps 0 and 3 (at least three K-steps
+        // for it to land); the wave steps down from the MFMA cluster's priority while it issues
+        if (s == 0 || s == 3) {
+          __builtin_amdgcn_s_setprio(0);
+          dma_batch(td, s == 3, wave, lane, torg, tw, other);
+          __builtin_amdgcn_s_setprio(1);
         }
       };
       pass_kloop(buf, ktab_g, vb, sub_off, issue, lane, acc);
@@ -251,31 +266,37 @@ __device__ __forceinline__ void conv_block(unsigned char *smem, const unsigned *
 __device__ __forceinline__ void prime(unsigned char *smem, const TileDma &td, const unsigned char *org,
                                       int64_t part_bytes, const unsigned char *wglobal, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < DCH; ++i) dma_chunk(td, i, wave, lane, org, part_bytes, wglobal, smem);
+  for (int half = 0; half < 2; ++half) dma_batch(td, half, wave, lane, org, wglobal, smem);
   __syncthreads();
 }
 
-// The persistent workgroup's walk: group = blockIdx.x & 7 takes bricks group, group + 8, ...;
-// inside a brick its S = gridDim.x / 8 workgroups share the 32 blocks (slot, slot + S, ...).
+// The persistent workgroup's walk: group = blockIdx.x & 7 (one XCD under round-robin placement)
+// takes the CONTIGUOUS range of bricks [group * per, (group + 1) * per), per = ceil(bricks / 8):
+// consecutive bricks are x neighbours, so the halo face they share is still in that XCD's L2
+// when the next one starts; inside a brick the group's S = gridDim.x / 8 workgroups share the
+// 32 blocks (slot, slot + S, ...).
 struct Cursor {
   int k, j;                  // brick, block inside the brick
+  int kend;
   int bx, by, bz;
 };
-__device__ __forceinline__ bool cursor_seek(const Walk &w, int nbricks, int slot, int S, Cursor &c) {
+__device__ __forceinline__ bool cursor_seek(const Walk &w, int slot, int S, Cursor &c) {
   for (;;) {
-    if (c.j >= 32) { c.j = slot; c.k += 8; }
-    if (c.k >= nbricks) return false;
+    if (c.j >= 32) { c.j = slot; c.k += 1; }
+    if (c.k >= c.kend) return false;
     if (walk_block(w, c.k, c.j, c.bx, c.by, c.bz)) return true;
     c.j += S;
   }
 }
 __device__ __forceinline__ bool cursor_first(const Walk &w, int nbricks, int group, int slot, int S, Cursor &c) {
-  c.k = group; c.j = slot;
-  return cursor_seek(w, nbricks, slot, S, c);
+  const int per = (nbricks + 7) / 8;
+  c.k = group * per; c.j = slot;
+  c.kend = (group + 1) * per < nbricks ? (group + 1) * per : nbricks;
+  return cursor_seek(w, slot, S, c);
 }
-__device__ __forceinline__ bool cursor_next(const Walk &w, int nbricks, int slot, int S, Cursor &c) {
+__device__ __forceinline__ bool cursor_next(const Walk &w, int slot, int S, Cursor &c) {
   c.j += S;
-  return cursor_seek(w, nbricks, slot, S, c);
+  return cursor_seek(w, slot, S, c);
 }
 
 // A lane's three accumulator tiles of a 48-channel layer packed with fpl_out_channel(il = 2):
