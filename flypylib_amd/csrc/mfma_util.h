@@ -172,13 +172,23 @@ struct Frag2 { h16x8 hi, lo; };             // a B fragment
 // the half it writes (hipcc emits two conversions back, a packed subtract and a packed
 // conversion for the same arithmetic - 4 instructions instead of 2 in kernels whose VALU
 // issue is what the MFMAs wait for).
+// The result is written INTO THE REGISTER OF `a` ("+v").  hipcc's hazard recognizer does not
+// look inside an asm statement: given a free output register it may pick one that is the dead
+// part of the destination tuple of an MFMA still in flight (only element 0 of a 4-register
+// result live, say), and that MFMA's late write-back then lands on top of the asm's result -
+// seen in round 4 as run-to-run differences of 1e-5 in the head kernel, wherever the
+// allocator happened to make that choice.  `a` is always the result of an ordinary VALU
+// instruction (a ReLU or a pool maximum) whose own write the compiler did guard, and no MFMA
+// can have a live register in its destination, so reusing it is safe by construction.
 __device__ __forceinline__ Pair2 split_pk(float a, float b) {
   Pair2 r;
   r.hi = cvt_pk_h16(a, b);
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(r.lo)
-      : "v"(r.hi), "v"(a), "v"(b));
+  unsigned lo = __builtin_bit_cast(unsigned, a);
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "+v"(lo)
+      : "v"(r.hi), "v"(b));
+  r.lo = lo;
   return r;
 }
 #else
@@ -225,9 +235,14 @@ __device__ __forceinline__ Pair2 split_pk(float a, float b, unsigned &ovf) {
 __device__ __forceinline__ Pair2 split_pk_relu(float a, float b, unsigned &ovf) {
   return split_pk(relu_f32(a), relu_f32(b), ovf);
 }
-// signed values: the guard looks at |hi|
+// signed values straight from an accumulator (a convolution without ReLU: none of the
+// reference's graphs has one in front of a split tensor): plain C, no asm on an MFMA result;
+// the guard looks at |hi|
 __device__ __forceinline__ Pair2 split_pk_signed(float a, float b, unsigned &ovf) {
-  const Pair2 r = split_pk(a, b);
+  Pair2 r;
+  r.hi = cvt_pk_h16(a, b);
+  const h16x2 h = __builtin_bit_cast(h16x2, r.hi);
+  r.lo = cvt_pk_h16(a - (float)h[0], b - (float)h[1]);
   ovf_note(ovf, r.hi & 0x7FFF7FFFu);
   return r;
 }

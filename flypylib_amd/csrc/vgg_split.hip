@@ -911,6 +911,7 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_c5_tail(TailXArgs a) {
     asm volatile("" : "+s"(zero));
     head_chain(acc, a.w6 + zero, a.w7 + zero, a.w8 + zero, a.shift6 + zero, a.shift7 + zero, a.bias8, lane, ovf,
                logit);
+
     const int cz = 8 * cur.bz + wave, cx = 16 * cur.bx + c;
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
