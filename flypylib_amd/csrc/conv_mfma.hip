@@ -496,7 +496,10 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
           // packed pair IS the K-step of conv1 32->32 in SLOT_SPATIAL order
           f32x4 a8[2], t9;
           if (SPLIT) {
-            const Frag2 h7 = pack_relu_split(acc[sub][0], acc[sub][1], ovf);
+            // (the guard counts voxels of the layer only: past OD / OH / OW the tile held the
+            // source's slack - stale scratch - and the result is never stored)
+            unsigned ovs = 0u;
+            const Frag2 h7 = pack_relu_split(acc[sub][0], acc[sub][1], ovs);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
               f32x4 sh;
@@ -504,8 +507,9 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
               for (int r = 0; r < 4; ++r) sh[r] = a.sh8[16 * b + 4 * g + r];
               a8[b] = mfma3(a.w8[b * 64 + lane], a.w8[(2 + b) * 64 + lane], h7, sh);
             }
-            t9 = mfma3(a.w9[lane], a.w9[64 + lane], pack_relu_split(a8[0], a8[1], ovf),
+            t9 = mfma3(a.w9[lane], a.w9[64 + lane], pack_relu_split(a8[0], a8[1], ovs),
                        f32x4{0.f, 0.f, 0.f, 0.f});
+            ovf = pk_max_i16(ovf, (oz < a.OD && oy < a.OH && ox < a.OW) ? ovs : 0u);
           } else {
             const h16x8 h7 = pack_relu(acc[sub][0], acc[sub][1]);
 #pragma unroll
