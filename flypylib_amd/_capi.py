@@ -127,10 +127,13 @@ def load_library(path=None):
     # NEEDED libamdhip64 resolves to the copy torch already loaded, and device tensors,
     # streams and this library's contexts share one runtime (train._DeviceStager,
     # pipeline buffers, torch.distributed).
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # (FPL_NO_TORCH_PRELOAD=1 skips it - a host without torch-side device buffers does not
+    # need it; a torch install that fails to import must not take this package down with it)
+    if not os.environ.get('FPL_NO_TORCH_PRELOAD'):
+        try:
+            import torch  # noqa: F401
+        except Exception:       # noqa: BLE001 - ImportError, or OSError / RuntimeError of a broken install
+            pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a symbol is missing
@@ -592,6 +595,10 @@ class Trainer:
             if 'float32' not in str(x.dtype) or 'uint8' not in str(y.dtype) or \
                     not x.is_contiguous() or not y.is_contiguous():
                 raise TypeError('device batches must be contiguous float32 data / uint8 labels')
+            for t in (x, y):        # a raw pointer of another GPU would be a memory fault, not an error
+                if not getattr(t, 'is_cuda', False) or t.device.index != self.ctx.device:
+                    raise TypeError('device batches must live on this trainer\'s GPU (cuda:%d), got %s'
+                                    % (self.ctx.device, getattr(t, 'device', type(t))))
         shape = tuple(int(v) for v in x.shape)
         if len(shape) == 5:
             shape = shape[:4]                     # trailing channel axis of 1

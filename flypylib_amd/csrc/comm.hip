@@ -15,6 +15,8 @@
 
 #include <mutex>
 
+#include <unistd.h>
+
 #include "common.h"
 
 namespace {
@@ -98,16 +100,41 @@ int load_rccl(fpl_ctx *ctx) {
 
 }  // namespace
 
-void fpl_comm_release(fpl_ctx *ctx) {
-  if (ctx && ctx->comm && g_rccl.handle) {
-    g_rccl.CommDestroy((ncclComm_t)ctx->comm);
-  }
-  if (ctx) {
-    ctx->comm = nullptr;
-    ctx->comm_rank = 0;
-    ctx->comm_nranks = 1;
-  }
+// take the communicator out of the context (nobody else will see it afterwards)
+static void *comm_take(fpl_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(ctx->comm_mu);
+  void *c = ctx->comm;
+  ctx->comm = nullptr;
+  ctx->comm_rank = 0;
+  ctx->comm_nranks = 1;
+  return c;
 }
+
+void fpl_comm_release(fpl_ctx *ctx) {
+  if (!ctx) return;
+  void *c = comm_take(ctx);
+  if (c && g_rccl.handle) g_rccl.CommDestroy((ncclComm_t)c);
+}
+
+// a collective's hold on the communicator: copied under the lock together with the count that
+// fpl_comm_abort waits on, so the communicator cannot be freed between the copy and the call
+struct CommUse {
+  fpl_ctx *ctx;
+  void *comm = nullptr;
+  explicit CommUse(fpl_ctx *c) : ctx(c) {
+    std::lock_guard<std::mutex> lk(ctx->comm_mu);
+    if (!ctx->comm_aborting.load() && ctx->comm) {
+      comm = ctx->comm;
+      ++ctx->comm_inflight;
+    }
+  }
+  ~CommUse() {
+    if (comm) {
+      std::lock_guard<std::mutex> lk(ctx->comm_mu);
+      --ctx->comm_inflight;
+    }
+  }
+};
 
 extern "C" {
 
@@ -135,6 +162,7 @@ int fpl_comm_init(fpl_ctx *ctx, int32_t rank, int32_t nranks,
   memcpy(&id, unique_id, sizeof(id));
   ncclComm_t comm = nullptr;
   FPL_NCCL(ctx, g_rccl.CommInitRank(&comm, nranks, id, rank));
+  std::lock_guard<std::mutex> lk(ctx->comm_mu);
   ctx->comm = comm;
   ctx->comm_rank = rank;
   ctx->comm_nranks = nranks;
@@ -154,14 +182,25 @@ int fpl_comm_destroy(fpl_ctx *ctx) {
 int fpl_comm_abort(fpl_ctx *ctx) {
   if (!ctx) return fpl_fail(nullptr, "fpl_comm_abort: ctx is NULL");
   // no stream synchronisation: the point is to get out of a collective that will never
-  // complete because a peer is gone.  May be called from another host thread.
-  if (ctx->comm && g_rccl.handle) {
-    if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)ctx->comm);
-    else g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+  // complete because a peer is gone.  May be called from another host thread: new collectives
+  // are refused from here on, calls that already hold the communicator get a moment to return
+  // (an enqueue takes microseconds), and one that is still inside - blocked in the collective
+  // this abort is meant to break - is what ncclCommAbort exists for.
+  ctx->comm_aborting.store(true);
+  for (int i = 0; i < 200; ++i) {
+    {
+      std::lock_guard<std::mutex> lk(ctx->comm_mu);
+      if (ctx->comm_inflight == 0) break;
+    }
+    usleep(10000);
   }
-  ctx->comm = nullptr;
-  ctx->comm_rank = 0;
-  ctx->comm_nranks = 1;
+  void *c = comm_take(ctx);
+  if (c && g_rccl.handle) {
+    if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)c);
+    // else: no abort entry point in this librccl - the communicator is LEAKED; ncclCommDestroy
+    // would wait for the stuck collective
+  }
+  ctx->comm_aborting.store(false);
   return 0;
 }
 
@@ -176,28 +215,30 @@ int fpl_comm_info(fpl_ctx *ctx, int32_t *rank, int32_t *nranks, char *lib_path,
 
 int fpl_comm_allreduce_sum_f32(fpl_ctx *ctx, float *dev_ptr, int64_t n) {
   if (!ctx || !dev_ptr) return fpl_fail(ctx, "fpl_comm_allreduce_sum_f32: NULL argument");
-  FPL_REQUIRE(ctx, ctx->comm != nullptr,
-              "fpl_comm_allreduce_sum_f32: no communicator (call fpl_comm_init)");
+  CommUse use(ctx);
+  FPL_REQUIRE(ctx, use.comm != nullptr,
+              "fpl_comm_allreduce_sum_f32: no communicator (call fpl_comm_init; or it was aborted)");
   FPL_REQUIRE(ctx, n >= 0, "fpl_comm_allreduce_sum_f32: n %lld", (long long)n);
   if (n == 0) return 0;
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   {
     TimedLaunch tl(ctx, "rccl_allreduce_f32");
     FPL_NCCL(ctx, g_rccl.AllReduce(dev_ptr, dev_ptr, (size_t)n, ncclFloat, ncclSum,
-                                   (ncclComm_t)ctx->comm, ctx->stream));
+                                   (ncclComm_t)use.comm, ctx->stream));
   }
   return 0;
 }
 
 int fpl_comm_broadcast_f32(fpl_ctx *ctx, float *dev_ptr, int64_t n, int32_t root) {
   if (!ctx || !dev_ptr) return fpl_fail(ctx, "fpl_comm_broadcast_f32: NULL argument");
-  FPL_REQUIRE(ctx, ctx->comm != nullptr,
-              "fpl_comm_broadcast_f32: no communicator (call fpl_comm_init)");
+  CommUse use(ctx);
+  FPL_REQUIRE(ctx, use.comm != nullptr,
+              "fpl_comm_broadcast_f32: no communicator (call fpl_comm_init; or it was aborted)");
   FPL_REQUIRE(ctx, root >= 0 && root < ctx->comm_nranks, "fpl_comm_broadcast_f32: root %d", root);
   if (n <= 0) return 0;
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   FPL_NCCL(ctx, g_rccl.Broadcast(dev_ptr, dev_ptr, (size_t)n, ncclFloat, root,
-                                 (ncclComm_t)ctx->comm, ctx->stream));
+                                 (ncclComm_t)use.comm, ctx->stream));
   return 0;
 }
 

@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -73,9 +75,14 @@ struct fpl_ctx {
   std::vector<PendingTiming> pending;
   std::vector<hipEvent_t> event_pool;
   V2oState v2o;
-  // RCCL communicator of this GPU (comm.hip); ncclComm_t kept opaque here
+  // RCCL communicator of this GPU (comm.hip); ncclComm_t kept opaque here.  fpl_comm_abort may
+  // come from another host thread than the one inside a collective: `comm` changes hands under
+  // comm_mu, comm_inflight counts the calls that hold a copy of it
   void *comm = nullptr;
   int comm_rank = 0, comm_nranks = 1;
+  std::mutex comm_mu;
+  int comm_inflight = 0;
+  std::atomic<bool> comm_aborting{false};
   // executor chosen by the last fpl_infer_volume / fpl_program_forward (fpl_last_path)
   char last_path[64] = {0};
   // half-range guard of the split-operand kernels (mfma_util.h): a device word the kernels

@@ -21,7 +21,8 @@ _PRECISIONS = {'auto': _capi.PREC_AUTO, 'f32': _capi.PREC_F32, 'fp32': _capi.PRE
                'float32': _capi.PREC_F32, 'bf16': _capi.PREC_BF16,
                'f16': _capi.PREC_F16, 'float16': _capi.PREC_F16,
                # split IEEE halves (hi + lo, three MFMAs per product): fp32-grade
-               # probabilities at a third of the 16-bit rate; vgg_like only
+               # probabilities at a third of the 16-bit rate; vgg_like, vgg_like2 and the
+               # unet_like / unet_like2 / 3 / 4 skeleton (other graphs are refused)
                'f16s': _capi.PREC_F16S, 'split': _capi.PREC_F16S}
 
 
@@ -125,10 +126,11 @@ class FplNetwork:
 
     # ---- persistence (reference :81-97) ------------------------------------------------
     def save_network(self, filepath, keras_h5=True):
-        """pickle + `<path>.weights.npz`, and (keras_h5) the weights once more as
-        `<path>.keras.h5` in Keras' layout - the file name and tree the reference writes
-        next to its pickle; it carries no `model_config`, so on the Keras side rebuild
-        the model from its factory and `load_weights` it"""
+        """pickle + `<path>.weights.npz`, and (keras_h5) the network once more as
+        `<path>.keras.h5` - the file Keras' `model.save` writes next to the reference's pickle:
+        weights, `model_config`, `training_config` and (after training) `optimizer_weights`
+        (keras_io.py; whether Keras' `load_model` accepts the written JSON could not be run
+        here - without it, rebuild the model from its factory and `load_weights`)"""
         self.train_single.save(filepath + '.weights.npz')
         if keras_h5:
             self.train_single.save(filepath + '.keras.h5')
@@ -208,10 +210,12 @@ class FplNetwork:
         shell is zero.
 
         precision (default: the network's, 'auto'): 'auto' = fp32-grade results on the
-        fastest executor that delivers them - split IEEE halves for vgg_like (within
-        ~2e-6 of fp32, detections identical; 'f16s'), the fp32 MFMA kernels for every
-        other architecture ('f32'); 'f16' / 'bf16' = plain 16-bit operands (up to ~1e-3 /
-        ~8e-3 off fp32 on trained weights, 3x faster than 'f16s')."""
+        fastest executor that delivers them - split IEEE halves ('f16s': within ~4e-6 of
+        fp32, the same detected point set) for vgg_like, vgg_like2, unet_like and
+        unet_like2 / 3 / 4, rerun on the fp32 MFMA kernels when a weight, an input voxel or
+        an activation leaves the IEEE-half range (the kernels check), and the fp32 MFMA
+        kernels ('f32') for every other architecture; 'f16' / 'bf16' = plain 16-bit operands
+        (up to ~1e-3 / ~8e-3 off fp32 on trained weights, 3x faster than 'f16s')."""
         if isinstance(image, str):
             from . import keras_io
             image = np.load(image) if image.endswith('.npy') else keras_io.read_main(image)

@@ -352,7 +352,11 @@ class TowerGroup:
             q.put(None)
         for t in self._threads:
             t.join(None if self._broken is None else 5.0)    # daemon threads: never hang here
-        for tr, ctx in zip(self.trainers, self.ctxs):
+        for t, tr, ctx in zip(self._threads, self.trainers, self.ctxs):
+            if t.is_alive():
+                # a tower still inside a library call (after a failure): its trainer and context
+                # are NOT torn down under it - leaked with the daemon thread
+                continue
             tr.close()
             if self.reduce_kind == 'rccl' and ctx.comm_info()['nranks']:
                 ctx.comm_destroy()
@@ -422,6 +426,9 @@ class _DeviceStager:
         import torch
         self._torch = torch
         self._dev = torch.device('cuda', device)
+        if device >= torch.cuda.device_count():
+            raise ValueError('torch sees %d GPUs; the trainer is on device %d (the stager needs the '
+                             'same device numbering as the library)' % (torch.cuda.device_count(), device))
         self._stream = torch.cuda.Stream(self._dev)
         self._rows, self._need, self._need_msg = rows, need, need_msg
 

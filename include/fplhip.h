@@ -41,12 +41,19 @@ enum fpl_dtype { FPL_U8 = 0, FPL_F32 = 1, FPL_F64 = 2 };
  * operands with fp32 accumulation - bfloat16 (8 significant bits), IEEE half (11
  * bits, range 65504: probabilities within ~1e-3 of fp32 on trained weights; same speed
  * as bf16), or SPLIT IEEE halves (FPL_PREC_F16S: every operand as hi + lo, ~22 bits,
- * three MFMAs per product: probabilities within ~2e-6 of fp32 - inside the reference's
- * 1e-3 gate with detections identical to the fp32 path's - at a third of the 16-bit
- * rate; vgg_like only, other graphs are refused) */
+ * three MFMAs per product: probabilities within ~4e-6 of fp32 - inside the reference's
+ * 1e-3 gate, the same detected point set as the fp32 path's, order included up to
+ * confidences that tie to 1e-6 - at a third of the 16-bit rate).  Split kernels exist for
+ * vgg_like, vgg_like2 (stride-4 lattices) and unet_like / unet_like2 / unet_like3 /
+ * unet_like4 (cubic tiles); other graphs are refused at FPL_PREC_F16S.  Its operands are
+ * IEEE halves: a folded weight, a normalised input voxel or an activation beyond 65504
+ * makes the call FAIL (the kernels check every value they split) - never a wrong result. */
 enum fpl_precision {
-  /* fp32-GRADE, fastest executor that delivers it: FPL_PREC_F16S where it exists
-   * (vgg_like), else FPL_PREC_F32 - what FplNetwork.infer uses unless told otherwise */
+  /* what FplNetwork.infer uses unless told otherwise: fp32-GRADE results on the fastest
+   * executor that delivers them - FPL_PREC_F16S where split kernels exist AND every value
+   * stays inside the half range (a call that leaves it is rerun on the fp32 executor:
+   * the reference predicts in fp32, flypylib/fplnetwork.py:175-176, which has no such
+   * limit), else FPL_PREC_F32 */
   FPL_PREC_AUTO = -1,
   FPL_PREC_F32 = 0, FPL_PREC_BF16 = 1, FPL_PREC_F16 = 2, FPL_PREC_F16S = 3
 };
@@ -141,7 +148,9 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
 
 /* name of the executor the last fpl_infer_volume / fpl_program_forward of this
  * context ran on: "vgg_fused_f16" | "vgg_fused_bf16" | "vgg_split_f16" | "unet_split_f16" | "unet_mfma_f16" |
- * "unet_mfma_bf16" | "mfma_f32" | "perop_f32" | "none" (empty slab).  The 16-bit
+ * "unet_mfma_bf16" | "mfma_f32" | "perop_f32" | "none" (empty slab); with the suffix
+ * "(range)" - "mfma_f32(range)" - when FPL_PREC_AUTO fell back to fp32 because a weight,
+ * an input voxel or an activation left the IEEE-half range of the split kernels.  The 16-bit
  * fused kernels are keyed on the architectures of flypylib/fplmodels.py; any other
  * graph runs on the fp32 executors - this says which, instead of leaving the caller
  * to infer it from the speed. */

@@ -7,9 +7,10 @@ What is held, per precision, against the fp32 path of the same library (itself h
 1e-4 of the CPU oracle here, 2e-7 typical):
 
   f16s  split IEEE halves (vgg_like and unet_like2): fp32-grade - max |dp| < 1e-5 - and the detections
-        of its prediction are IDENTICAL to those of the fp32 prediction (same voxels,
-        confidences within 1e-5), also on a 582^3 substack at the pipeline's voxel2obj
-        parameters.  This is the path that meets "within 1e-3, identical detections".
+        of its prediction are the SAME POINT SET as those of the fp32 prediction (the same
+        voxels, confidences within 1e-5, the same order except between confidences that tie
+        to 1e-6: tests/helpers.py::same_detections), also on a 582^3 substack at the pipeline's
+        voxel2obj parameters.  This is the path that meets "within 1e-3, identical detections".
   f16   plain IEEE half: inside the 1e-3 gate on this fixture (8.3e-4 / 7.0e-4 observed)
         but without margin, and its detections may differ from fp32's in a tie-break.
   bf16  bounded at what 8 significant bits deliver.
@@ -28,6 +29,7 @@ pytestmark = pytest.mark.gpu
 
 def _same_detections(a, b, conf_tol):
     moved = helpers.same_detections(a, b, conf_tol, tie=1e-6)
+    print('detections out of order inside a 1e-6 tie:', moved, 'of', len(a['conf']))
     assert moved <= max(2, len(a['conf']) // 100), moved
 
 
@@ -81,8 +83,8 @@ def test_gate_on_trained_weights(ctx, name):
 def test_split_detections_identical_on_a_substack(ctx):
     """one substack of the pipeline (512 + 2 * 35 = 582 voxels, uint8 in, r = 27, sigma = 5,
     `fplobjdetect.py:845,1031-1034`): voxel2obj of the split-half prediction == voxel2obj of
-    the fp32 prediction - same voxels in the same order, confidences within 1e-5 - and the
-    probabilities within 1e-5"""
+    the fp32 prediction - the same voxels, confidences within 1e-5, the same order except
+    between confidences that tie to 1e-6 - and the probabilities within 1e-5"""
     net = trained_network('vgg_like', tile=102)
     # blobs 48 +- 3 voxels apart: further than obj_min_dist, as T-bars are - every blob is
     # one smoothed peak.  (At the training pitch of 16 the sigma-5 smoothing leaves a
