@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libfplhip.so')
 MEM_HOST, MEM_DEVICE = 0, 1
 U8, F32, F64 = 0, 1, 2
 PREC_AUTO, PREC_F32, PREC_BF16, PREC_F16, PREC_F16S = -1, 0, 1, 2, 3
-ABI_VERSION = 7
+ABI_VERSION = 8
 COMM_ID_BYTES = 128
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     'fpl_v2o_set_seg': (C.c_int, [_vp, _vp, _i32, C.c_int, _pi64, _i64]),
     'fpl_v2o_select': (C.c_int, [_vp, _pi64, _i32, _vp]),
     'fpl_v2o_smooth_f64': (C.c_int, [_vp, _vp, C.c_int, _pi64, _i32, _vp, _i32]),
+    'fpl_v2o_set_integer': (C.c_int, [_vp, _i32]),
     'fpl_v2o_select_f64': (C.c_int, [_vp, _pi64, _i32, _vp]),
     'fpl_v2o_rank_f64': (C.c_int, [_vp, C.c_double, _pi64]),
     'fpl_v2o_values_f64': (C.c_int, [_vp, _pi64, _i64, _vp]),
@@ -87,6 +88,8 @@ SIGNATURES = {
     'fpl_trainer_grad_ptr': (C.c_int, [_vp, C.POINTER(_vp), _pi64]),
     'fpl_trainer_get_weights': (C.c_int, [_vp, _vp, _i64]),
     'fpl_trainer_set_weights': (C.c_int, [_vp, _vp, _i64]),
+    'fpl_trainer_get_opt_state': (C.c_int, [_vp, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
+    'fpl_trainer_set_opt_state': (C.c_int, [_vp, _vp, _vp, _i64, _i64]),
     'fpl_trainer_get_grads': (C.c_int, [_vp, _vp, _i64]),
     'fpl_trainer_set_grads': (C.c_int, [_vp, _vp, _i64]),
     'fpl_last_path': (C.c_char_p, [_vp]),
@@ -358,6 +361,10 @@ class Context:
         self.check(self.lib.fpl_v2o_smooth_f64(self.h, _ptr(pred), _mem_of(pred),
                                                _arr(dims, C.c_int64), int(r), _ptr(w),
                                                int((w.size - 1) // 2)))
+
+    def v2o_set_integer(self, on=True):
+        """the next v2o_smooth_f64 filters an INTEGER volume (truncation after every pass)"""
+        self.check(self.lib.fpl_v2o_set_integer(self.h, int(bool(on))))
 
     def v2o_select_f64(self, ranks):
         ranks = np.ascontiguousarray(ranks, np.int64)
@@ -647,6 +654,22 @@ class Trainer:
                                for w in weights])
         self.ctx.check(self.ctx.lib.fpl_trainer_set_weights(self.h, _ptr(flat),
                                                             flat.size))
+
+    def get_opt_state(self):
+        """Adam state as (m, v, steps): lists in get_weights() order + the update count"""
+        m, v = np.empty(self.n_w, np.float32), np.empty(self.n_w, np.float32)
+        steps = C.c_int64()
+        self.ctx.check(self.ctx.lib.fpl_trainer_get_opt_state(self.h, _ptr(m), _ptr(v), self.n_w,
+                                                              C.byref(steps)))
+        return self._split(m), self._split(v), int(steps.value)
+
+    def set_opt_state(self, m, v, steps):
+        fm = np.concatenate([np.asarray(w, np.float32).reshape(-1) for w in m])
+        fv = np.concatenate([np.asarray(w, np.float32).reshape(-1) for w in v])
+        if fm.size != self.n_w or fv.size != self.n_w:
+            raise ValueError('optimizer state of %d / %d values for %d weights' % (fm.size, fv.size, self.n_w))
+        self.ctx.check(self.ctx.lib.fpl_trainer_set_opt_state(self.h, _ptr(fm), _ptr(fv), self.n_w,
+                                                              int(steps)))
 
     # ---- data parallelism
     def get_grads_flat(self):

@@ -49,6 +49,7 @@ struct V2oState {
   // float64 predictions (v2o_f64.hip): the smoothed volume in double, its voxels sorted
   // by value (order statistics, dense ranks); `smoothed` then holds rank surrogates
   bool f64 = false;
+  bool trunc_passes = false;    // fpl_v2o_set_integer: the next fpl_v2o_smooth_f64 filters an INTEGER volume
   double *smoothed64 = nullptr;
   size_t cap64_bytes = 0;
   unsigned long long *sort_keys = nullptr;     // ascending monotone keys of smoothed64

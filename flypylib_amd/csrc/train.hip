@@ -977,6 +977,25 @@ int fpl_trainer_set_weights(fpl_trainer *t, const float *w, int64_t n) {
   return copy_arena(t, t->w, const_cast<float *>(w), n, false);
 }
 
+// Adam state: first / second moments in the weight arena's layout (moving-statistics slots
+// unused) and the number of updates applied - what Keras' model.save keeps as
+// `optimizer_weights` (flypylib/fplnetwork.py:15-17,81-97 save through it)
+int fpl_trainer_get_opt_state(fpl_trainer *t, float *m, float *v, int64_t n, int64_t *steps) {
+  if (!t || !m || !v || !steps) return fpl_fail(nullptr, "fpl_trainer_get_opt_state: NULL");
+  FPL_TRY(copy_arena(t, t->m, m, n, true));
+  FPL_TRY(copy_arena(t, t->v, v, n, true));
+  *steps = t->step_count;
+  return 0;
+}
+int fpl_trainer_set_opt_state(fpl_trainer *t, const float *m, const float *v, int64_t n, int64_t steps) {
+  if (!t || !m || !v) return fpl_fail(nullptr, "fpl_trainer_set_opt_state: NULL");
+  if (steps < 0) return fpl_fail(t->ctx, "fpl_trainer_set_opt_state: %lld steps", (long long)steps);
+  FPL_TRY(copy_arena(t, t->m, const_cast<float *>(m), n, false));
+  FPL_TRY(copy_arena(t, t->v, const_cast<float *>(v), n, false));
+  t->step_count = steps;
+  return 0;
+}
+
 int fpl_trainer_set_grads(fpl_trainer *t, const float *g, int64_t n) {
   if (!t || !g) return fpl_fail(nullptr, "fpl_trainer_set_grads: NULL");
   return copy_arena(t, t->g, const_cast<float *>(g), n, false);

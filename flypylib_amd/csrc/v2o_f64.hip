@@ -52,7 +52,8 @@ template <int AXIS>
 __global__ __launch_bounds__(256) void gauss_pass_f64(const double *__restrict__ in,
                                                       double *__restrict__ out, int64_t P0,
                                                       int64_t P1, int64_t P2,
-                                                      const double *__restrict__ w, int wr, int r) {
+                                                      const double *__restrict__ w, int wr, int r,
+                                                      int trunc_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P0 * P1 * P2) return;
   const int64_t x = i % P2, y = (i / P2) % P1, z = i / (P2 * P1);
@@ -63,6 +64,9 @@ __global__ __launch_bounds__(256) void gauss_pass_f64(const double *__restrict__
   };
   double acc = mul_rn(load(0), w[0]);
   for (int j = wr; j >= 1; --j) acc = add_rn(acc, mul_rn(add_rn(load(-j), load(j)), w[j]));
+  // an integer volume: scipy stores every pass in the array's own type - a C cast of the
+  // double, i.e. truncation toward zero (the values stay in range: a convex combination)
+  if (trunc_out) acc = __builtin_trunc(acc);
   if (AXIS == 2 && r > 0 &&
       (z < r || y < r || x < r || z >= P0 - r || y >= P1 - r || x >= P2 - r))
     acc = 0.0;
@@ -185,9 +189,11 @@ int fpl_v2o_smooth_f64(fpl_ctx *ctx, const double *pred, int pred_mem, const int
   }
   {
     TimedLaunch tl(ctx, "v2o64_gauss");
-    gauss_pass_f64<0><<<grid, 256, 0, st>>>(S.smoothed64, scratch, P[0], P[1], P[2], w_dev, wr, r);
-    gauss_pass_f64<1><<<grid, 256, 0, st>>>(scratch, S.smoothed64, P[0], P[1], P[2], w_dev, wr, r);
-    gauss_pass_f64<2><<<grid, 256, 0, st>>>(S.smoothed64, scratch, P[0], P[1], P[2], w_dev, wr, r);
+    const int tr = S.trunc_passes ? 1 : 0;
+    S.trunc_passes = false;                 // holds for one call
+    gauss_pass_f64<0><<<grid, 256, 0, st>>>(S.smoothed64, scratch, P[0], P[1], P[2], w_dev, wr, r, tr);
+    gauss_pass_f64<1><<<grid, 256, 0, st>>>(scratch, S.smoothed64, P[0], P[1], P[2], w_dev, wr, r, tr);
+    gauss_pass_f64<2><<<grid, 256, 0, st>>>(S.smoothed64, scratch, P[0], P[1], P[2], w_dev, wr, r, tr);
   }
   FPL_HIP(ctx, hipGetLastError());
   FPL_HIP(ctx, hipMemcpyAsync(S.smoothed64, scratch, (size_t)n_pad * sizeof(double),
@@ -197,6 +203,12 @@ int fpl_v2o_smooth_f64(fpl_ctx *ctx, const double *pred, int pred_mem, const int
   S.r = r;
   S.f64 = true;
   S.valid = true;          // dims and radius are set; `smoothed` is filled by fpl_v2o_rank_f64
+  return 0;
+}
+
+int fpl_v2o_set_integer(fpl_ctx *ctx, int32_t on) {
+  if (!ctx) return fpl_fail(nullptr, "fpl_v2o_set_integer: ctx is NULL");
+  ctx->v2o.trunc_passes = on != 0;
   return 0;
 }
 

@@ -60,8 +60,10 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     pred: (Z,Y,X) float32 numpy array, or a float32 device tensor of that shape; a float64
     numpy array is smoothed, thresholded and compared in float64, as the reference does
     for its input's own dtype (the results differ from the float32 ones: no rounding
-    between the smoothing passes).  Other dtypes raise, as scipy's filter does for
-    float16 in the reference.
+    between the smoothing passes); an INTEGER numpy array likewise in its own type - scipy
+    filters it with float64 accumulation and truncates back to the integer type after
+    every axis, the point list comes back as int64 (reference :167-168, :233-236).
+    float16 raises, as scipy's filter does in the reference.
     Smoothing + percentile(97)-or-`thd` threshold + greedy non-maxima suppression
     with minimum distance `obj_min_dist`; detections inside `buffer_sz` of the
     volume faces are dropped; `volume_offset` (x,y,z) is added.
@@ -78,14 +80,19 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
         pred = _load_main(pred)
     r = int(obj_min_dist)
     f64 = False
+    int_pred = False
     if isinstance(pred, np.ndarray):
         if pred.dtype == np.float64:
             f64 = True
+        elif np.issubdtype(pred.dtype, np.integer):
+            # an integer volume is smoothed in its own type: exact doubles on the float64
+            # kernels, truncated after every axis pass (fpl_v2o_set_integer)
+            f64 = int_pred = True
+            pred = pred.astype(np.float64)
         elif pred.dtype != np.float32:
-            # the reference smooths in the array's own dtype: float32 (what
-            # FplNetwork.infer returns) and float64 exist on the device; scipy itself
-            # refuses float16, and integer volumes would be smoothed in integers
-            raise TypeError('voxel2obj: pred must be float32 or float64, got %s' % pred.dtype)
+            # the reference smooths in the array's own dtype; scipy itself refuses float16
+            raise TypeError('voxel2obj: pred must be float32, float64 or an integer type, got %s'
+                            % pred.dtype)
         pred = np.ascontiguousarray(pred)
     pred_sz = tuple(int(s) for s in pred.shape)
     assert len(pred_sz) == 3, 'pred must be (Z,Y,X)'
@@ -101,6 +108,8 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
         # float64 values are fetched afterwards
         if seg is None and seg_sz_thd is not None:
             raise ValueError('seg_sz_thd needs a segmentation')
+        if int_pred:
+            ctx.v2o_set_integer(True)
         ctx.v2o_smooth_f64(pred, pred_sz, r, weights)
         if seg is not None:
             if isinstance(seg, str):
@@ -157,6 +166,10 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma,
     obj_pred = obj_pred[~np.any(obj_pred >= max_bound, axis=1)]
 
     obj_pred = obj_pred + np.array([tuple(volume_offset) + (0,)])
+    if int_pred and pts.shape[0]:
+        # the reference's rows are [xx, yy, zz, max_val] with an integer max_val: np.asarray
+        # makes them int64, and its in-place arithmetic keeps that (:233-252)
+        obj_pred = obj_pred.astype(np.int64)
     obj_out = {'locs': obj_pred[:, :3], 'conf': obj_pred[:, 3]}
     if return_info:
         return obj_out, dict(thresh=thresh, rounds=rounds,

@@ -128,11 +128,77 @@ def graph_weights_from_layers(graph, layers):
     return out
 
 
+def _trainable_slots(graph):
+    """weight slots in the order of Keras' `model.trainable_weights`: layer by layer, kernel
+    (, bias) / gamma, beta - the moving statistics are not trainable"""
+    out = []
+    for node in graph.nodes:
+        if node.kind == 'conv':
+            out.extend(node.weight_slots)
+        elif node.kind == 'bn':
+            out.extend(node.weight_slots[:2])
+    return out
+
+
+def optimizer_tree(graph):
+    """the `optimizer_weights` group `model.save` writes for Adam (Keras 2.0 - 2.1,
+    `keras/optimizers.py`: `self.weights = [self.iterations] + ms + vs`, the TensorFlow-1
+    variable names of a model compiled once): iterations, then the first and the second
+    moments in `trainable_weights` order.  `load_model` hands the arrays to
+    `optimizer.set_weights` in the order of the `weight_names` attribute."""
+    m, v, it = graph.opt_state
+    slots = _trainable_slots(graph)
+    names = ['Adam/iterations:0']
+    arrays = [np.asarray(it, np.int64)]
+    for k, src in enumerate((m, v)):
+        for i, slot in enumerate(slots):
+            j = k * len(slots) + i
+            names.append('training/Adam/Variable%s:0' % ('_%d' % j if j else ''))
+            arrays.append(np.asarray(src[slot], np.float32))
+    tree = {'attrs': {'weight_names': np.array([n.encode() for n in names], dtype='S')}, 'groups': {}}
+    for n, a in zip(names, arrays):
+        parts = n.split('/')
+        g = tree
+        for part in parts[:-1]:
+            g = g.setdefault('groups', {}).setdefault(part, {})
+        g.setdefault('datasets', {})[parts[-1]] = a
+    return tree
+
+
+def optimizer_state_from_file(graph, root):
+    """(m, v, iterations) in get_weights() order from a whole-model file's `optimizer_weights`
+    (Adam: iterations + two arrays per trainable weight), or None"""
+    if 'optimizer_weights' not in root:
+        return None
+    grp = root['optimizer_weights']
+    if 'weight_names' not in grp.attrs:
+        return None
+    names = [_text(w) for w in np.atleast_1d(grp.attrs['weight_names'])]
+    slots = _trainable_slots(graph)
+    if len(names) < 1 + 2 * len(slots):
+        return None                         # another optimizer's state
+    try:
+        arrays = [np.asarray(grp[n][...]) for n in names]
+    except (KeyError, NotImplementedError, ValueError):
+        return None                         # a layout this reader does not follow: Adam starts afresh
+    it = int(np.asarray(arrays[0]).reshape(-1)[0])
+    m = [np.zeros_like(w) for w in graph.weights]
+    v = [np.zeros_like(w) for w in graph.weights]
+    for i, slot in enumerate(slots):
+        a, b = arrays[1 + i], arrays[1 + len(slots) + i]
+        if a.shape != graph.weights[slot].shape or b.shape != graph.weights[slot].shape:
+            return None
+        m[slot], v[slot] = a.astype(np.float32), b.astype(np.float32)
+    return m, v, it
+
+
 def load_weights(graph, path):
-    """set `graph`'s weights from a Keras .h5 (weights-only or whole-model file)"""
+    """set `graph`'s weights - and, from a whole-model file that carries it, its optimizer
+    state - from a Keras .h5 (weights-only or whole-model file)"""
     f = open_h5(path)
     try:
         graph.set_weights(graph_weights_from_layers(graph, keras_layers(f)))
+        graph.opt_state = optimizer_state_from_file(graph, f)
     finally:
         if hasattr(f, 'close'):
             f.close()
@@ -265,8 +331,8 @@ def save_weights(graph, path, as_model_save=True):
     writes (`fplnetwork.py:16-17,83`) - the weights under the group 'model_weights' and the
     root attributes `model_config` / `training_config` / `keras_version` / `backend`, so
     that the reference's `load_model(path, custom_objects)` can rebuild and load the
-    network; otherwise the bare `save_weights` layout.  Optimizer state
-    (`optimizer_weights`) is not written: `load_model` then starts Adam afresh."""
+    network; otherwise the bare `save_weights` layout.  A graph that has been trained also
+    writes Adam's state as `optimizer_weights` (optimizer_tree), as `model.save` does."""
     import json
     tree = weight_tree(graph)
     if as_model_save:
@@ -276,4 +342,6 @@ def save_weights(graph, path, as_model_save=True):
         tree['attrs']['model_config'] = np.bytes_(json.dumps(model_config(graph)).encode('utf8'))
         tree['attrs']['training_config'] = np.bytes_(
             json.dumps(training_config(graph.compile_args)).encode('utf8'))
+        if getattr(graph, 'opt_state', None) is not None:
+            tree['groups']['optimizer_weights'] = optimizer_tree(graph)
     h5min.write(path, tree)

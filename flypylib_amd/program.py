@@ -68,6 +68,10 @@ class LayerGraph:
         self.output = None
         self._rng = np.random.default_rng(seed)
         self.compile_args = None
+        # Adam state of the last training (m, v: lists in get_weights() order - the moving
+        # statistics' slots are unused; iterations: updates applied), or None: what Keras keeps
+        # in a compiled model's optimizer and `model.save` in `optimizer_weights`
+        self.opt_state = None
         self.inputs_node = self._add('input', [], {}, 1, self.in_sz)
 
     # ---- graph construction -------------------------------------------------
@@ -213,7 +217,13 @@ class LayerGraph:
             from . import keras_io
             keras_io.save_weights(self, path)
         else:
-            np.savez(path if path.endswith('.npz') else path + '.npz', *self.weights)
+            extra = {}
+            if self.opt_state is not None:
+                m, v, it = self.opt_state
+                extra = {'opt_iterations': np.int64(it)}
+                extra.update({'opt_m_%d' % i: a for i, a in enumerate(m)})
+                extra.update({'opt_v_%d' % i: a for i, a in enumerate(v)})
+            np.savez(path if path.endswith('.npz') else path + '.npz', *self.weights, **extra)
 
     def load(self, path):
         if path.endswith('.h5'):
@@ -221,7 +231,12 @@ class LayerGraph:
             keras_io.load_weights(self, path)
             return
         with np.load(path if path.endswith('.npz') else path + '.npz') as z:
-            self.set_weights([z['arr_%d' % i] for i in range(len(z.files))])
+            n = len([k for k in z.files if k.startswith('arr_')])
+            self.set_weights([z['arr_%d' % i] for i in range(n)])
+            self.opt_state = None
+            if 'opt_iterations' in z.files:
+                self.opt_state = ([z['opt_m_%d' % i] for i in range(n)],
+                                  [z['opt_v_%d' % i] for i in range(n)], int(z['opt_iterations']))
 
     def randomize_bn(self, seed=1):
         """non-trivial BN statistics for synthetic benchmarks"""

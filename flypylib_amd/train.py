@@ -332,6 +332,13 @@ class TowerGroup:
     def get_weights(self):
         return self.trainers[0].get_weights()
 
+    def get_opt_state(self):
+        return self.trainers[0].get_opt_state()       # the towers' Adam states are identical
+
+    def set_opt_state(self, m, v, steps):
+        for tr in self.trainers:
+            tr.set_opt_state(m, v, steps)
+
     def step(self, data, labels, batch_size, seed):
         """tower i trains on rows [i*batch_size, (i+1)*batch_size); returns the
         metrics of the whole batch (mean over the equally sized towers)"""
@@ -461,6 +468,10 @@ def _single_trainer(network, graph, loss, opt, opt_args):
         cached[1].close()
     ctx = runtime.get_context(network._device)
     trainer = _capi.Trainer(ctx, graph, loss=loss, **opt_args)
+    if getattr(graph, 'opt_state', None) is not None:
+        # a loaded network resumes with the optimizer it was saved with (Keras' load_model
+        # restores `optimizer_weights`, flypylib/fplnetwork.py:32-44)
+        trainer.set_opt_state(*graph.opt_state)
     network._trainer = (key, trainer)
     return trainer
 
@@ -507,6 +518,8 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
         if par._towers is None or par._towers_key != key:
             par.close()
             par._towers = TowerGroup(graph, par.devices, loss, _OPTIMIZERS[opt])
+            if getattr(graph, 'opt_state', None) is not None:
+                par._towers.set_opt_state(*graph.opt_state)
             par._towers_key = key
         towers = par._towers
         towers.set_weights(graph.get_weights())
@@ -564,6 +577,7 @@ def fit_generator(network, generator, steps_per_epoch, epochs, log_file,
                 step_no += 1
             weights = towers.get_weights() if towers else trainer.get_weights()
             graph.set_weights(weights)
+            graph.opt_state = (towers or trainer).get_opt_state()     # travels with every checkpoint
             vals = [tot[k] / steps_per_epoch for k in cols]
             if world > 1:
                 # the towers' mean, as Keras reports it for the concatenated batch

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FPL_ABI_VERSION 7
+#define FPL_ABI_VERSION 8
 
 typedef struct fpl_ctx fpl_ctx;
 typedef struct fpl_program fpl_program;
@@ -214,6 +214,12 @@ int fpl_v2o_nms_seg(fpl_ctx *ctx, double thresh, int32_t seg_dilate, int32_t seg
  * flat indices). */
 int fpl_v2o_smooth_f64(fpl_ctx *ctx, const double *pred, int pred_mem, const int64_t dims[3],
                        int32_t r, const double *weights, int32_t wr);
+/* INTEGER predictions (any integer dtype, handed over as exact doubles): scipy filters an
+ * integer array with float64 accumulation and stores every axis pass in the array's own type -
+ * a C cast, truncation toward zero (fplobjdetect.py:167-168 on an integer `pred`); numpy's
+ * percentile of it is a float64.  fpl_v2o_set_integer(ctx, 1) makes the NEXT
+ * fpl_v2o_smooth_f64 truncate after every pass; the rest of the float64 call order is unchanged. */
+int fpl_v2o_set_integer(fpl_ctx *ctx, int32_t on);
 int fpl_v2o_select_f64(fpl_ctx *ctx, const int64_t *ranks, int32_t n_ranks, double *rank_values);
 int fpl_v2o_rank_f64(fpl_ctx *ctx, double thresh, int64_t *n_candidates);
 int fpl_v2o_values_f64(fpl_ctx *ctx, const int64_t *flat, int64_t n, double *out);
@@ -287,6 +293,14 @@ int fpl_trainer_apply(fpl_trainer *t, float grad_scale);
 int fpl_trainer_grad_ptr(fpl_trainer *t, void **dev_ptr, int64_t *n_floats);
 int fpl_trainer_get_weights(fpl_trainer *t, float *out, int64_t n_weights);
 int fpl_trainer_set_weights(fpl_trainer *t, const float *w, int64_t n_weights);
+/* optimizer state: Adam's first / second moments (weight-arena layout; the slots of the
+ * moving statistics are unused) and the number of updates applied.  replaces: the
+ * `optimizer_weights` group of Keras' model.save, through which the reference keeps its
+ * optimizer across save_network / load_network and in the per-epoch files
+ * (flypylib/fplnetwork.py:9-17,32-44,81-97) */
+int fpl_trainer_get_opt_state(fpl_trainer *t, float *m, float *v, int64_t n_weights, int64_t *steps);
+int fpl_trainer_set_opt_state(fpl_trainer *t, const float *m, const float *v, int64_t n_weights,
+                              int64_t steps);
 /* tensors of the last step, for parity tests: grads (host copy of the arena) */
 int fpl_trainer_get_grads(fpl_trainer *t, float *out, int64_t n_weights);
 /* overwrite the gradient arena from the host (host-staged reductions: towers that

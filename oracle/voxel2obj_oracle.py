@@ -121,7 +121,10 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma, volume_offset=(0, 0, 0),
                 vol[seg == sid] = 0
     thresh = np.maximum(np.percentile(vol, 97), thd)
     picked = greedy_nms(vol, thresh, r, seg, seg_dilate, seg_force)
-    pts = (np.asarray(picked, dtype=np.float64) if picked
+    # reference :233-236: np.asarray of the [xx, yy, zz, max_val] rows - int64 for an integer
+    # volume (its values are integers of the array's dtype), float64 otherwise, and for no rows
+    int_rows = bool(picked) and np.issubdtype(vol.dtype, np.integer)
+    pts = (np.asarray(picked, dtype=np.int64 if int_rows else np.float64) if picked
            else np.zeros((0, 4)))
     pts[:, :3] -= r
     lo = np.array([buf[0], buf[1], buf[2], -np.inf])
@@ -131,4 +134,6 @@ def voxel2obj(pred, obj_min_dist, smoothing_sigma, volume_offset=(0, 0, 0),
                    np.inf])
     pts = pts[~np.any(pts >= hi, axis=1)]
     pts = pts + np.array([tuple(volume_offset) + (0,)])
+    if int_rows:
+        pts = pts.astype(np.int64)              # (in place `+=` in the reference keeps int64)
     return {'locs': pts[:, :3], 'conf': pts[:, 3]}

@@ -152,6 +152,27 @@ def gen_voxel2obj_f64():
     np.savez_compressed(os.path.join(HERE, 'voxel2obj_f64.npz'), **out)
 
 
+def gen_voxel2obj_int():
+    """integer predictions through the reference's voxel2obj: scipy filters an integer array
+    with float64 accumulation and a C cast (truncation) back to the integer type after every
+    axis; np.percentile gives a float64; the point list comes back as int64"""
+    from tests.helpers import V2O_INT_CASES, make_pred_int
+    out = {'names': np.array([c[0] for c in V2O_INT_CASES])}
+    for name, kind, seed, shape, dtype, scale, r, sigma, thd, buf, off, segp in V2O_INT_CASES:
+        pred = make_pred_int(kind, seed, shape, dtype, scale)
+        kw = {}
+        if segp is not None:
+            sseed, n_sites, tiny, dil, szt, force = segp
+            kw = dict(seg=synth.voronoi_segmentation(sseed, shape, n_sites, tiny), seg_dilate=dil,
+                      seg_sz_thd=szt, seg_force=force)
+        res = fplobjdetect.voxel2obj(pred.copy(), r, sigma, tuple(off), buf, thd, **kw)
+        out[name + '_locs'], out[name + '_conf'] = res['locs'], res['conf']
+        out[name + '_pred_sha'] = np.array(sha(pred))
+        print('%-12s %4d detections, dtypes %s / %s' % (name, len(res['conf']), res['locs'].dtype,
+                                                        res['conf'].dtype))
+    np.savez_compressed(os.path.join(HERE, 'voxel2obj_int.npz'), **out)
+
+
 class _FakeNet:
     """crop-identity stand-in for the Keras inference network"""
 
@@ -391,6 +412,7 @@ if __name__ == '__main__':
     gen_keras_tiny()
     gen_voxel2obj_seg()
     gen_voxel2obj_f64()
+    gen_voxel2obj_int()
     gen_synapses()
     gen_fri_get_image()
     gen_set_filter()

@@ -98,6 +98,20 @@ def make_pred_f64(kind, seed, shape):
     return base * (1.0 + 1e-9 * synth.hash_uniform_f32(seed + 7000, shape).astype(np.float64))
 
 
+# integer predictions (name, generator, seed, shape, dtype, scale, r, sigma, thd, buffer, offset, seg)
+V2O_INT_CASES = [
+    ('u8_blobs', 'blobs', 71, (60, 56, 64), 'uint8', 255, 9, 2.0, 20, 2, (0, 0, 0), None),
+    ('u8_pct', 'uniform', 72, (40, 44, 48), 'uint8', 255, 5, 1.5, 0, 0, (0, 0, 0), None),
+    ('i16_blobs', 'blobs', 73, (48, 52, 50), 'int16', 1000, 7, 3.0, 100, (1, 2, 3), (5, 6, 7), None),
+    ('i32_seg', 'blobs', 74, (56, 48, 52), 'int32', 100000, 9, 2.0, 5000, 0, (0, 0, 0), (6, 8, 30, 1, 60, 3)),
+]
+
+
+def make_pred_int(kind, seed, shape, dtype, scale):
+    """an integer volume: the float32 generator's values scaled and rounded"""
+    return np.round(make_pred(kind, seed, shape).astype(np.float64) * scale).astype(dtype)
+
+
 def same_detections(a, b, conf_tol, tie=2e-6):
     """Two `voxel2obj` / pipeline results name the same point SET (the north star's gate) with
     confidences within conf_tol, in the same descending-confidence order wherever that order

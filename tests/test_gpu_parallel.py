@@ -495,6 +495,40 @@ def test_save_network_load_network_round_trip_incl_keras_h5(ctx, tmp_path):
         fplnetwork.load_network(p)
 
 
+def test_a_reloaded_network_resumes_with_its_optimizer(ctx, tmp_path):
+    """Keras keeps Adam's moments and step count in the saved model (`optimizer_weights`) and
+    load_model restores them (fplnetwork.py:15-17,32-44,81-97): after save_network /
+    load_network - through the .npz and through the Keras file alone - the trainer starts from
+    the saved state, not from zero moments"""
+    import os
+    from flypylib_amd import fplnetwork
+    net = FplNetwork(fplmodels.vgg_like)
+    synth.synthetic_weights(net.train_single, 21)
+    rng = np.random.default_rng(3)
+
+    def gen():
+        while True:
+            yield (rng.standard_normal((8, 18, 18, 18, 1)).astype(np.float32),
+                   (rng.random((8, 1, 1, 1, 1)) > 0.5).astype(np.uint8))
+    net.train(gen(), 5, 1, None, None)
+    m0, v0, it0 = net.train_single.opt_state
+    assert it0 == 5 and any(np.abs(a).max() > 0 for a in m0)
+    p = str(tmp_path / 'net.p')
+    net.save_network(p)
+    for drop in (None, '.weights.npz'):
+        if drop:
+            os.remove(p + drop)                 # the reference's pair: pickle + Keras file
+        again = fplnetwork.load_network(p)
+        m1, v1, it1 = again.train_single.opt_state
+        assert it1 == 5 and all(np.array_equal(a, b) for a, b in zip(m0, m1))
+        assert all(np.array_equal(a, b) for a, b in zip(v0, v1))
+        again.train(gen(), 2, 1, None, None)
+        m2, v2, it2 = again.train_single.opt_state
+        assert it2 == 7                         # resumed, not restarted
+        tr = again._trainer[1]
+        assert tr.get_opt_state()[2] == 7
+
+
 def test_load_network_from_a_keras_file_written_by_libhdf5(ctx, tmp_path):
     """the reference's pair - pickle + `<path>.keras.h5` - with the `.h5` written by the
     HDF5 C library the way h5py >= 3 / tf.keras write it (variable-length string

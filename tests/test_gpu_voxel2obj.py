@@ -248,8 +248,32 @@ def test_float64_predictions_match_the_reference_bit_for_bit(ctx, golden, case):
     assert len(again['conf']) == len(res['conf']) and not np.array_equal(again['conf'], res['conf'])
 
 
+@pytest.mark.parametrize('case', helpers.V2O_INT_CASES, ids=[c[0] for c in helpers.V2O_INT_CASES])
+def test_integer_predictions_match_the_reference_bit_for_bit(ctx, golden, case):
+    """an integer `pred` (uint8 / int16 / int32) is smoothed in its own type - scipy
+    accumulates in float64 and truncates back to the integer type after every axis pass - then
+    thresholded by a float64 percentile; the reference returns int64 rows
+    (fplobjdetect.py:158-236): its own point lists, with and without a segmentation"""
+    g = golden('voxel2obj_int.npz')
+    name, kind, seed, shape, dtype, scale, r, sigma, thd, buf, off, segp = case
+    pred = helpers.make_pred_int(kind, seed, shape, dtype, scale)
+    assert helpers.sha(pred) == str(g[name + '_pred_sha'])
+    kw = {}
+    if segp is not None:
+        sseed, n_sites, tiny, dil, szt, force = segp
+        kw = dict(seg=synth.voronoi_segmentation(sseed, shape, n_sites, tiny), seg_dilate=dil,
+                  seg_sz_thd=szt, seg_force=force)
+    res = fplobjdetect.voxel2obj(pred, r, sigma, tuple(off), buf, thd, **kw)
+    assert len(g[name + '_conf']) > 5
+    assert res['locs'].dtype == g[name + '_locs'].dtype and res['conf'].dtype == g[name + '_conf'].dtype
+    assert np.array_equal(res['locs'], g[name + '_locs']), name
+    assert np.array_equal(res['conf'], g[name + '_conf']), name
+    # the float32 pipeline still works afterwards, and rounds differently
+    f32 = fplobjdetect.voxel2obj(pred.astype(np.float32), r, sigma, tuple(off), buf, thd, **kw)
+    assert f32['conf'].dtype == np.float64 and not np.array_equal(f32['conf'], res['conf'])
+
+
 def test_other_dtypes_are_refused_as_in_the_reference(ctx):
-    """scipy's gaussian_filter raises on float16 (the reference would fail there too);
-    integer volumes would be smoothed in integer arithmetic - neither is offered"""
-    with pytest.raises(TypeError, match='float32 or float64'):
+    """scipy's gaussian_filter raises on float16 (the reference would fail there too)"""
+    with pytest.raises(TypeError, match='float32, float64 or an integer'):
         fplobjdetect.voxel2obj(np.zeros((20, 20, 20), np.float16), 5, 2.0)

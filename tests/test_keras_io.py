@@ -351,3 +351,62 @@ def test_main_dataset_volume_files(tmp_path):
     assert np.array_equal(keras_io.read_main(str(tmp_path / 'lm_labels.h5')), labels)
     assert np.array_equal(keras_io.read_main(str(tmp_path / 'lm_mask.h5')), mask)
     assert labels.sum() == 123            # set_filter(3): 123 voxels
+
+
+def _graph_with_opt_state(seed=5):
+    g = fplmodels.vgg_like(30)[0]
+    synth.synthetic_weights(g, seed)
+    g.compile(loss='binary_crossentropy', optimizer='adam', metrics=['accuracy'])
+    rng = np.random.default_rng(seed)
+    m = [rng.standard_normal(w.shape).astype(np.float32) * 1e-3 for w in g.weights]
+    v = [rng.random(w.shape).astype(np.float32) * 1e-6 for w in g.weights]
+    for node in g.nodes:                      # the moving statistics have no optimizer state
+        if node.kind == 'bn':
+            for slot in node.weight_slots[2:]:
+                m[slot][...] = 0
+                v[slot][...] = 0
+    g.opt_state = (m, v, 1234)
+    return g
+
+
+def test_optimizer_state_round_trips_through_the_keras_file_and_the_npz(tmp_path):
+    """Keras' model.save keeps the optimizer (`optimizer_weights`: iterations, then Adam's
+    first and second moments in trainable_weights order) and load_model restores it - the
+    reference saves and loads networks through both (fplnetwork.py:9-17,32-44,81-97)"""
+    g = _graph_with_opt_state()
+    for name in ('w.h5', 'w.npz'):
+        p = str(tmp_path / name)
+        g.save(p)
+        h = fplmodels.vgg_like(30)[0]
+        assert h.opt_state is None
+        h.load(p)
+        assert all(np.array_equal(a, b) for a, b in zip(h.get_weights(), g.get_weights()))
+        m, v, it = h.opt_state
+        assert it == 1234
+        assert all(np.array_equal(a, b) for a, b in zip(m, g.opt_state[0]))
+        assert all(np.array_equal(a, b) for a, b in zip(v, g.opt_state[1]))
+    # a graph that was never trained writes no optimizer group and loads without one
+    g.opt_state = None
+    g.save(str(tmp_path / 'plain.h5'))
+    h.load(str(tmp_path / 'plain.h5'))
+    assert h.opt_state is None
+
+
+@needs_libhdf5
+def test_libhdf5_reads_the_optimizer_group(tmp_path):
+    """the group as Keras 2.0 - 2.1 lays it out: `weight_names` lists 'Adam/iterations:0' and
+    'training/Adam/Variable[_k]:0' - nested groups - iterations first, then ms, then vs"""
+    g = _graph_with_opt_state(6)
+    p = str(tmp_path / 'm.h5')
+    g.save(p)
+    t = h5lib.read_tree(p)
+    ow = t['groups']['optimizer_weights']
+    names = [n.decode() if isinstance(n, bytes) else str(n) for n in np.atleast_1d(ow['attrs']['weight_names'])]
+    n_train = sum(2 if n.kind == 'bn' else len(n.weight_slots) for n in g.nodes if n.kind in ('conv', 'bn'))
+    assert names[0] == 'Adam/iterations:0' and len(names) == 1 + 2 * n_train
+    assert names[1] == 'training/Adam/Variable:0' and names[2] == 'training/Adam/Variable_1:0'
+    assert int(np.asarray(ow['groups']['Adam']['datasets']['iterations:0'])) == 1234
+    adam = ow['groups']['training']['groups']['Adam']['datasets']
+    first_kernel = g.opt_state[0][g.nodes[1].weight_slots[0]]
+    assert np.array_equal(adam['Variable:0'], first_kernel)
+    assert np.array_equal(adam['Variable_%d:0' % n_train], g.opt_state[1][g.nodes[1].weight_slots[0]])

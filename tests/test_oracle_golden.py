@@ -138,3 +138,22 @@ def test_float64_voxel2obj_oracle_matches_reference(golden, case):
     assert np.array_equal(res['conf'], g[name + '_conf'])
     f32 = voxel2obj_oracle.voxel2obj(pred.astype(np.float32), r, sigma, tuple(off), buf, thd, **kw)
     assert not np.array_equal(f32['conf'], res['conf'])
+
+
+@pytest.mark.parametrize('case', helpers.V2O_INT_CASES, ids=[c[0] for c in helpers.V2O_INT_CASES])
+def test_integer_voxel2obj_oracle_matches_reference(golden, case):
+    """integer predictions: scipy's filter truncates back to the integer type after every axis,
+    the reference's rows come back as int64 - the oracle gives the reference's point lists"""
+    g = golden('voxel2obj_int.npz')
+    name, kind, seed, shape, dtype, scale, r, sigma, thd, buf, off, segp = case
+    pred = helpers.make_pred_int(kind, seed, shape, dtype, scale)
+    assert helpers.sha(pred) == str(g[name + '_pred_sha'])
+    kw = {}
+    if segp is not None:
+        sseed, n_sites, tiny, dil, szt, force = segp
+        kw = dict(seg=synth.voronoi_segmentation(sseed, shape, n_sites, tiny), seg_dilate=dil,
+                  seg_sz_thd=szt, seg_force=force)
+    res = voxel2obj_oracle.voxel2obj(pred, r, sigma, tuple(off), buf, thd, **kw)
+    assert res['locs'].dtype == g[name + '_locs'].dtype == np.int64
+    assert np.array_equal(res['locs'], g[name + '_locs'])
+    assert np.array_equal(res['conf'], g[name + '_conf'])
