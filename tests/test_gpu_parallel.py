@@ -329,9 +329,18 @@ def test_trainer_state_survives_train_calls(ctx):
     c.train(_gen(batches[:1]), 1, 1, None, None)
     c._trainer[1].close()
     c._trainer = None
+    c.train_single.opt_state = None             # (the state also lives with the graph: round 4)
     c.train(_gen(batches[1:]), 1, 1, None, None)
     with pytest.raises(AssertionError):
         _same_training(a.train_single.get_weights(), c.train_single.get_weights(), 2)
+    # ... and a NEW trainer picks the state up from the graph, as a reloaded Keras model does
+    d = FplNetwork(fplmodels.vgg_like)
+    d.train_single.set_weights(w0)
+    d.train(_gen(batches[:1]), 1, 1, None, None)
+    d._trainer[1].close()
+    d._trainer = None
+    d.train(_gen(batches[1:]), 1, 1, None, None)
+    _same_training(a.train_single.get_weights(), d.train_single.get_weights(), 2)
 
 
 # ---- make_train_parallel: one process per rank -----------------------------------------
