@@ -57,11 +57,12 @@ KERNEL_LAYERS = {
 PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f16s': 2500.0, 'f32': 157.3}     # MI355X_MICROARCH.md, dense
 
 
-def cpu_baseline(seconds_budget=8.0):
+def cpu_baseline(seconds_budget=30.0, tiles=36):
     """CPU oracle (oracle/cnn_oracle.py, torch-CPU fp32 conv3d) on reference tiles
-    102^3 -> 88^3 of the 520^3 case (configs[0]): all host cores of the box's share for
-    ~seconds_budget, then ONE thread for two tiles (the figure BASELINE.md quotes a
-    single-process Keras-CPU run against).  Runs BEFORE the GPU legs."""
+    102^3 -> 88^3 of the 520^3 case (configs[0]): one full z row of its 6 x 6 x 6 lattice -
+    36 tiles - on all host cores of the box's share (or what fits seconds_budget), then ONE
+    thread for two tiles (the figure BASELINE.md quotes a single-process Keras-CPU run
+    against).  Runs BEFORE the GPU legs."""
     import torch
     from flypylib_amd import fplmodels, synth
     from oracle import cnn_oracle
@@ -82,7 +83,7 @@ def cpu_baseline(seconds_budget=8.0):
         cnn_oracle.vgg_like_forward(tile, g.weights, 4)
         n += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_budget or n >= 64:
+        if dt > seconds_budget or n >= tiles:
             break
     torch.set_num_threads(1)
     t1 = time.perf_counter()

@@ -3,6 +3,7 @@ library surface.  No compute calls - there is no GPU in the build container."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -244,3 +245,27 @@ def test_voxel2obj_smoothing_compiles_without_fp64_fma(tmp_path):
         assert bodies, kernel
         for body in bodies:
             assert 'v_mul_f64' in body and 'v_add_f64' in body, kernel
+
+
+def test_headline_kernels_compile_without_scratch_spills():
+    """the split-half kernels of the headline path as hipcc builds them (the build's own flags;
+    metadata of the device assembly): the persistent mid and tail kernels and vgg_like2's tail
+    keep every register in the register file - a block-invariant load hoisted out of the
+    persistent loop, or the head chain run four sub-steps abreast, showed up here as 100 - 200
+    spilled registers in round 4.  The stem (256 registers, two waves per SIMD) still spills a
+    handful outside its MFMA chains; the bound keeps it from growing."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from flypylib_amd.csrc import build
+    if not shutil.which(build.HIPCC) and not os.path.exists(build.HIPCC):
+        pytest.skip('hipcc not available')
+    import kernel_resources
+    res = kernel_resources.kernel_resources('vgg_split.hip')
+    seen = set()
+    for name, v in res.items():
+        for key, limit in (('vggs_mid_pool', 0), ('vggs_c5_tail', 0), ('vggs_stem_pool', 48), ('vggs2_conv3', 0)):
+            if key in name:
+                seen.add(key)
+                assert v['vgpr_spill_count'] <= limit, (name, v)
+                assert v['vgpr_count'] <= 256
+    assert seen == {'vggs_mid_pool', 'vggs_c5_tail', 'vggs_stem_pool', 'vggs2_conv3'}
