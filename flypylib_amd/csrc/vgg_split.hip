@@ -145,6 +145,7 @@ struct StemSArgs {
   // per loaded voxel), conv1's pooled outputs are checked where they are split for the store
   unsigned *flag;
   float xlim;
+  unsigned char *dump;     // 64 B nobody reads: where lanes outside P1 store (x8::store12_sel)
 };
 
 __device__ __forceinline__ int stem_row_off(int row) {
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
   // tiles[buf][part]: buf 0 / 1, part hi / lo
   unsigned short *tiles = reinterpret_cast<unsigned short *>(smem);
   unsigned *lut = reinterpret_cast<unsigned *>(smem + 4 * S_TILE * 2);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: task counters in SGPRs
   const int c = lane & 15, g = lane >> 4;
   const int nblocks = a.nbx * a.nby * a.nbz;
   int q = blockIdx.x;
@@ -368,12 +370,20 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
   auto clampq = [&](int qq, int qlast) { return qq < nblocks ? qq : qlast; };
   StemRows<SRC> rr;
   StemEdge<SRC> ee;
+  StemBits hb;                          // the next row group, converted: carried from task to task
   {
     const StemBlock n0 = stem_block(a, clampq(q + G, q), lane);
     const SRC *bn;
     const unsigned tn = stem_row_tab<SRC>(a, n0, wrow0, lane, bn);
     stem_load_rows<SRC>(bn, tn, n0.xc, 0, rr);
     stem_load_edge<SRC>(a, n0, wrow0, lane, ee);
+    stem_convert_rows<SRC>(a, n0, lut, rr, hb, xmax);
+    stem_load_rows<SRC>(bn, tn, n0.xc, S_RPT, rr);
+    // four stores behind those loads, as every task of the loop below leaves them: the loop's
+    // wait for `rr` is then vmcnt(4 + ...) on the entry path too (the counter retires in order)
+    const f32x4 z3[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    __builtin_amdgcn_sched_barrier(0);
+    x8::store12_sel(a.p1, 0, g, z3, ovf, false, a.dump);
   }
   int cur = 0;
   for (;;) {
@@ -388,16 +398,18 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
     unsigned short *tnext = tiles + (cur ^ 1) * 2 * S_TILE;
 #pragma unroll 1
     for (int ti = 0; ti < S_TASKS; ++ti) {
-      // next block's tile, S_TASKS groups of S_RPT rows: group ti was loaded one task ago;
-      // it is converted here (table reads) and written after the first half of this
-      // task's MFMAs, where the loads of group ti + 1 - or, in the last task, of group 0
-      // of the block after next - are issued
-      StemBits hb;
-      stem_convert_rows<SRC>(a, nxt, lut, rr, hb, xmax);
-      const bool last = ti + 1 == S_TASKS;
-      const SRC *lbase = last ? base_2 : base_n;
-      const unsigned ltab = last ? tab_2 : tab_n, lxc = last ? nx2.xc : nxt.xc;
-      const int lidx = last ? 0 : S_RPT * (ti + 1);
+      // The next block's tile arrives in S_TASKS groups of S_RPT rows, three tasks per group:
+      // group ti + 2 is LOADED at the end of this task, in front of its P1 stores; group ti + 1
+      // (loaded a task ago, `rr`) is CONVERTED late in this task; group ti (`hb`) is WRITTEN
+      // to the idle tile buffer after the first half of this task's MFMAs.  Groups 8 and 9 are
+      // groups 0 and 1 of the block after next.  The vector-memory counter retires in order:
+      // with the loads issued BEFORE the task's stores, the conversion's wait for them
+      // (vmcnt(4)) leaves the stores in flight - issued behind them it was a wait for an HBM
+      // write every task.
+      const bool conv2 = ti + 1 >= S_TASKS, load2 = ti + 2 >= S_TASKS;
+      const SRC *lbase = load2 ? base_2 : base_n;
+      const unsigned ltab = load2 ? tab_2 : tab_n, lxc = load2 ? nx2.xc : nxt.xc;
+      const int lidx = S_RPT * ((ti + 2) & (S_TASKS - 1));
       const int task = wave + S_WAVES * ti;
       const int row = task >> 1, xh = task & 1;
       const int pzl = row / S_PY, pyl = row % S_PY;
@@ -408,67 +420,100 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       // INT: planes of padding in the 3 x 3 x 3 window of this lane's outputs (0 inside)
       const int xrel = (int)(blk.gx0 + 2 * (16 * xh + c) + 3 - a.SX);
       const int yrel = (int)(blk.gy0 + 2 * pyl + 3 - a.SY), zrel = (int)(blk.gz0 + 2 * pzl + 3 - a.z_hi);
+      // The 8 sub-steps (sub = 2 sp + e: window position sp, x parity e) as a software pipeline:
+      // the LDS reads of sub-step i + 1 - the gathered taps and, for uint8 volumes, the initial
+      // accumulator values - are issued before the MFMAs of sub-step i and land under them
+      // (left in place they were issued right in front of their use, and each wave spent 40 %
+      // of its cycles in s_waitcnt: profiles/r04_pmc_hbm_1024_f16s.json).
+      struct Gin {
+        unsigned p[INT ? 1 : 2][3], s0[INT ? 1 : 2], s1[INT ? 1 : 2];
+        f32x4 init[3];
+      };
+      auto gather = [&](int sub, Gin &o) {
+        const int sp = sub >> 1, e = sub & 1;
+        const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
 #pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        f32x4 a2[2][3];
-        const int pzy = 4 * min(max(zrel + (sp >> 1), 0), 3) + min(max(yrel + (sp & 1), 0), 3);
+        for (int part = 0; part < (INT ? 1 : 2); ++part) {
+          const unsigned char *tp = tb + part * (S_TILE * 2) + base + so;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {                 // sub = 2 sp + e: x parity e
-          const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
-          Frag2 bf;
+          for (int i = 0; i < 3; ++i) o.p[part][i] = *reinterpret_cast<const unsigned *>(tp + offP[e][i]);
+          o.s0[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
+          o.s1[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
+        }
+        if (INT) {
+          const int pzy = 4 * min(max(zrel + (sp >> 1), 0), 3) + min(max(yrel + (sp & 1), 0), 3);
+          const unsigned char *tp = shtab + ((4 * pzy + min(max(xrel + e, 0), 3)) * 48 + 4 * g) * 4;
 #pragma unroll
-          for (int part = 0; part < (INT ? 1 : 2); ++part) {
-            const unsigned char *tp = tb + part * (S_TILE * 2) + base + so;
-            u32x4 raw;
+          for (int b = 0; b < 3; ++b) o.init[b] = *reinterpret_cast<const f32x4 *>(tp + 64 * b);
+        }
+      };
+      Gin gcur, gnxt;
+      gather(0, gcur);
+      f32x4 a2[2][3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) raw[i] = *reinterpret_cast<const unsigned *>(tp + offP[e][i]);
-            const unsigned s0 = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
-            const unsigned s1 = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
-            raw[3] = s0 | (s1 << 16);
-            if (part == 0) bf.hi = __builtin_bit_cast(h16x8, raw);
-            else bf.lo = __builtin_bit_cast(h16x8, raw);
-          }
-          f32x4 a1[3];
-          if (INT) {
-            const unsigned char *tp = shtab + ((4 * pzy + min(max(xrel + e, 0), 3)) * 48 + 4 * g) * 4;
+      for (int sub = 0; sub < 8; ++sub) {
+        const int sp = sub >> 1, e = sub & 1;
+        if (sub + 1 < 8) gather(sub + 1, gnxt);
+        __builtin_amdgcn_sched_barrier(0);
+        Frag2 bf;
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
-              a1[b] = mfma16(w1[1][e][b], bf.hi, *reinterpret_cast<const f32x4 *>(tp + 64 * b));
-          } else {
+        for (int part = 0; part < (INT ? 1 : 2); ++part) {
+          const u32x4 raw = {gcur.p[part][0], gcur.p[part][1], gcur.p[part][2], gcur.s0[part] | (gcur.s1[part] << 16)};
+          if (part == 0) bf.hi = __builtin_bit_cast(h16x8, raw);
+          else bf.lo = __builtin_bit_cast(h16x8, raw);
+        }
+        f32x4 a1[3];
+        if (INT) {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, sh1[b]);
+          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, gcur.init[b]);
+        } else {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.lo, a1[b]);
-          }
+          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, sh1[b]);
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.hi, a1[b]);
-          const Frag2 h0 = pack_relu_split(a1[0], a1[1]);
-          const h16x8 hx = pack_relu_split_x(a1[2]);
-          // conv1 48->48 as chain48, M-blocks interleaved (independent accumulators)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][b], h0.hi, sh2g[b]);
-#pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.lo, a2[e][b]);
-#pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[2][b], hx, a2[e][b]);
-#pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[3][b], hx, a2[e][b]);
-#pragma unroll
-          for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.hi, a2[e][b]);
+          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.lo, a1[b]);
         }
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.hi, a1[b]);
+        const Frag2 h0 = pack_relu_split(a1[0], a1[1]);
+        const h16x8 hx = pack_relu_split_x(a1[2]);
+        // conv1 48->48 as chain48, M-blocks interleaved (independent accumulators)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
-        if (sp == 1) {
-          stem_write_rows<!INT>(tnext, wrow0, S_RPT * ti, lane, hb);
-          stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
+        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][b], h0.hi, sh2g[b]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.lo, a2[e][b]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[2][b], hx, a2[e][b]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[3][b], hx, a2[e][b]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.hi, a2[e][b]);
+        if (e == 1) {
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
+          if (sp == 1) stem_write_rows<!INT>(tnext, wrow0, S_RPT * ti, lane, hb);
+          if (sp == 2) {
+            // (opaque to the optimiser here: otherwise the first instruction of the conversion -
+            // and with it the wait for the loads - is hoisted to the top of the task)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < S_RPT; ++k) {
+              unsigned t = sizeof(SRC) == 1 ? (unsigned)rr.v[k] : __builtin_bit_cast(unsigned, (float)rr.v[k]);
+              asm volatile("" : "+v"(t));
+              rr.v[k] = sizeof(SRC) == 1 ? (SRC)t : (SRC)__builtin_bit_cast(float, t);
+            }
+            stem_convert_rows<SRC>(a, conv2 ? nx2 : nxt, lut, rr, hb, xmax);
+          }
         }
+        gcur = gnxt;
       }
+      stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
+      __builtin_amdgcn_sched_barrier(0);          // the stores stay behind the loads
       const int pz = blk.pz0 + pzl, py = blk.py0 + pyl, px = blk.px0 + 16 * xh + c;
-      if (pz < a.p1.Z && py < a.p1.Y && px < a.p1.X)
-        x8::store12(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, poolf, ovf);
+      x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, poolf, ovf,
+                      pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
     }
     if (!has_next) break;
     stem_store_edge<SRC>(a, tnext, lut, wrow0, lane, ee, xmax);
@@ -1576,6 +1621,8 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   void *p1v, *p2v;
   FPL_TRY(tmp.alloc((size_t)(p1.bytes() + p1.slack_bytes()), &p1v));
   FPL_TRY(tmp.alloc((size_t)(p2.bytes() + p2.slack_bytes()), &p2v));
+  void *dumpv;
+  FPL_TRY(tmp.alloc(256, &dumpv));
   // workgroups of the persistent kernels: one per CU, a multiple of the 8 XCDs
   const unsigned pgrid = (unsigned)std::max(8, ctx->n_cu / 8 * 8);
   const unsigned char *F = st->frags;
@@ -1604,7 +1651,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
         a.c0 = st->int_c0;
       }
       a.p1 = p1;
-      a.flag = flag; a.xlim = st->xlim;
+      a.flag = flag; a.xlim = st->xlim; a.dump = (unsigned char *)dumpv;
       a.nbx = (int)ceil_div64(P1X, S_PX); a.nby = (int)ceil_div64(P1Y, S_PY);
       a.nbz = (int)ceil_div64(P1Z, S_PZ);
       // persistent: one workgroup of 8 waves per CU walks the blocks

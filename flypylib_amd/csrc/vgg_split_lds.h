@@ -322,4 +322,27 @@ __device__ __forceinline__ void store12(const Tensor &t, int64_t vox, int g, con
   *reinterpret_cast<u32x2 *>(h + part) = u32x2{lo[4], lo[5]};
 }
 
+// The same store without a branch around it: lanes with `valid` false write their four pieces
+// to `dump` (64 B of scratch nobody reads; the pieces apart, so that no two merge into one store) and leave the guard alone.  For a kernel whose
+// loads in flight are counted against the stores behind them (vggs_stem_pool): with the
+// stores in a conditional block the wait-count pass has to assume the path without them.
+__device__ __forceinline__ void store12_sel(const Tensor &t, int64_t vox, int g, const f32x4 (&v)[3],
+                                            unsigned &ovf, bool valid, unsigned char *dump) {
+  unsigned hi[6], lo[6], o2 = 0u;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const Pair2 p0 = split_pk(v[b][0], v[b][1], o2), p1 = split_pk(v[b][2], v[b][3], o2);
+    hi[2 * b] = p0.hi; hi[2 * b + 1] = p1.hi;
+    lo[2 * b] = p0.lo; lo[2 * b + 1] = p1.lo;
+  }
+  ovf_note(ovf, valid ? o2 : 0u);
+  const int64_t part = t.part_bytes();
+  unsigned char *q = t.p + (int64_t)g * 2 * part + vox * 16;
+  unsigned char *h = t.p + (int64_t)(4 + (g >> 1)) * 2 * part + vox * 16 + 8 * (g & 1);
+  *reinterpret_cast<u32x4 *>(valid ? q : dump) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+  *reinterpret_cast<u32x4 *>(valid ? q + part : dump + 16) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+  *reinterpret_cast<u32x2 *>(valid ? h : dump + 32) = u32x2{hi[4], hi[5]};
+  *reinterpret_cast<u32x2 *>(valid ? h + part : dump + 48) = u32x2{lo[4], lo[5]};
+}
+
 }  // namespace x8
