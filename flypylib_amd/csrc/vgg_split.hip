@@ -385,6 +385,24 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     x8::store12_sel(a.p1, 0, g, z3, ovf, false, a.dump);
   }
+  // ---- the task loop, as ONE instruction stream laid out by hand ----------------------------
+  // A 16x16x32 MFMA holds the SIMD's issue port for 8 of its 16 cycles, an ordinary VALU
+  // instruction for 4 (v_fma_mix*_f16: 8) - tools/micro/mfma_valu_overlap.hip - and a stage
+  // (one sub-step: x parity e of window position sp) is 21 MFMAs next to ~58 VALU slots of
+  // ReLU, hi / lo conversion and pooling: issue-bound, but only if the two kinds alternate.
+  // Left to the compiler (and to two waves per SIMD running the same phases) they came in
+  // blocks: 19.8 ms, the SUM of the matrix pipe's 11.5 ms and the VALU's.  So the layers of a
+  // sub-step are skewed by one stage - stage k issues conv3 of sub-step k + 1 and conv1 of
+  // sub-step k, whose ReLU / split reads accumulators finished a stage ago - and the stage is
+  // written as 15 slots of [one MFMA, one piece of VALU work], pinned by sched_barriers, then
+  // a tail of six MFMAs under which the LDS reads of the next stage are issued (and, once a
+  // task, the previous task's P1 store or the next tile's row conversion).  The skew runs
+  // across tasks; only a block's first task primes it and its last one drains it.
+  struct Gin {                          // what conv3 of one sub-step reads from LDS
+    unsigned p[INT ? 1 : 2][3], s0[INT ? 1 : 2], s1[INT ? 1 : 2];
+    f32x4 init[3];
+  };
+  struct Geo { int base, xrel, yrel, zrel, pzl, pyl, xh; };
   int cur = 0;
   for (;;) {
     const int qn = q + G;
@@ -396,122 +414,174 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
     const unsigned tab_2 = stem_row_tab<SRC>(a, nx2, wrow0, lane, base_2);
     const unsigned char *tb = reinterpret_cast<const unsigned char *>(tiles + cur * 2 * S_TILE);
     unsigned short *tnext = tiles + (cur ^ 1) * 2 * S_TILE;
+    auto geo = [&](int ti) {
+      Geo t;
+      const int task = wave + S_WAVES * ti;
+      const int row = task >> 1;
+      t.xh = task & 1; t.pzl = row / S_PY; t.pyl = row % S_PY;
+      t.base = 2 * (((2 * t.pzl) * S_TY + 2 * t.pyl) * S_TP + 2 * (16 * t.xh + c));
+      // INT: planes of padding in the 3 x 3 x 3 window of this lane's outputs (0 inside)
+      t.xrel = (int)(blk.gx0 + 2 * (16 * t.xh + c) + 3 - a.SX);
+      t.yrel = (int)(blk.gy0 + 2 * t.pyl + 3 - a.SY);
+      t.zrel = (int)(blk.gz0 + 2 * t.pzl + 3 - a.z_hi);
+      return t;
+    };
+    auto gather = [&](const Geo &t, int sub, Gin &o) {
+      const int sp = sub >> 1, e = sub & 1;
+      const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
+#pragma unroll
+      for (int part = 0; part < (INT ? 1 : 2); ++part) {
+        const unsigned char *tp = tb + part * (S_TILE * 2) + t.base + so;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.p[part][i] = *reinterpret_cast<const unsigned *>(tp + offP[e][i]);
+        o.s0[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
+        o.s1[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
+      }
+      if (INT) {
+        const int pzy = 4 * min(max(t.zrel + (sp >> 1), 0), 3) + min(max(t.yrel + (sp & 1), 0), 3);
+        const unsigned char *tp = shtab + ((4 * pzy + min(max(t.xrel + e, 0), 3)) * 48 + 4 * g) * 4;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o.init[b] = *reinterpret_cast<const f32x4 *>(tp + 64 * b);
+      }
+    };
+    auto frag = [&](const Gin &gi, int part) {
+      const u32x4 raw = {gi.p[part][0], gi.p[part][1], gi.p[part][2], gi.s0[part] | (gi.s1[part] << 16)};
+      return __builtin_bit_cast(h16x8, raw);
+    };
+    constexpr int NC3 = INT ? 6 : 9;                    // conv3's MFMAs per sub-step
+    // MFMA i of conv3, x parity e, on the gathered fragments
+    auto c3 = [&](int i, int e, const Gin &gi, h16x8 bh, h16x8 bl, f32x4 (&o)[3]) {
+      const int b = i % 3, grp = i / 3;
+      if (grp == 0) o[b] = mfma16(w1[1][e][b], bh, INT ? gi.init[b] : sh1[b]);
+      else if (!INT && grp == 1) o[b] = mfma16(w1[0][e][b], bl, o[b]);
+      else o[b] = mfma16(w1[0][e][b], bh, o[b]);
+    };
+    // the state the skew carries from stage to stage (and task to task)
+    Gin G;                              // taps (+ initial values) of the sub-step conv3 does next
+    f32x4 a1n[3];                       // conv3 of the sub-step whose conv1 comes next
+    f32x4 s2[3];                        // conv1's shift, re-read per stage (registers)
+    f32x4 a2[2][3];                     // conv1 of the x pair being pooled
+    f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) a2[e][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {                                   // prime: conv3 of (task 0, sub-step 0), reads of sub-step 1
+      const Geo t0 = geo(0);
+      gather(t0, 0, G);
+      const h16x8 bh = frag(G, 0), bl = INT ? bh : frag(G, INT ? 0 : 1);
+#pragma unroll
+      for (int i = 0; i < NC3; ++i) c3(i, 0, G, bh, bl, a1n);
+      gather(t0, 1, G);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) s2[b] = sh2g[b];
+    }
 #pragma unroll 1
     for (int ti = 0; ti < S_TASKS; ++ti) {
       // The next block's tile arrives in S_TASKS groups of S_RPT rows, three tasks per group:
-      // group ti + 2 is LOADED at the end of this task, in front of its P1 stores; group ti + 1
-      // (loaded a task ago, `rr`) is CONVERTED late in this task; group ti (`hb`) is WRITTEN
-      // to the idle tile buffer after the first half of this task's MFMAs.  Groups 8 and 9 are
-      // groups 0 and 1 of the block after next.  The vector-memory counter retires in order:
-      // with the loads issued BEFORE the task's stores, the conversion's wait for them
-      // (vmcnt(4)) leaves the stores in flight - issued behind them it was a wait for an HBM
-      // write every task.
+      // group ti + 2 is LOADED at the end of this task; group ti + 1 (loaded a task ago, `rr`)
+      // is CONVERTED late in this task; group ti (`hb`) is WRITTEN to the idle tile buffer in
+      // its middle.  Groups 8 and 9 are groups 0 and 1 of the block after next.  The
+      // vector-memory counter retires in order: task ti - 1's P1 stores are issued (stage 0
+      // of this task) BEHIND the loads of its end, so the conversion's wait for those loads
+      // leaves the stores in flight.
       const bool conv2 = ti + 1 >= S_TASKS, load2 = ti + 2 >= S_TASKS;
       const SRC *lbase = load2 ? base_2 : base_n;
       const unsigned ltab = load2 ? tab_2 : tab_n, lxc = load2 ? nx2.xc : nxt.xc;
       const int lidx = S_RPT * ((ti + 2) & (S_TASKS - 1));
-      const int task = wave + S_WAVES * ti;
-      const int row = task >> 1, xh = task & 1;
-      const int pzl = row / S_PY, pyl = row % S_PY;
-      const int base = 2 * (((2 * pzl) * S_TY + 2 * pyl) * S_TP + 2 * (16 * xh + c));
-      // max-pool in fp32 (the split of the maximum is the maximum of the splits: the
-      // representation is monotonic); the initial 0 is the ReLU
-      f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      // INT: planes of padding in the 3 x 3 x 3 window of this lane's outputs (0 inside)
-      const int xrel = (int)(blk.gx0 + 2 * (16 * xh + c) + 3 - a.SX);
-      const int yrel = (int)(blk.gy0 + 2 * pyl + 3 - a.SY), zrel = (int)(blk.gz0 + 2 * pzl + 3 - a.z_hi);
-      // The 8 sub-steps (sub = 2 sp + e: window position sp, x parity e) as a software pipeline:
-      // the LDS reads of sub-step i + 1 - the gathered taps and, for uint8 volumes, the initial
-      // accumulator values - are issued before the MFMAs of sub-step i and land under them
-      // (left in place they were issued right in front of their use, and each wave spent 40 %
-      // of its cycles in s_waitcnt: profiles/r04_pmc_hbm_1024_f16s.json).
-      struct Gin {
-        unsigned p[INT ? 1 : 2][3], s0[INT ? 1 : 2], s1[INT ? 1 : 2];
-        f32x4 init[3];
-      };
-      auto gather = [&](int sub, Gin &o) {
-        const int sp = sub >> 1, e = sub & 1;
-        const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
-#pragma unroll
-        for (int part = 0; part < (INT ? 1 : 2); ++part) {
-          const unsigned char *tp = tb + part * (S_TILE * 2) + base + so;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) o.p[part][i] = *reinterpret_cast<const unsigned *>(tp + offP[e][i]);
-          o.s0[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
-          o.s1[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
-        }
-        if (INT) {
-          const int pzy = 4 * min(max(zrel + (sp >> 1), 0), 3) + min(max(yrel + (sp & 1), 0), 3);
-          const unsigned char *tp = shtab + ((4 * pzy + min(max(xrel + e, 0), 3)) * 48 + 4 * g) * 4;
-#pragma unroll
-          for (int b = 0; b < 3; ++b) o.init[b] = *reinterpret_cast<const f32x4 *>(tp + 64 * b);
-        }
-      };
-      Gin gcur, gnxt;
-      gather(0, gcur);
-      f32x4 a2[2][3];
+      const Geo tg = geo(ti), tn = geo((ti + 1) & (S_TASKS - 1)), tp = geo((ti + S_TASKS - 1) & (S_TASKS - 1));
 #pragma unroll
       for (int sub = 0; sub < 8; ++sub) {
-        const int sp = sub >> 1, e = sub & 1;
-        if (sub + 1 < 8) gather(sub + 1, gnxt);
-        __builtin_amdgcn_sched_barrier(0);
-        Frag2 bf;
-#pragma unroll
-        for (int part = 0; part < (INT ? 1 : 2); ++part) {
-          const u32x4 raw = {gcur.p[part][0], gcur.p[part][1], gcur.p[part][2], gcur.s0[part] | (gcur.s1[part] << 16)};
-          if (part == 0) bf.hi = __builtin_bit_cast(h16x8, raw);
-          else bf.lo = __builtin_bit_cast(h16x8, raw);
-        }
+        const int sp = sub >> 1, e = sub & 1, en = e ^ 1;
         f32x4 a1[3];
-        if (INT) {
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, gcur.init[b]);
-        } else {
+        for (int b = 0; b < 3; ++b) a1[b] = a1n[b];
+        const h16x8 bh = frag(G, 0), bl = INT ? bh : frag(G, INT ? 0 : 1);
+        float r[12];
+        unsigned hi[6], lo[6];
+        // VALU pieces: A = ReLU + hi conversion of value pair p, B = its lo halves,
+        // PL = two max-pool updates from the finished x pair
+        auto A = [&](int p) {
+          r[2 * p] = relu_f32(a1[p >> 1][2 * (p & 1)]);
+          r[2 * p + 1] = relu_f32(a1[p >> 1][2 * (p & 1) + 1]);
+          hi[p] = cvt_pk_h16(r[2 * p], r[2 * p + 1]);
+        };
+        auto B = [&](int p) {                           // (mfma_util.h::split_pk: tied to r's register)
+          unsigned l = __builtin_bit_cast(unsigned, r[2 * p]);
+          asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]\n\t"
+              "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+              : "+v"(l) : "v"(hi[p]), "v"(r[2 * p + 1]));
+          lo[p] = l;
+        };
+        auto PL = [&](int k) {
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[1][e][b], bf.hi, sh1[b]);
+          for (int j = 2 * k; j < 2 * k + 2; ++j)
+            poolf[j >> 2][j & 3] = __builtin_fmaxf(__builtin_fmaxf(poolf[j >> 2][j & 3], a2[0][j >> 2][j & 3]),
+                                                   a2[1][j >> 2][j & 3]);
+        };
+        // MFMA i of conv1: hi x hi and lo x hi first (they need only the hi halves)
+        auto c1 = [&](int i) {
+          const int b = i % 3, grp = i / 3;
+          const u32x4 h0h = {hi[0], hi[1], hi[2], hi[3]}, h0l = {lo[0], lo[1], lo[2], lo[3]};
+          const u32x4 hxv = {hi[4], hi[5], lo[4], lo[5]};
+          if (grp == 0) a2[e][b] = mfma16(w2[1][b], __builtin_bit_cast(h16x8, h0h), s2[b]);
+          if (grp == 1) a2[e][b] = mfma16(w2[0][b], __builtin_bit_cast(h16x8, h0h), a2[e][b]);
+          if (grp == 2) a2[e][b] = mfma16(w2[0][b], __builtin_bit_cast(h16x8, h0l), a2[e][b]);
+          if (grp == 3) a2[e][b] = mfma16(w2[2][b], __builtin_bit_cast(h16x8, hxv), a2[e][b]);
+          if (grp == 4) a2[e][b] = mfma16(w2[3][b], __builtin_bit_cast(h16x8, hxv), a2[e][b]);
+        };
 #pragma unroll
-          for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.lo, a1[b]);
+        for (int s = 0; s < 15; ++s) {
+          if (s < 6) c3(s, en, G, bh, bl, a1n);
+          else c1(s - 6);
+          if (s < 6 && e == 0) PL(s);                   // the pair finished a stage ago (sub 0: the last task's)
+          if (s < 4) A(s);
+          else if (s < 8) B(s - 4);
+          else if (s < 10) A(s - 4);
+          else if (s < 12) B(s - 6);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- tail: LDS reads of the stage after next, the unpaired MFMAs, the once-a-task work
+        if (sub + 2 < 8) gather(tg, sub + 2, G);
+        else gather(tn, sub + 2 - 8, G);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) a1[b] = mfma16(w1[0][e][b], bf.hi, a1[b]);
-        const Frag2 h0 = pack_relu_split(a1[0], a1[1]);
-        const h16x8 hx = pack_relu_split_x(a1[2]);
-        // conv1 48->48 as chain48, M-blocks interleaved (independent accumulators)
+        for (int b = 0; b < 3; ++b) s2[b] = sh2g[b];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[1][b], h0.hi, sh2g[b]);
+        for (int i = 6; i < NC3; ++i) c3(i, en, G, bh, bl, a1n);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.lo, a2[e][b]);
+        for (int i = 9; i < 15; ++i) c1(i);
+        if (sub == 0) {
+          // the previous task's pooled voxel (its last pair was pooled in the slots above)
+          const int pz = blk.pz0 + tp.pzl, py = blk.py0 + tp.pyl, px = blk.px0 + 16 * tp.xh + c;
+          x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, poolf, ovf,
+                          ti > 0 && pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[2][b], hx, a2[e][b]);
+          for (int b = 0; b < 3; ++b) poolf[b] = f32x4{0.f, 0.f, 0.f, 0.f};     // (the ReLU)
+        }
+        if (sub == 3) stem_write_rows<!INT>(tnext, wrow0, S_RPT * ti, lane, hb);
+        if (sub == 5) {
+          // (opaque to the optimiser here: otherwise the first instruction of the conversion -
+          // and with it the wait for the loads - is hoisted to the top of the task)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[3][b], hx, a2[e][b]);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) a2[e][b] = mfma16(w2[0][b], h0.hi, a2[e][b]);
-        if (e == 1) {
-#pragma unroll
-          for (int b = 0; b < 3; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
-          if (sp == 1) stem_write_rows<!INT>(tnext, wrow0, S_RPT * ti, lane, hb);
-          if (sp == 2) {
-            // (opaque to the optimiser here: otherwise the first instruction of the conversion -
-            // and with it the wait for the loads - is hoisted to the top of the task)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < S_RPT; ++k) {
-              unsigned t = sizeof(SRC) == 1 ? (unsigned)rr.v[k] : __builtin_bit_cast(unsigned, (float)rr.v[k]);
-              asm volatile("" : "+v"(t));
-              rr.v[k] = sizeof(SRC) == 1 ? (SRC)t : (SRC)__builtin_bit_cast(float, t);
-            }
-            stem_convert_rows<SRC>(a, conv2 ? nx2 : nxt, lut, rr, hb, xmax);
+          for (int k = 0; k < S_RPT; ++k) {
+            unsigned t = sizeof(SRC) == 1 ? (unsigned)rr.v[k] : __builtin_bit_cast(unsigned, (float)rr.v[k]);
+            asm volatile("" : "+v"(t));
+            rr.v[k] = sizeof(SRC) == 1 ? (SRC)t : (SRC)__builtin_bit_cast(float, t);
           }
+          stem_convert_rows<SRC>(a, conv2 ? nx2 : nxt, lut, rr, hb, xmax);
         }
-        gcur = gnxt;
+        if (sub == 7) stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
-      __builtin_amdgcn_sched_barrier(0);          // the stores stay behind the loads
-      const int pz = blk.pz0 + pzl, py = blk.py0 + pyl, px = blk.px0 + 16 * xh + c;
+    }
+    {                                   // drain: the last task's last pair and its store
+      const Geo t7 = geo(S_TASKS - 1);
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
+      const int pz = blk.pz0 + t7.pzl, py = blk.py0 + t7.pyl, px = blk.px0 + 16 * t7.xh + c;
       x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, poolf, ovf,
                       pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
     }
