@@ -683,16 +683,22 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
       bf[s] = *reinterpret_cast<const h16x8 *>(a.in + s * a.plane + m * CC + 8 * g);
+    // (the fragment reads are the same in every trip: without an offset the optimiser cannot
+    // see through, they are all hoisted out of the loop - 512 registers and 96 spilled ones
+    // in the 128 -> 128 split instance)
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    const unsigned char *wq = wl + zero;
     f32x4 acc[MB];
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
       acc[b] = sh[b];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wl + ((s * WMB + b) * 64 + lane) * 16),
+        acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wq + ((s * WMB + b) * 64 + lane) * 16),
                         bf[s], acc[b]);
         if (SPLIT)
-          acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wl + ((s * WMB + MB + b) * 64 + lane) * 16),
+          acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wq + ((s * WMB + MB + b) * 64 + lane) * 16),
                           bf[s], acc[b]);
       }
     }
