@@ -1455,9 +1455,25 @@ __global__ __launch_bounds__(256) void conv3_wgrad_cin1_f32(WgradArgs a, int64_t
 // input volume stays in L2) straight from global memory, one row ahead of the MFMAs.  The
 // LDS form above ran load -> barrier -> multiply -> barrier and reached a quarter of the
 // dY stream's HBM rate.
-__global__ __launch_bounds__(256) void conv3_wgrad_cin1_direct_f32(WgradArgs a, int64_t rows, int nbx) {
+// BG: dY is the input gradient of the BatchNorm (+ ReLU) that follows this convolution, made
+// from that layer's output gradient and input while loading (FplBnGrad, fast_paths.h).
+template <bool BG>
+__global__ __launch_bounds__(256) void conv3_wgrad_cin1_direct_f32(WgradArgs a, int64_t rows, int nbx,
+                                                                   FplBnGrad bg) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
+  // BG: this lane's three channels' constants
+  float bm[3], bs[3], bgam[3], bbet[3], bs0[3], bs1[3];
+  if (BG) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int co = 16 * b + c;
+      const bool ok = co < a.cout;
+      bm[b] = ok ? bg.bn.mean[co] : 0.f; bs[b] = ok ? bg.bn.invstd[co] : 0.f;
+      bgam[b] = ok ? bg.bn.gamma[co] : 0.f; bbet[b] = ok ? bg.bn.beta[co] : 0.f;
+      bs0[b] = ok ? bg.sum_g[co] : 0.f; bs1[b] = ok ? bg.sum_gx[co] : 0.f;
+    }
+  }
   int64_t toff[2];
   bool tap_ok[2];
 #pragma unroll
@@ -1479,7 +1495,9 @@ __global__ __launch_bounds__(256) void conv3_wgrad_cin1_direct_f32(WgradArgs a, 
     const int z = (int)(t % a.od);
     const int64_t n = t / a.od;
     const float *xr = a.x + (((int64_t)n * a.D + z) * a.H + y) * a.W;
-    const float *yr = a.dy + ((((int64_t)n * a.od + z) * a.oh + y) * a.ow) * a.cout;
+    const int64_t yoff = ((((int64_t)n * a.od + z) * a.oh + y) * a.ow) * a.cout;
+    const float *yr = (BG ? bg.g : a.dy) + yoff;
+    const float *yx = BG ? bg.x + yoff : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int xv = x0 + 4 * j + g;
@@ -1488,7 +1506,18 @@ __global__ __launch_bounds__(256) void conv3_wgrad_cin1_direct_f32(WgradArgs a, 
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
         const int co = 16 * b + c;
-        bn[j][b] = (ok && co < a.cout) ? yr[(int64_t)xs * a.cout + co] : 0.f;
+        const bool okc = ok && co < a.cout;
+        if (BG) {
+          // train.hip::bn_backward4<RELU = true>, the same operations in the same order
+          const float d = okc ? yr[(int64_t)xs * a.cout + co] : 0.f;
+          const float xq = okc ? yx[(int64_t)xs * a.cout + co] : 0.f;
+          const float gq = __fmaf_rn(__fmul_rn(__fsub_rn(xq, bm[b]), bs[b]), bgam[b], bbet[b]) > 0.f ? d : 0.f;
+          const float xh = (xq - bm[b]) * bs[b];
+          const float v = bgam[b] * bs[b] * (gq - bg.inv_m * bs0[b] - xh * bg.inv_m * bs1[b]);
+          bn[j][b] = okc ? v : 0.f;
+        } else {
+          bn[j][b] = okc ? yr[(int64_t)xs * a.cout + co] : 0.f;
+        }
       }
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) an[j][mb] = (ok && tap_ok[mb]) ? xr[xs + toff[mb]] : 0.f;
@@ -1834,10 +1863,17 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
 }
 
 // dw [k^3][cin][cout] += weight gradient (float atomics)
+bool fpl_tm_bn_grad_supported(int k, int cin, int cout) {
+  return k == 3 && cin == 1 && cout <= 48 && !getenv("FPL_WGRAD_CIN1_LDS");
+}
+
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
-                      const float *dy, int k, int cout, float *dw, const FplBnView *bn) {
+                      const float *dy, int k, int cout, float *dw, const FplBnView *bn,
+                      const FplBnGrad *bg) {
   FPL_REQUIRE(ctx, !bn || fpl_tm_bn_view_supported(k, cin, cout),
               "conv wgrad: no BatchNorm-view kernel for k %d, %d -> %d", k, cin, cout);
+  FPL_REQUIRE(ctx, !bg || fpl_tm_bn_grad_supported(k, cin, cout),
+              "conv wgrad: no BatchNorm-gradient kernel for k %d, %d -> %d", k, cin, cout);
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
   const int ncc = (cin + 15) / 16, nco = (cout + 47) / 48;
   DevTemp tmp(ctx);
@@ -1875,7 +1911,8 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
     }
     const int64_t rows = (int64_t)n * od * oh * nbx;
     const unsigned gridd = (unsigned)std::min<int64_t>(ceil_div64(rows, 4), (int64_t)ctx->n_cu * 8);
-    conv3_wgrad_cin1_direct_f32<<<gridd, 256, 0, ctx->stream>>>(a, rows, nbx);
+    if (bg) conv3_wgrad_cin1_direct_f32<true><<<gridd, 256, 0, ctx->stream>>>(a, rows, nbx, *bg);
+    else conv3_wgrad_cin1_direct_f32<false><<<gridd, 256, 0, ctx->stream>>>(a, rows, nbx, FplBnGrad{});
     return 0;
   }
   constexpr int SMEM = TILE_BYTES + 256 * WG_YP;

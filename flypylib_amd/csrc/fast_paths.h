@@ -108,8 +108,17 @@ struct FplBnStat { const float *x; FplBnView bn; double *part; };
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
                       int k, int cin, const float *Wd, const float *zeros, float *dx,
                       const FplBnStat *bstat = nullptr);
+// `bg` (optional, fpl_tm_bn_grad_supported(k, cin, cout)): dy is not a tensor but the input
+// gradient of a training-mode BatchNorm (+ ReLU) whose output gradient is bg->g and whose
+// input - this convolution's output - is bg->x: dy = gamma * invstd * (g' - sum_g / M - xhat *
+// sum_gx / M), g' = g where bn(x) > 0 (train.hip::bn_backward4, the same rounding sequence),
+// computed while loading.  That BN's elementwise backward pass - one write and one read
+// of the layer's largest tensor - is then not run at all.
+struct FplBnGrad { const float *g, *x; FplBnView bn; const float *sum_g, *sum_gx; float inv_m; };
+bool fpl_tm_bn_grad_supported(int k, int cin, int cout);
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
-                      const float *dy, int k, int cout, float *dw, const FplBnView *bn = nullptr);
+                      const float *dy, int k, int cout, float *dw, const FplBnView *bn = nullptr,
+                      const FplBnGrad *bg = nullptr);
 
 // Split-operand IEEE-half path for vgg_like (vgg_split.hip, FPL_PREC_F16S): every
 // activation and folded weight is carried as hi + lo (two halves, ~22 significant bits)

@@ -1130,6 +1130,9 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   std::vector<int> bn_view(nt, -1);            // tensor -> BN layer whose relu output it is
   std::vector<double *> bn_bstat(nl, nullptr); // BN layer -> backward sums made by its consumer
   std::vector<int> bn_bstat_rows(nl, 0);
+  // tensor -> its gradient is not written: the convolution that made the tensor forms it in
+  // its weight-gradient loader from the BatchNorm's output gradient (FplBnGrad, fast_paths.h)
+  std::vector<FplBnGrad> bn_grad(nt, FplBnGrad{});
   for (int li = 0; li + 2 < nl; ++li) {
     if (!bn_fused[li] || pool_fused[li] || !use_mfma || !use_mfma_bwd) continue;
     const fpl_layer &B = t->layers[li], &R = t->layers[li + 1];
@@ -1381,8 +1384,9 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
           FplBnView bv;
           const bool viewed = bn_view[L.src0] >= 0;
           const float *xin = viewed ? view_of(L.src0, &bv) : val[L.src0];
+          const FplBnGrad *bgv = bn_grad[L.dst].g ? &bn_grad[L.dst] : nullptr;
           FPL_TRY(fpl_tm_conv_wgrad(ctx, xin, batch, a.d, a.h, a.w, a.c, dy, L.k,
-                                    L.cout, t->g + L.w_off[0], viewed ? &bv : nullptr));
+                                    L.cout, t->g + L.w_off[0], viewed ? &bv : nullptr, bgv));
           if (L.use_bias) {
             const int rr = red_rows(n_vox), nb = (int)ceil_div64(n_vox, rr);
             const int R = std::max(1, 256 / L.cout);
@@ -1513,6 +1517,24 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
         accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
         accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
         const int acc = dx && !assign[L.src0];
+        // The tensor's only reader is the weight gradient of the first convolution (cin = 1:
+        // no input gradient): that kernel makes dx from dy and x itself - this pass's write
+        // and that kernel's read of the step's largest tensor (1.46 GB each at 32 x 64^3) go
+        int prod = -1;
+        for (int lp = 0; lp < li; ++lp)
+          if (t->layers[lp].dst == L.src0) prod = lp;
+        if (dx && v4 && bn_fused[li] && !acc && prod >= 0 && t->layers[prod].kind == FPL_L_CONV &&
+            t->layers[prod].src0 == 0 && !t->layers[prod].use_bias && use_mfma_bwd &&
+            fpl_tm_bwd_supported(t->layers[prod].k, t->layers[prod].cin, t->layers[prod].cout) &&
+            fpl_tm_bn_grad_supported(t->layers[prod].k, t->layers[prod].cin, t->layers[prod].cout) &&
+            !getenv("FPL_TRAIN_BNGRAD_SEPARATE")) {
+          FplBnGrad &bgv = bn_grad[L.src0];
+          bgv.g = dy; bgv.x = val[L.src0];
+          bgv.bn.mean = bn_mean[li]; bgv.bn.invstd = bn_invstd[li];
+          bgv.bn.gamma = t->w + L.w_off[0]; bgv.bn.beta = t->w + L.w_off[1];
+          bgv.sum_g = sdy; bgv.sum_gx = sdyx; bgv.inv_m = 1.f / (float)M;
+          break;
+        }
         if (dx && v4) {
           typedef const float4 *cf4;
 #define FPL_BNB4(RELU, ACC, YP)                                                            \

@@ -118,8 +118,10 @@ def test_fused_and_separate_bn_relu_pool_agree(ctx, monkeypatch):
 def test_bn_in_the_conv_loader_and_sums_in_the_dgrad_epilogue(ctx, monkeypatch):
     """round 3's fusions around the first block's 1x1x1 convolution - BatchNorm + ReLU applied
     by its loader (forward and weight gradient), the BN backward sums made in its input-
-    gradient epilogue - against the same step with the sums in their own pass
-    (FPL_TRAIN_BNSTAT_SEPARATE) and with every layer as its own kernel (FPL_TRAIN_UNFUSED):
+    gradient epilogue - and round 4's: the first BatchNorm's input gradient made by the first
+    convolution's weight-gradient loader instead of an elementwise pass - against the same step
+    with the sums in their own pass (FPL_TRAIN_BNSTAT_SEPARATE), with that elementwise pass
+    (FPL_TRAIN_BNGRAD_SEPARATE) and with every layer as its own kernel (FPL_TRAIN_UNFUSED):
     identical up to the order of fp64 partial sums and the float atomics of the weight
     gradients.  (The oracle holds the default, fused, step in the tests above.)"""
     g = fplmodels.vgg_like()[0]
@@ -131,7 +133,7 @@ def test_bn_in_the_conv_loader_and_sums_in_the_dgrad_epilogue(ctx, monkeypatch):
     loss_f, acc_f = tr.step(data, lab, seed=5)
     grads_f = [x.copy() for x in tr.get_grads()]
     tr.close()
-    for env in ('FPL_TRAIN_BNSTAT_SEPARATE', 'FPL_TRAIN_UNFUSED'):
+    for env in ('FPL_TRAIN_BNSTAT_SEPARATE', 'FPL_TRAIN_BNGRAD_SEPARATE', 'FPL_TRAIN_UNFUSED'):
         monkeypatch.setenv(env, '1')
         tr2 = _capi.Trainer(ctx, g)
         loss_s, acc_s = tr2.step(data, lab, seed=5)
