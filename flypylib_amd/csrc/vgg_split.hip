@@ -26,6 +26,7 @@
 #include "fast_paths.h"
 #include "mfma_util.h"
 #include "pack_weights.h"
+#include <type_traits>
 #include "vgg_split_lds.h"
 #include "vgg_tiles.h"
 
@@ -126,7 +127,7 @@ constexpr int S_RPT = 3;                       // rows per task iteration
 static_assert(S_RPT * S_TASKS >= S_WROWS && S_WROWS <= 64, "stem fill schedule");
 constexpr int S_SHTAB = 64 * 48;                // u8 path: floats of the initial-value table
 constexpr int S_SH2 = 4 * 12;                   // conv1's shift as [g][b][r] floats (one 16-B read per M-block)
-constexpr int S_SMEM = 4 * S_TILE * 2 + 256 * 4 + S_SHTAB * 4 + S_SH2 * 4;
+constexpr int S_SMEM = 4 * S_TILE * 2 + 256 * 4 + S_SHTAB * 4 + 2 * S_SH2 * 4;   // shift2 and -shift2
 
 struct StemSArgs {
   const void *src;
@@ -323,8 +324,17 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
   h16x8 w1[2][2][3], w2[4][3];
   // conv1's shift lives in LDS (12 registers fewer across the task loop: no spills)
   float *sh2t = reinterpret_cast<float *>(smem + 4 * S_TILE * 2 + 256 * 4 + S_SHTAB * 4);
-  if (tid < S_SH2) sh2t[tid] = a.shift2[x8::out_channel((tid % 12) / 4, tid / 12, tid % 4)];
+  if (tid < S_SH2) {
+    const float v = a.shift2[x8::out_channel((tid % 12) / 4, tid / 12, tid % 4)];
+    sh2t[tid] = v;
+    sh2t[S_SH2 + tid] = -v;
+  }
+  // conv1's shift is the same for the eight window positions of a pooled voxel, and
+  // max_i(x_i + s) = max_i(x_i) + s with the same rounding: the accumulators start from 0, the
+  // running maximum from -s (which is the ReLU: max(max_i x_i, -s) + s), and s is added once per
+  // task in front of the store - two table reads per task where every sub-step made three
   const f32x4 *sh2g = reinterpret_cast<const f32x4 *>(sh2t + 12 * g);
+  const f32x4 *sh2n = reinterpret_cast<const f32x4 *>(sh2t + S_SH2 + 12 * g);
   f32x4 sh1[3];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -426,165 +436,183 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       t.zrel = (int)(blk.gz0 + 2 * t.pzl + 3 - a.z_hi);
       return t;
     };
-    auto gather = [&](const Geo &t, int sub, Gin &o) {
-      const int sp = sub >> 1, e = sub & 1;
-      const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
+    // uint8 volumes: a block whose windows stay clear of the padding past the volume (all but the
+    // far faces' blocks) starts every conv3 accumulator from ONE vector per lane - entry 0 of the
+    // table - so its pass is compiled without the three 16-B table reads per sub-step
+    const bool interior = INT && blk.gx0 + 2 * S_PX + 2 <= a.SX && blk.gy0 + 2 * S_PY + 2 <= a.SY &&
+                          blk.gz0 + 2 * S_PZ + 2 <= a.z_hi;
+    auto block_pass = [&](auto edge_t) {
+      constexpr bool EDGE = decltype(edge_t)::value;
+      f32x4 kin[3];
+      if (INT && !EDGE) {
 #pragma unroll
-      for (int part = 0; part < (INT ? 1 : 2); ++part) {
-        const unsigned char *tp = tb + part * (S_TILE * 2) + t.base + so;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) o.p[part][i] = *reinterpret_cast<const unsigned *>(tp + offP[e][i]);
-        o.s0[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
-        o.s1[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
+        for (int b = 0; b < 3; ++b) kin[b] = *reinterpret_cast<const f32x4 *>(shtab + (4 * g) * 4 + 64 * b);
       }
-      if (INT) {
-        const int pzy = 4 * min(max(t.zrel + (sp >> 1), 0), 3) + min(max(t.yrel + (sp & 1), 0), 3);
-        const unsigned char *tp = shtab + ((4 * pzy + min(max(t.xrel + e, 0), 3)) * 48 + 4 * g) * 4;
+      auto gather = [&](const Geo &t, int sub, Gin &o) {
+        const int sp = sub >> 1, e = sub & 1;
+        const int so = 2 * ((((sp >> 1) & 1) * S_TY + (sp & 1)) * S_TP);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) o.init[b] = *reinterpret_cast<const f32x4 *>(tp + 64 * b);
-      }
-    };
-    auto frag = [&](const Gin &gi, int part) {
-      const u32x4 raw = {gi.p[part][0], gi.p[part][1], gi.p[part][2], gi.s0[part] | (gi.s1[part] << 16)};
-      return __builtin_bit_cast(h16x8, raw);
-    };
-    constexpr int NC3 = INT ? 6 : 9;                    // conv3's MFMAs per sub-step
-    // MFMA i of conv3, x parity e, on the gathered fragments
-    auto c3 = [&](int i, int e, const Gin &gi, h16x8 bh, h16x8 bl, f32x4 (&o)[3]) {
-      const int b = i % 3, grp = i / 3;
-      if (grp == 0) o[b] = mfma16(w1[1][e][b], bh, INT ? gi.init[b] : sh1[b]);
-      else if (!INT && grp == 1) o[b] = mfma16(w1[0][e][b], bl, o[b]);
-      else o[b] = mfma16(w1[0][e][b], bh, o[b]);
-    };
-    // the state the skew carries from stage to stage (and task to task)
-    Gin G;                              // taps (+ initial values) of the sub-step conv3 does next
-    f32x4 a1n[3];                       // conv3 of the sub-step whose conv1 comes next
-    f32x4 s2[3];                        // conv1's shift, re-read per stage (registers)
-    f32x4 a2[2][3];                     // conv1 of the x pair being pooled
-    f32x4 poolf[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        for (int part = 0; part < (INT ? 1 : 2); ++part) {
+          const unsigned char *tp = tb + part * (S_TILE * 2) + t.base + so;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+          for (int i = 0; i < 3; ++i) o.p[part][i] = *reinterpret_cast<const unsigned *>(tp + offP[e][i]);
+          o.s0[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
+          o.s1[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
+        }
+        if (INT && EDGE) {
+          const int pzy = 4 * min(max(t.zrel + (sp >> 1), 0), 3) + min(max(t.yrel + (sp & 1), 0), 3);
+          const unsigned char *tp = shtab + ((4 * pzy + min(max(t.xrel + e, 0), 3)) * 48 + 4 * g) * 4;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) a2[e][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {                                   // prime: conv3 of (task 0, sub-step 0), reads of sub-step 1
-      const Geo t0 = geo(0);
-      gather(t0, 0, G);
-      const h16x8 bh = frag(G, 0), bl = INT ? bh : frag(G, INT ? 0 : 1);
+          for (int b = 0; b < 3; ++b) o.init[b] = *reinterpret_cast<const f32x4 *>(tp + 64 * b);
+        }
+      };
+      auto frag = [&](const Gin &gi, int part) {
+        const u32x4 raw = {gi.p[part][0], gi.p[part][1], gi.p[part][2], gi.s0[part] | (gi.s1[part] << 16)};
+        return __builtin_bit_cast(h16x8, raw);
+      };
+      constexpr int NC3 = INT ? 6 : 9;                    // conv3's MFMAs per sub-step
+      // MFMA i of conv3, x parity e, on the gathered fragments
+      auto c3 = [&](int i, int e, const Gin &gi, h16x8 bh, h16x8 bl, f32x4 (&o)[3]) {
+        const int b = i % 3, grp = i / 3;
+        if (grp == 0) o[b] = mfma16(w1[1][e][b], bh, INT ? (EDGE ? gi.init[b] : kin[b]) : sh1[b]);
+        else if (!INT && grp == 1) o[b] = mfma16(w1[0][e][b], bl, o[b]);
+        else o[b] = mfma16(w1[0][e][b], bh, o[b]);
+      };
+      // the state the skew carries from stage to stage (and task to task)
+      Gin G;                              // taps (+ initial values) of the sub-step conv3 does next
+      f32x4 a1n[3];                       // conv3 of the sub-step whose conv1 comes next
+      f32x4 a2[2][3];                     // conv1 of the x pair being pooled
+      f32x4 poolf[3];                     // running maximum of the task, started from -shift2
 #pragma unroll
-      for (int i = 0; i < NC3; ++i) c3(i, 0, G, bh, bl, a1n);
-      gather(t0, 1, G);
+      for (int b = 0; b < 3; ++b) poolf[b] = sh2n[b];
 #pragma unroll
-      for (int b = 0; b < 3; ++b) s2[b] = sh2g[b];
-    }
-#pragma unroll 1
-    for (int ti = 0; ti < S_TASKS; ++ti) {
-      // The next block's tile arrives in S_TASKS groups of S_RPT rows, three tasks per group:
-      // group ti + 2 is LOADED at the end of this task; group ti + 1 (loaded a task ago, `rr`)
-      // is CONVERTED late in this task; group ti (`hb`) is WRITTEN to the idle tile buffer in
-      // its middle.  Groups 8 and 9 are groups 0 and 1 of the block after next.  The
-      // vector-memory counter retires in order: task ti - 1's P1 stores are issued (stage 0
-      // of this task) BEHIND the loads of its end, so the conversion's wait for those loads
-      // leaves the stores in flight.
-      const bool conv2 = ti + 1 >= S_TASKS, load2 = ti + 2 >= S_TASKS;
-      const SRC *lbase = load2 ? base_2 : base_n;
-      const unsigned ltab = load2 ? tab_2 : tab_n, lxc = load2 ? nx2.xc : nxt.xc;
-      const int lidx = S_RPT * ((ti + 2) & (S_TASKS - 1));
-      const Geo tg = geo(ti), tn = geo((ti + 1) & (S_TASKS - 1)), tp = geo((ti + S_TASKS - 1) & (S_TASKS - 1));
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int sub = 0; sub < 8; ++sub) {
-        const int sp = sub >> 1, e = sub & 1, en = e ^ 1;
-        f32x4 a1[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) a1[b] = a1n[b];
+        for (int b = 0; b < 3; ++b) a2[e][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      {                                   // prime: conv3 of (task 0, sub-step 0), reads of sub-step 1
+        const Geo t0 = geo(0);
+        gather(t0, 0, G);
         const h16x8 bh = frag(G, 0), bl = INT ? bh : frag(G, INT ? 0 : 1);
-        float r[12];
-        unsigned hi[6], lo[6];
-        // VALU pieces: A = ReLU + hi conversion of value pair p, B = its lo halves,
-        // PL = two max-pool updates from the finished x pair
-        auto A = [&](int p) {
-          r[2 * p] = relu_f32(a1[p >> 1][2 * (p & 1)]);
-          r[2 * p + 1] = relu_f32(a1[p >> 1][2 * (p & 1) + 1]);
-          hi[p] = cvt_pk_h16(r[2 * p], r[2 * p + 1]);
-        };
-        auto B = [&](int p) {                           // (mfma_util.h::split_pk: tied to r's register)
-          unsigned l = __builtin_bit_cast(unsigned, r[2 * p]);
-          asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]\n\t"
-              "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-              : "+v"(l) : "v"(hi[p]), "v"(r[2 * p + 1]));
-          lo[p] = l;
-        };
-        auto PL = [&](int k) {
 #pragma unroll
-          for (int j = 2 * k; j < 2 * k + 2; ++j)
-            poolf[j >> 2][j & 3] = __builtin_fmaxf(__builtin_fmaxf(poolf[j >> 2][j & 3], a2[0][j >> 2][j & 3]),
-                                                   a2[1][j >> 2][j & 3]);
-        };
-        // MFMA i of conv1: hi x hi and lo x hi first (they need only the hi halves)
-        auto c1 = [&](int i) {
-          const int b = i % 3, grp = i / 3;
-          const u32x4 h0h = {hi[0], hi[1], hi[2], hi[3]}, h0l = {lo[0], lo[1], lo[2], lo[3]};
-          const u32x4 hxv = {hi[4], hi[5], lo[4], lo[5]};
-          if (grp == 0) a2[e][b] = mfma16(w2[1][b], __builtin_bit_cast(h16x8, h0h), s2[b]);
-          if (grp == 1) a2[e][b] = mfma16(w2[0][b], __builtin_bit_cast(h16x8, h0h), a2[e][b]);
-          if (grp == 2) a2[e][b] = mfma16(w2[0][b], __builtin_bit_cast(h16x8, h0l), a2[e][b]);
-          if (grp == 3) a2[e][b] = mfma16(w2[2][b], __builtin_bit_cast(h16x8, hxv), a2[e][b]);
-          if (grp == 4) a2[e][b] = mfma16(w2[3][b], __builtin_bit_cast(h16x8, hxv), a2[e][b]);
-        };
+        for (int i = 0; i < NC3; ++i) c3(i, 0, G, bh, bl, a1n);
+        gather(t0, 1, G);
+      }
+#pragma unroll 1
+      for (int ti = 0; ti < S_TASKS; ++ti) {
+        // The next block's tile arrives in S_TASKS groups of S_RPT rows, three tasks per group:
+        // group ti + 2 is LOADED at the end of this task; group ti + 1 (loaded a task ago, `rr`)
+        // is CONVERTED late in this task; group ti (`hb`) is WRITTEN to the idle tile buffer in
+        // its middle.  Groups 8 and 9 are groups 0 and 1 of the block after next.  The
+        // vector-memory counter retires in order: task ti - 1's P1 stores are issued (stage 0
+        // of this task) BEHIND the loads of its end, so the conversion's wait for those loads
+        // leaves the stores in flight.
+        const bool conv2 = ti + 1 >= S_TASKS, load2 = ti + 2 >= S_TASKS;
+        const SRC *lbase = load2 ? base_2 : base_n;
+        const unsigned ltab = load2 ? tab_2 : tab_n, lxc = load2 ? nx2.xc : nxt.xc;
+        const int lidx = S_RPT * ((ti + 2) & (S_TASKS - 1));
+        const Geo tg = geo(ti), tn = geo((ti + 1) & (S_TASKS - 1)), tp = geo((ti + S_TASKS - 1) & (S_TASKS - 1));
 #pragma unroll
-        for (int s = 0; s < 15; ++s) {
-          if (s < 6) c3(s, en, G, bh, bl, a1n);
-          else c1(s - 6);
-          if (s < 6 && e == 0) PL(s);                   // the pair finished a stage ago (sub 0: the last task's)
-          if (s < 4) A(s);
-          else if (s < 8) B(s - 4);
-          else if (s < 10) A(s - 4);
-          else if (s < 12) B(s - 6);
+        for (int sub = 0; sub < 8; ++sub) {
+          const int sp = sub >> 1, e = sub & 1, en = e ^ 1;
+          f32x4 a1[3];
+#pragma unroll
+          for (int b = 0; b < 3; ++b) a1[b] = a1n[b];
+          const h16x8 bh = frag(G, 0), bl = INT ? bh : frag(G, INT ? 0 : 1);
+          float r[12];
+          unsigned hi[6], lo[6];
+          // VALU pieces: A = ReLU + hi conversion of value pair p, B = its lo halves,
+          // PL = two max-pool updates from the finished x pair
+          auto A = [&](int p) {
+            r[2 * p] = relu_f32(a1[p >> 1][2 * (p & 1)]);
+            r[2 * p + 1] = relu_f32(a1[p >> 1][2 * (p & 1) + 1]);
+            hi[p] = cvt_pk_h16(r[2 * p], r[2 * p + 1]);
+          };
+          auto B = [&](int p) {                           // (mfma_util.h::split_pk: tied to r's register)
+            unsigned l = __builtin_bit_cast(unsigned, r[2 * p]);
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "+v"(l) : "v"(hi[p]), "v"(r[2 * p + 1]));
+            lo[p] = l;
+          };
+          auto PL = [&](int k) {
+#pragma unroll
+            for (int j = 2 * k; j < 2 * k + 2; ++j)
+              poolf[j >> 2][j & 3] = __builtin_fmaxf(__builtin_fmaxf(poolf[j >> 2][j & 3], a2[0][j >> 2][j & 3]),
+                                                     a2[1][j >> 2][j & 3]);
+          };
+          // MFMA i of conv1: hi x hi and lo x hi first (they need only the hi halves)
+          auto c1 = [&](int i) {
+            const int b = i % 3, grp = i / 3;
+            const u32x4 h0h = {hi[0], hi[1], hi[2], hi[3]}, h0l = {lo[0], lo[1], lo[2], lo[3]};
+            const u32x4 hxv = {hi[4], hi[5], lo[4], lo[5]};
+            if (grp == 0) a2[e][b] = mfma16(w2[1][b], __builtin_bit_cast(h16x8, h0h), f32x4{0.f, 0.f, 0.f, 0.f});
+            if (grp == 1) a2[e][b] = mfma16(w2[0][b], __builtin_bit_cast(h16x8, h0h), a2[e][b]);
+            if (grp == 2) a2[e][b] = mfma16(w2[0][b], __builtin_bit_cast(h16x8, h0l), a2[e][b]);
+            if (grp == 3) a2[e][b] = mfma16(w2[2][b], __builtin_bit_cast(h16x8, hxv), a2[e][b]);
+            if (grp == 4) a2[e][b] = mfma16(w2[3][b], __builtin_bit_cast(h16x8, hxv), a2[e][b]);
+          };
+#pragma unroll
+          for (int s = 0; s < 15; ++s) {
+            if (s < 6) c3(s, en, G, bh, bl, a1n);
+            else c1(s - 6);
+            if (s < 6 && e == 0) PL(s);                   // the pair finished a stage ago (sub 0: the last task's)
+            if (s < 4) A(s);
+            else if (s < 8) B(s - 4);
+            else if (s < 10) A(s - 4);
+            else if (s < 12) B(s - 6);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // ---- tail: LDS reads of the stage after next, the unpaired MFMAs, the once-a-task work
+          if (sub + 2 < 8) gather(tg, sub + 2, G);
+          else gather(tn, sub + 2 - 8, G);
+#pragma unroll
+          for (int i = 6; i < NC3; ++i) c3(i, en, G, bh, bl, a1n);
+#pragma unroll
+          for (int i = 9; i < 15; ++i) c1(i);
+          if (sub == 0) {
+            // the previous task's pooled voxel (its last pair was pooled in the slots above)
+            const int pz = blk.pz0 + tp.pzl, py = blk.py0 + tp.pyl, px = blk.px0 + 16 * tp.xh + c;
+            f32x4 pv[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) pv[b] = poolf[b] + sh2g[b];
+            x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, pv, ovf,
+                            ti > 0 && pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) poolf[b] = sh2n[b];                       // (the ReLU)
+          }
+          if (sub == 3) stem_write_rows<!INT>(tnext, wrow0, S_RPT * ti, lane, hb);
+          if (sub == 5) {
+            // (opaque to the optimiser here: otherwise the first instruction of the conversion -
+            // and with it the wait for the loads - is hoisted to the top of the task)
+#pragma unroll
+            for (int k = 0; k < S_RPT; ++k) {
+              unsigned t = sizeof(SRC) == 1 ? (unsigned)rr.v[k] : __builtin_bit_cast(unsigned, (float)rr.v[k]);
+              asm volatile("" : "+v"(t));
+              rr.v[k] = sizeof(SRC) == 1 ? (SRC)t : (SRC)__builtin_bit_cast(float, t);
+            }
+            stem_convert_rows<SRC>(a, conv2 ? nx2 : nxt, lut, rr, hb, xmax);
+          }
+          if (sub == 7) stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- tail: LDS reads of the stage after next, the unpaired MFMAs, the once-a-task work
-        if (sub + 2 < 8) gather(tg, sub + 2, G);
-        else gather(tn, sub + 2 - 8, G);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) s2[b] = sh2g[b];
-#pragma unroll
-        for (int i = 6; i < NC3; ++i) c3(i, en, G, bh, bl, a1n);
-#pragma unroll
-        for (int i = 9; i < 15; ++i) c1(i);
-        if (sub == 0) {
-          // the previous task's pooled voxel (its last pair was pooled in the slots above)
-          const int pz = blk.pz0 + tp.pzl, py = blk.py0 + tp.pyl, px = blk.px0 + 16 * tp.xh + c;
-          x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, poolf, ovf,
-                          ti > 0 && pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
-#pragma unroll
-          for (int b = 0; b < 3; ++b) poolf[b] = f32x4{0.f, 0.f, 0.f, 0.f};     // (the ReLU)
-        }
-        if (sub == 3) stem_write_rows<!INT>(tnext, wrow0, S_RPT * ti, lane, hb);
-        if (sub == 5) {
-          // (opaque to the optimiser here: otherwise the first instruction of the conversion -
-          // and with it the wait for the loads - is hoisted to the top of the task)
-#pragma unroll
-          for (int k = 0; k < S_RPT; ++k) {
-            unsigned t = sizeof(SRC) == 1 ? (unsigned)rr.v[k] : __builtin_bit_cast(unsigned, (float)rr.v[k]);
-            asm volatile("" : "+v"(t));
-            rr.v[k] = sizeof(SRC) == 1 ? (SRC)t : (SRC)__builtin_bit_cast(float, t);
-          }
-          stem_convert_rows<SRC>(a, conv2 ? nx2 : nxt, lut, rr, hb, xmax);
-        }
-        if (sub == 7) stem_load_rows<SRC>(lbase, ltab, lxc, lidx, rr);
-        __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    {                                   // drain: the last task's last pair and its store
-      const Geo t7 = geo(S_TASKS - 1);
+      {                                   // drain: the last task's last pair and its store
+        const Geo t7 = geo(S_TASKS - 1);
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < 3; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
-      const int pz = blk.pz0 + t7.pzl, py = blk.py0 + t7.pyl, px = blk.px0 + 16 * t7.xh + c;
-      x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, poolf, ovf,
-                      pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
-    }
+          for (int r = 0; r < 4; ++r)
+            poolf[b][r] = __builtin_fmaxf(__builtin_fmaxf(poolf[b][r], a2[0][b][r]), a2[1][b][r]);
+        const int pz = blk.pz0 + t7.pzl, py = blk.py0 + t7.pyl, px = blk.px0 + 16 * t7.xh + c;
+        f32x4 pv[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) pv[b] = poolf[b] + sh2g[b];
+        x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, pv, ovf,
+                        pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
+      }
+    };
+    if (interior) block_pass(std::false_type{});
+    else block_pass(std::true_type{});
     if (!has_next) break;
     stem_store_edge<SRC>(a, tnext, lut, wrow0, lane, ee, xmax);
     stem_load_edge<SRC>(a, nx2, wrow0, lane, ee);
