@@ -249,12 +249,10 @@ def test_voxel2obj_smoothing_compiles_without_fp64_fma(tmp_path):
 
 def test_headline_kernels_compile_without_scratch_spills():
     """the split-half kernels of the headline path as hipcc builds them (the build's own flags;
-    metadata of the device assembly): the persistent stem (uint8 volumes), mid and tail kernels
+    metadata of the device assembly): the persistent stem (both volume types), mid and tail kernels
     and vgg_like2's tail keep every register in the register file - a block-invariant load
     hoisted out of the persistent loop, or the head chain run four sub-steps abreast, showed up
-    here as 100 - 200 spilled registers in round 4.  The float-volume stem (an lo tile and three
-    more MFMAs per sub-step in the same 256 registers) spills a handful outside its MFMA
-    chains; the bound keeps it from growing.  The U-Net's split 1x1x1 convolutions likewise
+    here as 100 - 200 spilled registers in round 4.  The U-Net's split 1x1x1 convolutions likewise
     (128 -> 128 was 512 registers and 96 spilled ones with its LDS fragment reads hoisted)."""
     import shutil
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -266,7 +264,7 @@ def test_headline_kernels_compile_without_scratch_spills():
     seen = set()
     for name, v in res.items():
         for key, limit in (('vggs_mid_pool', 0), ('vggs_c5_tail', 0), ('vggs_stem_poolIh', 0),
-                           ('vggs_stem_poolIf', 16), ('vggs2_conv3', 0)):
+                           ('vggs_stem_poolIf', 0), ('vggs2_conv3', 0)):
             if key in name:
                 seen.add(key)
                 assert v['vgpr_spill_count'] <= limit, (name, v)
