@@ -60,6 +60,23 @@ int fpl_ctx_create(int device_id, fpl_ctx **out) {
     return fpl_fail(nullptr,
                     "fpl_ctx_create: device %d is %s; this library is built "
                     "for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+  // The HIP runtime in the process may not be the one this library was built against (the
+  // Python binding loads PyTorch's bundled libamdhip64 first so that both share one runtime):
+  // say so once when even the major versions differ; FPL_HIP_VERSION_CHECK=1 reports any
+  // difference.
+  {
+    static bool said = false;
+    int rt = 0;
+    if (!said && hipRuntimeGetVersion(&rt) == hipSuccess) {
+      const int built_major = HIP_VERSION_MAJOR, built_minor = HIP_VERSION_MINOR;
+      const int rt_major = rt / 10000000, rt_minor = (rt / 100000) % 100;
+      const bool strict = getenv("FPL_HIP_VERSION_CHECK") != nullptr;
+      if (rt_major != built_major || (strict && rt_minor != built_minor))
+        fprintf(stderr, "libfplhip: built against HIP %d.%d, running on the HIP %d.%d runtime "
+                        "already in this process\n", built_major, built_minor, rt_major, rt_minor);
+      said = true;
+    }
+  }
   fpl_ctx *ctx = new fpl_ctx();
   ctx->device = device_id;
   ctx->n_cu = prop.multiProcessorCount;
