@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
             f32x4 pv[3];
 #pragma unroll
             for (int b = 0; b < 3; ++b) pv[b] = poolf[b] + sh2g[b];
-            x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, pv, ovf,
+            x8::store12_sel(a.p1, a.p1.vox(pz, py, px), g, pv, ovf,
                             ti > 0 && pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
 #pragma unroll
             for (int b = 0; b < 3; ++b) poolf[b] = sh2n[b];                       // (the ReLU)
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
         f32x4 pv[3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) pv[b] = poolf[b] + sh2g[b];
-        x8::store12_sel(a.p1, ((int64_t)pz * a.p1.Y + py) * a.p1.X + px, g, pv, ovf,
+        x8::store12_sel(a.p1, a.p1.vox(pz, py, px), g, pv, ovf,
                         pz < a.p1.Z && py < a.p1.Y && px < a.p1.X, a.dump);
       }
     };
@@ -758,14 +758,14 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_mid_pool(MidXArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   x8::ktab_init(ktab, tid);
-  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p1.Y, a.p1.X, (unsigned)a.p1.part_bytes());
+  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p1.Y, a.p1.XP, (unsigned)a.p1.part_bytes());
   const int S = (int)gridDim.x >> 3, nbricks = a.walk.bricks();
   const int group = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
   x8::Cursor cur;
   if (!x8::cursor_first(a.walk, nbricks, group, slot, S, cur)) return;
   const int64_t part = a.p1.part_bytes();
   auto origin = [&](const x8::Cursor &q) {
-    return a.p1.p + (((int64_t)(8 * q.bz) * a.p1.Y + 4 * q.by) * a.p1.X + 16 * q.bx) * 16;
+    return a.p1.p + a.p1.vox(8 * q.bz, 4 * q.by, 16 * q.bx) * 16;
   };
   const int pzl = wave >> 1, pyl = wave & 1;
   const unsigned vb = (unsigned)(((2 * pzl) * x8::ZS + (2 * pyl) * x8::TX + c) * 16);
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_mid_pool(MidXArgs a) {
     const int pz = 4 * cur.bz + pzl, py = 2 * cur.by + pyl, px = 8 * cur.bx + (c >> 1);
     const bool inside = pz < a.p2.Z && py < a.p2.Y && px < a.p2.X;
     if ((c & 1) == 0 && inside)
-      x8::store12(a.p2, ((int64_t)pz * a.p2.Y + py) * a.p2.X + px, g, pooled, ovf);
+      x8::store12(a.p2, a.p2.vox(pz, py, px), g, pooled, ovf);
     // edge tiles read past the tensor (x8::Tensor): only what is stored counts for the guard
     ovf_all = pk_max_i16(ovf_all, inside ? ovf : 0u);
     if (!has_next) break;
@@ -1019,14 +1019,14 @@ __global__ __launch_bounds__(64 * x8::WAVES, 2) void vggs_c5_tail(TailXArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   x8::ktab_init(ktab, tid);
-  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p2.Y, a.p2.X, (unsigned)a.p2.part_bytes());
+  const x8::TileDma td = x8::tile_dma_init(wave, lane, a.p2.Y, a.p2.XP, (unsigned)a.p2.part_bytes());
   const int S = (int)gridDim.x >> 3, nbricks = a.walk.bricks();
   const int group = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
   x8::Cursor cur;
   if (!x8::cursor_first(a.walk, nbricks, group, slot, S, cur)) return;
   const int64_t part = a.p2.part_bytes();
   auto origin = [&](const x8::Cursor &q) {
-    return a.p2.p + (((int64_t)(8 * q.bz) * a.p2.Y + 4 * q.by) * a.p2.X + 16 * q.bx) * 16;
+    return a.p2.p + a.p2.vox(8 * q.bz, 4 * q.by, 16 * q.bx) * 16;
   };
   const unsigned vb = (unsigned)((wave * x8::ZS + c) * 16);
   auto sub_off = [](int sub) -> unsigned { return (unsigned)(sub * x8::TX * 16); };
@@ -1672,6 +1672,11 @@ int split2_infer(fpl_ctx *ctx, SplitState *st, const void *src, int src_dtype, f
 // Slab orchestration: as the vgg_like branch of fpl_fast_infer_volume_* (vgg_fused.hip;
 // the lattice equivalence with FplNetwork.infer, flypylib/fplnetwork.py:146-187, is
 // argued there), with P1 / P2 in the split layout.
+// Row pitch (voxels of 16 B) of an x8 tensor of X voxels per row.  (Pitches padded by 14 - 126
+// voxels were measured on the 520^3 volume - 4128-B rows - and changed nothing: what made that
+// size slow was the walk order, vgg_split_lds.h::Cursor.)
+static int x8_pitch(int X) { return X; }
+
 int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int src_dtype,
                            float mean, float sd, const int64_t dims[3],
                            const std::vector<int32_t> origins[3], const int32_t out_sz[3],
@@ -1691,9 +1696,10 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   const int64_t cz_lo = fz_lo / 4, cz_hi = ceil_div64(fz_hi, 4);
   const int CY = (int)ceil_div64(VY, 4), CX = (int)ceil_div64(VX, 4);
   const int P2Y = CY + 2, P2X = CX + 2, P1Y = 2 * P2Y + 2, P1X = 2 * P2X + 2;
+  const int P1XP = x8_pitch(P1X), P2XP = x8_pitch(P2X);       // row pitches (voxels)
   // chunk of coarse rows bounded by a scratch budget (P1 dominates;
   // FPL_VGG_SCRATCH_MB shrinks it so that tests can force several chunks)
-  const int64_t p1_row_bytes = (int64_t)P1Y * P1X * VOX;
+  const int64_t p1_row_bytes = (int64_t)P1Y * P1XP * VOX;
   const char *budget_env = getenv("FPL_VGG_SCRATCH_MB");
   const int64_t budget = budget_env ? (int64_t)atoll(budget_env) << 20 : (int64_t)64 << 30;
   int64_t cz_chunk = std::max<int64_t>(4, (budget / p1_row_bytes - 6) / 2);
@@ -1705,7 +1711,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   // the tile loads address a pass's hi AND lo plane from one scalar base with 32-bit lane
   // offsets: two part planes of the chunk plus the tile's reach stay below 4 GiB
   {
-    const int64_t max_rows = (((int64_t)1 << 32) / 16 / ((int64_t)P1Y * P1X) - (x8::TZ + 2));
+    const int64_t max_rows = (((int64_t)1 << 32) / 16 / ((int64_t)P1Y * P1XP) - (x8::TZ + 2));
     FPL_REQUIRE(ctx, max_rows >= 14,
                 "vgg split path: a %lld x %lld plane is too large for the tile loader's 32-bit "
                 "offsets", (long long)SY, (long long)SX);
@@ -1715,7 +1721,7 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   unsigned *flag;
   FPL_TRY(fpl_range_flag(ctx, &flag));
   // P1 / P2 as planes of 8-channel passes (vgg_split_lds.h) with read slack behind them
-  x8::Tensor p1 = {nullptr, (int)(2 * cz_chunk + 6), P1Y, P1X}, p2 = {nullptr, (int)(cz_chunk + 2), P2Y, P2X};
+  x8::Tensor p1 = {nullptr, (int)(2 * cz_chunk + 6), P1Y, P1X, P1XP}, p2 = {nullptr, (int)(cz_chunk + 2), P2Y, P2X, P2XP};
   void *p1v, *p2v;
   FPL_TRY(tmp.alloc((size_t)(p1.bytes() + p1.slack_bytes()), &p1v));
   FPL_TRY(tmp.alloc((size_t)(p2.bytes() + p2.slack_bytes()), &p2v));
@@ -1728,8 +1734,8 @@ int fpl_split_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src, int
   for (int64_t c0 = cz_lo; c0 < cz_hi; c0 += cz_chunk) {
     const int CZ = (int)std::min<int64_t>(cz_chunk, cz_hi - c0);
     const int P2Z = CZ + 2, P1Z = 2 * P2Z + 2;
-    p1 = x8::Tensor{(unsigned char *)p1v, P1Z, P1Y, P1X};
-    p2 = x8::Tensor{(unsigned char *)p2v, P2Z, P2Y, P2X};
+    p1 = x8::Tensor{(unsigned char *)p1v, P1Z, P1Y, P1X, P1XP};
+    p2 = x8::Tensor{(unsigned char *)p2v, P2Z, P2Y, P2X, P2XP};
     // edge tiles read up to TZ planes past the last pass plane: zeros, not stale scratch
     FPL_HIP(ctx, hipMemsetAsync(p1.p + p1.bytes(), 0, (size_t)p1.slack_bytes(), stream));
     FPL_HIP(ctx, hipMemsetAsync(p2.p + p2.bytes(), 0, (size_t)p2.slack_bytes(), stream));

@@ -63,29 +63,19 @@ static_assert(PLANE % 2 == 0, "");
 struct Tensor {
   unsigned char *p;
   int Z, Y, X;
-  __host__ __device__ int64_t part_bytes() const { return (int64_t)Z * Y * X * 16; }
+  int XP;                    // row pitch in voxels (>= X; x_pitch())
+  __host__ __device__ int64_t part_bytes() const { return (int64_t)Z * Y * XP * 16; }
   __host__ __device__ int64_t pass_bytes() const { return 2 * part_bytes(); }
   __host__ __device__ int64_t bytes() const { return NQ * pass_bytes(); }
-  __host__ __device__ int64_t slack_bytes() const { return ((int64_t)(TZ + 1) * Y * X + 64) * 16; }
+  __host__ __device__ int64_t slack_bytes() const { return ((int64_t)(TZ + 1) * Y * XP + 64) * 16; }
+  __host__ __device__ int64_t vox(int z, int y, int x) const { return ((int64_t)z * Y + y) * XP + x; }
 };
 
-// Work order of the persistent workgroups.  Workgroups go round-robin over the 8 XCDs (each
-// with its own L2): workgroup b is slot b >> 3 of group b & 7, and a group walks BRICKS of
-// 4 (x) x 4 (y) x 2 (z) blocks - the 32 blocks its CUs hold at a time are neighbours whose
-// tiles overlap inside one L2.  (Placement is a matter of speed only.)
+// The block grid of a persistent kernel (the order the workgroups walk it in: Cursor, below)
 struct Walk {
   int nbx, nby, nbz;         // blocks
   __host__ __device__ int bricks() const { return ((nbx + 3) / 4) * ((nby + 3) / 4) * ((nbz + 1) / 2); }
 };
-// block of brick k for slot s; false: that slot of the brick lies outside the grid
-__device__ __forceinline__ bool walk_block(const Walk &w, int k, int slot, int &bx, int &by, int &bz) {
-  const int nx4 = (w.nbx + 3) / 4, ny4 = (w.nby + 3) / 4;
-  const int kx = k % nx4, t = k / nx4;
-  bx = 4 * kx + (slot & 3);
-  by = 4 * (t % ny4) + ((slot >> 2) & 3);
-  bz = 2 * (t / ny4) + (slot >> 4);
-  return bx < w.nbx && by < w.nby && bz < w.nbz;
-}
 
 // per-lane constants of a wave's share of the tile: chunk j = wave + 8 i holds slots
 // 64 j .. 64 j + 63 of [hi plane | lo plane]; off[i] = byte offset of the slot's voxel from the
@@ -270,33 +260,50 @@ __device__ __forceinline__ void prime(unsigned char *smem, const TileDma &td, co
   __syncthreads();
 }
 
-// The persistent workgroup's walk: group = blockIdx.x & 7 (one XCD under round-robin placement)
-// takes the CONTIGUOUS range of bricks [group * per, (group + 1) * per), per = ceil(bricks / 8):
-// consecutive bricks are x neighbours, so the halo face they share is still in that XCD's L2
-// when the next one starts; inside a brick the group's S = gridDim.x / 8 workgroups share the
-// 32 blocks (slot, slot + S, ...).
+// The persistent workgroup's walk.  The blocks are numbered in BRICK-MAJOR order (bricks of 4 x 4
+// x 2 blocks, x fastest; the bricks at the far faces hold fewer blocks) and group = blockIdx.x & 7
+// (one XCD under round-robin placement) takes the CONTIGUOUS range [group * per, (group + 1) *
+// per) of that numbering, per = ceil(blocks / 8); its S = gridDim.x / 8 workgroups take every
+// S-th block of the range.  The S blocks in flight at a time are neighbours of one or two bricks,
+// whose halo faces sit in that XCD's L2, and every workgroup gets the same number of blocks +- 1.
+// (Until round 4 a workgroup owned ONE slot of every brick: with 17 x 65 x 33 blocks - the
+// 520^3 volume - the workgroups of slot 0 had 27 % more blocks than the average, and the kernel
+// took as long as they did.)
+__device__ __forceinline__ void walk_decode(const Walk &w, int i, int &bx, int &by, int &bz) {
+  const int layer = w.nbx * w.nby * 2;
+  const int kz = i / layer;
+  int r = i - kz * layer;
+  const int wz = min(2, w.nbz - 2 * kz);
+  const int rowb = w.nbx * 4 * wz;
+  const int ky = r / rowb;
+  r -= ky * rowb;
+  const int wy = min(4, w.nby - 4 * ky);
+  const int bb = 4 * wy * wz;
+  const int kx = r / bb;
+  r -= kx * bb;
+  const int wx = min(4, w.nbx - 4 * kx);
+  bx = 4 * kx + r % wx;
+  r /= wx;
+  by = 4 * ky + r % wy;
+  bz = 2 * kz + r / wy;
+}
 struct Cursor {
-  int k, j;                  // brick, block inside the brick
-  int kend;
+  int i, iend;               // block number, end of the group's range
   int bx, by, bz;
 };
-__device__ __forceinline__ bool cursor_seek(const Walk &w, int slot, int S, Cursor &c) {
-  for (;;) {
-    if (c.j >= 32) { c.j = slot; c.k += 1; }
-    if (c.k >= c.kend) return false;
-    if (walk_block(w, c.k, c.j, c.bx, c.by, c.bz)) return true;
-    c.j += S;
-  }
+__device__ __forceinline__ bool cursor_first(const Walk &w, int /*nbricks*/, int group, int slot, int S, Cursor &c) {
+  const int total = w.nbx * w.nby * w.nbz, per = (total + 7) / 8;
+  c.i = group * per + slot;
+  c.iend = (group + 1) * per < total ? (group + 1) * per : total;
+  if (c.i >= c.iend) return false;
+  walk_decode(w, c.i, c.bx, c.by, c.bz);
+  return true;
 }
-__device__ __forceinline__ bool cursor_first(const Walk &w, int nbricks, int group, int slot, int S, Cursor &c) {
-  const int per = (nbricks + 7) / 8;
-  c.k = group * per; c.j = slot;
-  c.kend = (group + 1) * per < nbricks ? (group + 1) * per : nbricks;
-  return cursor_seek(w, slot, S, c);
-}
-__device__ __forceinline__ bool cursor_next(const Walk &w, int slot, int S, Cursor &c) {
-  c.j += S;
-  return cursor_seek(w, slot, S, c);
+__device__ __forceinline__ bool cursor_next(const Walk &w, int /*slot*/, int S, Cursor &c) {
+  c.i += S;
+  if (c.i >= c.iend) return false;
+  walk_decode(w, c.i, c.bx, c.by, c.bz);
+  return true;
 }
 
 // A lane's three accumulator tiles of a 48-channel layer packed with fpl_out_channel(il = 2):
