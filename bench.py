@@ -286,7 +286,15 @@ def spawn_ranks(n):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # exactly ONE line on stdout: the JSON line (libraries - gloo, for one - print their own
+    # chatter on the rank's stdout; that goes to stderr here)
+    lines = out.decode().splitlines()
+    js = [ln for ln in lines if ln.startswith('{')]
+    for ln in lines:
+        if not ln.startswith('{'):
+            sys.stderr.write(ln + '\n')
+    if js:
+        sys.stdout.write(js[-1] + '\n')
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
