@@ -368,6 +368,85 @@ __global__ __launch_bounds__(256, 2) void conv3_f32(Conv3F a) {
 }
 
 // ---- 1x1x1 conv as a voxel GEMM (fp32) ----------------------------------------------
+// ---- the pooled-gradient view (FplPoolGrad, fast_paths.h) on the device ----------------
+// unsigned division by a run-time constant: q = (t + ((n - t) >> s1)) >> s2, t = umulhi(n, m)
+struct FastDiv { unsigned m, s1, s2, d; };
+static FastDiv fast_div(unsigned d) {
+  FastDiv f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1; f.s2 = l > 1 ? l - 1 : 0; f.d = d;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
+  const unsigned t = __umulhi(n, f.m);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+struct PoolGradDev {
+  const float *dyp; const uint32_t *arg; const float *x;
+  const float *mean, *invstd, *gamma, *beta, *sum_g, *sum_gx;
+  float inv_m;
+  FastDiv dW, dH, dD;
+  int oh, ow, od;
+};
+static PoolGradDev pool_grad_dev(const FplPoolGrad &g) {
+  PoolGradDev p;
+  p.dyp = g.dyp; p.arg = g.arg; p.x = g.x;
+  p.mean = g.bn.mean; p.invstd = g.bn.invstd; p.gamma = g.bn.gamma; p.beta = g.bn.beta;
+  p.sum_g = g.sum_g; p.sum_gx = g.sum_gx; p.inv_m = g.inv_m;
+  p.dW = fast_div((unsigned)g.W); p.dH = fast_div((unsigned)g.H); p.dD = fast_div((unsigned)g.D);
+  p.od = g.D / 2; p.oh = g.H / 2; p.ow = g.W / 2;
+  return p;
+}
+// voxel m of (n, D, H, W) -> its pooling window (row of dyp / arg) and its position 0..7 in it
+struct VoxPos { unsigned x, y, z, t; };
+__device__ __forceinline__ VoxPos pool_coords(const PoolGradDev &p, unsigned m) {
+  VoxPos v;
+  const unsigned r1 = fdiv(m, p.dW);
+  v.x = m - r1 * p.dW.d;
+  const unsigned r2 = fdiv(r1, p.dH);
+  v.y = r1 - r2 * p.dH.d;
+  v.t = fdiv(r2, p.dD);
+  v.z = r2 - v.t * p.dD.d;
+  return v;
+}
+// ... of the voxel j < W places further along x (row, plane and volume wrap)
+__device__ __forceinline__ VoxPos pool_coords_step(const PoolGradDev &p, VoxPos v, unsigned j) {
+  v.x += j;
+  if (v.x >= p.dW.d) {
+    v.x -= p.dW.d; v.y += 1;
+    if (v.y >= p.dH.d) {
+      v.y = 0; v.z += 1;
+      if (v.z >= p.dD.d) { v.z = 0; v.t += 1; }
+    }
+  }
+  return v;
+}
+__device__ __forceinline__ void pool_window(const PoolGradDev &p, const VoxPos &v, unsigned &win, unsigned &pos) {
+  win = ((v.t * p.od + (v.z >> 1)) * p.oh + (v.y >> 1)) * p.ow + (v.x >> 1);
+  pos = ((v.z & 1) << 2) | ((v.y & 1) << 1) | (v.x & 1);
+}
+__device__ __forceinline__ void pool_locate(const PoolGradDev &p, unsigned m, unsigned &win, unsigned &pos) {
+  pool_window(p, pool_coords(p, m), win, pos);
+}
+// one value of train.hip::bn_backward_pool4 (ACC = false): ga * is * (g' - s0 / M - xhat * s1 / M),
+// g' = d where this voxel is the window's arg-max and bn(x) > 0 (the forward pass's own rounding
+// sequence for the mask).  The per-channel factors are folded once per kernel: A = ga * is,
+// K0 = s0 / M, K1 = s1 / M (the elementwise pass multiplies them out per value; the results
+// agree to a rounding or two, tests/test_gpu_train.py holds both against each other).
+struct PoolGradK { float mean, is, ga, be, A, K0, K1; };
+__device__ __forceinline__ PoolGradK pool_grad_k(float mean, float is, float ga, float be, float s0, float s1,
+                                                 float inv_m) {
+  return PoolGradK{mean, is, ga, be, ga * is, inv_m * s0, inv_m * s1};
+}
+__device__ __forceinline__ float pool_grad_value(float d, bool is_max, float xq, const PoolGradK &k) {
+  const float xh = __fmul_rn(__fsub_rn(xq, k.mean), k.is);
+  const bool hit = is_max && __fmaf_rn(xh, k.ga, k.be) > 0.f;
+  const float gq = hit ? d : 0.f;
+  return k.A * ((gq - k.K0) - xh * k.K1);
+}
+
 struct Conv1F {
   const float *in; int64_t M; int cin;     // cin padded to 16 in the fragments
   const float *w;                          // fragments [kblock][mb][lane][4]
@@ -377,6 +456,7 @@ struct Conv1F {
   double *stats;                           // STATS: part[grid][2][cout]
   FplBnView bn = {nullptr, nullptr, nullptr, nullptr};   // conv1_f32_wreg<.., BN>: in -> relu(bn(in))
   const float *bsx = nullptr;    // conv1_f32_wreg<.., BSTAT>: BN input at the OUTPUT positions; stats = BN backward sums
+  PoolGradDev pg = {};           // conv1_f32_wreg<.., PG>: `in` is not read, the input rows are made from this view
 };
 
 // train.hip's bn_affine: the forward value and every recomputation of the ReLU mask in the
@@ -448,9 +528,22 @@ __global__ __launch_bounds__(256) void conv1_f32(Conv1F a) {
 // BSTAT (an input-gradient launch): the outputs are the gradient of relu(bn(x)); `stats`
 // then receives the BN backward sums (sum g, sum g * xhat; g = output where bn(x) > 0)
 // instead of the outputs' moments - x is read at the output positions (cout = 16 * NKB)
-template <int MB, int NKB, bool STATS, bool BN = false, bool BSTAT = false>
-__global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
+template <int MB, int NKB, bool STATS, bool BN = false, bool BSTAT = false, bool PG = false>
+__global__ __launch_bounds__(256, BSTAT ? 2 : 1) void conv1_f32_wreg(Conv1F a) {
   static_assert(!BSTAT || (STATS && BN && MB == NKB), "BSTAT: statistics of a BN view, cout = cin");
+  static_assert(!PG || BSTAT, "PG: the input-gradient form");
+  // PG: the six per-channel vectors of the pooled layer's BatchNorm, as prm below
+  __shared__ f32x4 prg[PG ? 7 * NKB * 4 : 1];       // rows: mean, invstd, gamma, beta, A, K0, K1 (PoolGradK)
+  if (PG) {
+    for (int ch = threadIdx.x; ch < NKB * 16; ch += 256) {
+      const PoolGradK k = pool_grad_k(a.pg.mean[ch], a.pg.invstd[ch], a.pg.gamma[ch], a.pg.beta[ch],
+                                      a.pg.sum_g[ch], a.pg.sum_gx[ch], a.pg.inv_m);
+      float *t = reinterpret_cast<float *>(prg);
+      t[0 * NKB * 16 + ch] = k.mean; t[1 * NKB * 16 + ch] = k.is; t[2 * NKB * 16 + ch] = k.ga;
+      t[3 * NKB * 16 + ch] = k.be; t[4 * NKB * 16 + ch] = k.A; t[5 * NKB * 16 + ch] = k.K0;
+      t[6 * NKB * 16 + ch] = k.K1;
+    }
+  }
   __shared__ double red[STATS ? 4 * 2 * 16 * MB : 1];
   // BN: the four per-channel vectors, read back as 16-B pieces of a lane's four channels
   __shared__ f32x4 prm[BN ? 4 * NKB * 4 : 1];
@@ -479,19 +572,51 @@ __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
   const int64_t groups = (a.M + 15) / 16, stride = (int64_t)gridDim.x * 4;
   int64_t grp = (int64_t)blockIdx.x * 4 + wave;
   f32x4 nx[NKB];
-  {
-    const int64_t m = min(grp * 16 + c, a.M - 1);
-    if (grp < groups)
+  // PG: the raw operands of the next group's rows (pooled gradient, arg-max word, BN input)
+  f32x4 nd[PG ? NKB : 1];
+  unsigned na[PG ? NKB : 1], npos = 0u;
+  auto fetch = [&](int64_t fg) {
+    const int64_t m = min(fg * 16 + c, a.M - 1);
+    if (PG) {
+      unsigned win;
+      pool_locate(a.pg, (unsigned)m, win, npos);
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-        nx[kb] = *reinterpret_cast<const f32x4 *>(a.in + m * (16 * NKB) + 16 * kb + 4 * g);
-  }
+      for (int kb = 0; kb < NKB; ++kb) {
+        nx[kb] = *reinterpret_cast<const f32x4 *>(a.pg.x + m * (16 * NKB) + 16 * kb + 4 * g);
+        nd[kb] = *reinterpret_cast<const f32x4 *>(a.pg.dyp + (int64_t)win * (16 * NKB) + 16 * kb + 4 * g);
+        na[kb] = a.pg.arg[(int64_t)win * (4 * NKB) + 4 * kb + g];
+      }
+      return;
+    }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+      nx[kb] = *reinterpret_cast<const f32x4 *>(a.in + m * (16 * NKB) + 16 * kb + 4 * g);
+  };
+  if (grp < groups) fetch(grp);
   for (; grp < groups; grp += stride) {
     const int64_t m = grp * 16 + c;
     const bool ok = m < a.M;
     f32x4 bf[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) bf[kb] = nx[kb];
+    if (PG) {
+      // (re-read per group: hoisted out of the loop the 21 table vectors cost 84 registers and a
+      // wave per SIMD)
+      int zero = 0;
+      asm volatile("" : "+s"(zero));
+      const f32x4 *prq = prg + zero;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const f32x4 pm = prq[(0 * NKB + kb) * 4 + g], ps = prq[(1 * NKB + kb) * 4 + g],
+                    pg = prq[(2 * NKB + kb) * 4 + g], pb = prq[(3 * NKB + kb) * 4 + g],
+                    pA = prq[(4 * NKB + kb) * 4 + g], p0 = prq[(5 * NKB + kb) * 4 + g],
+                    p1 = prq[(6 * NKB + kb) * 4 + g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bf[kb][q] = pool_grad_value(nd[kb][q], ((na[kb] >> (8 * q)) & 255u) == npos, bf[kb][q],
+                                      PoolGradK{pm[q], ps[q], pg[q], pb[q], pA[q], p0[q], p1[q]});
+      }
+    }
     if (BN && !BSTAT) {
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
@@ -501,15 +626,10 @@ __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
         for (int q = 0; q < 4; ++q) bf[kb][q] = bn_relu_f(bf[kb][q], pm[q], ps[q], pg[q], pb[q]);
       }
     }
-    if (grp + stride < groups) {
-      const int64_t m2 = min((grp + stride) * 16 + c, a.M - 1);
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-        nx[kb] = *reinterpret_cast<const f32x4 *>(a.in + m2 * (16 * NKB) + 16 * kb + 4 * g);
-    }
+    if (grp + stride < groups) fetch(grp + stride);
     f32x4 acc[MB];
 #pragma unroll
-    for (int b = 0; b < MB; ++b) acc[b] = sh[b];
+    for (int b = 0; b < MB; ++b) acc[b] = PG ? f32x4{0.f, 0.f, 0.f, 0.f} : sh[b];   // (an input gradient has no shift)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -524,8 +644,11 @@ __global__ __launch_bounds__(256) void conv1_f32_wreg(Conv1F a) {
         store_quad(dst, 16 * b + 4 * g, a.cout, o, FPL_ACT_NONE);
         if (BSTAT) {
           const f32x4 xv = *reinterpret_cast<const f32x4 *>(a.bsx + m * a.cout + 16 * b + 4 * g);
-          const f32x4 pm = prm[(0 * NKB + b) * 4 + g], ps = prm[(1 * NKB + b) * 4 + g],
-                      pg = prm[(2 * NKB + b) * 4 + g], pb = prm[(3 * NKB + b) * 4 + g];
+          int zero = 0;                                     // (as above: keep the table in LDS)
+          asm volatile("" : "+s"(zero));
+          const f32x4 *prn = prm + zero;
+          const f32x4 pm = prn[(0 * NKB + b) * 4 + g], ps = prn[(1 * NKB + b) * 4 + g],
+                      pg = prn[(2 * NKB + b) * 4 + g], pb = prn[(3 * NKB + b) * 4 + g];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float gq = bn_relu_f(xv[r], pm[r], ps[r], pg[r], pb[r]) > 0.f ? o[r] : 0.f;
@@ -923,9 +1046,11 @@ int launch1(fpl_ctx *ctx, Conv1F &a) {
   // weights-in-registers form for the 48- and 96-channel inputs of the vgg / U-Net blocks
   if constexpr (MB == 3) {
     if (a.cin == 48 && a.bsx) {
-      conv1_f32_wreg<3, 3, true, true, true><<<grid, 256, 0, ctx->stream>>>(a);
+      if (a.pg.x) conv1_f32_wreg<3, 3, true, true, true, true><<<grid, 256, 0, ctx->stream>>>(a);
+      else conv1_f32_wreg<3, 3, true, true, true><<<grid, 256, 0, ctx->stream>>>(a);
       return 0;
     }
+    if (a.pg.x) return fpl_fail(ctx, "conv1: the pooled-gradient view needs the BatchNorm-statistics form");
   }
   if (a.bsx) return fpl_fail(ctx, "conv1: no BatchNorm-statistics epilogue for %d -> %d", a.cin, a.cout);
   if constexpr (MB <= 3) {
@@ -1613,11 +1738,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad_f32(Wgrad1Args a) {
 // Partials per workgroup, then a deterministic sum (no float atomics).
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 
-template <bool BN>
+// PG: dY is the input gradient of the BatchNorm + ReLU + pool layer behind this convolution,
+// made from the pooled gradient while loading (PoolGradDev above)
+template <bool BN, bool PG = false>
 __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict__ x,
                                                          const float *__restrict__ dy,
                                                          int64_t M, float *__restrict__ part,
-                                                         FplBnView bn) {
+                                                         FplBnView bn, PoolGradDev pgd) {
   __shared__ float red[4][2304];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -1627,6 +1754,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict
     ps = *reinterpret_cast<const f32x3 *>(bn.invstd + 3 * c);
     pg = *reinterpret_cast<const f32x3 *>(bn.gamma + 3 * c);
     pb = *reinterpret_cast<const f32x3 *>(bn.beta + 3 * c);
+  }
+  PoolGradK qk[3] = {};                 // PG: the pooled layer's BN and sums, channels 3c .. 3c + 2
+  if (PG) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      qk[q] = pool_grad_k(pgd.mean[3 * c + q], pgd.invstd[3 * c + q], pgd.gamma[3 * c + q], pgd.beta[3 * c + q],
+                          pgd.sum_g[3 * c + q], pgd.sum_gx[3 * c + q], pgd.inv_m);
   }
   f32x4 acc[3][3];
 #pragma unroll
@@ -1638,14 +1772,33 @@ __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict
   // the next group's rows are in flight while this one is multiplied (same group order as
   // the two-groups-per-iteration form it replaces: same sums)
   f32x3 an[4], bn_[4];
+  f32x3 xn[PG ? 4 : 1];            // PG: the pooled layer's BN input rows
+  unsigned hitn[PG ? 4 : 1];       // PG: bit q = this voxel is the arg-max of channel 3c + q's window
   auto fetch = [&](int64_t grp) {
+    VoxPos v0 = {};
+    if (PG) v0 = pool_coords(pgd, (unsigned)min(grp * 16 + 4 * g, M - 1));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t m = grp * 16 + 4 * g + j;                    // k-slot (g, j) = voxel
       const bool ok = m < M;
       const int64_t mm = ok ? m : 0;
       an[j] = *reinterpret_cast<const f32x3 *>(x + mm * 48 + 3 * c);
-      bn_[j] = *reinterpret_cast<const f32x3 *>(dy + mm * 48 + 3 * c);
+      if (PG) {
+        unsigned win, pos;
+        // (rows past M: any window - their x rows are zeroed below)
+        pool_window(pgd, ok ? pool_coords_step(pgd, v0, (unsigned)j) : VoxPos{0u, 0u, 0u, 0u}, win, pos);
+        bn_[j] = *reinterpret_cast<const f32x3 *>(pgd.dyp + (int64_t)win * 48 + 3 * c);
+        xn[j] = *reinterpret_cast<const f32x3 *>(pgd.x + mm * 48 + 3 * c);
+        // the three arg-max bytes of channels 3c .. 3c + 2 as one (unaligned) 32-bit load; its
+        // fourth byte is the next channel's, or - behind the very last window - allocator padding
+        const unsigned char *ab = reinterpret_cast<const unsigned char *>(pgd.arg) + (int64_t)win * 48 + 3 * c;
+        unsigned aw;
+        __builtin_memcpy(&aw, ab, 4);
+        hitn[j] = ((aw & 255u) == pos ? 1u : 0u) | (((aw >> 8) & 255u) == pos ? 2u : 0u) |
+                  (((aw >> 16) & 255u) == pos ? 4u : 0u);
+      } else {
+        bn_[j] = *reinterpret_cast<const f32x3 *>(dy + mm * 48 + 3 * c);
+      }
       if (!ok) an[j] = f32x3{0.f, 0.f, 0.f};
     }
   };
@@ -1655,6 +1808,13 @@ __global__ __launch_bounds__(256) void conv1_wgrad48_f32(const float *__restrict
     f32x3 av[4], bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { av[j] = an[j]; bv[j] = bn_[j]; }
+    if (PG) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          bv[j][q] = pool_grad_value(bv[j][q], ((hitn[j] >> q) & 1u) != 0u, xn[j][q], qk[q]);
+    }
     if (BN) {
       // rows past M were zeroed by fetch(); relu(bn(0)) is not 0, but their dY rows are
       // loaded from voxel 0 - zero THOSE instead
@@ -1806,9 +1966,11 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
 // dx is OVERWRITTEN (the caller accumulates when a tensor has several consumers)
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
                       int k, int cin, const float *Wd, const float *zeros, float *dx,
-                      const FplBnStat *bstat) {
+                      const FplBnStat *bstat, const FplPoolGrad *pg) {
   FPL_REQUIRE(ctx, !bstat || fpl_tm_bn_view_supported(k, cin, cout),
               "conv dgrad: no BatchNorm-statistics epilogue for k %d, %d -> %d", k, cin, cout);
+  FPL_REQUIRE(ctx, !pg || (bstat && fpl_tm_pool_grad_supported(k, cin, cout)),
+              "conv dgrad: no pooled-gradient view for k %d, %d -> %d", k, cin, cout);
   DevTemp tmp(ctx);
   const int ncc = (cout + 15) / 16, k3 = k * k * k;
   if (k == 1) {
@@ -1821,6 +1983,7 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
     c.in = dy; c.M = (int64_t)n * od * oh * ow; c.cin = cout; c.w = (const float *)fr;
     c.shift = zeros; c.act = FPL_ACT_NONE; c.out = dx; c.cout = cin; c.stats = nullptr;
     if (bstat) { c.bsx = bstat->x; c.bn = bstat->bn; c.stats = bstat->part; }
+    if (pg) c.pg = pool_grad_dev(*pg);
     switch (mb) {
       case 1: return launch1<1>(ctx, c);
       case 2: return launch1<2>(ctx, c);
@@ -1863,13 +2026,17 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
 }
 
 // dw [k^3][cin][cout] += weight gradient (float atomics)
+bool fpl_tm_pool_grad_supported(int k, int cin, int cout) { return k == 1 && cin == 48 && cout == 48; }
+
 bool fpl_tm_bn_grad_supported(int k, int cin, int cout) {
   return k == 3 && cin == 1 && cout <= 48 && !getenv("FPL_WGRAD_CIN1_LDS");
 }
 
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
                       const float *dy, int k, int cout, float *dw, const FplBnView *bn,
-                      const FplBnGrad *bg) {
+                      const FplBnGrad *bg, const FplPoolGrad *pg) {
+  FPL_REQUIRE(ctx, !pg || fpl_tm_pool_grad_supported(k, cin, cout),
+              "conv wgrad: no pooled-gradient view for k %d, %d -> %d", k, cin, cout);
   FPL_REQUIRE(ctx, !bn || fpl_tm_bn_view_supported(k, cin, cout),
               "conv wgrad: no BatchNorm-view kernel for k %d, %d -> %d", k, cin, cout);
   FPL_REQUIRE(ctx, !bg || fpl_tm_bn_grad_supported(k, cin, cout),
@@ -1886,8 +2053,11 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
       void *part;
       FPL_TRY(tmp.alloc((size_t)nblk * 2304 * 4, &part));
       TimedLaunch tl(ctx, "mfma_wgrad1_f32");
-      if (bn) conv1_wgrad48_f32<true><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, *bn);
-      else conv1_wgrad48_f32<false><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, FplBnView{});
+      const PoolGradDev pgd = pg ? pool_grad_dev(*pg) : PoolGradDev{};
+      if (bn && pg) conv1_wgrad48_f32<true, true><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, *bn, pgd);
+      else if (pg) conv1_wgrad48_f32<false, true><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, FplBnView{}, pgd);
+      else if (bn) conv1_wgrad48_f32<true><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, *bn, pgd);
+      else conv1_wgrad48_f32<false><<<nblk, 256, 0, ctx->stream>>>(x, dy, a.M, (float *)part, FplBnView{}, pgd);
       wgrad_partials_add<<<36, 256, 0, ctx->stream>>>((const float *)part, nblk, 2304, dw);
       return 0;
     }

@@ -105,9 +105,22 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
 // BN's backward sums (sum g, sum g * xhat with g = dx where bn(x) > 0) into
 // part[fpl_tm_conv_stats_rows(.., k = 1, ..)][2][cin] - the BN backward's first pass
 struct FplBnStat { const float *x; FplBnView bn; double *part; };
+// `pg` (optional, fpl_tm_pool_grad_supported(k, cin, cout); weight AND input gradient of the
+// same 1x1x1 convolution): dy is not a tensor but the input gradient of a training-mode
+// BatchNorm + ReLU + MaxPooling3D(2) layer, made while loading from the POOLED output gradient
+// pg->dyp (n, D/2, H/2, W/2, C), the arg-max bytes pg->arg (one per pooled value, four
+// channels per word: train.hip::bn_relu_pool4) and the BN input pg->x (n, D, H, W, C) =
+// this convolution's output: train.hip::bn_backward_pool4's arithmetic, the same rounding
+// sequence.  That pass - a write and a read of the layer's full-resolution tensor - is then not run.
+struct FplPoolGrad {
+  const float *dyp; const uint32_t *arg; const float *x;
+  FplBnView bn; const float *sum_g, *sum_gx; float inv_m;
+  int D, H, W;
+};
+bool fpl_tm_pool_grad_supported(int k, int cin, int cout);
 int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int ow, int cout,
                       int k, int cin, const float *Wd, const float *zeros, float *dx,
-                      const FplBnStat *bstat = nullptr);
+                      const FplBnStat *bstat = nullptr, const FplPoolGrad *pg = nullptr);
 // `bg` (optional, fpl_tm_bn_grad_supported(k, cin, cout)): dy is not a tensor but the input
 // gradient of a training-mode BatchNorm (+ ReLU) whose output gradient is bg->g and whose
 // input - this convolution's output - is bg->x: dy = gamma * invstd * (g' - sum_g / M - xhat *
@@ -118,7 +131,7 @@ struct FplBnGrad { const float *g, *x; FplBnView bn; const float *sum_g, *sum_gx
 bool fpl_tm_bn_grad_supported(int k, int cin, int cout);
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
                       const float *dy, int k, int cout, float *dw, const FplBnView *bn = nullptr,
-                      const FplBnGrad *bg = nullptr);
+                      const FplBnGrad *bg = nullptr, const FplPoolGrad *pg = nullptr);
 
 // Split-operand IEEE-half path for vgg_like (vgg_split.hip, FPL_PREC_F16S): every
 // activation and folded weight is carried as hi + lo (two halves, ~22 significant bits)

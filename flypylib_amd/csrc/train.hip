@@ -1133,6 +1133,9 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   // tensor -> its gradient is not written: the convolution that made the tensor forms it in
   // its weight-gradient loader from the BatchNorm's output gradient (FplBnGrad, fast_paths.h)
   std::vector<FplBnGrad> bn_grad(nt, FplBnGrad{});
+  // ... or, behind a BatchNorm + ReLU + pool layer, the 1x1x1 convolution's weight- AND
+  // input-gradient loaders form it from the pooled gradient (FplPoolGrad)
+  std::vector<FplPoolGrad> pool_grad(nt, FplPoolGrad{});
   for (int li = 0; li + 2 < nl; ++li) {
     if (!bn_fused[li] || pool_fused[li] || !use_mfma || !use_mfma_bwd) continue;
     const fpl_layer &B = t->layers[li], &R = t->layers[li + 1];
@@ -1385,8 +1388,9 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
           const bool viewed = bn_view[L.src0] >= 0;
           const float *xin = viewed ? view_of(L.src0, &bv) : val[L.src0];
           const FplBnGrad *bgv = bn_grad[L.dst].g ? &bn_grad[L.dst] : nullptr;
+          const FplPoolGrad *pgv = pool_grad[L.dst].x ? &pool_grad[L.dst] : nullptr;
           FPL_TRY(fpl_tm_conv_wgrad(ctx, xin, batch, a.d, a.h, a.w, a.c, dy, L.k,
-                                    L.cout, t->g + L.w_off[0], viewed ? &bv : nullptr, bgv));
+                                    L.cout, t->g + L.w_off[0], viewed ? &bv : nullptr, bgv, pgv));
           if (L.use_bias) {
             const int rr = red_rows(n_vox), nb = (int)ceil_div64(n_vox, rr);
             const int R = std::max(1, 256 / L.cout);
@@ -1408,7 +1412,7 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
             bn_bstat[bl] = (double *)q;
             bn_bstat_rows[bl] = (int)rows;
             FPL_TRY(fpl_tm_conv_dgrad(ctx, dy, batch, o.d, o.h, o.w, o.c, L.k, L.cin,
-                                      t->w + L.w_off[0], t->zeros, dx, &bs));
+                                      t->w + L.w_off[0], t->zeros, dx, &bs, pgv));
           } else if (dx && assign[L.src0]) {
             FPL_TRY(fpl_tm_conv_dgrad(ctx, dy, batch, o.d, o.h, o.w, o.c, L.k, L.cin,
                                       t->w + L.w_off[0], t->zeros, dx));
@@ -1483,6 +1487,30 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
           finish_sums<<<C, 256, 0, st>>>(part, nbp, C, sdy, sdyx, 1.f);
           accum<<<1, 256, 0, st>>>(sdy, t->g + L.w_off[1], C);
           accum<<<1, 256, 0, st>>>(sdyx, t->g + L.w_off[0], C);
+          // The tensor's only reader is the 1x1x1 convolution that made it, whose weight- and
+          // input-gradient kernels can form dx from the pooled gradient themselves (the input
+          // gradient in its BatchNorm-statistics form, i.e. behind a viewed BN): this pass's
+          // write of the layer's full-resolution tensor and one read of it go
+          {
+            int prod = -1;
+            for (int lp = 0; lp < li; ++lp)
+              if (t->layers[lp].dst == L.src0) prod = lp;
+            if (dx && assign[L.src0] && prod >= 0 && t->layers[prod].kind == FPL_L_CONV &&
+                !t->layers[prod].use_bias && use_mfma_bwd && bn_view[t->layers[prod].src0] >= 0 &&
+                assign[t->layers[prod].src0] && grad[t->layers[prod].src0] &&
+                fpl_tm_bwd_supported(t->layers[prod].k, t->layers[prod].cin, t->layers[prod].cout) &&
+                fpl_tm_pool_grad_supported(t->layers[prod].k, t->layers[prod].cin, t->layers[prod].cout) &&
+                !getenv("FPL_TRAIN_BNSTAT_SEPARATE") && !getenv("FPL_TRAIN_POOLGRAD_SEPARATE") &&
+                (int64_t)batch * a.vox() < ((int64_t)1 << 31)) {
+              FplPoolGrad &pgv = pool_grad[L.src0];
+              pgv.dyp = dy; pgv.arg = (const uint32_t *)arg[pl]; pgv.x = val[L.src0];
+              pgv.bn.mean = bn_mean[li]; pgv.bn.invstd = bn_invstd[li];
+              pgv.bn.gamma = t->w + L.w_off[0]; pgv.bn.beta = t->w + L.w_off[1];
+              pgv.sum_g = sdy; pgv.sum_gx = sdyx; pgv.inv_m = 1.f / (float)M;
+              pgv.D = a.d; pgv.H = a.h; pgv.W = a.w;
+              break;
+            }
+          }
           if (dx) {
             const int64_t np4 = Mp * (C / 4);
 #define FPL_BNP4(ACC)                                                                         \

@@ -121,7 +121,9 @@ def test_bn_in_the_conv_loader_and_sums_in_the_dgrad_epilogue(ctx, monkeypatch):
     gradient epilogue - and round 4's: the first BatchNorm's input gradient made by the first
     convolution's weight-gradient loader instead of an elementwise pass - against the same step
     with the sums in their own pass (FPL_TRAIN_BNSTAT_SEPARATE), with that elementwise pass
-    (FPL_TRAIN_BNGRAD_SEPARATE) and with every layer as its own kernel (FPL_TRAIN_UNFUSED):
+    (FPL_TRAIN_BNGRAD_SEPARATE), with the pooled layer's input gradient written by its own pass
+    instead of being formed in the 1x1x1 convolution's two backward loaders
+    (FPL_TRAIN_POOLGRAD_SEPARATE) and with every layer as its own kernel (FPL_TRAIN_UNFUSED):
     identical up to the order of fp64 partial sums and the float atomics of the weight
     gradients.  (The oracle holds the default, fused, step in the tests above.)"""
     g = fplmodels.vgg_like()[0]
@@ -133,7 +135,8 @@ def test_bn_in_the_conv_loader_and_sums_in_the_dgrad_epilogue(ctx, monkeypatch):
     loss_f, acc_f = tr.step(data, lab, seed=5)
     grads_f = [x.copy() for x in tr.get_grads()]
     tr.close()
-    for env in ('FPL_TRAIN_BNSTAT_SEPARATE', 'FPL_TRAIN_BNGRAD_SEPARATE', 'FPL_TRAIN_UNFUSED'):
+    for env in ('FPL_TRAIN_BNSTAT_SEPARATE', 'FPL_TRAIN_BNGRAD_SEPARATE', 'FPL_TRAIN_POOLGRAD_SEPARATE',
+                'FPL_TRAIN_UNFUSED'):
         monkeypatch.setenv(env, '1')
         tr2 = _capi.Trainer(ctx, g)
         loss_s, acc_s = tr2.step(data, lab, seed=5)
