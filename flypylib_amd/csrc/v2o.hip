@@ -336,6 +336,90 @@ __global__ __launch_bounds__(512) void gauss_z_win(
   }
 }
 
+// z pass, ring form (round 4): a thread walks a SEGMENT of its (y, x) column, 2 WR outputs at a
+// time, with the 4 WR inputs they need in registers as two halves; after a step the upper half is
+// the next step's lower half and the other is refilled from 2 WR values loaded - as floats, one
+// step ahead - while the step was computed.  Every input is read once (the window form above
+// re-reads 2 WR of every GZ_OUT + 2 WR: 2.7 x through L2), a thread's loads are in flight under
+// its own arithmetic instead of all in front of it, and the arithmetic per output is the same
+// sequence (bit-identical results).  The column is cut into `nseg` segments so that the grid has
+// enough waves; a segment's first window is its only re-read.
+template <int WR>
+__global__ __launch_bounds__(512) void gauss_z_ring(
+    PadView pv, float *__restrict__ out, int P0, int P1, int P2,
+    const double *__restrict__ w, int nxb, int nseg, int seg_len) {
+  constexpr int H = 2 * WR;                        // outputs per step = half a window
+  const unsigned wid = blockIdx.x;
+  const int seg = (int)(wid % (unsigned)nseg);
+  const unsigned rest = wid / (unsigned)nseg;
+  const int xb = (int)(rest % (unsigned)nxb), y = (int)(rest / (unsigned)nxb);
+  const int x = xb * (int)blockDim.x + (int)threadIdx.x;
+  if (x >= P2) return;
+  const int a_lo = seg * seg_len, a_hi = min(P0, a_lo + seg_len);     // outputs [a_lo, a_hi)
+  if (a_lo >= a_hi) return;
+  const int r = pv.r, D0 = (int)pv.D0, D1 = (int)pv.D1, D2 = (int)pv.D2;
+  const int yy = y - r, xx = x - r;
+  const bool col_ok = yy >= 0 && xx >= 0 && yy < D1 && xx < D2;
+  const int pplane = P1 * P2;
+  float *dst = out + ((int64_t)a_lo * P1 + y) * P2 + x;
+  if (!col_ok) {                                   // a column of the zero padding
+    for (int a = a_lo; a < a_hi; ++a, dst += pplane) *dst = 0.f;
+    return;
+  }
+  const int plane = D1 * D2;
+  const float *col = pv.pred + (int64_t)yy * D2 + xx;
+  // H consecutive padded inputs starting at padded z index `a` (reflected at the padded
+  // volume's ends, zero outside the prediction)
+  auto load_half = [&](int a, float (&f)[H]) {
+    if (a - r >= 0 && a + H - r <= D0) {
+      const float *q = col + (int64_t)(a - r) * plane;
+#pragma unroll
+      for (int i = 0; i < H; ++i) f[i] = q[(int64_t)i * plane];
+    } else {
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const int zz = reflect1(a + i, P0) - r;
+        f[i] = (zz >= 0 && zz < D0) ? col[(int64_t)zz * plane] : 0.f;
+      }
+    }
+  };
+  double wk[WR + 1];
+#pragma unroll
+  for (int j = 0; j <= WR; ++j) wk[j] = w[j];
+  double h0[H], h1[H];
+  float nf[H];
+  load_half(a_lo - WR, nf);
+#pragma unroll
+  for (int i = 0; i < H; ++i) h0[i] = (double)nf[i];
+  load_half(a_lo - WR + H, nf);
+#pragma unroll
+  for (int i = 0; i < H; ++i) h1[i] = (double)nf[i];
+  // one step: outputs a0 .. a0 + H - 1 from the window [lo | hi] (input a0 - WR + k at k);
+  // the next step's new half (inputs a0 + 3 WR ...) is loaded first and converted into `lo` last
+  auto step = [&](int a0, double (&lo)[H], double (&hi)[H]) {
+    const bool more = a0 + H < a_hi;
+    if (more) load_half(a0 + H + WR, nf);
+#pragma unroll
+    for (int o = 0; o < H; ++o) {
+      auto at = [&](int k) -> double { return k < H ? lo[k] : hi[k - H]; };
+      double acc = mul_rn(at(WR + o), wk[0]);
+#pragma unroll
+      for (int j = WR; j >= 1; --j)
+        acc = add_rn(acc, mul_rn(add_rn(at(WR + o - j), at(WR + o + j)), wk[j]));
+      if (a0 + o < a_hi) dst[(int64_t)o * pplane] = (float)acc;
+    }
+    dst += (int64_t)H * pplane;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < H; ++i) lo[i] = (double)nf[i];
+    }
+  };
+  for (int a0 = a_lo; a0 < a_hi; a0 += 2 * H) {
+    step(a0, h0, h1);
+    if (a0 + H < a_hi) step(a0 + H, h1, h0);
+  }
+}
+
 // y and x passes fused through one LDS tile: a workgroup takes GYX_TY consecutive y
 // rows of one z plane over the WHOLE x extent.  Phase 1 (lanes along x, coalesced):
 // a thread slides the register window of gauss_pass_win<1> down its column and stores
@@ -617,7 +701,18 @@ int launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t
   // 32-bit in-column / in-plane offsets of gauss_z_win
   const bool small = (GZ_OUT + 2 * WR) * pv.D1 * pv.D2 < ((int64_t)1 << 31) &&
                      P[1] * P[2] * GZ_OUT < ((int64_t)1 << 31) && P[0] >= 2 * WR;
-  if (small && !getenv("FPL_V2O_UNFUSED")) {
+  if (small && !getenv("FPL_V2O_UNFUSED") && !getenv("FPL_V2O_ZWIN")) {
+    // ring form: segments of a multiple of 4 WR outputs (two steps), about a quarter of the column
+    const int bd = best_block(P[2]);
+    const int64_t nxb = ceil_div64(P[2], bd);
+    const int64_t seg_len = std::max<int64_t>(4 * WR, ceil_div64(ceil_div64(P[0], 4), 4 * WR) * 4 * WR);
+    const int64_t nseg = ceil_div64(P[0], seg_len);
+    const int64_t nwork = nxb * nseg * P[1];
+    FPL_REQUIRE(ctx, nwork < ((int64_t)1 << 31), "voxel2obj: volume too large");
+    TimedLaunch tl(ctx, "v2o_gauss_z");
+    gauss_z_ring<WR><<<(unsigned)nwork, bd, 0, st>>>(
+        pv, fused ? b : a, (int)P[0], (int)P[1], (int)P[2], w_dev, (int)nxb, (int)nseg, (int)seg_len);
+  } else if (small && !getenv("FPL_V2O_UNFUSED")) {
     const int bd = best_block(P[2]);
     const int64_t nxb = ceil_div64(P[2], bd), nzb = ceil_div64(P[0], GZ_OUT);
     const int64_t nwork = nxb * nzb * P[1];

@@ -240,7 +240,7 @@ def test_voxel2obj_smoothing_compiles_without_fp64_fma(tmp_path):
     text = asm.read_text()
     assert not re.search(r'v_fma(c|ak|mk)?_f64', text), 'fp64 FMA in v2o.hip device code'
     # per smoothing kernel: the separately rounded product and sum are there
-    for kernel in ('gauss_z_win', 'gauss_yx_fused', 'gauss_pass_win', 'gauss_x_lds', 'gauss_pass'):
+    for kernel in ('gauss_z_win', 'gauss_z_ring', 'gauss_yx_fused', 'gauss_pass_win', 'gauss_x_lds', 'gauss_pass'):
         bodies = re.findall(r'^_ZN[^\n]*%sI[^\n]*:[^\n]*\n(.*?)s_endpgm' % kernel, text, re.S | re.M)
         assert bodies, kernel
         for body in bodies:
