@@ -459,11 +459,15 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
           o.s0[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][0]);
           o.s1[part] = *reinterpret_cast<const unsigned short *>(tp + offS[e][1]);
         }
+      };
+      // (edge blocks of uint8 volumes) the sub-step's initial accumulator values
+      auto gather_init = [&](const Geo &t, int sub, f32x4 (&o)[3]) {
         if (INT && EDGE) {
+          const int sp = sub >> 1, e = sub & 1;
           const int pzy = 4 * min(max(t.zrel + (sp >> 1), 0), 3) + min(max(t.yrel + (sp & 1), 0), 3);
           const unsigned char *tp = shtab + ((4 * pzy + min(max(t.xrel + e, 0), 3)) * 48 + 4 * g) * 4;
 #pragma unroll
-          for (int b = 0; b < 3; ++b) o.init[b] = *reinterpret_cast<const f32x4 *>(tp + 64 * b);
+          for (int b = 0; b < 3; ++b) o[b] = *reinterpret_cast<const f32x4 *>(tp + 64 * b);
         }
       };
       auto frag = [&](const Gin &gi, int part) {
@@ -472,14 +476,20 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
       };
       constexpr int NC3 = INT ? 6 : 9;                    // conv3's MFMAs per sub-step
       // MFMA i of conv3, x parity e, on the gathered fragments
-      auto c3 = [&](int i, int e, const Gin &gi, h16x8 bh, h16x8 bl, f32x4 (&o)[3]) {
+      auto c3 = [&](int i, int e, const f32x4 (&gin)[3], h16x8 bh, h16x8 bl, f32x4 (&o)[3]) {
         const int b = i % 3, grp = i / 3;
-        if (grp == 0) o[b] = mfma16(w1[1][e][b], bh, INT ? (EDGE ? gi.init[b] : kin[b]) : sh1[b]);
+        if (grp == 0) o[b] = mfma16(w1[1][e][b], bh, INT ? (EDGE ? gin[b] : kin[b]) : sh1[b]);
         else if (!INT && grp == 1) o[b] = mfma16(w1[0][e][b], bl, o[b]);
         else o[b] = mfma16(w1[0][e][b], bh, o[b]);
       };
       // the state the skew carries from stage to stage (and task to task)
-      Gin G;                              // taps (+ initial values) of the sub-step conv3 does next
+      // taps of the sub-steps conv3 does next: position q (8 x task + sub-step) in Gd[q % NGB].
+      // uint8 volumes read them THREE positions ahead into two buffers (5 registers each: a
+      // full stage between an LDS read and its use; one position less left every stage waiting
+      // ~250 cycles on lgkmcnt), float volumes (10 registers a buffer) two ahead into one.
+      constexpr int NGB = INT ? 2 : 1, DEPTH = NGB + 1;
+      Gin Gd[NGB];
+      f32x4 gin[3];                       // (edge blocks) initial values, one position ahead of their use
       f32x4 a1n[3];                       // conv3 of the sub-step whose conv1 comes next
       f32x4 a2[2][3];                     // conv1 of the x pair being pooled
       f32x4 poolf[3];                     // running maximum of the task, started from -shift2
@@ -491,11 +501,14 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
         for (int b = 0; b < 3; ++b) a2[e][b] = f32x4{0.f, 0.f, 0.f, 0.f};
       {                                   // prime: conv3 of (task 0, sub-step 0), reads of sub-step 1
         const Geo t0 = geo(0);
-        gather(t0, 0, G);
-        const h16x8 bh = frag(G, 0), bl = INT ? bh : frag(G, INT ? 0 : 1);
+        gather(t0, 0, Gd[0]);
+        gather_init(t0, 0, gin);
+        const h16x8 bh = frag(Gd[0], 0), bl = INT ? bh : frag(Gd[0], INT ? 0 : 1);
 #pragma unroll
-        for (int i = 0; i < NC3; ++i) c3(i, 0, G, bh, bl, a1n);
-        gather(t0, 1, G);
+        for (int i = 0; i < NC3; ++i) c3(i, 0, gin, bh, bl, a1n);
+        gather_init(t0, 1, gin);
+#pragma unroll
+        for (int q = 1; q < DEPTH; ++q) gather(t0, q, Gd[q % NGB]);
       }
 #pragma unroll 1
       for (int ti = 0; ti < S_TASKS; ++ti) {
@@ -517,6 +530,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
           f32x4 a1[3];
 #pragma unroll
           for (int b = 0; b < 3; ++b) a1[b] = a1n[b];
+          const Gin &G = Gd[(sub + 1) % NGB];
           const h16x8 bh = frag(G, 0), bl = INT ? bh : frag(G, INT ? 0 : 1);
           float r[12];
           unsigned hi[6], lo[6];
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
           };
 #pragma unroll
           for (int s = 0; s < 15; ++s) {
-            if (s < 6) c3(s, en, G, bh, bl, a1n);
+            if (s < 6) c3(s, en, gin, bh, bl, a1n);
             else c1(s - 6);
             if (s < 6 && e == 0) PL(s);                   // the pair finished a stage ago (sub 0: the last task's)
             if (s < 4) A(s);
@@ -563,10 +577,12 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
           // ---- tail: LDS reads of the stage after next, the unpaired MFMAs, the once-a-task work
-          if (sub + 2 < 8) gather(tg, sub + 2, G);
-          else gather(tn, sub + 2 - 8, G);
+          if (sub + DEPTH < 8) gather(tg, sub + DEPTH, Gd[(sub + DEPTH) % NGB]);
+          else gather(tn, sub + DEPTH - 8, Gd[(sub + DEPTH) % NGB]);
+          if (sub + 2 < 8) gather_init(tg, sub + 2, gin);
+          else gather_init(tn, sub + 2 - 8, gin);
 #pragma unroll
-          for (int i = 6; i < NC3; ++i) c3(i, en, G, bh, bl, a1n);
+          for (int i = 6; i < NC3; ++i) c3(i, en, gin, bh, bl, a1n);
 #pragma unroll
           for (int i = 9; i < 15; ++i) c1(i);
           if (sub == 0) {
