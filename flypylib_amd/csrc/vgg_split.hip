@@ -396,21 +396,22 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
     x8::store12_sel(a.p1, 0, g, z3, ovf, false, a.dump);
   }
   // ---- the task loop, as ONE instruction stream laid out by hand ----------------------------
-  // A 16x16x32 MFMA holds the SIMD's issue port for 8 of its 16 cycles, an ordinary VALU
-  // instruction for 4 (v_fma_mix*_f16: 8) - tools/micro/mfma_valu_overlap.hip - and a stage
-  // (one sub-step: x parity e of window position sp) is 21 MFMAs next to ~58 VALU slots of
-  // ReLU, hi / lo conversion and pooling: issue-bound, but only if the two kinds alternate.
-  // Left to the compiler (and to two waves per SIMD running the same phases) they came in
-  // blocks: 19.8 ms, the SUM of the matrix pipe's 11.5 ms and the VALU's.  So the layers of a
+  // A SIMD issues one VALU-class instruction - MFMAs included - per ~4.4 cycles whatever its number
+  // of waves; two ordinary VALU instructions per 16-cycle MFMA are free, every further one costs
+  // its issue time, v_fma_mix*_f16 counts twice (tools/micro/mfma_valu_overlap.hip,
+  // profiles/r04_micro_mfma_valu_overlap.txt).  A stage (one sub-step: x parity e of window
+  // position sp) is 21 MFMAs next to ~58 such slots of ReLU, hi / lo conversion and pooling:
+  // at the port's limit, and only if the two kinds alternate.  Left to the compiler (and to two
+  // waves per SIMD running the same phases) they came in blocks: 19.8 ms, about the SUM of the
+  // matrix pipe's 11.5 ms and the VALU's.  So the layers of a
   // sub-step are skewed by one stage - stage k issues conv3 of sub-step k + 1 and conv1 of
   // sub-step k, whose ReLU / split reads accumulators finished a stage ago - and the stage is
   // written as 15 slots of [one MFMA, one piece of VALU work], pinned by sched_barriers, then
   // a tail of six MFMAs under which the LDS reads of the next stage are issued (and, once a
   // task, the previous task's P1 store or the next tile's row conversion).  The skew runs
   // across tasks; only a block's first task primes it and its last one drains it.
-  struct Gin {                          // what conv3 of one sub-step reads from LDS
+  struct Gin {                          // the taps conv3 of one sub-step reads from the LDS tile
     unsigned p[INT ? 1 : 2][3], s0[INT ? 1 : 2], s1[INT ? 1 : 2];
-    f32x4 init[3];
   };
   struct Geo { int base, xrel, yrel, zrel, pzl, pyl, xh; };
   int cur = 0;
