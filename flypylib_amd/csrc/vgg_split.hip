@@ -15,10 +15,13 @@
 // 2^-25 absolute.  Observed: probabilities within 2e-6 of the fp32 oracle on the trained
 // fixture, at 3x the MFMA work of the 16-bit path instead of the 16x of fp32 MFMAs.
 //
-// Layout of P1 / P2 in HBM: per voxel NPASS = 2 passes of CHP = 24 channels, each pass
-// [hi 24][lo 24] halves = 96 B, 192 B per voxel.  A 3x3x3 conv runs its K loop once per
-// pass on a 6 x 6 x 18 x 96 B tile (the shipped kernels' tile size: two workgroups per
-// CU), K-steps over (tap, channel-in-pass): 21 per pass.
+// Two generations of the 3x3x3 48 -> 48 K loop live here.  vgg_like (round 4): P1 / P2 as planes
+// of 8-channel passes and the all-LDS K loop of vgg_split_lds.h (one persistent 8-wave
+// workgroup per CU, tile AND weight fragments double-buffered in LDS by LDS-DMA): vggs_mid_pool,
+// vggs_c5_tail.  vgg_like2 (round 3, the constants below): per voxel NPASS = 2 passes of CHP =
+// 24 channels, each pass [hi 24][lo 24] halves = 96 B, 192 B per voxel; the K loop runs once
+// per pass on a 6 x 6 x 18 x 96 B tile (two 4-wave workgroups per CU, weight fragments per wave
+// from L2), 21 K-steps per pass: vggs2_conv3, vggs_c5_tail_p24.
 #define FPL_F16 1   // the operand halves are IEEE halves (mfma_util.h, pack_weights.h)
 #include <algorithm>
 #include <cmath>
