@@ -73,6 +73,24 @@ constexpr int grp_k0(int gi) {
 }
 constexpr int grp_k1(int gi) { return gi >= 12 ? 8 : 2 * (gi / 3) + 1; }   // pairs only
 constexpr unsigned grp_off(int k, int ty) { return (unsigned)(((k / 3) * ty * TX + k % 3) * PITCH); }
+// Parity form (split build, sources that are an UpSampling3D(2): conv3 192->64's first 128 channels,
+// the head's first 64).  The tile's voxel pairs along z and y are copies of one low-resolution
+// voxel, so the three taps of an axis collapse to two with pre-summed weights that depend on the
+// output's parity p = o & 1 (block origins are even, the source is not cropped):
+//   p = 0: rows o, o + 1 are the same voxel -> (w0 + w1) at row o,  w2 at row o + 2
+//   p = 1: rows o + 1, o + 2 are the same   ->  w0 at row o,  (w1 + w2) at row o + 1
+// z parity is the wave's (one z plane per wave), y parity the sub-step's, x is left to the lanes:
+// 2 x 3 x 2 = 12 taps instead of 27.  Row groups k = (dz', dx), six of them; sequence
+// M0 M1 P(0,1) M2 M3 P(2,3) M4 M5 P(4,5); a group is FOUR K-steps (dy', sub-step parity), each
+// feeding the sub-steps of its parity: 36 weight steps of R / 2 x MB MFMAs where the plain form
+// has 42 of R x MB - 43 % of the MFMAs, 86 % of the weight stream.  The pre-summed weights are
+// made in fp32 and split afterwards (pack_conv3_parity); a wave reads the stream of its z parity.
+constexpr int NCHU = 6, NGU = 9, KCU = 4;
+constexpr bool grpu_pair(int gi) { return gi % 3 == 2; }
+constexpr int grpu_k0(int gi) { return gi % 3 == 2 ? 2 * (gi / 3) : 2 * (gi / 3) + gi % 3; }
+constexpr int grpu_k1(int gi) { return 2 * (gi / 3) + 1; }
+// second row of an axis for parity p: o + 2 (p = 0) or o + 1 (p = 1)
+constexpr int par_row(int p) { return p ? 1 : 2; }
 // Geometry of a block of 4 (z: one plane per wave) x R (y: rows per wave) x 16 (x: lanes)
 // outputs.  R = 4 everywhere but the 32-output-channel kernels (unet_like2's stem: R = 8, 96
 // rows = 12 blocks; its head: R = 6, 82 rows = 14 blocks): a weight fragment then feeds 8 / 6
@@ -198,6 +216,10 @@ struct Conv3Args {
   // the host for raw inputs |x| <= xlim, which the kernel checks per raw voxel
   unsigned *flag;
   float xlim;
+  // parity form (UPSP instantiations): `w` = the weight stream of even z planes, the odd planes'
+  // `wstream` bytes behind it; total_steps = K-steps of one stream (all launches: set by launch_conv3)
+  int parity, total_steps;
+  int64_t wstream;
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -225,8 +247,9 @@ struct Conv3Args {
 constexpr int RZ = TZ + 2, RY = TY + 2, RX = TX + 2;     // raw tile 8 x 8 x 20
 constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
-template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false, int R = 4>
+template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false, int R = 4, bool UPSP = false>
 __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FPLK(conv3)(Conv3Args a) {
+  static_assert(!UPSP || (SPLIT && !STEM && !POOL), "the parity form: split build, plain sources");
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
   static_assert(!HEAD || (MB == 2 && !POOL), "the head variant is conv3 ->32");
   static_assert(R % 2 == 0, "pool pairs");
@@ -241,7 +264,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
   unsigned *offtab = reinterpret_cast<unsigned *>(smem + TILE_BYTES);
   // STEM: [0, TABN) = raw-tile offset of tile voxel v; then the bf16 raw tile
   unsigned short *rawt = reinterpret_cast<unsigned short *>(offtab + TABN);   // split: hi, then lo
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = UPSP ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;   // (scalar: the parity form's row offsets)
   const int c = lane & 15, g = lane >> 4;
   const int G = (int)gridDim.x;                     // multiple of 8 (host)
   // consecutive logical workgroups share an XCD (and its L2): halo reuse
@@ -403,7 +427,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
 #pragma unroll
     for (int r = 0; r < 4; ++r) shv[b][r] = a.shift[4 * MB * g + 4 * b + r];
   f32x4 acc[R][MB];
-  const int total_steps = a.ncc * NG * KC;
+  const int total_steps = a.total_steps;
   __syncthreads();                                  // offset tables visible
   // The tile loads go out BEFORE the weight loads, as in the steady state of the
   // loop below: vmcnt retires in order, and with this order the waits hipcc derives
@@ -413,8 +437,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
   // Weight fragments (MB x 1 KiB per K-step, the same for every wave) come straight
   // from L2 into registers, WQ K-steps ahead of their use and across tile / block
   // boundaries: no LDS ring and no barrier inside the K loop.
-  const unsigned char *wl = a.w + lane * 16;
-  static_assert((NG * KC) % WQ == 0, "the fragment queue's phase is static inside a chunk");
+  const unsigned char *wl = a.w + lane * 16 + ((UPSP && (wave & 1)) ? a.wstream : 0);
+  static_assert((NG * KC) % WQ == 0 && (NGU * KCU) % WQ == 0, "the fragment queue's phase is static inside a chunk");
   h16x8 wq[WQ][MB];
 #pragma unroll
   for (int d = 0; d < WQ; ++d)
@@ -429,9 +453,20 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
     return tile + vbase + grp_off(grp_k0(gi), TY) + r * ROW;
   };
 
+  // parity form: row group k = (dz', dx); its second z row depends on the wave's parity
+  const unsigned zsel = (unsigned)(par_row(wave & 1) * TY * TX * PITCH);
+  auto grpu_off = [&](int k) -> unsigned { return (k / 3 ? zsel : 0u) + (unsigned)((k % 3) * PITCH); };
+  auto row_addr_u = [&](int gi, int r) -> const unsigned char * {
+    if (grpu_pair(gi))
+      return tile + pbase + (g >= 2 ? grpu_off(grpu_k1(gi)) : grpu_off(grpu_k0(gi))) + r * ROW;
+    return tile + vbase + grpu_off(grpu_k0(gi)) + r * ROW;
+  };
+  int chunk_base = 0;               // K-steps of the weight stream in front of the current chunk
+
   for (;;) {
     for (int cc = 0; cc < a.ncc; ++cc) {
       if (cc == 0) {
+        chunk_base = 0;
 #pragma unroll
         for (int b = 0; b < MB; ++b)
 #pragma unroll
@@ -449,6 +484,40 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
       }
       __syncthreads();            // tile visible
       h16x8 brow[2][R + 2];
+      if (UPSP && a.src[cc].ups) {
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r)
+          brow[0][r] = *reinterpret_cast<const h16x8 *>(row_addr_u(0, r));
+#pragma unroll
+        for (int gi = 0; gi < NGU; ++gi) {
+          const int ng = gi + 1 < NGU ? gi + 1 : 0;
+#pragma unroll
+          for (int q = 0; q < KCU; ++q) {
+            const int dyp = q >> 1, py = q & 1;       // y tap of the pair, sub-step parity served
+            const int st = gi * KCU + q;
+#pragma unroll
+            for (int r = (R + 2) * q / KCU; r < (R + 2) * (q + 1) / KCU; ++r)
+              brow[(gi + 1) & 1][r] = *reinterpret_cast<const h16x8 *>(row_addr_u(ng, r));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int sub = py; sub < R; sub += 2)
+#pragma unroll
+              for (int b = 0; b < MB; ++b)
+                acc[sub][b] = mfma16(wq[st % WQ][b], brow[gi & 1][sub + (dyp ? par_row(py) : 0)], acc[sub][b]);
+            __builtin_amdgcn_s_setprio(0);
+            {
+              int nxt = chunk_base + st + WQ;
+              nxt = nxt < total_steps ? nxt : nxt - total_steps;
+#pragma unroll
+              for (int b = 0; b < MB; ++b)
+                wq[st % WQ][b] =
+                    *reinterpret_cast<const h16x8 *>(wl + ((size_t)nxt * MB + b) * 1024);
+            }
+          }
+        }
+        chunk_base += NGU * KCU;
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < R + 2; ++r)
         brow[0][r] = *reinterpret_cast<const h16x8 *>(row_addr(0, r));
@@ -471,7 +540,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
               acc[sub][b] = mfma16(wq[st % WQ][b], brow[gi & 1][sub + dy], acc[sub][b]);
           __builtin_amdgcn_s_setprio(0);
           {
-            int nxt = cc * (NG * KC) + st + WQ;
+            int nxt = chunk_base + st + WQ;
             nxt = nxt < total_steps ? nxt : nxt - total_steps;   // next block starts over
 #pragma unroll
             for (int b = 0; b < MB; ++b)
@@ -480,6 +549,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
           }
         }
       }
+      chunk_base += NG * KC;
     }
     // ---- epilogue: (ReLU) -> bf16, channels-last store
     {
@@ -936,6 +1006,10 @@ struct UnetState {
   size_t off_w[12] = {0}, off_s[12] = {0};
   size_t half_bytes[12] = {0};   // conv3 with 128 outputs: bytes of the first 64-channel half
   size_t off_w7t = 0;            // conv 7 with the dy / dx taps swapped (edge strip)
+  // split build, parity form of the two convolutions that read an UpSampling3D source:
+  // [0] = conv3 192->64 (l_up1), [1] = conv3 96->32 (l_up2): both weight streams, one after the other
+  size_t off_wp[2] = {0, 0}, wp_stream[2] = {0, 0};
+  int wp_steps[2] = {0, 0};
   float bias_tail = 0.f;
   float xlim = 0.f;              // split build: input limit of the stem's half-range bound
 };
@@ -1074,6 +1148,64 @@ void pack_conv3(const float *A, const fpl_op &op, int co0, int ncout, bool trans
   }
 }
 
+// The parity form's two weight streams (split build; NCHU above): stream pz = what a wave of z
+// parity pz reads, chunk after chunk - the first `n_ups` chunks (the UpSampling3D source) as 36
+// parity steps [group 9][dy' 2][sub-step parity 2], the rest as pack_conv3's 42.  Pre-summed
+// weights are formed in fp32 from the layer's own (tap sets Z / Y below), BN scale and the hi / lo
+// split applied afterwards by fpl_pack_frags.  *steps = K-steps of one stream.
+void pack_conv3_parity(const float *A, const fpl_op &op, int ncout, int n_ups, std::vector<uint16_t> *f,
+                       int *steps) {
+  const int ncc = op.cin / RCH, mb = (ncout + 15) / 16;
+  std::vector<float> scale(A + op.scale_off, A + op.scale_off + ncout);
+  std::vector<uint16_t> plain;
+  pack_conv3(A, op, 0, ncout, false, &plain);                    // [chunk][42][mb] fragments
+  const size_t plain_chunk = (size_t)NG * KC * mb * 512;
+  // taps of an axis that fall on the pair's first / second low-resolution voxel, by parity
+  auto taps = [](int par, int second, int *t) {                  // returns the count
+    if (par == 0) { if (!second) { t[0] = 0; t[1] = 1; return 2; } t[0] = 2; return 1; }
+    if (!second) { t[0] = 0; return 1; }
+    t[0] = 1; t[1] = 2; return 2;
+  };
+  const int nstu = NGU * KCU;
+  std::vector<float> sub((size_t)nstu * CC * ncout);
+  f->clear();
+  *steps = n_ups * nstu + (ncc - n_ups) * NG * KC;
+  for (int pz = 0; pz < 2; ++pz)
+    for (int cc = 0; cc < ncc; ++cc) {
+      if (cc >= n_ups) {
+        f->insert(f->end(), plain.begin() + cc * plain_chunk, plain.begin() + (cc + 1) * plain_chunk);
+        continue;
+      }
+      std::fill(sub.begin(), sub.end(), 0.f);
+      for (int gi = 0; gi < NGU; ++gi)
+        for (int q = 0; q < KCU; ++q) {
+          const int dyp = q >> 1, py = q & 1;
+          for (int ch = 0; ch < CC; ++ch) {
+            const int k = (grpu_pair(gi) && ch >= RCH) ? grpu_k1(gi) : grpu_k0(gi);
+            const int dzp = k / 3, dx = k % 3;
+            int tz[2], ty[2];
+            const int nz = taps(pz, dzp, tz), ny = taps(py, dyp, ty);
+            float *dst = &sub[((size_t)(gi * KCU + q) * CC + ch) * ncout];
+            for (int iz = 0; iz < nz; ++iz)
+              for (int iy = 0; iy < ny; ++iy) {
+                const float *w = A + op.w_off +
+                                 ((size_t)(tz[iz] * 9 + ty[iy] * 3 + dx) * op.cin + cc * RCH + ch % RCH) * op.cout;
+                for (int co = 0; co < ncout; ++co) dst[co] += w[co];
+              }
+          }
+        }
+      std::vector<uint16_t> fc[2];
+      for (int part = 0; part < PM; ++part)
+        fpl_pack_frags(sub.data(), scale.data(), nstu, CC, ncout, mb, nstu, SLOT_SPATIAL, &fc[part], true, part);
+      for (int gi = 0; gi < NGU; ++gi)
+        for (int q = 0; q < KCU; ++q) {
+          const int ks = gi * KCU + q, part = grpu_pair(gi) ? 1 : 0;
+          f->insert(f->end(), fc[part].begin() + (size_t)ks * mb * 512,
+                    fc[part].begin() + (size_t)(ks + 1) * mb * 512);
+        }
+    }
+}
+
 // 1x1x1 conv on a (physical) channels-last row: K-steps over chunks of 32 physical
 // channels; split: [K-step][set][mb] as pack_conv3
 void pack_conv1(const float *A, const fpl_op &op, bool il, std::vector<uint16_t> *f) {
@@ -1105,6 +1237,7 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
   const float *A = prog->arena_host.data();
   const int l_up2 = d.l_up2(), l_last = d.nconv - 1;
   st->off_w7t = 0;
+  st->wp_steps[0] = st->wp_steps[1] = 0;
   for (int l = 0; l < d.nconv; ++l) {
     const fpl_op &op = prog->ops[d.conv[l]];
     std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
@@ -1144,6 +1277,17 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
       f.insert(f.end(), h1.begin(), h1.end());
     } else if (op.k == 3) {
       pack_conv3(A, op, 0, op.cout, false, &f);
+      if (SPLIT && l == l_up2) {
+        // parity form: the leading chunks of the concatenated input are the upsampled source
+        const int w = 1, n_ups = 64 / RCH;
+        if (op.cin / RCH > n_ups) {
+          std::vector<uint16_t> fp;
+          pack_conv3_parity(A, op, op.cout, n_ups, &fp, &st->wp_steps[w]);
+          st->off_wp[w] = all.size() * sizeof(uint16_t);
+          st->wp_stream[w] = fp.size() / 2 * sizeof(uint16_t);
+          all.insert(all.end(), fp.begin(), fp.end());
+        }
+      }
       if (l == l_up2) {          // the transposed edge strip swaps the roles of dy and dx
         std::vector<uint16_t> ft;
         pack_conv3(A, op, 0, op.cout, true, &ft);
@@ -1213,9 +1357,11 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
   return 0;
 }
 
-template <int MB, bool STEM = false, bool POOL = false, bool HEAD = false, int R = 4>
+template <int MB, bool STEM = false, bool POOL = false, bool HEAD = false, int R = 4, bool UPSP = false>
 int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   constexpr bool PF = true;
+  if (!UPSP) { a.parity = 0; a.wstream = 0; a.total_steps = a.ncc * NG * KC; }
+  FPL_REQUIRE(ctx, UPSP == (a.parity != 0) && (!UPSP || !a.transposed), "conv3: parity form / template mismatch");
   typedef Geo<R> GE;
   // STEM keeps the bf16 raw tile behind the (single) offset table
   constexpr int SMEM = GE::TILE_BYTES + (STEM ? GE::TABN * 4 + GE::NRAW * 2 * PM : GE::TAB_BYTES);
@@ -1224,7 +1370,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   // drive several GPUs, one context each; setting it twice is harmless)
   static bool attr_set[FPL_MAX_DEVICES] = {false};
   if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL, HEAD, R>,
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(conv3)<MB, PF, STEM, POOL, HEAD, R, UPSP>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
@@ -1260,7 +1406,7 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
   TimedLaunch tl(ctx, name);
   FPL_REQUIRE(ctx, POOL == (a.pool_out != nullptr) && (!POOL || a.relu),
               "conv3: pool output / template mismatch");
-  FPLK(conv3)<MB, PF, STEM, POOL, HEAD, R><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
+  FPLK(conv3)<MB, PF, STEM, POOL, HEAD, R, UPSP><<<(unsigned)grid, 256, SMEM, ctx->stream>>>(a);
   return 0;
 }
 
@@ -1336,7 +1482,13 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.transposed = 0; a.xorg = 0; a.main_w = 0;
     memset(&a.io, 0, sizeof(a.io)); a.w8 = a.w9 = nullptr; a.sh8 = nullptr; a.bias9 = 0.f;
     a.flag = flag; a.xlim = st->xlim;
+    a.parity = 0; a.total_steps = 0; a.wstream = 0;
     return a;
+  };
+  // split build: the parity form for sources that are an UpSampling3D (FPL_UNET_NOPARITY=1: A/B)
+  const bool use_par = SPLIT && !getenv("FPL_UNET_NOPARITY");
+  auto set_parity = [&](Conv3Args &a, int w) {
+    a.w = F + st->off_wp[w]; a.parity = 1; a.wstream = (int64_t)st->wp_stream[w]; a.total_steps = st->wp_steps[w];
   };
   if (D.first1) {  // unet_like: conv3 1->32 and conv1 32->32 chained, c1 + pooled p1
     StemC1Args a;
@@ -1420,6 +1572,10 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.ncc = n3 + n2;
     for (int cc = 0; cc < n3; ++cc) a.src[cc] = src_of(c3, db, 128, cc, 2, 0);
     for (int cc = 0; cc < n2; ++cc) a.src[n3 + cc] = src_of(c2, d2, 64, cc, 1, D.crop2);
+    // (The parity form was measured here too - 64 outputs at four rows per wave - and is not used:
+    // it halves the MFMAs a weight fragment feeds, 8 per 4 KiB, and the per-wave fragment stream
+    // then needs twice what the CU's vector-memory path delivers: 3.66 -> 5.19 ms for 27 tiles.
+    // The head below - 32 outputs, six rows - has the same ratio at half the bytes: 5.73 -> 5.05.)
     FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
   }
   conv1(FPLK(conv1)<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), lu1 + 1, c4, "unet_conv1_64_64");
@@ -1439,6 +1595,16 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
       a.w8 = (const h16x8 *)(F + st->off_w[lu2 + 1]); a.sh8 = S + st->off_s[lu2 + 1];
       a.w9 = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias9 = st->bias_tail;
       a.out = nullptr;
+    }
+    const unsigned char *w_plain = a.w;
+#ifdef FPL_SPLIT
+    if (use_par && st->wp_steps[1]) {
+      set_parity(a, 1);
+      if (io) FPL_TRY((launch_conv3<2, false, false, true, 6, true>(ctx, a, n, "unet_conv3_96_32_head")));
+      else FPL_TRY((launch_conv3<2, false, false, false, 6, true>(ctx, a, n, "unet_conv3_96_32")));
+    } else
+#endif
+    if (io) {
       FPL_TRY((launch_conv3<2, false, false, true, 6>(ctx, a, n, "unet_conv3_96_32_head")));
     } else {
       FPL_TRY((launch_conv3<2, false, false, false, 6>(ctx, a, n, "unet_conv3_96_32")));
@@ -1446,6 +1612,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     if (strip) {
       Conv3Args e = a;
       e.main_w = 0; e.transposed = 1; e.xorg = d5a - rem;
+      e.parity = 0; e.wstream = 0; e.total_steps = 0; (void)w_plain;
       e.w = F + st->off_w7t;
       if (io) FPL_TRY((launch_conv3<2, false, false, true>(ctx, e, n, "unet_conv3_96_32_head_edge")));
       else FPL_TRY((launch_conv3<2>(ctx, e, n, "unet_conv3_96_32_edge")));

@@ -43,6 +43,31 @@ def test_unet_split_matches_emulation_and_fp32(ctx, shape, tile):
     assert ctx.last_path() == 'unet_split_f16' and np.array_equal(auto, got)
 
 
+def test_unet_head_parity_form_agrees_with_the_plain_taps(ctx, monkeypatch):
+    """the head's conv3 reads UpSampling3D(2)(c4) for 64 of its 96 input channels: by default its
+    27 taps collapse to 12 with weights pre-summed per output parity along z and y (fp32 sums,
+    split afterwards); FPL_UNET_NOPARITY=1 runs the 27 taps.  Same probabilities up to the
+    rounding of the pre-summed weights' lo halves, both within the gate of the fp32 path.  The
+    100^3 tile has the 82-wide layer: main columns in the parity form, edge strip in the plain one."""
+    for shape, tile in (((60, 52, 70), 36), ((110, 100, 104), 100)):
+        g = fplmodels.unet_like2(tile)[0]
+        synth.synthetic_weights(g, 43)
+        prog = _capi.Program(ctx, g, (1, 1, 1))
+        u8 = synth.em_volume_u8(15, shape)
+        kw = dict(mean=128.0, std=33.0)
+        par = prog.infer_volume(u8, (tile,) * 3, (9,) * 3, precision=_capi.PREC_F16S, **kw)
+        f32gpu = prog.infer_volume(u8, (tile,) * 3, (9,) * 3, precision=_capi.PREC_F32, **kw)
+        monkeypatch.setenv('FPL_UNET_NOPARITY', '1')
+        plain = prog.infer_volume(u8, (tile,) * 3, (9,) * 3, precision=_capi.PREC_F16S, **kw)
+        monkeypatch.delenv('FPL_UNET_NOPARITY')
+        assert not np.array_equal(par, plain), 'the switch changed nothing: is the parity form running?'
+        print('parity vs plain %.2e, vs fp32 %.2e / %.2e' % (np.abs(par - plain).max(), np.abs(par - f32gpu).max(),
+                                                            np.abs(plain - f32gpu).max()))
+        assert np.abs(par - plain).max() < 3e-6
+        assert np.abs(par - f32gpu).max() < TOL and np.abs(plain - f32gpu).max() < TOL
+        prog.close()
+
+
 def test_unet_split_slabs_equal_whole(ctx):
     tile = 36
     g = fplmodels.unet_like2(tile)[0]
