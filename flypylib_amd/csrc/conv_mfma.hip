@@ -73,23 +73,24 @@ constexpr int grp_k0(int gi) {
 }
 constexpr int grp_k1(int gi) { return gi >= 12 ? 8 : 2 * (gi / 3) + 1; }   // pairs only
 constexpr unsigned grp_off(int k, int ty) { return (unsigned)(((k / 3) * ty * TX + k % 3) * PITCH); }
-// Parity form (split build, sources that are an UpSampling3D(2): conv3 192->64's first 128 channels,
-// the head's first 64).  The tile's voxel pairs along z and y are copies of one low-resolution
-// voxel, so the three taps of an axis collapse to two with pre-summed weights that depend on the
-// output's parity p = o & 1 (block origins are even, the source is not cropped):
-//   p = 0: rows o, o + 1 are the same voxel -> (w0 + w1) at row o,  w2 at row o + 2
-//   p = 1: rows o + 1, o + 2 are the same   ->  w0 at row o,  (w1 + w2) at row o + 1
-// z parity is the wave's (one z plane per wave), y parity the sub-step's, x is left to the lanes:
-// 2 x 3 x 2 = 12 taps instead of 27.  Row groups k = (dz', dx), six of them; sequence
-// M0 M1 P(0,1) M2 M3 P(2,3) M4 M5 P(4,5); a group is FOUR K-steps (dy', sub-step parity), each
-// feeding the sub-steps of its parity: 36 weight steps of R / 2 x MB MFMAs where the plain form
-// has 42 of R x MB - 43 % of the MFMAs, 86 % of the weight stream.  The pre-summed weights are
-// made in fp32 and split afterwards (pack_conv3_parity); a wave reads the stream of its z parity.
-constexpr int NCHU = 6, NGU = 9, KCU = 4;
-constexpr bool grpu_pair(int gi) { return gi % 3 == 2; }
-constexpr int grpu_k0(int gi) { return gi % 3 == 2 ? 2 * (gi / 3) : 2 * (gi / 3) + gi % 3; }
-constexpr int grpu_k1(int gi) { return 2 * (gi / 3) + 1; }
-// second row of an axis for parity p: o + 2 (p = 0) or o + 1 (p = 1)
+// Parity form (sources that are an UpSampling3D(2): conv3 192->64's first 128 input
+// channels, the head's first 64).  The tile's z planes come in pairs that are copies of one
+// low-resolution plane, so the three z taps collapse to two with pre-summed weights that depend
+// on the output plane's parity p = z & 1 (block origins are even, the source is not cropped):
+//   p = 0: planes z, z + 1 are the same -> (w0 + w1) at plane z,  w2 at plane z + 2
+//   p = 1: planes z + 1, z + 2 are      ->  w0 at plane z,  (w1 + w2) at plane z + 1
+// A wave owns one z plane, so its parity is the wave's: the upsampled chunk's row groups (dz',
+// dx) are the plain sequence's first six (split build: M0 M1 P(0,1) M2 M3 P(2,3) M4 M5 P(4,5), NGU = 9
+// groups) of KC steps - with the "dz = 1" plane one or two planes on, and the dz = 2 groups gone: 27
+// weight steps instead of 42 (16-bit builds: 18 instead of 27), MFMAs and weight stream both at
+// two thirds.  The pre-summed weights are
+// made in fp32 and split afterwards (pack_conv3_parity); a wave reads the stream of its parity.
+// (Pre-summing along y as well - sub-step parity, 36 steps feeding half the sub-steps each, 43 %
+// of the MFMAs but 86 % of the weight stream - was built too: the same time for the head, a
+// slowdown for the 64-output layer, whose fragment stream is what the CU's vector-memory path
+// can just deliver; profiles/r04_unet_parity_proxy.txt.)
+constexpr int NGU = SPLIT ? 9 : 6;
+// second plane of the pair for parity p: z + 2 (p = 0) or z + 1 (p = 1)
 constexpr int par_row(int p) { return p ? 1 : 2; }
 // Geometry of a block of 4 (z: one plane per wave) x R (y: rows per wave) x 16 (x: lanes)
 // outputs.  R = 4 everywhere but the 32-output-channel kernels (unet_like2's stem: R = 8, 96
@@ -249,7 +250,7 @@ constexpr int NRAW = RZ * RY * RX;                       // 1280 = 5 per thread
 
 template <int MB, bool PF, bool STEM = false, bool POOL = false, bool HEAD = false, int R = 4, bool UPSP = false>
 __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FPLK(conv3)(Conv3Args a) {
-  static_assert(!UPSP || (SPLIT && !STEM && !POOL), "the parity form: split build, plain sources");
+  static_assert(!UPSP || (!STEM && !POOL), "the parity form: plain sources");
   static_assert(!STEM || (MB == 2 && PF), "the stem variant is conv3 32->32");
   static_assert(!HEAD || (MB == 2 && !POOL), "the head variant is conv3 ->32");
   static_assert(R % 2 == 0, "pool pairs");
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
   // from L2 into registers, WQ K-steps ahead of their use and across tile / block
   // boundaries: no LDS ring and no barrier inside the K loop.
   const unsigned char *wl = a.w + lane * 16 + ((UPSP && (wave & 1)) ? a.wstream : 0);
-  static_assert((NG * KC) % WQ == 0 && (NGU * KCU) % WQ == 0, "the fragment queue's phase is static inside a chunk");
+  static_assert((NG * KC) % WQ == 0 && (NGU * KC) % WQ == 0, "the fragment queue's phase is static inside a chunk");
   h16x8 wq[WQ][MB];
 #pragma unroll
   for (int d = 0; d < WQ; ++d)
@@ -447,20 +448,21 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
       wq[d][b] = *reinterpret_cast<const h16x8 *>(wl + (size_t)(d * MB + b) * 1024);
   // split: a paired group's rows - hi planes only, lanes g >= 2 at the second group
   const unsigned pbase = (unsigned)(((wave * TY) * TX + c) * PITCH + (g & 1) * PLANE);
+  // UPSP (parity form): in an upsampled chunk the row groups (dz', dx) ARE the plain
+  // loop's first six - same main / pair sequence - with the dz = 1 plane replaced by the pair's
+  // second low-resolution voxel (one or two planes on, by the wave's parity) and the dz = 2
+  // groups dropped: `zplane` = byte offset of the "dz = 1" plane for the current chunk
+  unsigned zplane = (unsigned)(TY * TX * PITCH);
+  auto goff = [&](int k) -> unsigned {
+    if (UPSP && k / 3 == 1) return zplane + (unsigned)((k % 3) * PITCH);
+    return grp_off(k, TY);
+  };
   auto row_addr = [&](int gi, int r) -> const unsigned char * {
     if (grp_pair(gi))
-      return tile + pbase + (g >= 2 ? grp_off(grp_k1(gi), TY) : grp_off(grp_k0(gi), TY)) + r * ROW;
-    return tile + vbase + grp_off(grp_k0(gi), TY) + r * ROW;
+      return tile + pbase + (g >= 2 ? goff(grp_k1(gi)) : goff(grp_k0(gi))) + r * ROW;
+    return tile + vbase + goff(grp_k0(gi)) + r * ROW;
   };
 
-  // parity form: row group k = (dz', dx); its second z row depends on the wave's parity
-  const unsigned zsel = (unsigned)(par_row(wave & 1) * TY * TX * PITCH);
-  auto grpu_off = [&](int k) -> unsigned { return (k / 3 ? zsel : 0u) + (unsigned)((k % 3) * PITCH); };
-  auto row_addr_u = [&](int gi, int r) -> const unsigned char * {
-    if (grpu_pair(gi))
-      return tile + pbase + (g >= 2 ? grpu_off(grpu_k1(gi)) : grpu_off(grpu_k0(gi))) + r * ROW;
-    return tile + vbase + grpu_off(grpu_k0(gi)) + r * ROW;
-  };
   int chunk_base = 0;               // K-steps of the weight stream in front of the current chunk
 
   for (;;) {
@@ -484,45 +486,14 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
       }
       __syncthreads();            // tile visible
       h16x8 brow[2][R + 2];
-      if (UPSP && a.src[cc].ups) {
-#pragma unroll
-        for (int r = 0; r < R + 2; ++r)
-          brow[0][r] = *reinterpret_cast<const h16x8 *>(row_addr_u(0, r));
-#pragma unroll
-        for (int gi = 0; gi < NGU; ++gi) {
-          const int ng = gi + 1 < NGU ? gi + 1 : 0;
-#pragma unroll
-          for (int q = 0; q < KCU; ++q) {
-            const int dyp = q >> 1, py = q & 1;       // y tap of the pair, sub-step parity served
-            const int st = gi * KCU + q;
-#pragma unroll
-            for (int r = (R + 2) * q / KCU; r < (R + 2) * (q + 1) / KCU; ++r)
-              brow[(gi + 1) & 1][r] = *reinterpret_cast<const h16x8 *>(row_addr_u(ng, r));
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int sub = py; sub < R; sub += 2)
-#pragma unroll
-              for (int b = 0; b < MB; ++b)
-                acc[sub][b] = mfma16(wq[st % WQ][b], brow[gi & 1][sub + (dyp ? par_row(py) : 0)], acc[sub][b]);
-            __builtin_amdgcn_s_setprio(0);
-            {
-              int nxt = chunk_base + st + WQ;
-              nxt = nxt < total_steps ? nxt : nxt - total_steps;
-#pragma unroll
-              for (int b = 0; b < MB; ++b)
-                wq[st % WQ][b] =
-                    *reinterpret_cast<const h16x8 *>(wl + ((size_t)nxt * MB + b) * 1024);
-            }
-          }
-        }
-        chunk_base += NGU * KCU;
-        continue;
-      }
+      const bool ups2 = UPSP && a.src[cc].ups;
+      if (UPSP) zplane = ups2 ? (unsigned)(par_row(wave & 1) * TY * TX * PITCH) : (unsigned)(TY * TX * PITCH);
 #pragma unroll
       for (int r = 0; r < R + 2; ++r)
         brow[0][r] = *reinterpret_cast<const h16x8 *>(row_addr(0, r));
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
+        if (UPSP && gi >= NGU && ups2) continue;       // (dz = 2 does not exist there)
         // next row group (wraps to the first; the wrapped read of the last group is unused)
         const int ng = gi + 1 < NG ? gi + 1 : 0;
 #pragma unroll
@@ -549,7 +520,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
           }
         }
       }
-      chunk_base += NG * KC;
+      chunk_base += ups2 ? NGU * KC : NG * KC;
     }
     // ---- epilogue: (ReLU) -> bf16, channels-last store
     {
@@ -1148,11 +1119,11 @@ void pack_conv3(const float *A, const fpl_op &op, int co0, int ncout, bool trans
   }
 }
 
-// The parity form's two weight streams (split build; NCHU above): stream pz = what a wave of z
-// parity pz reads, chunk after chunk - the first `n_ups` chunks (the UpSampling3D source) as 36
-// parity steps [group 9][dy' 2][sub-step parity 2], the rest as pack_conv3's 42.  Pre-summed
-// weights are formed in fp32 from the layer's own (tap sets Z / Y below), BN scale and the hi / lo
-// split applied afterwards by fpl_pack_frags.  *steps = K-steps of one stream.
+// The parity form's two weight streams: stream pz = what a wave of z parity pz
+// reads, chunk after chunk - the first `n_ups` chunks (the UpSampling3D source) as NGU x KC steps
+// [group][dy], the rest as pack_conv3's NG x KC.  The pre-summed z weights are formed in fp32 from the
+// layer's own, BN scale and the hi / lo split applied afterwards by fpl_pack_frags.
+// *steps = K-steps of one stream.
 void pack_conv3_parity(const float *A, const fpl_op &op, int ncout, int n_ups, std::vector<uint16_t> *f,
                        int *steps) {
   const int ncc = op.cin / RCH, mb = (ncout + 15) / 16;
@@ -1160,13 +1131,13 @@ void pack_conv3_parity(const float *A, const fpl_op &op, int ncout, int n_ups, s
   std::vector<uint16_t> plain;
   pack_conv3(A, op, 0, ncout, false, &plain);                    // [chunk][42][mb] fragments
   const size_t plain_chunk = (size_t)NG * KC * mb * 512;
-  // taps of an axis that fall on the pair's first / second low-resolution voxel, by parity
+  // z taps that fall on the pair's first / second low-resolution plane, by parity
   auto taps = [](int par, int second, int *t) {                  // returns the count
     if (par == 0) { if (!second) { t[0] = 0; t[1] = 1; return 2; } t[0] = 2; return 1; }
     if (!second) { t[0] = 0; return 1; }
     t[0] = 1; t[1] = 2; return 2;
   };
-  const int nstu = NGU * KCU;
+  const int nstu = NGU * KC;
   std::vector<float> sub((size_t)nstu * CC * ncout);
   f->clear();
   *steps = n_ups * nstu + (ncc - n_ups) * NG * KC;
@@ -1178,28 +1149,24 @@ void pack_conv3_parity(const float *A, const fpl_op &op, int ncout, int n_ups, s
       }
       std::fill(sub.begin(), sub.end(), 0.f);
       for (int gi = 0; gi < NGU; ++gi)
-        for (int q = 0; q < KCU; ++q) {
-          const int dyp = q >> 1, py = q & 1;
+        for (int dy = 0; dy < KC; ++dy)
           for (int ch = 0; ch < CC; ++ch) {
-            const int k = (grpu_pair(gi) && ch >= RCH) ? grpu_k1(gi) : grpu_k0(gi);
-            const int dzp = k / 3, dx = k % 3;
-            int tz[2], ty[2];
-            const int nz = taps(pz, dzp, tz), ny = taps(py, dyp, ty);
-            float *dst = &sub[((size_t)(gi * KCU + q) * CC + ch) * ncout];
-            for (int iz = 0; iz < nz; ++iz)
-              for (int iy = 0; iy < ny; ++iy) {
-                const float *w = A + op.w_off +
-                                 ((size_t)(tz[iz] * 9 + ty[iy] * 3 + dx) * op.cin + cc * RCH + ch % RCH) * op.cout;
-                for (int co = 0; co < ncout; ++co) dst[co] += w[co];
-              }
+            const int k = (grp_pair(gi) && ch >= RCH) ? grp_k1(gi) : grp_k0(gi);   // (dz', dx)
+            int tz[2];
+            const int nz = taps(pz, k / 3, tz);
+            float *dst = &sub[((size_t)(gi * KC + dy) * CC + ch) * ncout];
+            for (int iz = 0; iz < nz; ++iz) {
+              const float *w = A + op.w_off +
+                               ((size_t)(tz[iz] * 9 + dy * 3 + k % 3) * op.cin + cc * RCH + ch % RCH) * op.cout;
+              for (int co = 0; co < ncout; ++co) dst[co] += w[co];
+            }
           }
-        }
       std::vector<uint16_t> fc[2];
       for (int part = 0; part < PM; ++part)
         fpl_pack_frags(sub.data(), scale.data(), nstu, CC, ncout, mb, nstu, SLOT_SPATIAL, &fc[part], true, part);
       for (int gi = 0; gi < NGU; ++gi)
-        for (int q = 0; q < KCU; ++q) {
-          const int ks = gi * KCU + q, part = grpu_pair(gi) ? 1 : 0;
+        for (int dy = 0; dy < KC; ++dy) {
+          const int ks = gi * KC + dy, part = grp_pair(gi) ? 1 : 0;
           f->insert(f->end(), fc[part].begin() + (size_t)ks * mb * 512,
                     fc[part].begin() + (size_t)(ks + 1) * mb * 512);
         }
@@ -1277,9 +1244,9 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
       f.insert(f.end(), h1.begin(), h1.end());
     } else if (op.k == 3) {
       pack_conv3(A, op, 0, op.cout, false, &f);
-      if (SPLIT && l == l_up2) {
-        // parity form: the leading chunks of the concatenated input are the upsampled source
-        const int w = 1, n_ups = 64 / RCH;
+      if (l == d.l_up1() || l == l_up2) {
+        // parity forms: the leading chunks of the concatenated input are the upsampled source
+        const int w = l == l_up2, n_ups = (l == l_up2 ? 64 : 128) / RCH;
         if (op.cin / RCH > n_ups) {
           std::vector<uint16_t> fp;
           pack_conv3_parity(A, op, op.cout, n_ups, &fp, &st->wp_steps[w]);
@@ -1485,10 +1452,11 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.parity = 0; a.total_steps = 0; a.wstream = 0;
     return a;
   };
-  // split build: the parity form for sources that are an UpSampling3D (FPL_UNET_NOPARITY=1: A/B)
-  const bool use_par = SPLIT && !getenv("FPL_UNET_NOPARITY");
+  // the parity form for sources that are an UpSampling3D(2) (FPL_UNET_NOPARITY=1: A/B)
+  const bool use_par = !getenv("FPL_UNET_NOPARITY");
   auto set_parity = [&](Conv3Args &a, int w) {
-    a.w = F + st->off_wp[w]; a.parity = 1; a.wstream = (int64_t)st->wp_stream[w]; a.total_steps = st->wp_steps[w];
+    a.w = F + st->off_wp[w]; a.parity = 1; a.wstream = (int64_t)st->wp_stream[w];
+    a.total_steps = st->wp_steps[w];
   };
   if (D.first1) {  // unet_like: conv3 1->32 and conv1 32->32 chained, c1 + pooled p1
     StemC1Args a;
@@ -1572,11 +1540,11 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.ncc = n3 + n2;
     for (int cc = 0; cc < n3; ++cc) a.src[cc] = src_of(c3, db, 128, cc, 2, 0);
     for (int cc = 0; cc < n2; ++cc) a.src[n3 + cc] = src_of(c2, d2, 64, cc, 1, D.crop2);
-    // (The parity form was measured here too - 64 outputs at four rows per wave - and is not used:
-    // it halves the MFMAs a weight fragment feeds, 8 per 4 KiB, and the per-wave fragment stream
-    // then needs twice what the CU's vector-memory path delivers: 3.66 -> 5.19 ms for 27 tiles.
-    // The head below - 32 outputs, six rows - has the same ratio at half the bytes: 5.73 -> 5.05.)
-    FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
+    if (use_par && st->wp_steps[0]) {
+      set_parity(a, 0);
+      FPL_TRY((launch_conv3<4, false, false, false, 4, true>(ctx, a, n, "unet_conv3_192_64")));
+    } else
+      FPL_TRY((launch_conv3<4>(ctx, a, n, "unet_conv3_192_64")));
   }
   conv1(FPLK(conv1)<64, 4, 0>, 8, c4a, (int64_t)n * cube(d4a), lu1 + 1, c4, "unet_conv1_64_64");
   {  // conv3 (up2(c4) 64 | crop(c1) 32) -> 32.  unet_like2's output width 82 = 5 x 16 + 2:
@@ -1597,14 +1565,11 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
       a.out = nullptr;
     }
     const unsigned char *w_plain = a.w;
-#ifdef FPL_SPLIT
     if (use_par && st->wp_steps[1]) {
       set_parity(a, 1);
       if (io) FPL_TRY((launch_conv3<2, false, false, true, 6, true>(ctx, a, n, "unet_conv3_96_32_head")));
       else FPL_TRY((launch_conv3<2, false, false, false, 6, true>(ctx, a, n, "unet_conv3_96_32")));
-    } else
-#endif
-    if (io) {
+    } else if (io) {
       FPL_TRY((launch_conv3<2, false, false, true, 6>(ctx, a, n, "unet_conv3_96_32_head")));
     } else {
       FPL_TRY((launch_conv3<2, false, false, false, 6>(ctx, a, n, "unet_conv3_96_32")));

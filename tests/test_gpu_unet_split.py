@@ -43,12 +43,13 @@ def test_unet_split_matches_emulation_and_fp32(ctx, shape, tile):
     assert ctx.last_path() == 'unet_split_f16' and np.array_equal(auto, got)
 
 
-def test_unet_head_parity_form_agrees_with_the_plain_taps(ctx, monkeypatch):
-    """the head's conv3 reads UpSampling3D(2)(c4) for 64 of its 96 input channels: by default its
-    27 taps collapse to 12 with weights pre-summed per output parity along z and y (fp32 sums,
-    split afterwards); FPL_UNET_NOPARITY=1 runs the 27 taps.  Same probabilities up to the
-    rounding of the pre-summed weights' lo halves, both within the gate of the fp32 path.  The
-    100^3 tile has the 82-wide layer: main columns in the parity form, edge strip in the plain one."""
+def test_unet_parity_form_agrees_with_the_plain_taps(ctx, monkeypatch):
+    """conv3 192->64 and the head's conv3 read an UpSampling3D(2) for 128 of 192 / 64 of 96 input
+    channels: by default their three z taps on those channels collapse to two with weights
+    pre-summed per output-plane parity (fp32 sums, split afterwards; 18 taps instead of 27);
+    FPL_UNET_NOPARITY=1 runs the 27 taps.  Same probabilities up to the rounding of the
+    pre-summed weights' lo halves, both within the gate of the fp32 path.  The 100^3 tile has the
+    82-wide layer: main columns in the parity form, edge strip in the plain one."""
     for shape, tile in (((60, 52, 70), 36), ((110, 100, 104), 100)):
         g = fplmodels.unet_like2(tile)[0]
         synth.synthetic_weights(g, 43)
