@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: vgg_like sliding-window inference Mvoxels/s on a synthetic
-uint8 EM volume (BASELINE.json metric; N=1 workload = configs[1]: 1024^3; the 520^3 volume
-of the metric string is timed in the same run and reported as `value_520`).
+uint8 EM volume - BASELINE.json's metric on the volume its metric string names: 520^3 per GPU
+(`--size 520`, the default; weak scaling: Z = 520 N).  configs[1]'s 1024^3 volume is timed in the
+same run as a leg and reported as `value_1024`.
 
 The headline precision is 'f16s' - split IEEE halves, three MFMAs per product: the fastest
 executor whose probabilities are fp32-grade (2 - 4e-6 off fp32 on the trained fixture,
@@ -13,7 +14,7 @@ star's gate.  Plain f16 / bf16 (3x the rate, ~1e-3 / ~8e-3 off) and fp32 are leg
 
 One step = one pass of FplNetwork.infer's hot path (normalise -> tile lattice ->
 3D-CNN -> upsample -> stitch) over the volume, input uint8 and output float32
-both resident in HBM.  With N ranks the volume is N x 1024 rows along Z and every
+both resident in HBM.  With N ranks the volume is N x `size` rows along Z and every
 rank takes a contiguous slab of tile rows (weak scaling, no collective on the
 data path; RCCL is only used for the barrier / max-over-ranks of the clock).
 
@@ -131,6 +132,31 @@ def _infer_pass(ctx, prog, torch, size, tile, off, prec, steps, warmup, seed=202
     return dt, kern, ctx.last_path()
 
 
+def host_leg(ctx, prog, tile, off, n=520, reps=5):
+    """The public API end to end (`FplNetwork.infer`, flypylib/fplnetwork.py:136-189: a host
+    uint8 array in, a full-resolution float32 host array out - 4 B per voxel over PCIe, which,
+    not the GPU, bounds it): wall time of `Program.infer_volume(host array)`
+    at the default precision, the call FplNetwork.infer makes.  Pageable numpy buffers, as a
+    caller of the reference would hold."""
+    from flypylib_amd import _capi, synth
+    u8 = synth.em_volume_u8(5, (n, n, n))
+    prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
+    calls = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0,
+                                precision=_capi.PREC_AUTO)
+        calls.append(time.perf_counter() - t0)
+    dt = sorted(calls)[reps // 2]
+    vox = (n - 2 * off) ** 3
+    nbytes = n ** 3 * 5
+    return dict(workload='FplNetwork.infer equivalent: host uint8 %d^3 -> host float32 (pageable '
+                         'numpy arrays), precision auto; H2D 1 B + D2H 4 B per voxel' % n,
+                executor=ctx.last_path(), ms=round(dt * 1e3, 3), mvox_s=round(vox / dt / 1e6, 1),
+                bound='pcie', pcie_gbs=round(nbytes / dt / 1e9, 2), out_checksum=float(out[off:-off:37, off:-off:41, off:-off:43].sum()),
+                ms_calls=[round(c * 1e3, 3) for c in calls])
+
+
 def secondary_legs(ctx, torch, prog, tile, off, size, steps):
     """Driver-timed twins of the numbers DESIGN.md quotes beside the headline: the same
     step in the other arithmetic types, the metric string's 520^3 size, and short legs
@@ -151,11 +177,15 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
                           achieved_tflops=round(tf, 2), peak_tflops=PEAK_TFLOPS[pname],
                           frac=round(tf / PEAK_TFLOPS[pname], 4), kernel_ms=kern)
 
-    vgg_leg('configs1_f16', size, _capi.PREC_F16, 'f16', k)
-    vgg_leg('configs1_bf16', size, _capi.PREC_BF16, 'bf16', k)
-    vgg_leg('configs1_f32', size, _capi.PREC_F32, 'f32', 1)
+    # configs[1]: the 1024^3 volume in every arithmetic type (f16s = the headline's executor)
+    vgg_leg('configs1_f16s', 1024, _capi.PREC_F16S, 'f16s', k)
+    vgg_leg('configs1_f16', 1024, _capi.PREC_F16, 'f16', k)
+    vgg_leg('configs1_bf16', 1024, _capi.PREC_BF16, 'bf16', k)
+    vgg_leg('configs1_f32', 1024, _capi.PREC_F32, 'f32', 1)
+    # the metric's own 520^3 volume: the headline's executor again (a twin of `value`) and plain f16
     vgg_leg('configs0_520_f16s', 520, _capi.PREC_F16S, 'f16s', k)
     vgg_leg('configs0_520_f16', 520, _capi.PREC_F16, 'f16', k)
+    legs['infer_host_520'] = host_leg(ctx, prog, tile, off)
 
     # configs[2]: unet_like2 on the reference lattice (tile 100, pitch 82), 510^3 sample:
     # split halves (fp32-grade, what 'auto' runs) and plain f16
@@ -267,13 +297,19 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
     return legs
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, timeout=None):
     """`python bench.py --gpus N` without a launcher: N children of this script, one per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would), started before this
     process makes any GPU call.  Rank 0's stdout (the JSON line) is relayed; the exit code is
-    non-zero if any rank's is."""
+    non-zero if any rank's is.  The children are POLLED: when one exits non-zero its peers -
+    which may sit in a rendezvous or a collective waiting for it until the backend's own
+    timeout - are terminated (then killed), and the launcher returns 1; likewise after
+    `timeout` seconds overall (FPL_BENCH_TIMEOUT, default 1500)."""
     import socket
     import subprocess
+    import threading
+    if timeout is None:
+        timeout = float(os.environ.get('FPL_BENCH_TIMEOUT', '1500'))
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
@@ -284,22 +320,51 @@ def spawn_ranks(n):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()                     # rank 0's pipe is drained while the children are polled
+    t0 = time.monotonic()
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            why = 'rank %d exited with code %d' % next((r, c) for r, c in enumerate(codes) if c not in (None, 0))
+        elif time.monotonic() - t0 > timeout:
+            why = 'no result after %.0f s' % timeout
+        if why:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t1 = time.monotonic()
+            while any(p.poll() is None for p in procs) and time.monotonic() - t1 < 10.0:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(10.0)
+    codes = [p.returncode for p in procs]
     # exactly ONE line on stdout: the JSON line (libraries - gloo, for one - print their own
     # chatter on the rank's stdout; that goes to stderr here)
-    lines = out.decode().splitlines()
+    lines = b''.join(chunks).decode(errors='replace').splitlines()
     js = [ln for ln in lines if ln.startswith('{')]
     for ln in lines:
         if not ln.startswith('{'):
             sys.stderr.write(ln + '\n')
-    if js:
+    if js and not why:
         sys.stdout.write(js[-1] + '\n')
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if why:
+        sys.stderr.write('bench.py: %s; the other ranks were stopped\n' % why)
     if bad:
         sys.stderr.write('bench.py: ranks failed (rank, exit code): %s\n' % bad)
-    return 1 if bad else 0
+    return 1 if (bad or why) else 0
 
 
 def ranks_seen(dist, backend):
@@ -318,6 +383,22 @@ def launcher_selftest(rank, world, backend):
     mode = os.environ['FPL_BENCH_SELFTEST']
     if mode == 'fail%d' % rank:
         sys.exit(3)
+    if mode == 'hang':                  # every rank just sits there: the launcher's own timeout
+        time.sleep(600)
+        return
+    if mode.startswith('die') and world > 1:
+        # die<r>: every rank joins the process group; rank r then exits non-zero while the
+        # others wait for it inside a collective (what a GPU fault on one rank looks like)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        ranks_seen(dist, 'gloo')
+        if mode == 'die%d' % rank:
+            os._exit(5)
+        import torch
+        t = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(t)              # never completes: the dead rank is missing
+        time.sleep(600)
+        return
     n = 1
     if world > 1 and not mode.startswith('fail'):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -333,8 +414,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--size', type=int, default=1024,
-                    help='volume edge per GPU (Z is size*gpus)')
+    ap.add_argument('--size', type=int, default=520,
+                    help='volume edge per GPU (Z is size*gpus); 520 = the volume BASELINE.json\'s '
+                         'metric names, 1024 = configs[1]')
     ap.add_argument('--precision', default='f16s', choices=['f16s', 'f16', 'bf16', 'f32'],
                     help='MFMA operands (fp32 accumulation).  f16s (default): split IEEE halves, '
                          'three MFMAs per product - fp32-grade (2 - 4e-6 off fp32, detections '
@@ -510,7 +592,8 @@ def main():
 
     if rank == 0:
         value = valid_global * args.steps / dt / 1e6
-        leg520 = (legs or {}).get('configs0_520_%s' % args.precision)
+        leg1024 = (legs or {}).get('configs1_%s' % args.precision)
+        host520 = (legs or {}).get('infer_host_520')
         line = {
             'metric': 'inference Mvoxels/sec, vgg_like (rf 18, 22^3 coarse -> 88^3 '
                       'per reference tile), synthetic EM uint8 volume',
@@ -518,16 +601,22 @@ def main():
             'n_ranks_seen': n_seen,       # ranks that joined the max-over-ranks collective
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3),
-            # BASELINE.json's metric string names the 520^3 volume (configs[0]'s size): the
-            # same executor on it, timed in this run (legs.configs0_520_*)
-            'value_520': leg520['mvox_s'] if leg520 else None,
-            'ms_per_step_520': leg520['ms'] if leg520 else None,
+            # configs[1]'s 1024^3 volume on the same executor, timed in this run
+            # (legs.configs1_<dtype>), and the public host -> host API on the 520^3 volume
+            # (PCIe-bound: legs.infer_host_520) - neither is `value`
+            'value_1024': leg1024['mvox_s'] if leg1024 else None,
+            'ms_per_step_1024': leg1024['ms'] if leg1024 else None,
+            'value_host_to_host_520': host520['mvox_s'] if host520 else None,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': 'configs[1]: vgg_like inference, %dx%dx%d '
+            'config': {'workload': '%s: vgg_like inference, %dx%dx%d '
                                    'synthetic uint8 volume, reference tile '
                                    'lattice %d^3 (pitch %d), u8 in / f32 out '
-                                   'resident in HBM' % (Z, Y, X, tile, pitch),
+                                   'resident in HBM' % (
+                                       {520: 'the 520^3 volume of BASELINE.json\'s metric (configs[0]\'s '
+                                             'substack size) per GPU',
+                                        1024: 'configs[1]'}.get(args.size, 'custom size'),
+                                       Z, Y, X, tile, pitch),
                        'volume': [Z, Y, X], 'tile_in': tile, 'executor': executor,
                        'operands': {'f16': 'IEEE half MFMA operands, fp32 accumulate: worst '
                                            'voxel 1.5e-4 off fp32 on these weights, 0.7 - 0.8e-3 '

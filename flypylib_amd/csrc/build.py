@@ -24,6 +24,7 @@ LIB = os.path.join(LIB_DIR, 'libfplhip.so')
 ARCH = 'gfx950'
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 CXXFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC',
+            '-fvisibility=hidden', '-fvisibility-inlines-hidden',
             '-ffp-contract=on', '-Wall', '-Wno-unused-function',
             '-Wno-unused-but-set-variable', '-Wno-unused-variable',
             '-Wno-unused-value', '-Wno-unused-result']
@@ -108,7 +109,14 @@ def build(force=False, jobs=4, verbose=True):
     lib_stamp = LIB + '.sha256'
     if (rebuilt or not os.path.exists(LIB) or not os.path.exists(lib_stamp)
             or open(lib_stamp).read().strip() != lib_want):
-        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        # the export list = the C entry points include/fplhip.h declares, nothing else (the
+        # C++ internals are hidden by -fvisibility=hidden, libstdc++'s template instances -
+        # default visibility by their own headers - by this version script)
+        vs = os.path.join(OBJ_DIR, 'exports.map')
+        with open(vs, 'w') as f:
+            f.write('{ global: fpl_*; local: *; };\n')
+        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-Wl,--version-script=' + vs,
+               '-o', LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            text=True)
         if r.returncode != 0:

@@ -104,6 +104,11 @@ int fpl_fail(fpl_ctx *ctx, const char *fmt, ...);
 // sets the message and returns FPL_RC_RANGE, which fpl_infer_volume turns into the fp32
 // executor under FPL_PREC_AUTO and into an ordinary failure under FPL_PREC_F16S
 #define FPL_RC_RANGE 3
+// ... the same for a reason that belongs to THIS CALL's normalisation (mean / std folded into the
+// first layer), not to the program's weights: 'auto' reruns the call in fp32 but does not pin
+// the program to fp32 for later calls (fpl_fail_range_call)
+#define FPL_RC_RANGE_CALL 4
+int fpl_fail_range_call(fpl_ctx *ctx, const char *fmt, ...);
 // bits of the half-range flag word: which kernel family raised it (for the message)
 #define FPL_RANGE_INPUT 1u      // a normalised input voxel beyond the stem's input limit
 #define FPL_RANGE_STEM 2u

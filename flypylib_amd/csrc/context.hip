@@ -25,6 +25,17 @@ int fpl_fail_range(fpl_ctx *ctx, const char *fmt, ...) {
   return FPL_RC_RANGE;
 }
 
+int fpl_fail_range_call(fpl_ctx *ctx, const char *fmt, ...) {
+  char buf[FPL_MAX_ERR];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) memcpy(ctx->err, buf, sizeof(buf));
+  memcpy(g_fpl_err, buf, sizeof(buf));
+  return FPL_RC_RANGE_CALL;
+}
+
 int fpl_range_flag(fpl_ctx *ctx, unsigned **dev) {
   if (!ctx->range_flag_dev) {
     FPL_HIP(ctx, hipMalloc((void **)&ctx->range_flag_dev, sizeof(unsigned)));

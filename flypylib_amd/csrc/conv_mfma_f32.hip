@@ -1495,91 +1495,15 @@ __global__ __launch_bounds__(512) void conv3_wgrad_f32(WgradArgs a, int64_t tota
   }
 }
 
-// ---- weight gradient of a first layer (cin = 1): dW[tap][co] += sum_m x[m + tap] *
-// dY[m][co] is a (27 x voxels) x (voxels x cout) product, HBM-bound on dY.  A =
-// shifted copies of the scalar input (rows = taps, padded to 32), B = dY; persistent
-// workgroups keep their 2 x 3 accumulator tiles over many 4 x 4 x 16 blocks and add
-// them to dW once.  (The generic kernel would pad the single input channel to 16.)
-__global__ __launch_bounds__(256) void conv3_wgrad_cin1_f32(WgradArgs a, int64_t total_blocks,
-                                                           int nbx, int nby) {
-  float *xt = reinterpret_cast<float *>(smem);                       // 6 x 6 x 18 floats
-  unsigned char *yt = smem + ((TZ * TY * TX * 4 + 255) / 256) * 256;  // 256 voxels x 192 B
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  int toff[2];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int t = 16 * mb + c;
-    toff[mb] = t < 27 ? ((t / 9) * TY + (t / 3) % 3) * TX + t % 3 : 0;
-  }
-  f32x4 acc[2][3];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) acc[mb][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int64_t blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
-    const int x0 = (int)(blk % nbx) * 16, y0 = (int)((blk / nbx) % nby) * 4;
-    const int64_t bz = blk / ((int64_t)nbx * nby);
-    const int n = (int)(bz / a.zblocks), z0 = (int)(bz % a.zblocks) * 4;
-    __syncthreads();                               // previous block consumed
-    for (int p = tid; p < TZ * TY * TX; p += 256) {
-      const int z = z0 + p / (TY * TX), y = y0 + (p / TX) % TY, x = x0 + p % TX;
-      xt[p] = (z < a.D && y < a.H && x < a.W)
-                  ? a.x[(((int64_t)n * a.D + z) * a.H + y) * a.W + x] : 0.f;
-    }
-    for (int p = tid; p < 256 * 12; p += 256) {
-      const int vox = p / 12, pc = p % 12;
-      const int z = z0 + vox / 64, y = y0 + (vox / 16) % 4, x = x0 + vox % 16;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (z < a.od && y < a.oh && x < a.ow) {
-        const float *gp = a.dy + ((((int64_t)n * a.od + z) * a.oh + y) * a.ow + x) * a.cout;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (4 * pc + q < a.cout) v[q] = gp[4 * pc + q];
-      }
-      *reinterpret_cast<f32x4 *>(yt + (size_t)vox * WG_YP + pc * 16) = v;
-    }
-    __syncthreads();
-    // wave = z plane of the block; k-slot g of K-step j = voxel 4 j + g of the row
-#pragma unroll
-    for (int vy = 0; vy < 4; ++vy) {
-      const int rowx = (wave * TY + vy) * TX;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int xv = 4 * j + g;
-        float bv[3], av[2];
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          bv[b] = *reinterpret_cast<const float *>(
-              yt + (size_t)((wave * 4 + vy) * 16 + xv) * WG_YP + (16 * b + c) * 4);
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) av[mb] = xt[rowx + xv + toff[mb]];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) acc[mb][b] = mfma4(av[mb], bv[b], acc[mb][b]);
-      }
-    }
-  }
-  // D[row = tap 16 mb + 4 g + r][col = co 16 b + c]
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int tap = 16 * mb + 4 * g + r, co = 16 * b + c;
-        if (tap < 27 && co < a.cout && acc[mb][b][r] != 0.f)
-          atomicAdd(&a.dw[(int64_t)tap * a.cout + co], acc[mb][b][r]);
-      }
-}
 
-// The same product without LDS or barriers (round 3): a wave walks rows of 16 output voxels;
+// Weight gradient of a first layer (cin = 1): dW[tap][co] += sum_m x[m + tap] * dY[m][co], a
+// (27 x voxels) x (voxels x cout) product, HBM-bound on dY.  No LDS, no barriers (round 3;
+// the LDS-tile form of round 2 was removed in round 5): a wave walks rows of 16 output voxels;
 // lane (c, g) of K-step j reads its dY scalars (voxel 4j + g, channels 16b + c: 64
 // contiguous bytes per 16 lanes) and its two shifted input scalars (taps c and 16 + c; the
-// input volume stays in L2) straight from global memory, one row ahead of the MFMAs.  The
-// LDS form above ran load -> barrier -> multiply -> barrier and reached a quarter of the
-// dY stream's HBM rate.
+// input volume stays in L2) straight from global memory, one row ahead of the MFMAs.  (The
+// LDS form ran load -> barrier -> multiply -> barrier and reached a quarter of the dY
+// stream's HBM rate.)
 // BG: dY is the input gradient of the BatchNorm (+ ReLU) that follows this convolution, made
 // from that layer's output gradient and input while loading (FplBnGrad, fast_paths.h).
 template <bool BG>
@@ -2029,7 +1953,7 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
 bool fpl_tm_pool_grad_supported(int k, int cin, int cout) { return k == 1 && cin == 48 && cout == 48; }
 
 bool fpl_tm_bn_grad_supported(int k, int cin, int cout) {
-  return k == 3 && cin == 1 && cout <= 48 && !getenv("FPL_WGRAD_CIN1_LDS");
+  return k == 3 && cin == 1 && cout <= 48;
 }
 
 int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin,
@@ -2070,15 +1994,8 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
   a.x = x; a.D = D; a.H = H; a.W = W_; a.cin = cin; a.dy = dy; a.od = od; a.oh = oh; a.ow = ow;
   a.cout = cout; a.dw = dw; a.zblocks = (int)ceil_div64(od, 4); a.ncc = ncc; a.nco = nco;
   if (cin == 1 && cout <= 48) {
-    constexpr int SMEM1 = ((TZ * TY * TX * 4 + 255) / 256) * 256 + 256 * WG_YP;
-    const int nbx = (int)ceil_div64(ow, 16), nby = (int)ceil_div64(oh, 4);
-    const int64_t total = (int64_t)nbx * nby * n * a.zblocks;
-    const unsigned grid1 = (unsigned)std::min<int64_t>(total, (int64_t)ctx->n_cu * 3);
+    const int nbx = (int)ceil_div64(ow, 16);
     TimedLaunch tl(ctx, "mfma_wgrad3_f32_cin1");
-    if (getenv("FPL_WGRAD_CIN1_LDS")) {
-      conv3_wgrad_cin1_f32<<<grid1, 256, SMEM1, ctx->stream>>>(a, total, nbx, nby);
-      return 0;
-    }
     const int64_t rows = (int64_t)n * od * oh * nbx;
     const unsigned gridd = (unsigned)std::min<int64_t>(ceil_div64(rows, 4), (int64_t)ctx->n_cu * 8);
     if (bg) conv3_wgrad_cin1_direct_f32<true><<<gridd, 256, 0, ctx->stream>>>(a, rows, nbx, *bg);

@@ -491,9 +491,11 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     if (have_split && prog->half_range_bad_version != prog->arena_version) {
       const int rc = run(FPL_PREC_F16S, &bits);
       if (rc == 0 && !bits) return 0;
-      if (rc != 0 && rc != FPL_RC_RANGE) return rc;
-      // weights (rc) or activations (bits) beyond the half range: this network runs in fp32
-      // from now on (until its weights change); an out-of-range INPUT voxel only costs this call
+      if (rc != 0 && rc != FPL_RC_RANGE && rc != FPL_RC_RANGE_CALL) return rc;
+      // weights (FPL_RC_RANGE) or activations (bits) beyond the half range: this network runs in
+      // fp32 from now on (until its weights change); an out-of-range INPUT voxel, or a
+      // normalisation (mean / std of this call) the integer stem cannot take
+      // (FPL_RC_RANGE_CALL), only costs this call
       if (rc == FPL_RC_RANGE || (bits & ~FPL_RANGE_INPUT)) prog->half_range_bad_version = prog->arena_version;
     }
     const int rc = run(FPL_PREC_F32, &bits);
@@ -505,7 +507,7 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     return rc;
   }
   const int rc = run(precision, &bits);
-  if (rc == FPL_RC_RANGE) return 1;                  // message set by the packer
+  if (rc == FPL_RC_RANGE || rc == FPL_RC_RANGE_CALL) return 1;   // message set by the packer
   if (rc == 0 && bits)
     return fpl_fail(ctx, "fpl_infer_volume: %s exceeds the IEEE-half range (65504) of the split-operand "
                          "kernels (guard bits 0x%x): the result is not valid; use precision f32, or "

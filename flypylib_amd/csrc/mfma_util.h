@@ -180,15 +180,22 @@ struct Frag2 { h16x8 hi, lo; };             // a B fragment
 // allocator happened to make that choice.  `a` is always the result of an ordinary VALU
 // instruction (a ReLU or a pool maximum) whose own write the compiler did guard, and no MFMA
 // can have a live register in its destination, so reusing it is safe by construction.
-__device__ __forceinline__ Pair2 split_pk(float a, float b) {
-  Pair2 r;
-  r.hi = cvt_pk_h16(a, b);
+// THE one place this asm lives (tests/test_host_logic.py checks on the device assembly of every
+// split object that no v_fma_mix destination was last written by an MFMA).  "+&v": the first
+// instruction writes %0 before the second reads %2, so %0 must not share a register with an
+// input even when a and b are the same value.
+__device__ __forceinline__ unsigned split_lo_pk(float a, unsigned hi_pair, float b) {
   unsigned lo = __builtin_bit_cast(unsigned, a);
   asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]\n\t"
       "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "+v"(lo)
-      : "v"(r.hi), "v"(b));
-  r.lo = lo;
+      : "+&v"(lo)
+      : "v"(hi_pair), "v"(b));
+  return lo;
+}
+__device__ __forceinline__ Pair2 split_pk(float a, float b) {
+  Pair2 r;
+  r.hi = cvt_pk_h16(a, b);
+  r.lo = split_lo_pk(a, r.hi, b);
   return r;
 }
 #else

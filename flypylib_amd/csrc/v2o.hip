@@ -274,73 +274,15 @@ __global__ __launch_bounds__(256) void gauss_x_lds(
       if (lh[b]) atomicAdd(&hist0[b], (unsigned long long)lh[b]);
 }
 
-// z pass, register-window form without per-thread index arithmetic: a workgroup is
-// blockDim.x consecutive x of one (y, block of GZ_OUT z) strip; a thread slides its
-// window down the (y, x) column of the UNPADDED prediction (zero outside it: the
-// virtual padding of fplobjdetect.py:152-159, reflected at the padded volume's ends as
-// scipy does).  The 1-D grid is decoded per workgroup (uniform) so that the blocks an
-// XCD receives (b, b + 8, ...) walk consecutive z blocks of one strip: the 2*WR halo
-// planes a block shares with its z neighbour are L2 hits instead of HBM re-reads.
-constexpr int GZ_OUT = 12;       // 8 / 12 / 16 / 24 outputs per thread: 0.62 / 0.54 / 0.57 / 0.59 ms
-
-template <int WR>
-__global__ __launch_bounds__(512) void gauss_z_win(
-    PadView pv, float *__restrict__ out, int P0, int P1, int P2,
-    const double *__restrict__ w, int nxb, int nzb) {
-  constexpr int OUT = GZ_OUT, NW = OUT + 2 * WR;
-  const unsigned nwork = (unsigned)nxb * nzb * P1;
-  const unsigned per_xcd = (nwork + 7) / 8;
-  const unsigned slot = blockIdx.x >> 3;
-  const unsigned wid = (blockIdx.x & 7) * per_xcd + slot;
-  if (slot >= per_xcd || wid >= nwork) return;
-  const int zb = (int)(wid % (unsigned)nzb);
-  const unsigned rest = wid / (unsigned)nzb;
-  const int xb = (int)(rest % (unsigned)nxb), y = (int)(rest / (unsigned)nxb);
-  const int x = xb * (int)blockDim.x + (int)threadIdx.x;
-  if (x >= P2) return;
-  const int a0 = zb * OUT;
-  const int r = pv.r, D0 = (int)pv.D0, D1 = (int)pv.D1, D2 = (int)pv.D2;
-  const int yy = y - r, xx = x - r;
-  const bool col_ok = yy >= 0 && xx >= 0 && yy < D1 && xx < D2;
-  const int plane = D1 * D2;                       // < 2^31 / NW (checked by the host)
-  const float *col = pv.pred + (col_ok ? (int64_t)yy * D2 + xx : 0);
-  double win[NW];
-  const int z_lo = a0 - WR - r;                    // unpadded z of win[0]
-  const bool interior = a0 - WR >= 0 && a0 + OUT + WR <= P0;
-  if (!col_ok) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) win[i] = 0.0;
-  } else if (interior && z_lo >= 0 && z_lo + NW <= D0) {
-    const float *q = col + (int64_t)z_lo * plane;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) win[i] = (double)q[i * plane];
-  } else {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int zz = reflect1(a0 - WR + i, P0) - r;
-      win[i] = (zz >= 0 && zz < D0) ? (double)col[(int64_t)zz * plane] : 0.0;
-    }
-  }
-  double wk[WR + 1];
-#pragma unroll
-  for (int j = 0; j <= WR; ++j) wk[j] = w[j];
-  float *dst = out + ((int64_t)a0 * P1 + y) * P2 + x;
-  const int pplane = P1 * P2;
-#pragma unroll
-  for (int o = 0; o < OUT; ++o) {
-    double acc = mul_rn(win[WR + o], wk[0]);
-#pragma unroll
-    for (int j = WR; j >= 1; --j)
-      acc = add_rn(acc, mul_rn(add_rn(win[WR + o - j], win[WR + o + j]), wk[j]));
-    if (a0 + o < P0) dst[o * pplane] = (float)acc;
-  }
-}
+// (rounds 2 - 3 ran the z pass as a register-window kernel, gauss_z_win: every thread re-read
+// its 2 WR halo, 2.7 x the volume through L2; the ring form below replaced it in round 4 -
+// bit-identical, 0.546 -> 0.522 ms at 582^3 - and the window kernel was removed in round 5)
+constexpr int GZ_OUT = 12;       // (the size limit of the 32-bit offsets below still counts in these rows)
 
 // z pass, ring form (round 4): a thread walks a SEGMENT of its (y, x) column, 2 WR outputs at a
 // time, with the 4 WR inputs they need in registers as two halves; after a step the upper half is
 // the next step's lower half and the other is refilled from 2 WR values loaded - as floats, one
-// step ahead - while the step was computed.  Every input is read once (the window form above
-// re-reads 2 WR of every GZ_OUT + 2 WR: 2.7 x through L2), a thread's loads are in flight under
+// step ahead - while the step was computed.  Every input is read once, a thread's loads are in flight under
 // its own arithmetic instead of all in front of it, and the arithmetic per output is the same
 // sequence (bit-identical results).  The column is cut into `nseg` segments so that the grid has
 // enough waves; a segment's first window is its only re-read.
@@ -698,10 +640,10 @@ int launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t
   constexpr int OUT_ZY = 16;                 // outputs per thread of gauss_pass_win<0/1>
   const bool fused = gyx_fits(P, WR) && !getenv("FPL_V2O_UNFUSED");
   // fused: z pass -> b, y+x -> a;  separate passes: z -> a, y -> b, x -> a
-  // 32-bit in-column / in-plane offsets of gauss_z_win
+  // 32-bit in-column / in-plane offsets of gauss_z_ring
   const bool small = (GZ_OUT + 2 * WR) * pv.D1 * pv.D2 < ((int64_t)1 << 31) &&
                      P[1] * P[2] * GZ_OUT < ((int64_t)1 << 31) && P[0] >= 2 * WR;
-  if (small && !getenv("FPL_V2O_UNFUSED") && !getenv("FPL_V2O_ZWIN")) {
+  if (small && !getenv("FPL_V2O_UNFUSED")) {
     // ring form: segments of a multiple of 4 WR outputs (two steps), about a quarter of the column
     const int bd = best_block(P[2]);
     const int64_t nxb = ceil_div64(P[2], bd);
@@ -712,14 +654,6 @@ int launch_gauss_win(fpl_ctx *ctx, PadView pv, float *a, float *b, const int64_t
     TimedLaunch tl(ctx, "v2o_gauss_z");
     gauss_z_ring<WR><<<(unsigned)nwork, bd, 0, st>>>(
         pv, fused ? b : a, (int)P[0], (int)P[1], (int)P[2], w_dev, (int)nxb, (int)nseg, (int)seg_len);
-  } else if (small && !getenv("FPL_V2O_UNFUSED")) {
-    const int bd = best_block(P[2]);
-    const int64_t nxb = ceil_div64(P[2], bd), nzb = ceil_div64(P[0], GZ_OUT);
-    const int64_t nwork = nxb * nzb * P[1];
-    FPL_REQUIRE(ctx, nwork < ((int64_t)1 << 31), "voxel2obj: volume too large");
-    TimedLaunch tl(ctx, "v2o_gauss_z");
-    gauss_z_win<WR><<<(unsigned)(ceil_div64(nwork, 8) * 8), bd, 0, st>>>(
-        pv, fused ? b : a, (int)P[0], (int)P[1], (int)P[2], w_dev, (int)nxb, (int)nzb);
   } else {
     const int64_t n = ceil_div64(P[0], OUT_ZY) * P[1] * P[2];
     TimedLaunch tl(ctx, "v2o_gauss_z");

@@ -132,6 +132,13 @@ extern "C" {
 
 int fpl_v2o_smooth_f64(fpl_ctx *ctx, const double *pred, int pred_mem, const int64_t dims[3],
                        int32_t r, const double *weights, int32_t wr) {
+  // integer mode (fpl_v2o_set_integer) holds for ONE call: taken and cleared before anything
+  // below can fail, so that a failed call never leaves it set for the next float64 volume
+  int tr = 0;
+  if (ctx) {
+    tr = ctx->v2o.trunc_passes ? 1 : 0;
+    ctx->v2o.trunc_passes = false;
+  }
   if (!ctx || !pred || !dims || !weights)
     return fpl_fail(ctx, "fpl_v2o_smooth_f64: NULL argument");
   FPL_REQUIRE(ctx, r >= 0 && wr >= 0, "fpl_v2o_smooth_f64: negative radius");
@@ -189,8 +196,6 @@ int fpl_v2o_smooth_f64(fpl_ctx *ctx, const double *pred, int pred_mem, const int
   }
   {
     TimedLaunch tl(ctx, "v2o64_gauss");
-    const int tr = S.trunc_passes ? 1 : 0;
-    S.trunc_passes = false;                 // holds for one call
     gauss_pass_f64<0><<<grid, 256, 0, st>>>(S.smoothed64, scratch, P[0], P[1], P[2], w_dev, wr, r, tr);
     gauss_pass_f64<1><<<grid, 256, 0, st>>>(scratch, S.smoothed64, P[0], P[1], P[2], w_dev, wr, r, tr);
     gauss_pass_f64<2><<<grid, 256, 0, st>>>(S.smoothed64, scratch, P[0], P[1], P[2], w_dev, wr, r, tr);

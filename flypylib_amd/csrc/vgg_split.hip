@@ -546,11 +546,7 @@ __global__ __launch_bounds__(64 * S_WAVES, 2) void vggs_stem_pool(StemSArgs a) {
             hi[p] = cvt_pk_h16(r[2 * p], r[2 * p + 1]);
           };
           auto B = [&](int p) {                           // (mfma_util.h::split_pk: tied to r's register)
-            unsigned l = __builtin_bit_cast(unsigned, r[2 * p]);
-            asm("v_fma_mixlo_f16 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]\n\t"
-                "v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                : "+v"(l) : "v"(hi[p]), "v"(r[2 * p + 1]));
-            lo[p] = l;
+            lo[p] = split_lo_pk(r[2 * p], hi[p], r[2 * p + 1]);
           };
           auto PL = [&](int k) {
 #pragma unroll
@@ -1557,11 +1553,11 @@ int split_prepare_int(fpl_ctx *ctx, fpl_program *prog, SplitState *st, float mea
   }
   for (uint16_t h : st->w1_int_host)
     if ((h & 0x7C00u) == 0x7C00u)
-      return fpl_fail_range(ctx, "a first-layer weight divided by std %g exceeds the IEEE-half range; use "
+      return fpl_fail_range_call(ctx, "a first-layer weight divided by std %g exceeds the IEEE-half range; use "
                                  "precision f32 (or 'auto') for this normalisation", (double)sd);
   // half-range guard: the operand is |u - c0| <= max(c0, 255 - c0)
   if (!(stem_input_limit(A, op, scale.data(), st->shift1_int_host.data(), 64) >= std::max(c0, 255.0 - c0)))
-    return fpl_fail_range(ctx, "the first layer's outputs may exceed the IEEE-half range at mean %g, std %g; "
+    return fpl_fail_range_call(ctx, "the first layer's outputs may exceed the IEEE-half range at mean %g, std %g; "
                                "use precision f32 (or 'auto')", (double)mean, (double)sd);
   const size_t wb = st->w1_int_host.size() * sizeof(uint16_t);
   if (!st->w1_int) FPL_HIP(ctx, hipMalloc((void **)&st->w1_int, wb));

@@ -81,6 +81,8 @@ def load_network(filepath, device=None):
         tuple(network.infer_sz))
     network._device = runtime.default_device() if device is None else device
     network.train_single, _, _, _ = network.model()
+    # compile, THEN the saved weights and optimizer state (load_model's order, reference :38-40)
+    network.train_single.compile(**network.compile_args)
     if os.path.exists(filepath + '.weights.npz'):
         network.train_single.load(filepath + '.weights.npz')
     elif os.path.exists(filepath + '.keras.h5'):
@@ -88,7 +90,6 @@ def load_network(filepath, device=None):
     else:
         raise FileNotFoundError('%s: neither %s.weights.npz nor %s.keras.h5 (the reference\'s '
                                 'Keras file) is there' % (filepath, filepath, filepath))
-    network.train_single.compile(**network.compile_args)
     network.train_network = network.train_single
     network._parallel = None
     network._set_infer()

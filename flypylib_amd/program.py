@@ -207,7 +207,12 @@ class LayerGraph:
             self.count_params(), self.count_trainable()))
 
     def compile(self, **compile_args):
+        """Keras builds a fresh optimizer on `compile()`: a recompiled network starts Adam from
+        zero moments and step 0 (a loaded one gets its saved state back AFTER its compile:
+        fplnetwork.load_network, as `keras.models.load_model` does)"""
         self.compile_args = dict(compile_args)
+        self.opt_state = None
+        self.compile_generation = getattr(self, 'compile_generation', 0) + 1
 
     def save(self, path):
         """weights checkpoint: a Keras-layout `.h5` (what the reference's `model.save`

@@ -63,7 +63,12 @@ class ParallelTrainNetwork:
         self._towers = None
 
     def compile(self, **kw):
+        # (a new Keras model, a new optimizer: `multi_gpu.make_parallel` + compile,
+        # flypylib/fplnetwork.py:124-128 - the towers' Adam starts from zero)
         self.compile_args = dict(kw)
+        self.single.opt_state = None
+        self.single.compile_generation = getattr(self.single, 'compile_generation', 0) + 1
+        self.close()
 
     def get_weights(self):
         return self.single.get_weights()
@@ -457,7 +462,7 @@ class _DeviceStager:
 def _single_trainer(network, graph, loss, opt, opt_args):
     """one trainer per network, kept across train() calls like a compiled Keras
     model keeps its optimizer: Adam moments and the step count persist"""
-    key = (network._device, loss, opt, len(graph.weights))
+    key = (network._device, loss, opt, len(graph.weights), getattr(graph, 'compile_generation', 0))
     cached = getattr(network, '_trainer', None)
     if cached is not None and cached[0] == key and cached[1].h is not None \
             and cached[1].ctx.h is not None:

@@ -29,6 +29,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: these declarations ARE its export list
+ * (tests/test_host_logic.py holds `nm -D` of the built library to them) */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define FPL_ABI_VERSION 8
 
@@ -364,6 +369,9 @@ int fpl_timing_reset(fpl_ctx *ctx);
 int fpl_timing_get(fpl_ctx *ctx, char *names, double *ms, int64_t *launches,
                    int32_t cap, int32_t *n);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
