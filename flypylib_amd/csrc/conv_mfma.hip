@@ -18,10 +18,14 @@
 // <= 80 KiB LDS so two workgroups share a CU.  Details at the kernel.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "fast_paths.h"
 #include "mfma_util.h"
 #include "pack_weights.h"
+#ifdef FPL_SPLIT
+#include "vgg_tiles.h"      // glds16 (LDS-DMA), used by unet_split_lds.h
+#endif
 
 namespace {
 
@@ -983,12 +987,18 @@ struct UnetState {
   int wp_steps[2] = {0, 0};
   float bias_tail = 0.f;
   float xlim = 0.f;              // split build: input limit of the stem's half-range bound
+  // split build, all-LDS kernels (unet_split_lds.h): the planar-pass weight streams
+  unsigned char *frags8 = nullptr;
+  size_t off8[12] = {0}, half8[12] = {0};   // per conv; 128-output layers: bytes of the first 64-channel half
+  size_t off8t = 0;                         // the head's conv3 with dy / dx swapped (edge strip)
+  bool have8 = false;
 };
 
 void unet_state_free(fpl_ctx *, void *p) {
   UnetState *s = (UnetState *)p;
   if (s->frags) hipFree(s->frags);
   if (s->shifts) hipFree(s->shifts);
+  if (s->frags8) hipFree(s->frags8);
   delete s;
 }
 
@@ -1321,6 +1331,7 @@ int unet_prepare(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *
   FPL_HIP(ctx, hipMemcpy(st->frags, all.data(), all.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   FPL_HIP(ctx, hipMemcpy(st->shifts, shifts.data(), shifts.size() * sizeof(float), hipMemcpyHostToDevice));
   st->version = prog->arena_version;
+  st->have8 = false;              // (the all-LDS path repacks its own streams on first use)
   return 0;
 }
 
@@ -1383,6 +1394,386 @@ Src make_src(const h16_t *p, int dim, int C, int ch0, int up, int crop) {
   return s;
 }
 
+
+#ifdef FPL_SPLIT
+// =====================================================================================
+// The all-LDS executor for unet_like2 / unet_like3 / unet_like4 (round 5): kernels in
+// unet_split_lds.h, tensors as planes of 8-channel passes.  unet_like (whose second
+// convolutions are 1x1x1) stays on the kernels above.
+// =====================================================================================
+#include "unet_split_lds.h"
+
+// One pass (input channels [ci0, ci0 + 8)) of a 3x3x3 convolution, output channels [co0, co0 +
+// 16 mb), interleaved rows, appended to *f in the order the kernel's LDS-DMA wants it:
+//   plain pass (um = 0):  [K-step 0..6][hi b0..mb-1 | lo b0..mb-1]            (phase A = K-steps 0 - 3)
+//   upsampled pass:       [phase A, B][parity][K-step][hi | lo]
+// K-slot (s, g, j) = tap 4 s + g, channel ci0 + j.  Upsampled passes, um = UM_Z: 18 taps (dz', dy, dx),
+// the z weights pre-summed per output-plane parity pz (the parity form above), 5 K-steps (A = 0 - 2),
+// parities pz = 0, 1; um = UM_ZY: 12 taps (dz', dy', dx), z AND y weights pre-summed per (plane, row)
+// parity, 3 K-steps (A = 0 - 1), parities pz + 2 py.  Sums in fp32, BN scale and the hi / lo split
+// applied afterwards.  `transposed`: the dy / dx taps swapped (edge strip: the rows of the tile -
+// and with them the row parity - run along x).
+void pack_u3_pass(const float *A, const fpl_op &op, int ci0, int co0, int mb, int um, bool transposed,
+                  std::vector<uint16_t> *f) {
+  const int ncout = 16 * mb;
+  std::vector<float> scale(A + op.scale_off + co0, A + op.scale_off + co0 + ncout);
+  auto W = [&](int dz, int dy, int dx, int ci, int co) {      // (dy, dx) = tile row / column tap
+    const int tap = dz * 9 + (transposed ? dx * 3 + dy : dy * 3 + dx);
+    return A[op.w_off + ((size_t)tap * op.cin + ci) * op.cout + co];
+  };
+  auto emit = [&](const std::vector<uint16_t> (&fc)[2], int s0, int s1) {
+    for (int s = s0; s < s1; ++s)
+      for (int part = 0; part < 2; ++part)
+        f->insert(f->end(), fc[part].begin() + (size_t)s * mb * 512, fc[part].begin() + (size_t)(s + 1) * mb * 512);
+  };
+  if (um == u8::UM_NONE) {
+    std::vector<float> sub((size_t)27 * 8 * ncout);
+    for (int t = 0; t < 27; ++t)
+      for (int j = 0; j < 8; ++j)
+        for (int co = 0; co < ncout; ++co)
+          sub[((size_t)t * 8 + j) * ncout + co] = W(t / 9, (t / 3) % 3, t % 3, ci0 + j, co0 + co);
+    std::vector<uint16_t> fc[2];
+    for (int part = 0; part < 2; ++part)
+      fpl_pack_frags(sub.data(), scale.data(), 27, 8, ncout, mb, u8::KP, SLOT_SPATIAL, &fc[part], 1, part);
+    emit(fc, 0, u8::KP);
+    return;
+  }
+  // taps of one axis that fall on the pair's first / second low-resolution voxel, by output parity
+  auto fold = [](int par, int second, int *t) {
+    if (par == 0) { if (!second) { t[0] = 0; t[1] = 1; return 2; } t[0] = 2; return 1; }
+    if (!second) { t[0] = 0; return 1; }
+    t[0] = 1; t[1] = 2; return 2;
+  };
+  const bool zy = um == u8::UM_ZY;
+  const int npar = zy ? 4 : 2, ntap = zy ? 12 : 18, K = zy ? 3 : 5, KA = zy ? 2 : 3;
+  std::vector<uint16_t> fp[4][2];                              // [parity][part]
+  for (int par = 0; par < npar; ++par) {
+    const int pz = par & 1, py = par >> 1;
+    std::vector<float> sub((size_t)ntap * 8 * ncout, 0.f);
+    for (int t = 0; t < ntap; ++t) {
+      const int dzp = zy ? t / 6 : t / 9, dyp = zy ? (t / 3) % 2 : (t / 3) % 3, dx = t % 3;
+      int tz[2], ty[2], nz = fold(pz, dzp, tz), ny = 1;
+      ty[0] = dyp;
+      if (zy) ny = fold(py, dyp, ty);
+      for (int j = 0; j < 8; ++j)
+        for (int co = 0; co < ncout; ++co) {
+          float v = 0.f;
+          for (int iz = 0; iz < nz; ++iz)
+            for (int iy = 0; iy < ny; ++iy) v += W(tz[iz], ty[iy], dx, ci0 + j, co0 + co);
+          sub[((size_t)t * 8 + j) * ncout + co] = v;
+        }
+    }
+    for (int part = 0; part < 2; ++part)
+      fpl_pack_frags(sub.data(), scale.data(), ntap, 8, ncout, mb, K, SLOT_SPATIAL, &fp[par][part], 1, part);
+  }
+  for (int ph = 0; ph < 2; ++ph)
+    for (int par = 0; par < npar; ++par) {
+      const int s0 = ph ? KA : 0, s1 = ph ? K : KA;
+      for (int s = s0; s < s1; ++s)
+        for (int part = 0; part < 2; ++part)
+          f->insert(f->end(), fp[par][part].begin() + (size_t)s * mb * 512, fp[par][part].begin() + (size_t)(s + 1) * mb * 512);
+    }
+}
+
+// the whole stream of a convolution's launch: passes 0 .. cin / 8 - 1, the first n_ups upsampled (mode um)
+void pack_u3(const float *A, const fpl_op &op, int co0, int mb, int n_ups, int um, bool transposed, std::vector<uint16_t> *f) {
+  f->clear();
+  for (int p = 0; p < op.cin / 8; ++p) pack_u3_pass(A, op, 8 * p, co0, mb, p < n_ups ? um : u8::UM_NONE, transposed, f);
+}
+
+// 1x1x1 convolution on planar tensors: [K-step s][hi b0..mb-1 | lo b0..mb-1], K-slot (s, g, j) =
+// channel 32 s + 8 g + j, output channels [co0, co0 + 16 mb), interleaved rows
+void pack_u1(const float *A, const fpl_op &op, int co0, int mb, std::vector<uint16_t> *f) {
+  const int ncout = 16 * mb, ks = op.cin / 32;
+  std::vector<float> sub((size_t)op.cin * ncout), scale(A + op.scale_off + co0, A + op.scale_off + co0 + ncout);
+  for (int ci = 0; ci < op.cin; ++ci)
+    for (int co = 0; co < ncout; ++co) sub[(size_t)ci * ncout + co] = A[op.w_off + (size_t)ci * op.cout + co0 + co];
+  std::vector<uint16_t> fc[2];
+  for (int part = 0; part < 2; ++part)
+    fpl_pack_frags(sub.data(), scale.data(), 1, op.cin, ncout, mb, ks, SLOT_SPATIAL, &fc[part], 1, part);
+  f->clear();
+  for (int s = 0; s < ks; ++s)
+    for (int part = 0; part < 2; ++part)
+      f->insert(f->end(), fc[part].begin() + (size_t)s * mb * 512, fc[part].begin() + (size_t)(s + 1) * mb * 512);
+}
+
+// K-slot -> tap of the all-LDS stem (unet_split_lds.h): groups 0 - 2: j < 6 = the (dx = 0, 1) pair of
+// row 3 g + j / 2, j = 6, 7 = the dx = 2 single of rows 2 g, 2 g + 1; group 3: j = 0, 2, 4 = the dx = 2
+// singles of rows 6, 7, 8.  A row r = (dz, dy) = (r / 3, r % 3); tap = 3 r + dx.  -1: zero weight.
+int stem_slot_tap(int g, int j) {
+  if (g < 3) return j < 6 ? (3 * g + (j >> 1)) * 3 + (j & 1) : (2 * g + (j - 6)) * 3 + 2;
+  return (j < 6 && !(j & 1)) ? (6 + (j >> 1)) * 3 + 2 : -1;
+}
+// conv3 1 -> cout as [chunk of 16 output channels][part] fragments, plain rows
+void pack_stem_u8(const float *A, const fpl_op &op, std::vector<uint16_t> *f) {
+  f->assign((size_t)(op.cout / 16) * 2 * 512, 0);
+  for (int cc = 0; cc < op.cout / 16; ++cc)
+    for (int part = 0; part < 2; ++part)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int m = lane & 15, g = lane >> 4, co = 16 * cc + m;
+        for (int j = 0; j < 8; ++j) {
+          const int tap = stem_slot_tap(g, j);
+          if (tap < 0) continue;
+          (*f)[(((size_t)cc * 2 + part) * 64 + lane) * 8 + j] =
+              fpl_f32_to_h16_part(A[op.w_off + (size_t)tap * op.cout + co] * A[op.scale_off + co], part);
+        }
+      }
+}
+
+// which skeletons the all-LDS executor takes: every 3x3x3 second convolution (not unet_like)
+bool unet_lds_ok(const UnetDesc &d) { return !d.first1 && !d.second1; }
+
+// the planar weight streams, once per weight version (beside unet_prepare's fragments, whose
+// stem, head and shift tables this path shares)
+int unet_prepare_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetState *st) {
+  if (st->have8) return 0;
+  const float *A = prog->arena_host.data();
+  std::vector<uint16_t> all, f;
+  const int lu1 = d.l_up1(), lu2 = d.l_up2();
+  pack_stem_u8(A, prog->ops[d.conv[0]], &f);
+  st->off8[0] = 0;
+  all.insert(all.end(), f.begin(), f.end());
+  for (int l = 1; l < d.nconv - 2; ++l) {          // (the last two = the head epilogue)
+    const fpl_op &op = prog->ops[d.conv[l]];
+    st->off8[l] = all.size() * sizeof(uint16_t);
+    st->half8[l] = 0;
+    FPL_REQUIRE(ctx, op.cin % 16 == 0 && op.cin / 8 <= u8::MAXPASS && (op.cout == 32 || op.cout % 64 == 0),
+                "unet (all-LDS): conv %d -> %d", op.cin, op.cout);
+    if (op.k == 3) {
+      const int n_ups = l == lu1 ? 128 / 8 : l == lu2 ? 64 / 8 : 0;
+      // (the 32-output layers' upsampled passes run the zy form, the 64-output layers' the z form)
+      const int um = op.cout == 32 ? u8::UM_ZY : u8::UM_Z;
+      for (int h = 0; h < (op.cout > 64 ? op.cout / 64 : 1); ++h) {
+        pack_u3(A, op, 64 * h, op.cout == 32 ? 2 : 4, n_ups, um, false, &f);
+        if (h == 1) st->half8[l] = all.size() * sizeof(uint16_t) - st->off8[l];
+        all.insert(all.end(), f.begin(), f.end());
+      }
+      if (l == lu2) {
+        pack_u3(A, op, 0, 2, n_ups, u8::UM_ZY, true, &f);
+        st->off8t = all.size() * sizeof(uint16_t);
+        all.insert(all.end(), f.begin(), f.end());
+      }
+    } else {
+      FPL_REQUIRE(ctx, op.cin % 32 == 0 && op.cout % 64 == 0, "unet (all-LDS): conv1 %d -> %d", op.cin, op.cout);
+      for (int h = 0; h < op.cout / 64; ++h) {
+        pack_u1(A, op, 64 * h, 4, &f);
+        if (h == 1) st->half8[l] = all.size() * sizeof(uint16_t) - st->off8[l];
+        all.insert(all.end(), f.begin(), f.end());
+      }
+    }
+  }
+  for (uint16_t h : all)
+    if ((h & 0x7C00u) == 0x7C00u)
+      return fpl_fail_range(ctx, "a folded weight exceeds the IEEE-half range (65504); use precision bf16, f32 or "
+                                 "'auto' for this network");
+  if (st->frags8) FPL_HIP(ctx, hipFree(st->frags8));
+  st->frags8 = nullptr;
+  FPL_HIP(ctx, hipMalloc((void **)&st->frags8, all.size() * sizeof(uint16_t)));
+  FPL_HIP(ctx, hipMemcpy(st->frags8, all.data(), all.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  st->have8 = true;
+  return 0;
+}
+
+// a planar split tensor: n tiles of d^3 voxels, C channels as C / 8 passes x 2 parts x 16 B
+struct PlanarT {
+  unsigned char *p = nullptr;
+  int d = 0, C = 0;
+  int64_t part = 0;
+  const unsigned char *pass(int q, int crop = 0) const {
+    return p + (int64_t)q * 2 * part + (((int64_t)crop * d + crop) * d + crop) * 16;
+  }
+};
+
+template <int MB, int R, int UM, int EPI, bool STEM = false, bool TRANSPOSED = false>
+int launch_u3(fpl_ctx *ctx, u8::U3Args &a, int main_w, const char *name) {
+  typedef u8::Lds<MB, R, UM, STEM> L;
+  typedef u8::Geo8<R, UM> GE;
+  constexpr bool HAS_UPS = UM != u8::UM_NONE;
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)FPLK(u8::u3conv)<MB, R, UM, EPI, STEM, TRANSPOSED>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
+  }
+  FPL_REQUIRE(ctx, a.npass % 2 == 0 && a.nups % 2 == 0 && a.npass <= u8::MAXPASS && (HAS_UPS || a.nups == 0),
+              "u3conv: %d passes, %d upsampled", a.npass, a.nups);
+  FPL_REQUIRE(ctx, (int64_t)a.Ppart + ((int64_t)6 * a.PH * a.PW + 64) * 16 < ((int64_t)1 << 32) &&
+                       (int64_t)a.Upart + ((int64_t)4 * a.UH * a.UW + 64) * 16 < ((int64_t)1 << 32),
+              "u3conv: a pass plane beyond the 32-bit tile offsets (fewer tiles per batch)");
+  a.nbz = (int)ceil_div64(a.OD, u8::WZ);
+  if (TRANSPOSED) {            // lanes walk y, sub-steps walk x in [xorg, OW)
+    a.nbx = (int)ceil_div64(a.OH, 16); a.nby = (int)ceil_div64(a.OW - a.xorg, GE::BY);
+  } else {
+    a.nbx = (int)ceil_div64(main_w ? main_w : a.OW, 16); a.nby = (int)ceil_div64(a.OH, GE::BY);
+  }
+  const int64_t total = (int64_t)a.nbx * a.nby * a.nbz * a.n_tiles;
+  FPL_REQUIRE(ctx, total < ((int64_t)1 << 31), "u3conv: too many blocks");
+  a.dbg = getenv("FPL_U3_DBG") ? atoi(getenv("FPL_U3_DBG")) : 0;     // timing experiments (results are garbage)
+  // one persistent workgroup per CU, a multiple of the 8 XCDs
+  int64_t grid = std::min<int64_t>((int64_t)ctx->n_cu / 8 * 8, (total + 7) / 8 * 8);
+  grid = std::max<int64_t>(8, grid);
+  if (a.dbg & 32) {              // diagnostic run: per-workgroup cycle sums of wave 0 (unet_split_lds.h::stamp)
+    unsigned long long *dev = nullptr;
+    std::vector<unsigned long long> h((size_t)grid * 8, 0);
+    FPL_HIP(ctx, hipMalloc((void **)&dev, h.size() * 8));
+    FPL_HIP(ctx, hipMemset(dev, 0, h.size() * 8));
+    a.dbgbuf = dev;
+    FPLK(u8::u3conv)<MB, R, UM, EPI, STEM, TRANSPOSED><<<(unsigned)grid, 64 * u8::WAVES, L::BYTES, ctx->stream>>>(a);
+    FPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FPL_HIP(ctx, hipMemcpy(h.data(), dev, h.size() * 8, hipMemcpyDeviceToHost));
+    hipFree(dev);
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int64_t w = 0; w < grid; ++w)
+      for (int k = 0; k < 5; ++k) t[k] += (double)h[w * 8 + k];
+    const double nb = t[4] > 0 ? t[4] : 1;
+    fprintf(stderr, "[FPL_U3_DBG] %s: %.0f blocks; cycles per block (s_memtime): start %.0f  fill %.0f  kloop %.0f  epilogue %.0f\n",
+            name, t[4], t[0] / nb, t[1] / nb, t[2] / nb, t[3] / nb);
+    return 0;
+  }
+  TimedLaunch tl(ctx, name);
+  FPLK(u8::u3conv)<MB, R, UM, EPI, STEM, TRANSPOSED><<<(unsigned)grid, 64 * u8::WAVES, L::BYTES, ctx->stream>>>(a);
+  return 0;
+}
+
+int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetState *st, const float *in, int n, int T,
+                     const FplTileIO *io) {
+  FPL_TRY(unet_prepare_lds(ctx, prog, D, st));
+  DevTemp tmp(ctx);
+  unsigned *flag = nullptr;
+  FPL_TRY(fpl_range_flag(ctx, &flag));
+  const unsigned char *F = st->frags, *F8 = st->frags8;
+  const float *S = st->shifts;
+  const bool b3[2] = {prog->ops[D.conv[4]].k == 3, D.nbottom == 2 && prog->ops[D.conv[5]].k == 3};
+  const int d1a = T - 2, d1 = T - 4, dp1 = d1 / 2, d2a = dp1 - 2, d2 = dp1 - 4, dp2 = d2 / 2;
+  const int db0 = dp2 - (b3[0] ? 2 : 0), db = db0 - (b3[1] ? 2 : 0);
+  const int d4a = 2 * db - 2, d5a = 2 * d4a - 2;
+  (void)d1a;
+  FPL_REQUIRE(ctx, d1 > 0 && d1 % 2 == 0 && d2 > 0 && d2 % 2 == 0 && db > 0 && d2 - 2 * D.crop2 == 2 * db &&
+                       d1 - 2 * D.crop1 == 2 * d4a && d5a > 0,
+              "U-Net tile edge %d does not fit this architecture (pools need even sizes, skips must meet)", T);
+  auto cube = [](int d) { return (int64_t)d * d * d; };
+  auto talloc = [&](int d, int C, PlanarT *t) -> int {
+    t->d = d; t->C = C; t->part = (int64_t)n * cube(d) * 16;
+    // tiles of edge blocks read past the last plane: up to 5 planes + 18 rows + 18 voxels
+    const size_t slack = ((size_t)6 * d * d + 40 * d + 64) * 16;
+    void *q;
+    FPL_TRY(tmp.alloc((size_t)(C / 8) * 2 * t->part + slack, &q));
+    t->p = (unsigned char *)q;
+    return 0;
+  };
+  PlanarT c1, p1, c2a, c2, p2, c3a, c3, c4a, c4;
+  FPL_TRY(talloc(d1, 32, &c1));
+  FPL_TRY(talloc(dp1, 32, &p1));
+  FPL_TRY(talloc(d2a, 64, &c2a));
+  FPL_TRY(talloc(d2, 64, &c2));
+  FPL_TRY(talloc(dp2, 64, &p2));
+  if (D.nbottom == 2) FPL_TRY(talloc(db0, 128, &c3a));
+  FPL_TRY(talloc(db, 128, &c3));
+  FPL_TRY(talloc(d4a, 64, &c4a));
+  FPL_TRY(talloc(d4a, 64, &c4));
+  auto args = [&](int l, int co0, const PlanarT *outp, int od) {
+    u8::U3Args a;
+    memset(&a, 0, sizeof(a));
+    a.w = F8 + st->off8[l] + (co0 ? st->half8[l] : 0);
+    a.shift = S + st->off_s[l] + co0;
+    a.relu = 1;
+    if (outp) { a.out = outp->p + (int64_t)(co0 / 8) * 2 * outp->part; a.out_part = outp->part; }
+    a.OD = a.OH = a.OW = od;
+    a.n_tiles = n;
+    a.flag = flag; a.xlim = st->xlim;
+    a.PD = a.PH = a.PW = a.UD = a.UH = a.UW = 1;
+    return a;
+  };
+  auto plain_src = [&](u8::U3Args &a, const PlanarT &t, int crop) {
+    for (int q = 0; q < t.C / 8; ++q) a.src[a.npass++] = t.pass(q, crop);
+    a.PD = a.PH = a.PW = t.d; a.Ppart = (unsigned)t.part;
+  };
+  auto ups_src = [&](u8::U3Args &a, const PlanarT &t) {
+    for (int q = 0; q < t.C / 8; ++q) a.src[a.npass++] = t.pass(q, 0);
+    a.nups = a.npass;
+    a.UD = a.UH = a.UW = t.d; a.Upart = (unsigned)t.part;
+  };
+  {  // conv3 1->32 computed into the tile of conv3 32->32, MaxPooling3D(2) in the epilogue
+    u8::U3Args a = args(1, 0, &c1, d1);
+    a.npass = 4;
+    a.raw = in; a.T = T;
+    a.wstem = (const h16x8 *)(F8 + st->off8[0]); a.shstem = S + st->off_s[0];
+    a.pool = p1.p; a.pool_part = p1.part;
+    FPL_TRY((launch_u3<2, 6, u8::UM_NONE, u8::EPI_POOL, true>(ctx, a, 0, "unet_stem_conv3_32_32_pool")));
+  }
+  {  // conv3 32->64
+    u8::U3Args a = args(2, 0, &c2a, d2a);
+    plain_src(a, p1, 0);
+    FPL_TRY((launch_u3<4, 4, u8::UM_NONE, u8::EPI_STORE>(ctx, a, 0, "unet_conv3_32_64")));
+  }
+  {  // conv3 64->64, MaxPooling3D(2)
+    u8::U3Args a = args(3, 0, &c2, d2);
+    plain_src(a, c2a, 0);
+    a.pool = p2.p; a.pool_part = p2.part;
+    FPL_TRY((launch_u3<4, 4, u8::UM_NONE, u8::EPI_POOL>(ctx, a, 0, "unet_conv3_64_64_pool")));
+  }
+  auto conv1 = [&](auto kern, int nfrag, const PlanarT &x, int l, int co0, const PlanarT &y, const char *name) {
+    u8::U1Args a;
+    a.in = x.p; a.in_part = x.part; a.M = (int64_t)n * cube(x.d);
+    a.w = F8 + st->off8[l] + (co0 ? st->half8[l] : 0);
+    a.shift = S + st->off_s[l] + co0;
+    a.out = y.p + (int64_t)(co0 / 8) * 2 * y.part; a.out_part = y.part;
+    a.flag = flag;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
+    TimedLaunch tl(ctx, name);
+    kern<<<grid, 256, nfrag * 1024, ctx->stream>>>(a);
+  };
+  auto conv3_to128 = [&](int l, const PlanarT &x, const PlanarT &y, const char *name) -> int {
+    for (int h = 0; h < 2; ++h) {
+      u8::U3Args a = args(l, 64 * h, &y, y.d);
+      plain_src(a, x, 0);
+      FPL_TRY((launch_u3<4, 4, u8::UM_NONE, u8::EPI_STORE>(ctx, a, 0, name)));
+    }
+    return 0;
+  };
+  // ---- bottom
+  if (!b3[0]) {
+    for (int h = 0; h < 2; ++h) conv1(FPLK(u8::u1conv)<2, 4>, 16, p2, 4, 64 * h, c3, "unet_conv1_64_128");
+  } else {
+    const PlanarT &y0 = D.nbottom == 2 ? c3a : c3;
+    FPL_TRY(conv3_to128(4, p2, y0, "unet_conv3_64_128"));
+    if (b3[1]) FPL_TRY(conv3_to128(5, c3a, c3, "unet_conv3_128_128"));
+    else
+      for (int h = 0; h < 2; ++h) conv1(FPLK(u8::u1conv)<4, 4>, 32, c3a, 5, 64 * h, c3, "unet_conv1_128_128");
+  }
+  const int lu1 = D.l_up1(), lu2 = D.l_up2();
+  {  // conv3 (up2(c3) 128 | crop(c2) 64) -> 64
+    u8::U3Args a = args(lu1, 0, &c4a, d4a);
+    ups_src(a, c3);
+    plain_src(a, c2, D.crop2);
+    FPL_TRY((launch_u3<4, 4, u8::UM_Z, u8::EPI_STORE>(ctx, a, 0, "unet_conv3_192_64")));
+  }
+  conv1(FPLK(u8::u1conv)<2, 4>, 16, c4a, lu1 + 1, 0, c4, "unet_conv1_64_64");
+  {  // conv3 (up2(c4) 64 | crop(c1) 32) -> 32, then the head in the epilogue.  An output width that
+     // is not a multiple of 16 (unet_like2: 82 = 5 x 16 + 2) sends its last columns through the
+     // transposed strip (lanes along y, two columns per block) instead of a block column that
+     // would use 2 of its 16 lanes
+    u8::U3Args a = args(lu2, 0, nullptr, d5a);
+    ups_src(a, c4);
+    plain_src(a, c1, D.crop1);
+    a.io = *io;
+    a.w8 = (const h16x8 *)(F + st->off_w[lu2 + 1]); a.sh8 = S + st->off_s[lu2 + 1];
+    a.w9 = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias9 = st->bias_tail;
+    const int rem = d5a % 16;
+    const bool strip = rem > 0 && rem <= 4 && d5a > 16;
+    FPL_TRY((launch_u3<2, 6, u8::UM_ZY, u8::EPI_HEAD>(ctx, a, strip ? d5a - rem : 0, "unet_conv3_96_32_head")));
+    if (strip) {
+      u8::U3Args e = a;
+      e.w = F8 + st->off8t;
+      e.xorg = d5a - rem;
+      FPL_TRY((launch_u3<2, 1, u8::UM_ZY, u8::EPI_HEAD, false, true>(ctx, e, 0, "unet_conv3_96_32_head_edge")));
+    }
+  }
+  FPL_HIP(ctx, hipGetLastError());
+  return 0;
+}
+#endif  // FPL_SPLIT
+
 }  // namespace
 
 bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
@@ -1402,6 +1793,12 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   FPL_REQUIRE(ctx, !SPLIT || io, "fpl_unet_forward: the split-half build writes into a prediction volume");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
+#ifdef FPL_SPLIT
+  // unet_like2 / 3 / 4: the all-LDS kernels (FPL_UNET_OLDSPLIT=1: the round-4 kernels, A/B)
+  // (FPL_UNET_NOPARITY=1, the 27-tap cross-check of the parity form, exists on the round-4 kernels only)
+  if (unet_lds_ok(D) && !getenv("FPL_UNET_OLDSPLIT") && !getenv("FPL_UNET_NOPARITY"))
+    return unet_forward_lds(ctx, prog, D, st, in, n, T, io);
+#endif
   DevTemp tmp(ctx);
   unsigned *flag = nullptr;
   if (SPLIT) FPL_TRY(fpl_range_flag(ctx, &flag));
