@@ -1541,10 +1541,12 @@ int unet_prepare_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetSta
                 "unet (all-LDS): conv %d -> %d", op.cin, op.cout);
     if (op.k == 3) {
       const int n_ups = l == lu1 ? 128 / 8 : l == lu2 ? 64 / 8 : 0;
-      // (the 32-output layers' upsampled passes run the zy form, the 64-output layers' the z form)
-      const int um = op.cout == 32 ? u8::UM_ZY : u8::UM_Z;
-      for (int h = 0; h < (op.cout > 64 ? op.cout / 64 : 1); ++h) {
-        pack_u3(A, op, 64 * h, op.cout == 32 ? 2 : 4, n_ups, um, false, &f);
+      // Upsampled passes run the zy form, which exists for 32 output channels at a time (four
+      // parity streams of a 64-output layer's fragments do not fit in LDS): conv3 192->64 is two
+      // launches of 32 channels - a quarter fewer MFMAs than one 64-channel launch in the z form
+      const int half = n_ups ? 32 : 64, mbh = op.cout == 32 ? 2 : half / 16;
+      for (int h = 0; h < (op.cout > half ? op.cout / half : 1); ++h) {
+        pack_u3(A, op, half * h, mbh, n_ups, u8::UM_ZY, false, &f);
         if (h == 1) st->half8[l] = all.size() * sizeof(uint16_t) - st->off8[l];
         all.insert(all.end(), f.begin(), f.end());
       }
@@ -1586,7 +1588,7 @@ struct PlanarT {
 
 template <int MB, int R, int UM, int EPI, bool STEM = false, bool TRANSPOSED = false>
 int launch_u3(fpl_ctx *ctx, u8::U3Args &a, int main_w, const char *name) {
-  typedef u8::Lds<MB, R, UM, STEM> L;
+  typedef u8::Lds<MB, R, UM, STEM, STEM || EPI == u8::EPI_HEAD> L;
   typedef u8::Geo8<R, UM> GE;
   constexpr bool HAS_UPS = UM != u8::UM_NONE;
   static bool attr_set[FPL_MAX_DEVICES] = {false};
@@ -1679,6 +1681,7 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
     a.relu = 1;
     if (outp) { a.out = outp->p + (int64_t)(co0 / 8) * 2 * outp->part; a.out_part = outp->part; }
     a.OD = a.OH = a.OW = od;
+    a.keep_lo = 0; a.keep_hi = od;
     a.n_tiles = n;
     a.flag = flag; a.xlim = st->xlim;
     a.PD = a.PH = a.PW = a.UD = a.UH = a.UW = 1;
@@ -1699,6 +1702,9 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
     a.raw = in; a.T = T;
     a.wstem = (const h16x8 *)(F8 + st->off8[0]); a.shstem = S + st->off_s[0];
     a.pool = p1.p; a.pool_part = p1.part;
+    // c1's only reader (the head's conv3) sees it through Cropping3D(crop1): the shell outside is
+    // pooled into p1 but never stored (a third of this kernel's 128 B-per-voxel stores at crop 6 of 96)
+    a.keep_lo = D.crop1; a.keep_hi = d1 - D.crop1;
     FPL_TRY((launch_u3<2, 6, u8::UM_NONE, u8::EPI_POOL, true>(ctx, a, 0, "unet_stem_conv3_32_32_pool")));
   }
   {  // conv3 32->64
@@ -1742,11 +1748,13 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
       for (int h = 0; h < 2; ++h) conv1(FPLK(u8::u1conv)<4, 4>, 32, c3a, 5, 64 * h, c3, "unet_conv1_128_128");
   }
   const int lu1 = D.l_up1(), lu2 = D.l_up2();
-  {  // conv3 (up2(c3) 128 | crop(c2) 64) -> 64
-    u8::U3Args a = args(lu1, 0, &c4a, d4a);
+  // conv3 (up2(c3) 128 | crop(c2) 64) -> 64, as two launches of 32 output channels in the zy form;
+  // blocks of 4 x 14 x 16 (unet_like2's 42 rows are three of them: 4 x 8 x 16 computed 48)
+  for (int h = 0; h < 2; ++h) {
+    u8::U3Args a = args(lu1, 32 * h, &c4a, d4a);
     ups_src(a, c3);
     plain_src(a, c2, D.crop2);
-    FPL_TRY((launch_u3<4, 4, u8::UM_Z, u8::EPI_STORE>(ctx, a, 0, "unet_conv3_192_64")));
+    FPL_TRY((launch_u3<2, 7, u8::UM_ZY, u8::EPI_STORE>(ctx, a, 0, "unet_conv3_192_64")));
   }
   conv1(FPLK(u8::u1conv)<2, 4>, 16, c4a, lu1 + 1, 0, c4, "unet_conv1_64_64");
   {  // conv3 (up2(c4) 64 | crop(c1) 32) -> 32, then the head in the epilogue.  An output width that

@@ -91,7 +91,7 @@ template <int MB, int UM = UM_Z> struct Wt {
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-template <int MB, int R, int UM, bool STEM> struct Lds {
+template <int MB, int R, int UM, bool STEM, bool FRAGS = true> struct Lds {
   static constexpr int TB = Geo8<R, UM>::TILE_BYTES;
   static constexpr int WA = (UM ? cmax(Wt<MB, UM>::PA, Wt<MB, UM>::UA) : Wt<MB, UM>::PA) * 1024;
   static constexpr int WB = (UM ? cmax(Wt<MB, UM>::PB, Wt<MB, UM>::UB) : Wt<MB, UM>::PB) * 1024;
@@ -99,7 +99,8 @@ template <int MB, int R, int UM, bool STEM> struct Lds {
   // block-invariant operands (shift vector; stem / head fragments): kept in LDS, because a global
   // load inside the block loop waits - vmcnt retires in order - for every older vector-memory
   // operation of the wave: the epilogue's stores, the next block's raw-tile loads
-  static constexpr int OFF_CONST = OFF_KTAB + 2 * 32 * 4, CONST_BYTES = 256 + 6 * 1024 + 256;
+  // (FRAGS: the stem's / head's fragments; a plain store kernel keeps its shift vector only)
+  static constexpr int OFF_CONST = OFF_KTAB + 2 * 32 * 4, CONST_BYTES = FRAGS ? 256 + 6 * 1024 + 256 : 256;
   static constexpr int OFF_RAW = OFF_CONST + CONST_BYTES;             // STEM: the raw tile, [hi | lo << 16] per voxel
   static constexpr int OFF_ROFF = OFF_RAW + 2 * Geo8<R, UM>::NRAW * 2;    // STEM: raw offset of every tile slot (u16)
   static constexpr int BYTES = STEM ? OFF_ROFF + ((Geo8<R, UM>::NGRP * 16 * 2 + 15) / 16) * 16 : OFF_RAW;
@@ -118,6 +119,8 @@ struct U3Args {
   int relu;
   unsigned char *out; int64_t out_part;    // planar output: pass q at out + 2 q out_part
   int OD, OH, OW;
+  int keep_lo, keep_hi;                    // full-resolution stores only for voxels in [keep_lo, keep_hi) per axis (the
+                                           // tensor's one reader crops it: unet_like2's c1 is read through Cropping3D(6))
   unsigned char *pool; int64_t pool_part;  // EPI_POOL: the pooled tensor (OD/2, OH/2, OW/2)
   int n_tiles, nbx, nby, nbz;
   int xorg;                                // TRANSPOSED: the strip's first column
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
   static_assert(EPI != EPI_POOL || R % 2 == 0, "pool pairs");
   typedef Geo8<R, UM> GE;
   typedef Wt<MB, UM> WT;
-  typedef Lds<MB, R, UM, STEM> L;
+  typedef Lds<MB, R, UM, STEM, STEM || EPI == EPI_HEAD> L;
   typedef UK<UM> UKx;
   constexpr int TB = L::TB, TCHP = GE::TCHP, TCHU = GE::TCHU;
   unsigned char *WAb = smem + L::OFF_WA, *WBb = smem + L::OFF_WB;
@@ -712,7 +715,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
       for (int sub = 0; sub < R; ++sub) {
         const int oy = TRANSPOSED ? cur.y0 + c : cur.y0 + row0 + GE::SUBROW * sub;
         const int ox = TRANSPOSED ? cur.x0 + row0 + GE::SUBROW * sub : cur.x0 + c;
-        if (zin && oy < a.OH && ox < a.OW)
+        if (zin && oy < a.OH && ox < a.OW && oz >= a.keep_lo && oy >= a.keep_lo && ox >= a.keep_lo && oz < a.keep_hi &&
+            oy < a.keep_hi && ox < a.keep_hi)
           store_planar<MB>(a.out, a.out_part, (((int64_t)cur.n * a.OD + oz) * a.OH + oy) * a.OW + ox, g, acc[sub], a.relu != 0, ovf);
       }
     }

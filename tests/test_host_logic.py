@@ -292,6 +292,12 @@ def test_headline_kernels_compile_without_scratch_spills():
     assert len(conv1) >= 3
     for name, v in conv1.items():
         assert v['vgpr_spill_count'] == 0 and v['vgpr_count'] <= 256, (name, v)
+    # the U-Net's all-LDS kernels (round 5; csrc/unet_split_lds.h): stem + pool, 32->64, 64->64 + pool,
+    # 192->64 (zy form, 14 rows), head (zy form) and its edge strip - two waves per SIMD, no scratch
+    u3 = {n: v for n, v in res.items() if 'u3conv_f16s' in n}
+    assert len(u3) >= 6, sorted(u3)
+    for name, v in u3.items():
+        assert v['vgpr_spill_count'] == 0 and v['private_segment_fixed_size'] == 0 and v['vgpr_count'] <= 256, (name, v)
 
 
 def test_split_lo_halves_never_land_on_an_mfma_destination():
