@@ -23,9 +23,7 @@
 #include "fast_paths.h"
 #include "mfma_util.h"
 #include "pack_weights.h"
-#ifdef FPL_SPLIT
 #include "vgg_tiles.h"      // glds16 (LDS-DMA), used by unet_split_lds.h
-#endif
 
 namespace {
 
@@ -140,9 +138,11 @@ struct Src {             // one CC-channel chunk of the (virtual) concatenated i
 // lane (c, g) writes the 4*MB contiguous channels [4*MB*g, ...) of its voxel; `vox0` is the
 // voxel's position in chunk plane 0.
 // `ovf`: the split build's half-range guard (mfma_util.h)
+// `planar` (bf16 / f16 builds): the output is a planar tensor of the all-LDS kernels
+// (unet_split_lds.h): piece i of 8 channels at vox0 + i * plane, vox0 = the voxel's 16 B in piece 0
 template <int MB, bool RELU_ALWAYS>
 __device__ __forceinline__ void store_il(h16_t *vox0, int64_t plane, int g, const f32x4 (&acc)[MB], int relu,
-                                         unsigned &ovf) {
+                                         unsigned &ovf, int planar = 0) {
   static_assert(MB % 2 == 0, "16-B pieces");
   if (SPLIT) {
     // the lane's 4*MB real channels start at 4*MB*g; per 8 of them one 16-B piece of hi
@@ -179,7 +179,7 @@ __device__ __forceinline__ void store_il(h16_t *vox0, int64_t plane, int g, cons
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = pk_max_i16(o[q], 0u);
     }
-    *reinterpret_cast<u32x4 *>(vox0 + (ch / CC) * plane + ch % CC) = o;
+    *reinterpret_cast<u32x4 *>(planar ? vox0 + (ch / 8) * plane : vox0 + (ch / CC) * plane + ch % CC) = o;
   }
 }
 
@@ -225,6 +225,8 @@ struct Conv3Args {
   // `wstream` bytes behind it; total_steps = K-steps of one stream (all launches: set by launch_conv3)
   int parity, total_steps;
   int64_t wstream;
+  // bf16 / f16 builds: `out` / `pool_out` are planar tensors (store_il)
+  int planar;
 };
 
 // K order: channel chunk -> dz -> dx -> dy.  For a fixed (chunk, dz, dx) the four
@@ -574,8 +576,8 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
                       td.start[1] + a.io.off + oy) * a.io.X + td.start[2] + a.io.off + ox] =
                 1.f / (1.f + __expf(-logit));
         } else if (oz < a.OD && oy < a.OH && ox < a.OW)
-          store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * CC,
-                              a.oplane, g, acc[sub], a.relu, ovf);
+          store_il<MB, false>(a.out + ((((int64_t)n * a.OD + oz) * a.OH + oy) * a.OW + ox) * (a.planar ? 8 : CC),
+                              a.oplane, g, acc[sub], a.relu, ovf, a.planar);
       }
     }
     // ---- fused 2x2x2 max pool of the block (4 x 4 x 16 -> 2 x 2 x 8): y pairs are
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
         for (int yh = 0; yh < R / 2; ++yh) {
           const int py = by * (R / 2) + yh;
           if (pz < PD && py < PH && px < PW) {
-            h16_t *vox0 = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * CC;
+            h16_t *vox0 = a.pool_out + ((((int64_t)n * PD + pz) * PH + py) * PW + px) * (a.planar ? 8 : CC);
 #pragma unroll
             for (int h = 0; h < MB / 2; ++h) {
               const u32x4 o = xch[(((wave >> 1) * (R / 2) + yh) * (MB / 2) + h) * 64 + lane];
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(256, (MB == 2 && !SPLIT && R == 4) ? 3 : 2) void FP
 #pragma unroll
               for (int q = 0; q < 4; ++q) m[q] = pk_max_i16(pm[yh][h][q], o[q]);
               const int ch = 4 * MB * g + 8 * h;
-              *reinterpret_cast<u32x4 *>(vox0 + (ch / CC) * a.pplane + ch % CC) = m;
+              *reinterpret_cast<u32x4 *>(a.planar ? vox0 + (ch / 8) * a.pplane : vox0 + (ch / CC) * a.pplane + ch % CC) = m;
             }
           }
         }
@@ -1352,8 +1354,8 @@ int launch_conv3(fpl_ctx *ctx, Conv3Args &a, int n, const char *name) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_set[ctx->device % FPL_MAX_DEVICES] = true;
   }
-  a.oplane = (int64_t)n * a.OD * a.OH * a.OW * CC;
-  a.pplane = (int64_t)n * (a.OD / 2) * (a.OH / 2) * (a.OW / 2) * CC;
+  a.oplane = (int64_t)n * a.OD * a.OH * a.OW * (a.planar ? 8 : CC);
+  a.pplane = (int64_t)n * (a.OD / 2) * (a.OH / 2) * (a.OW / 2) * (a.planar ? 8 : CC);
   // offset tables: one per distinct source geometry
   a.ntab = 0;
   for (int i = 0; i < (STEM ? 0 : a.ncc); ++i) {
@@ -1395,12 +1397,13 @@ Src make_src(const h16_t *p, int dim, int C, int ch0, int up, int crop) {
 }
 
 
-#ifdef FPL_SPLIT
 // =====================================================================================
 // The all-LDS executor for unet_like2 / unet_like3 / unet_like4 (round 5): kernels in
-// unet_split_lds.h, tensors as planes of 8-channel passes.  unet_like (whose second
+// unet_split_lds.h, tensors as planes of CHP-channel passes (8 channels as hi + lo halves in the
+// split build, 16 channels as two planes of 8 in the bf16 / f16 builds).  unet_like (whose second
 // convolutions are 1x1x1) stays on the kernels above.
 // =====================================================================================
+constexpr int CHP = SPLIT ? 8 : 16;      // channels per pass
 #include "unet_split_lds.h"
 
 // One pass (input channels [ci0, ci0 + 8)) of a 3x3x3 convolution, output channels [co0, co0 +
@@ -1421,67 +1424,64 @@ void pack_u3_pass(const float *A, const fpl_op &op, int ci0, int co0, int mb, in
     const int tap = dz * 9 + (transposed ? dx * 3 + dy : dy * 3 + dx);
     return A[op.w_off + ((size_t)tap * op.cin + ci) * op.cout + co];
   };
-  auto emit = [&](const std::vector<uint16_t> (&fc)[2], int s0, int s1) {
-    for (int s = s0; s < s1; ++s)
-      for (int part = 0; part < 2; ++part)
-        f->insert(f->end(), fc[part].begin() + (size_t)s * mb * 512, fc[part].begin() + (size_t)(s + 1) * mb * 512);
+  // the two weight sets of a K-step: split build = the hi and the lo parts of the pass's 8 channels,
+  // plain builds = its channels 0 - 7 and 8 - 15
+  auto pack2 = [&](const std::vector<float> (&sub)[2], int ntap, int K, std::vector<uint16_t> (&fc)[2]) {
+    for (int set = 0; set < 2; ++set)
+      fpl_pack_frags(sub[SPLIT ? 0 : set].data(), scale.data(), ntap, 8, ncout, mb, K, SLOT_SPATIAL, &fc[set], 1,
+                     SPLIT ? set : 0);
   };
-  if (um == u8::UM_NONE) {
-    std::vector<float> sub((size_t)27 * 8 * ncout);
-    for (int t = 0; t < 27; ++t)
-      for (int j = 0; j < 8; ++j)
-        for (int co = 0; co < ncout; ++co)
-          sub[((size_t)t * 8 + j) * ncout + co] = W(t / 9, (t / 3) % 3, t % 3, ci0 + j, co0 + co);
-    std::vector<uint16_t> fc[2];
-    for (int part = 0; part < 2; ++part)
-      fpl_pack_frags(sub.data(), scale.data(), 27, 8, ncout, mb, u8::KP, SLOT_SPATIAL, &fc[part], 1, part);
-    emit(fc, 0, u8::KP);
-    return;
-  }
   // taps of one axis that fall on the pair's first / second low-resolution voxel, by output parity
   auto fold = [](int par, int second, int *t) {
     if (par == 0) { if (!second) { t[0] = 0; t[1] = 1; return 2; } t[0] = 2; return 1; }
     if (!second) { t[0] = 0; return 1; }
     t[0] = 1; t[1] = 2; return 2;
   };
-  const bool zy = um == u8::UM_ZY;
-  const int npar = zy ? 4 : 2, ntap = zy ? 12 : 18, K = zy ? 3 : 5, KA = zy ? 2 : 3;
-  std::vector<uint16_t> fp[4][2];                              // [parity][part]
+  const bool zy = um == u8::UM_ZY, ups = um != u8::UM_NONE;
+  const int npar = !ups ? 1 : zy ? 4 : 2, ntap = !ups ? 27 : zy ? 12 : 18;
+  const int K = !ups ? u8::KP : zy ? 3 : 5, KA = !ups ? u8::KPA : zy ? 2 : 3;
+  std::vector<uint16_t> fp[4][2];                              // [parity][set]
   for (int par = 0; par < npar; ++par) {
     const int pz = par & 1, py = par >> 1;
-    std::vector<float> sub((size_t)ntap * 8 * ncout, 0.f);
-    for (int t = 0; t < ntap; ++t) {
-      const int dzp = zy ? t / 6 : t / 9, dyp = zy ? (t / 3) % 2 : (t / 3) % 3, dx = t % 3;
-      int tz[2], ty[2], nz = fold(pz, dzp, tz), ny = 1;
-      ty[0] = dyp;
-      if (zy) ny = fold(py, dyp, ty);
-      for (int j = 0; j < 8; ++j)
-        for (int co = 0; co < ncout; ++co) {
-          float v = 0.f;
-          for (int iz = 0; iz < nz; ++iz)
-            for (int iy = 0; iy < ny; ++iy) v += W(tz[iz], ty[iy], dx, ci0 + j, co0 + co);
-          sub[((size_t)t * 8 + j) * ncout + co] = v;
+    std::vector<float> sub[2];
+    for (int half = 0; half < (SPLIT ? 1 : 2); ++half) {
+      sub[half].assign((size_t)ntap * 8 * ncout, 0.f);
+      for (int t = 0; t < ntap; ++t) {
+        int tz[2], ty[2], nz = 1, ny = 1, dx = t % 3;
+        if (!ups) { tz[0] = t / 9; ty[0] = (t / 3) % 3; }
+        else {
+          const int dzp = zy ? t / 6 : t / 9, dyp = zy ? (t / 3) % 2 : (t / 3) % 3;
+          nz = fold(pz, dzp, tz);
+          ty[0] = dyp;
+          if (zy) ny = fold(py, dyp, ty);
         }
+        for (int j = 0; j < 8; ++j)
+          for (int co = 0; co < ncout; ++co) {
+            float v = 0.f;
+            for (int iz = 0; iz < nz; ++iz)
+              for (int iy = 0; iy < ny; ++iy) v += W(tz[iz], ty[iy], dx, ci0 + 8 * half + j, co0 + co);
+            sub[half][((size_t)t * 8 + j) * ncout + co] = v;
+          }
+      }
     }
-    for (int part = 0; part < 2; ++part)
-      fpl_pack_frags(sub.data(), scale.data(), ntap, 8, ncout, mb, K, SLOT_SPATIAL, &fp[par][part], 1, part);
+    pack2(sub, ntap, K, fp[par]);
   }
   for (int ph = 0; ph < 2; ++ph)
     for (int par = 0; par < npar; ++par) {
       const int s0 = ph ? KA : 0, s1 = ph ? K : KA;
       for (int s = s0; s < s1; ++s)
-        for (int part = 0; part < 2; ++part)
-          f->insert(f->end(), fp[par][part].begin() + (size_t)s * mb * 512, fp[par][part].begin() + (size_t)(s + 1) * mb * 512);
+        for (int set = 0; set < 2; ++set)
+          f->insert(f->end(), fp[par][set].begin() + (size_t)s * mb * 512, fp[par][set].begin() + (size_t)(s + 1) * mb * 512);
     }
 }
 
 // the whole stream of a convolution's launch: passes 0 .. cin / 8 - 1, the first n_ups upsampled (mode um)
 void pack_u3(const float *A, const fpl_op &op, int co0, int mb, int n_ups, int um, bool transposed, std::vector<uint16_t> *f) {
   f->clear();
-  for (int p = 0; p < op.cin / 8; ++p) pack_u3_pass(A, op, 8 * p, co0, mb, p < n_ups ? um : u8::UM_NONE, transposed, f);
+  for (int p = 0; p < op.cin / CHP; ++p) pack_u3_pass(A, op, CHP * p, co0, mb, p < n_ups ? um : u8::UM_NONE, transposed, f);
 }
 
-// 1x1x1 convolution on planar tensors: [K-step s][hi b0..mb-1 | lo b0..mb-1], K-slot (s, g, j) =
+// 1x1x1 convolution on planar tensors: [K-step s][hi b0..mb-1 | lo b0..mb-1] (plain builds: [s][b]), K-slot (s, g, j) =
 // channel 32 s + 8 g + j, output channels [co0, co0 + 16 mb), interleaved rows
 void pack_u1(const float *A, const fpl_op &op, int co0, int mb, std::vector<uint16_t> *f) {
   const int ncout = 16 * mb, ks = op.cin / 32;
@@ -1489,11 +1489,11 @@ void pack_u1(const float *A, const fpl_op &op, int co0, int mb, std::vector<uint
   for (int ci = 0; ci < op.cin; ++ci)
     for (int co = 0; co < ncout; ++co) sub[(size_t)ci * ncout + co] = A[op.w_off + (size_t)ci * op.cout + co0 + co];
   std::vector<uint16_t> fc[2];
-  for (int part = 0; part < 2; ++part)
+  for (int part = 0; part < PM; ++part)
     fpl_pack_frags(sub.data(), scale.data(), 1, op.cin, ncout, mb, ks, SLOT_SPATIAL, &fc[part], 1, part);
   f->clear();
   for (int s = 0; s < ks; ++s)
-    for (int part = 0; part < 2; ++part)
+    for (int part = 0; part < PM; ++part)
       f->insert(f->end(), fc[part].begin() + (size_t)s * mb * 512, fc[part].begin() + (size_t)(s + 1) * mb * 512);
 }
 
@@ -1506,15 +1506,15 @@ int stem_slot_tap(int g, int j) {
 }
 // conv3 1 -> cout as [chunk of 16 output channels][part] fragments, plain rows
 void pack_stem_u8(const float *A, const fpl_op &op, std::vector<uint16_t> *f) {
-  f->assign((size_t)(op.cout / 16) * 2 * 512, 0);
+  f->assign((size_t)(op.cout / 16) * PM * 512, 0);
   for (int cc = 0; cc < op.cout / 16; ++cc)
-    for (int part = 0; part < 2; ++part)
+    for (int part = 0; part < PM; ++part)
       for (int lane = 0; lane < 64; ++lane) {
         const int m = lane & 15, g = lane >> 4, co = 16 * cc + m;
         for (int j = 0; j < 8; ++j) {
           const int tap = stem_slot_tap(g, j);
           if (tap < 0) continue;
-          (*f)[(((size_t)cc * 2 + part) * 64 + lane) * 8 + j] =
+          (*f)[(((size_t)cc * PM + part) * 64 + lane) * 8 + j] =
               fpl_f32_to_h16_part(A[op.w_off + (size_t)tap * op.cout + co] * A[op.scale_off + co], part);
         }
       }
@@ -1537,10 +1537,10 @@ int unet_prepare_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetSta
     const fpl_op &op = prog->ops[d.conv[l]];
     st->off8[l] = all.size() * sizeof(uint16_t);
     st->half8[l] = 0;
-    FPL_REQUIRE(ctx, op.cin % 16 == 0 && op.cin / 8 <= u8::MAXPASS && (op.cout == 32 || op.cout % 64 == 0),
+    FPL_REQUIRE(ctx, op.cin % 32 == 0 && op.cin / CHP <= u8::MAXPASS && (op.cout == 32 || op.cout % 64 == 0),
                 "unet (all-LDS): conv %d -> %d", op.cin, op.cout);
     if (op.k == 3) {
-      const int n_ups = l == lu1 ? 128 / 8 : l == lu2 ? 64 / 8 : 0;
+      const int n_ups = l == lu1 ? 128 / CHP : l == lu2 ? 64 / CHP : 0;
       // Upsampled passes run the zy form, which exists for 32 output channels at a time (four
       // parity streams of a 64-output layer's fragments do not fit in LDS): conv3 192->64 is two
       // launches of 32 channels - a quarter fewer MFMAs than one 64-channel launch in the z form
@@ -1564,10 +1564,13 @@ int unet_prepare_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetSta
       }
     }
   }
+#ifdef FPL_F16
   for (uint16_t h : all)
-    if ((h & 0x7C00u) == 0x7C00u)
-      return fpl_fail_range(ctx, "a folded weight exceeds the IEEE-half range (65504); use precision bf16, f32 or "
-                                 "'auto' for this network");
+    if ((h & 0x7C00u) == 0x7C00u) {
+      const char *msg = "a folded weight exceeds the IEEE-half range (65504); use precision bf16, f32 or 'auto' for this network";
+      return SPLIT ? fpl_fail_range(ctx, "%s", msg) : fpl_fail(ctx, "%s", msg);
+    }
+#endif
   if (st->frags8) FPL_HIP(ctx, hipFree(st->frags8));
   st->frags8 = nullptr;
   FPL_HIP(ctx, hipMalloc((void **)&st->frags8, all.size() * sizeof(uint16_t)));
@@ -1576,7 +1579,7 @@ int unet_prepare_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &d, UnetSta
   return 0;
 }
 
-// a planar split tensor: n tiles of d^3 voxels, C channels as C / 8 passes x 2 parts x 16 B
+// a planar tensor: n tiles of d^3 voxels, C channels as C / CHP passes x 2 planes x 16 B
 struct PlanarT {
   unsigned char *p = nullptr;
   int d = 0, C = 0;
@@ -1642,7 +1645,7 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
   FPL_TRY(unet_prepare_lds(ctx, prog, D, st));
   DevTemp tmp(ctx);
   unsigned *flag = nullptr;
-  FPL_TRY(fpl_range_flag(ctx, &flag));
+  if (SPLIT) FPL_TRY(fpl_range_flag(ctx, &flag));
   const unsigned char *F = st->frags, *F8 = st->frags8;
   const float *S = st->shifts;
   const bool b3[2] = {prog->ops[D.conv[4]].k == 3, D.nbottom == 2 && prog->ops[D.conv[5]].k == 3};
@@ -1659,7 +1662,7 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
     // tiles of edge blocks read past the last plane: up to 5 planes + 18 rows + 18 voxels
     const size_t slack = ((size_t)6 * d * d + 40 * d + 64) * 16;
     void *q;
-    FPL_TRY(tmp.alloc((size_t)(C / 8) * 2 * t->part + slack, &q));
+    FPL_TRY(tmp.alloc((size_t)(C / CHP) * 2 * t->part + slack, &q));
     t->p = (unsigned char *)q;
     return 0;
   };
@@ -1679,7 +1682,7 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
     a.w = F8 + st->off8[l] + (co0 ? st->half8[l] : 0);
     a.shift = S + st->off_s[l] + co0;
     a.relu = 1;
-    if (outp) { a.out = outp->p + (int64_t)(co0 / 8) * 2 * outp->part; a.out_part = outp->part; }
+    if (outp) { a.out = outp->p + (int64_t)(co0 / CHP) * 2 * outp->part; a.out_part = outp->part; }
     a.OD = a.OH = a.OW = od;
     a.keep_lo = 0; a.keep_hi = od;
     a.n_tiles = n;
@@ -1688,17 +1691,33 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
     return a;
   };
   auto plain_src = [&](u8::U3Args &a, const PlanarT &t, int crop) {
-    for (int q = 0; q < t.C / 8; ++q) a.src[a.npass++] = t.pass(q, crop);
+    for (int q = 0; q < t.C / CHP; ++q) a.src[a.npass++] = t.pass(q, crop);
     a.PD = a.PH = a.PW = t.d; a.Ppart = (unsigned)t.part;
   };
   auto ups_src = [&](u8::U3Args &a, const PlanarT &t) {
-    for (int q = 0; q < t.C / 8; ++q) a.src[a.npass++] = t.pass(q, 0);
+    for (int q = 0; q < t.C / CHP; ++q) a.src[a.npass++] = t.pass(q, 0);
     a.nups = a.npass;
     a.UD = a.UH = a.UW = t.d; a.Upart = (unsigned)t.part;
   };
-  {  // conv3 1->32 computed into the tile of conv3 32->32, MaxPooling3D(2) in the epilogue
+  if (!SPLIT) {
+    // bf16 / f16 builds: the stem pair on the round-4 kernel (two independent 4-wave workgroups per
+    // CU: one computes its 32-channel tile while the other multiplies - with a K loop a third as long
+    // as the split build's that overlap is worth more than the all-LDS loop: 10.1 against 12.6 ms),
+    // writing c1 and p1 as planar tensors
+    Conv3Args a;
+    memset(&a, 0, sizeof(a));
+    a.w = F + st->off_w[1]; a.shift = S + st->off_s[1]; a.relu = 1;
+    a.out = (h16_t *)c1.p; a.OD = a.OH = a.OW = d1;
+    a.ncc = 32 / RCH;
+    for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = make_src(nullptr, d1a, CC, 0, 1, 0);
+    a.raw = in; a.T = T;
+    a.wstem = (const h16x8 *)(F + st->off_w[0]); a.shstem = S + st->off_s[0];
+    a.pool_out = (h16_t *)p1.p;
+    a.planar = 1;
+    FPL_TRY((launch_conv3<2, true, true, false, 8>(ctx, a, n, "unet_stem_conv3_32_32_pool")));
+  } else {  // conv3 1->32 computed into the tile of conv3 32->32, MaxPooling3D(2) in the epilogue
     u8::U3Args a = args(1, 0, &c1, d1);
-    a.npass = 4;
+    a.npass = 32 / CHP;
     a.raw = in; a.T = T;
     a.wstem = (const h16x8 *)(F8 + st->off8[0]); a.shstem = S + st->off_s[0];
     a.pool = p1.p; a.pool_part = p1.part;
@@ -1723,11 +1742,11 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
     a.in = x.p; a.in_part = x.part; a.M = (int64_t)n * cube(x.d);
     a.w = F8 + st->off8[l] + (co0 ? st->half8[l] : 0);
     a.shift = S + st->off_s[l] + co0;
-    a.out = y.p + (int64_t)(co0 / 8) * 2 * y.part; a.out_part = y.part;
+    a.out = y.p + (int64_t)(co0 / CHP) * 2 * y.part; a.out_part = y.part;
     a.flag = flag;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, name);
-    kern<<<grid, 256, nfrag * 1024, ctx->stream>>>(a);
+    kern<<<grid, 256, nfrag * PM * 1024 / 2, ctx->stream>>>(a);
   };
   auto conv3_to128 = [&](int l, const PlanarT &x, const PlanarT &y, const char *name) -> int {
     for (int h = 0; h < 2; ++h) {
@@ -1780,7 +1799,6 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
   FPL_HIP(ctx, hipGetLastError());
   return 0;
 }
-#endif  // FPL_SPLIT
 
 }  // namespace
 
@@ -1801,12 +1819,10 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
   FPL_REQUIRE(ctx, !SPLIT || io, "fpl_unet_forward: the split-half build writes into a prediction volume");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
-#ifdef FPL_SPLIT
-  // unet_like2 / 3 / 4: the all-LDS kernels (FPL_UNET_OLDSPLIT=1: the round-4 kernels, A/B)
-  // (FPL_UNET_NOPARITY=1, the 27-tap cross-check of the parity form, exists on the round-4 kernels only)
-  if (unet_lds_ok(D) && !getenv("FPL_UNET_OLDSPLIT") && !getenv("FPL_UNET_NOPARITY"))
+  // unet_like2 / 3 / 4 into a prediction volume: the all-LDS kernels (FPL_UNET_OLDSPLIT=1: the round-4
+  // kernels, A/B; FPL_UNET_NOPARITY=1, the 27-tap cross-check of the parity form, exists on those only)
+  if (unet_lds_ok(D) && io && !getenv("FPL_UNET_OLDSPLIT") && !getenv("FPL_UNET_NOPARITY"))
     return unet_forward_lds(ctx, prog, D, st, in, n, T, io);
-#endif
   DevTemp tmp(ctx);
   unsigned *flag = nullptr;
   if (SPLIT) FPL_TRY(fpl_range_flag(ctx, &flag));
@@ -1854,7 +1870,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     a.transposed = 0; a.xorg = 0; a.main_w = 0;
     memset(&a.io, 0, sizeof(a.io)); a.w8 = a.w9 = nullptr; a.sh8 = nullptr; a.bias9 = 0.f;
     a.flag = flag; a.xlim = st->xlim;
-    a.parity = 0; a.total_steps = 0; a.wstream = 0;
+    a.parity = 0; a.total_steps = 0; a.wstream = 0; a.planar = 0;
     return a;
   };
   // the parity form for sources that are an UpSampling3D(2) (FPL_UNET_NOPARITY=1: A/B)

@@ -33,6 +33,11 @@
 //   * epilogues: planar hi / lo stores, MaxPooling3D(2), or the head (conv1 32->32, conv1 32->1,
 //     sigmoid, store into the prediction volume), as in conv3_f16s.
 //
+// PLAIN 16-bit builds (bf16 / f16; SPLIT false: conv_mfma.hip's other two builds include this file
+// too): the same kernels with a pass of SIXTEEN channels - plane 0 of a pass = its channels 0 - 7, plane
+// 1 = channels 8 - 15 (where the split build keeps hi and lo halves), weight set 0 / 1 per K-step
+// likewise - and two MFMAs per K-step, sub-step and M-block, (w0, a0) + (w1, a1), instead of three.
+//
 // The K loop's tile addressing is conflict-free as in vgg_split_lds.h: TX = 18 and a z-plane
 // stride ZS = 6 mod 16 put consecutive taps 1, 16 or ZS - 38 slots apart, 0 or 1 modulo 16.
 #pragma once
@@ -213,36 +218,43 @@ __device__ __forceinline__ void pass_kloop(const unsigned char *tile, const unsi
 #pragma unroll
     for (int b = 0; b < MB; ++b) wlo[b] = wfrag(0, MB + b);
 #pragma unroll
-    for (int sub = 0; sub < R; ++sub) bhi[sub] = *reinterpret_cast<const h16x8 *>(p + sub * ROW);
+    for (int sub = 0; sub < R; ++sub) (SPLIT ? bhi : blo)[sub] = *reinterpret_cast<const h16x8 *>(p + sub * ROW + (SPLIT ? 0 : PLANE * 16));
 #pragma unroll
     for (int b = 0; b < MB; ++b) whi[b] = wfrag(0, b);
 #pragma unroll
-    for (int sub = 0; sub < R; ++sub) blo[sub] = *reinterpret_cast<const h16x8 *>(p + sub * ROW + PLANE * 16);
+    for (int sub = 0; sub < R; ++sub) (SPLIT ? blo : bhi)[sub] = *reinterpret_cast<const h16x8 *>(p + sub * ROW + (SPLIT ? PLANE * 16 : 0));
   }
 #pragma unroll
   for (int s = 0; s < K; ++s) {
     const bool more = s + 1 < K, wnext = more && s + 1 != KA;       // (weights of step KA: behind the barrier)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int sub = 0; sub < R; ++sub)
+      for (int sub = 0; sub < R; ++sub)
 #pragma unroll
-      for (int b = 0; b < MB; ++b) acc[sub][b] = mfma16(wlo[b], bhi[sub], acc[sub][b]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) {
+        for (int b = 0; b < MB; ++b) acc[sub][b] = mfma16(wlo[b], bhi[sub], acc[sub][b]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {                    // (plain build: in front of its first group)
       const unsigned char *p = tile + vb + koff(s + 1);
 #pragma unroll
       for (int sub = 0; sub < R; ++sub) bhin[sub] = *reinterpret_cast<const h16x8 *>(p + sub * ROW);
     }
-    if (wnext) {
+    if (SPLIT ? wnext : false) {
 #pragma unroll
       for (int b = 0; b < MB; ++b) wlo[b] = wfrag(s + 1, MB + b);
     }
+    if (!SPLIT && wnext) {
+#pragma unroll
+      for (int b = 0; b < MB; ++b) whin[b] = wfrag(s + 1, b);
+    }
     __builtin_amdgcn_sched_barrier(0);
+    // split: (w_hi, a_lo); plain: (w1, a1)
 #pragma unroll
     for (int sub = 0; sub < R; ++sub)
 #pragma unroll
-      for (int b = 0; b < MB; ++b) acc[sub][b] = mfma16(whi[b], blo[sub], acc[sub][b]);
+      for (int b = 0; b < MB; ++b) acc[sub][b] = mfma16(SPLIT ? whi[b] : wlo[b], blo[sub], acc[sub][b]);
     __builtin_amdgcn_sched_barrier(0);
     if (more) {
       const unsigned char *p = tile + vb + koff(s + 1) + PLANE * 16;
@@ -250,8 +262,13 @@ __device__ __forceinline__ void pass_kloop(const unsigned char *tile, const unsi
       for (int sub = 0; sub < R; ++sub) blo[sub] = *reinterpret_cast<const h16x8 *>(p + sub * ROW);
     }
     if (wnext) {
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int b = 0; b < MB; ++b) whin[b] = wfrag(s + 1, b);
+        for (int b = 0; b < MB; ++b) whin[b] = wfrag(s + 1, b);
+      } else {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) wlo[b] = wfrag(s + 1, MB + b);
+      }
     }
     if (s == 0) issueA();
     if (s == KA) issueB();
@@ -332,25 +349,42 @@ __device__ __forceinline__ void dma_tile(const unsigned (&off)[TCH], const unsig
 }
 
 // planar store of a lane's 4 MB contiguous channels [4 MB g, 4 MB (g + 1)) of one voxel (interleaved
-// weight rows, pack_weights.h::fpl_out_channel): MB / 2 passes, hi and lo 16 B each; `vox` = the
-// voxel's index in a part plane; pass q of the tensor at p + 2 q part
+// weight rows, pack_weights.h::fpl_out_channel) as MB / 2 pieces of 8 channels.  Split build: piece i
+// (counted over the tensor's channels) is pass i, its hi and lo halves 16 B each; plain builds: plane
+// i & 1 of pass i >> 1, 16 B.  `vox` = the voxel's index in a part plane; pass q of the tensor at
+// p + 2 q part.
 template <int MB>
 __device__ __forceinline__ void store_planar(unsigned char *p, int64_t part, int64_t vox, int g, const f32x4 (&v)[MB], bool relu,
                                              unsigned &ovf) {
 #pragma unroll
   for (int h = 0; h < MB / 2; ++h) {
-    u32x4 hi, lo;
+    const int piece = (MB / 2) * g + h;
+    if constexpr (SPLIT) {
+      u32x4 hi, lo;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f32x4 &x = v[2 * h + q];
-      const Pair2 p0 = relu ? split_pk_relu(x[0], x[1], ovf) : split_pk_signed(x[0], x[1], ovf);
-      const Pair2 p1 = relu ? split_pk_relu(x[2], x[3], ovf) : split_pk_signed(x[2], x[3], ovf);
-      hi[2 * q] = p0.hi; hi[2 * q + 1] = p1.hi;
-      lo[2 * q] = p0.lo; lo[2 * q + 1] = p1.lo;
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 &x = v[2 * h + q];
+        const Pair2 p0 = relu ? split_pk_relu(x[0], x[1], ovf) : split_pk_signed(x[0], x[1], ovf);
+        const Pair2 p1 = relu ? split_pk_relu(x[2], x[3], ovf) : split_pk_signed(x[2], x[3], ovf);
+        hi[2 * q] = p0.hi; hi[2 * q + 1] = p1.hi;
+        lo[2 * q] = p0.lo; lo[2 * q + 1] = p1.lo;
+      }
+      unsigned char *d = p + (int64_t)piece * 2 * part + vox * 16;
+      *reinterpret_cast<u32x4 *>(d) = hi;
+      *reinterpret_cast<u32x4 *>(d + part) = lo;
+    } else {
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        o[2 * q] = cvt_pk_h16(v[2 * h + q][0], v[2 * h + q][1]);
+        o[2 * q + 1] = cvt_pk_h16(v[2 * h + q][2], v[2 * h + q][3]);
+      }
+      if (relu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pk_max_i16(o[q], 0u);
+      }
+      *reinterpret_cast<u32x4 *>(p + (int64_t)piece * part + vox * 16) = o;
     }
-    unsigned char *d = p + (int64_t)((MB / 2) * g + h) * 2 * part + vox * 16;
-    *reinterpret_cast<u32x4 *>(d) = hi;
-    *reinterpret_cast<u32x4 *>(d + part) = lo;
   }
 }
 
@@ -379,13 +413,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
   h16x8 *fragL = reinterpret_cast<h16x8 *>(smem + L::OFF_CONST + 256);
   float *sh2L = reinterpret_cast<float *>(smem + L::OFF_CONST + 256 + 6 * 1024);
   if (tid < 16 * MB) shiftL[tid] = a.shift[tid];
+  // (fragments per operand: the split build's come as hi and lo parts, PM = 2)
   if constexpr (STEM) {
-    if (tid < 256) fragL[tid] = a.wstem[tid];
+    if (tid < 128 * PM) fragL[tid] = a.wstem[tid];
     if (tid < 32) sh2L[tid] = a.shstem[tid];
   }
   if constexpr (EPI == EPI_HEAD) {
-    if (tid < 256) fragL[tid] = a.w8[tid];
-    else if (tid < 384) fragL[tid] = a.w9[tid - 256];
+    if (tid < 128 * PM) fragL[tid] = a.w8[tid];
+    else if (tid < 192 * PM) fragL[tid] = a.w9[tid - 128 * PM];
     if (tid < 32) sh2L[tid] = a.sh8[tid];
   }
   unsigned offP[STEM ? 1 : TCHP], offU[HAS_UPS ? TCHU : 1];
@@ -480,7 +515,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
       xmax = ax > xmax ? ax : xmax;
       const h16_t h = (h16_t)x;
       if (tid + 64 * WAVES * j < GE::NRAW)
-        rawt[tid + 64 * WAVES * j] = (unsigned)h16_bits(x) | ((unsigned)h16_bits(x - (float)h) << 16);
+        rawt[tid + 64 * WAVES * j] = (unsigned)h16_bits(x) | (SPLIT ? (unsigned)h16_bits(x - (float)h) << 16 : 0u);
     }
   };
   // passes 2 q and 2 q + 1 of the 32-channel tile into the two tile buffers: plain weight rows, so
@@ -501,16 +536,18 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       hi[d] = __builtin_amdgcn_perm(w[2 * d + 1], w[2 * d], 0x05040100u);
-      lo[d] = __builtin_amdgcn_perm(w[2 * d + 1], w[2 * d], 0x07060302u);
+      if (SPLIT) lo[d] = __builtin_amdgcn_perm(w[2 * d + 1], w[2 * d], 0x07060302u);
     }
     bf.hi = __builtin_bit_cast(h16x8, hi);
-    bf.lo = __builtin_bit_cast(h16x8, lo);
+    if (SPLIT) bf.lo = __builtin_bit_cast(h16x8, lo);
   };
-  auto fill = [&](int q) {
+  auto tab = [&](int grp) -> unsigned { return rawoff[16 * (grp < GE::NGRP ? grp : GE::NGRP - 1) + c]; };
+  // split build: fill(q) = passes 2 q and 2 q + 1 (16 channels: one M-block, three MFMAs per group)
+  auto fill = [&](auto q_) {             // (generic: only the build that calls it compiles it)
+    const int q = q_;
     const h16x8 wh = fragL[(q * 2 + 0) * 64 + lane], wl = fragL[(q * 2 + 1) * 64 + lane];
     const f32x4 sh = *reinterpret_cast<const f32x4 *>(sh2L + 16 * q + 4 * g);
     unsigned char *dst = smem + (g >> 1) * TB + 8 * (g & 1);
-    auto tab = [&](int grp) -> unsigned { return rawoff[16 * (grp < GE::NGRP ? grp : GE::NGRP - 1) + c]; };
     Frag2 bn;
     gather(tab(wave), bn);
     unsigned ro_nn = tab(wave + WAVES);
@@ -524,6 +561,29 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
       if (v < GE::PLANE_P) {
         *reinterpret_cast<u32x2 *>(dst + v * 16) = u32x2{p0.hi, p1.hi};
         *reinterpret_cast<u32x2 *>(dst + v * 16 + GE::PLANE_P * 16) = u32x2{p0.lo, p1.lo};
+      }
+    }
+  };
+  // plain builds: both passes (pass q = channels 16 q .. 16 q + 15 -> buffer q) from ONE gather:
+  // lane (c, g) holds channels 16 q + 4 g .. + 3: 8 B of plane g >> 1
+  auto fill_plain = [&](auto) {
+    const h16x8 w0 = fragL[lane], w1 = fragL[64 + lane];
+    const f32x4 sh0 = *reinterpret_cast<const f32x4 *>(sh2L + 4 * g), sh1 = *reinterpret_cast<const f32x4 *>(sh2L + 16 + 4 * g);
+    unsigned char *dst = smem + (g >> 1) * (GE::PLANE_P * 16) + 8 * (g & 1);
+    Frag2 bn;
+    gather(tab(wave), bn);
+    unsigned ro_nn = tab(wave + WAVES);
+    for (int grp = wave; grp < GE::NGRP; grp += WAVES) {
+      const h16x8 bc = bn.hi;
+      const int v = 16 * grp + c;
+      gather(ro_nn, bn);
+      ro_nn = tab(grp + 2 * WAVES);
+      const f32x4 a0 = mfma16(w0, bc, sh0), a1 = mfma16(w1, bc, sh1);
+      if (v < GE::PLANE_P) {
+        *reinterpret_cast<u32x2 *>(dst + v * 16) =
+            u32x2{pk_max_i16(cvt_pk_h16(a0[0], a0[1]), 0u), pk_max_i16(cvt_pk_h16(a0[2], a0[3]), 0u)};
+        *reinterpret_cast<u32x2 *>(dst + TB + v * 16) =
+            u32x2{pk_max_i16(cvt_pk_h16(a1[0], a1[1]), 0u), pk_max_i16(cvt_pk_h16(a1[2], a1[3]), 0u)};
       }
     }
   };
@@ -588,7 +648,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
       constexpr bool UPS = decltype(ups_tag)::value;
       if constexpr (STEM) {
         stamp(2);
-        if (!(a.dbg & 4)) fill(pp);
+        if (!(a.dbg & 4)) {
+          if constexpr (SPLIT) fill(pp);
+          else fill_plain(0);
+        }
         lds_barrier();
         stamp(1);
         // the next block's raw tile: requested here, behind the block's last fill - a wave waits
@@ -658,45 +721,62 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
       // loop the store into the volume makes the compiler reload them every time) and the sub-steps go
       // through the chain in STAGES, R independent MFMA chains abreast instead of R dependent ones
       // in a row: the matrix pipe sees 6 R + 3 R MFMAs nearly back to back.
-      h16x8 f8[4], f9[2];
-#pragma unroll
-      for (int f = 0; f < 4; ++f) f8[f] = fragL[f * 64 + lane];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) f9[f] = fragL[(4 + f) * 64 + lane];
       f32x4 sh8[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) sh8[b] = *reinterpret_cast<const f32x4 *>(sh2L + 16 * b + 4 * g);
       const FplTileDesc td = a.io.tiles[cur.n];
       unsigned ovs[R];
-      Frag2 h7[R];
-#pragma unroll
-      for (int sub = 0; sub < R; ++sub) {
-        ovs[sub] = 0u;
-        h7[sub] = pack_relu_split(acc[sub][0], acc[sub][1], ovs[sub]);
-      }
-      f32x4 a8[R][2];
-#pragma unroll
-      for (int sub = 0; sub < R; ++sub)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) a8[sub][b] = mfma16(f8[2 + b], h7[sub].hi, sh8[b]);
-#pragma unroll
-      for (int sub = 0; sub < R; ++sub)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) a8[sub][b] = mfma16(f8[b], h7[sub].lo, a8[sub][b]);
-#pragma unroll
-      for (int sub = 0; sub < R; ++sub)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) a8[sub][b] = mfma16(f8[b], h7[sub].hi, a8[sub][b]);
       f32x4 t9[R];
+      if constexpr (SPLIT) {
+        h16x8 f8[4], f9[2];            // [part][b], [part]
 #pragma unroll
-      for (int sub = 0; sub < R; ++sub) {
-        h7[sub] = pack_relu_split(a8[sub][0], a8[sub][1], ovs[sub]);
-        t9[sub] = mfma16(f9[1], h7[sub].hi, f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int f = 0; f < 4; ++f) f8[f] = fragL[f * 64 + lane];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) f9[f] = fragL[(4 + f) * 64 + lane];
+        Frag2 h7[R];
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub) {
+          ovs[sub] = 0u;
+          h7[sub] = pack_relu_split(acc[sub][0], acc[sub][1], ovs[sub]);
+        }
+        f32x4 a8[R][2];
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) a8[sub][b] = mfma16(f8[2 + b], h7[sub].hi, sh8[b]);
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) a8[sub][b] = mfma16(f8[b], h7[sub].lo, a8[sub][b]);
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) a8[sub][b] = mfma16(f8[b], h7[sub].hi, a8[sub][b]);
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub) {
+          h7[sub] = pack_relu_split(a8[sub][0], a8[sub][1], ovs[sub]);
+          t9[sub] = mfma16(f9[1], h7[sub].hi, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub) t9[sub] = mfma16(f9[0], h7[sub].lo, t9[sub]);
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub) t9[sub] = mfma16(f9[0], h7[sub].hi, t9[sub]);
+      } else {
+        h16x8 f8[2], f9;               // [b]; one fragment
+#pragma unroll
+        for (int f = 0; f < 2; ++f) f8[f] = fragL[f * 64 + lane];
+        f9 = fragL[2 * 64 + lane];
+        f32x4 a8[R][2];
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub) {
+          ovs[sub] = 0u;
+          const h16x8 h7 = pack_relu(acc[sub][0], acc[sub][1]);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) a8[sub][b] = mfma16(f8[b], h7, sh8[b]);
+        }
+#pragma unroll
+        for (int sub = 0; sub < R; ++sub) t9[sub] = mfma16(f9, pack_relu(a8[sub][0], a8[sub][1]), f32x4{0.f, 0.f, 0.f, 0.f});
       }
-#pragma unroll
-      for (int sub = 0; sub < R; ++sub) t9[sub] = mfma16(f9[0], h7[sub].lo, t9[sub]);
-#pragma unroll
-      for (int sub = 0; sub < R; ++sub) t9[sub] = mfma16(f9[0], h7[sub].hi, t9[sub]);
 #pragma unroll
       for (int sub = 0; sub < R; ++sub) {
         const int oy = TRANSPOSED ? cur.y0 + c : cur.y0 + row0 + GE::SUBROW * sub;
@@ -781,8 +861,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
   if ((a.dbg & 32) && tid == 0)
     for (int k = 0; k < 5; ++k) a.dbgbuf[(size_t)blockIdx.x * 8 + k] = tsum[k];
 #endif
-  if (!a.dbg) ovf_commit(ovf_all, a.flag, FPL_RANGE_UNET);
-  if (STEM && xmax > __builtin_bit_cast(unsigned, a.xlim)) atomicOr(a.flag, FPL_RANGE_INPUT);
+  if constexpr (SPLIT) {
+    if (!a.dbg) ovf_commit(ovf_all, a.flag, FPL_RANGE_UNET);
+    if (STEM && xmax > __builtin_bit_cast(unsigned, a.xlim)) atomicOr(a.flag, FPL_RANGE_INPUT);
+  }
 }
 
 // ---- 1x1x1 convolution on planar tensors: a K-step = 32 real channels = passes 4 s .. 4 s + 3
@@ -797,7 +879,7 @@ struct U1Args {
 };
 template <int KS, int MB>
 __global__ __launch_bounds__(256) void FPLK(u1conv)(U1Args a) {
-  constexpr int NF = KS * 2 * MB;
+  constexpr int NF = KS * PM * MB;                  // split: [s][hi MB | lo MB]; plain: [s][MB]
   unsigned char *wl = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -815,9 +897,13 @@ __global__ __launch_bounds__(256) void FPLK(u1conv)(U1Args a) {
     Frag2 bf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const unsigned char *p = a.in + (int64_t)(4 * s + g) * 2 * a.in_part + m * 16;
-      bf[s].hi = *reinterpret_cast<const h16x8 *>(p);
-      bf[s].lo = *reinterpret_cast<const h16x8 *>(p + a.in_part);
+      if constexpr (SPLIT) {
+        const unsigned char *p = a.in + (int64_t)(4 * s + g) * 2 * a.in_part + m * 16;
+        bf[s].hi = *reinterpret_cast<const h16x8 *>(p);
+        bf[s].lo = *reinterpret_cast<const h16x8 *>(p + a.in_part);
+      } else {          // 32 channels = 4 planes of 8: plane g & 1 of pass 2 s + (g >> 1)
+        bf[s].hi = *reinterpret_cast<const h16x8 *>(a.in + (int64_t)(4 * s + g) * a.in_part + m * 16);
+      }
     }
     int zero = 0;
     asm volatile("" : "+s"(zero));                  // (keeps the fragment reads inside the loop)
@@ -827,13 +913,17 @@ __global__ __launch_bounds__(256) void FPLK(u1conv)(U1Args a) {
     for (int b = 0; b < MB; ++b) {
       acc[b] = sh[b];
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        acc[b] = mfma3(*reinterpret_cast<const h16x8 *>(wq + ((s * 2 * MB + b) * 1024)),
-                       *reinterpret_cast<const h16x8 *>(wq + ((s * 2 * MB + MB + b) * 1024)), bf[s], acc[b]);
+      for (int s = 0; s < KS; ++s) {
+        if constexpr (SPLIT)
+          acc[b] = mfma3(*reinterpret_cast<const h16x8 *>(wq + ((s * 2 * MB + b) * 1024)),
+                         *reinterpret_cast<const h16x8 *>(wq + ((s * 2 * MB + MB + b) * 1024)), bf[s], acc[b]);
+        else
+          acc[b] = mfma16(*reinterpret_cast<const h16x8 *>(wq + ((s * MB + b) * 1024)), bf[s].hi, acc[b]);
+      }
     }
     if (ok) store_planar<MB>(a.out, a.out_part, m, g, acc, true, ovf);
   }
-  ovf_commit(ovf, a.flag, FPL_RANGE_UNET);
+  if constexpr (SPLIT) ovf_commit(ovf, a.flag, FPL_RANGE_UNET);
 }
 
 }  // namespace u8

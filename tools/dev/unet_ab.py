@@ -10,6 +10,7 @@ from flypylib_amd import _capi, fplmodels, synth, runtime
 ctx = runtime.get_context(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 510
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+PREC = {'f16s': _capi.PREC_F16S, 'f16': _capi.PREC_F16, 'bf16': _capi.PREC_BF16}[os.environ.get('FPL_AB_PREC', 'f16s')]
 g = fplmodels.unet_like2(100)[0]
 synth.synthetic_weights(g, 7)
 prog = _capi.Program(ctx, g, (1, 1, 1))
@@ -23,7 +24,7 @@ for v in sys.argv[3:]:
 for label, env, val in variants:
     if env:
         os.environ[env] = val
-    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_F16S, dims=dims, dst=dst)
+    kw = dict(mean=128.0, std=33.0, precision=PREC, dims=dims, dst=dst)
     def run():
         try:
             prog.infer_volume(src, (100,) * 3, (9,) * 3, **kw)
