@@ -1802,6 +1802,149 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
 
 }  // namespace
 
+#ifdef FPL_SPLIT
+// =====================================================================================
+// Training (round 5): the 3x3x3 48 -> 48 convolutions of a training step - forward and input
+// gradient, 2.6 of the step's 9.5 ms on v_mfma_f32_16x16x4_f32 - on split halves through the
+// all-LDS kernel above: fp32-grade products at five times the fp32 matrix rate.
+//   x (fp32, channels-last) --maxabs--> s = 2^e with max|x| s in [2^10, 2^11) --> planar hi / lo tensor
+//   of x s (zero shell of k - 1 voxels for the input gradient) --> u3conv<3, R, EPI_F32> with the
+//   weights (times their own power of two, flipped and transposed for the input gradient) split on
+//   the device --> y = acc / (s_x s_w) + bias, fp32 channels-last.
+// The scales are exact powers of two, so the only roundings are the two 11-bit halves per operand
+// (~22 bits; fp32 accumulation): gradients of 1e-7 are as well resolved as activations of 10.
+// =====================================================================================
+namespace {
+
+__global__ void ts_maxabs(const float *__restrict__ x, int64_t n, unsigned *out) {
+  unsigned m = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = max(m, __builtin_bit_cast(unsigned, x[i]) & 0x7FFFFFFFu);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+// sc[0] = s (a power of two with max s in [2^(t-1), 2^t)), sc[1] = 1 / s; sc[2] (if `other`) = 1 / (s other_s)
+__global__ void ts_scale(const unsigned *maxbits, int t, float *sc, const float *other) {
+  const float m = __builtin_bit_cast(float, *maxbits);
+  int e = 0;
+  float s = 1.f;
+  if (m > 0.f && m < 3.0e38f) {
+    frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1)
+    e = t - e;
+    e = e < -100 ? -100 : e > 100 ? 100 : e;
+    s = ldexpf(1.f, e);
+  }
+  sc[0] = s;
+  sc[1] = 1.f / s;
+  if (other) sc[2] = (1.f / s) * other[1];
+}
+// x (n, D, H, W, C = 48) fp32 -> planar split tensor of n tiles (D + 2 pad)^3..., 6 passes, values x s.
+// One thread per voxel: its 192 B read once (a thread per voxel AND pass fetched every line six times),
+// twelve 16-B stores, each a coalesced stream over the wave's consecutive voxels.
+__global__ void ts_to_planar(const float *__restrict__ x, int n, int D, int H, int W, int pad, const float *sc,
+                             unsigned char *out, int64_t part) {
+  constexpr int C = 48;
+  const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int64_t nv = (int64_t)n * Dp * Hp * Wp;
+  const float s = sc[0];
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(v % Wp) - pad;
+    int64_t t = v / Wp;
+    const int yy = (int)(t % Hp) - pad;
+    t /= Hp;
+    const int zz = (int)(t % Dp) - pad, b = (int)(t / Dp);
+    const bool in = zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const float *q = x + ((((int64_t)b * D + zz) * H + yy) * W + xx) * C;
+    f32x4 a[C / 4];
+#pragma unroll
+    for (int i = 0; i < C / 4; ++i) a[i] = in ? *reinterpret_cast<const f32x4 *>(q + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < C / 8; ++p) {
+      unsigned dummy = 0u;
+      const f32x4 a0 = a[2 * p], a1 = a[2 * p + 1];
+      const Pair2 p0 = split_pk_signed(a0[0] * s, a0[1] * s, dummy), p1 = split_pk_signed(a0[2] * s, a0[3] * s, dummy);
+      const Pair2 p2 = split_pk_signed(a1[0] * s, a1[1] * s, dummy), p3 = split_pk_signed(a1[2] * s, a1[3] * s, dummy);
+      unsigned char *d = out + (int64_t)p * 2 * part + v * 16;
+      *reinterpret_cast<u32x4 *>(d) = u32x4{p0.hi, p1.hi, p2.hi, p3.hi};
+      *reinterpret_cast<u32x4 *>(d + part) = u32x4{p0.lo, p1.lo, p2.lo, p3.lo};
+    }
+  }
+}
+// W fp32 [27][cin][cout] (Keras order) -> the kernel's stream [pass][K-step][hi MB | lo MB][lane][8], MB = 3,
+// interleaved rows, values W s_w; dgrad: the transposed convolution's weights W'[tap][co][ci] = W[26 - tap][ci][co]
+__global__ void ts_pack_w(const float *__restrict__ Wd, int cin, int cout, int dgrad, const float *sc, unsigned short *out,
+                          int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  int64_t t = i >> 9;
+  const int b = (int)(t % 3); t /= 3;
+  const int set = (int)(t & 1); t >>= 1;
+  const int s = (int)(t % u8::KP), p = (int)(t / u8::KP);
+  const int m = lane & 15, g = lane >> 4, tap = 4 * s + g;
+  const int ko = 12 * (m >> 2) + 4 * b + (m & 3), ki = 8 * p + j;       // output / input channel of THIS product
+  float v = 0.f;
+  if (tap < 27) v = dgrad ? Wd[((size_t)(26 - tap) * cin + ko) * cout + ki] : Wd[((size_t)tap * cin + ki) * cout + ko];
+  v *= sc[0];
+  const h16_t h = (h16_t)v;
+  out[i] = set ? h16_bits(v - (float)h) : h16_bits(v);
+}
+
+}  // namespace
+
+bool fpl_tm_conv3_split_supported(int k, int cin, int cout) { return k == 3 && cin == 48 && cout == 48; }
+
+// forward: x (n, D, H, W, 48) -> y (n, D - 2, H - 2, W - 2, 48) = conv3(x, Wd) + bias
+// dgrad:   x = dy (n, D, H, W, 48) -> y = dx (n, D + 2, H + 2, W + 2, 48) (bias = zeros)
+int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, const float *Wd, const float *bias,
+                       int dgrad, int relu, float *y) {
+  const int C = 48, pad = dgrad ? 2 : 0;
+  const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W_ + 2 * pad;
+  FPL_REQUIRE(ctx, Dp == Hp && Hp == Wp, "conv3 (split training): cubic patches only");
+  DevTemp tmp(ctx);
+  hipStream_t st = ctx->stream;
+  const int64_t nv = (int64_t)n * Dp * Hp * Wp, part = nv * 16;
+  void *q;
+  FPL_TRY(tmp.alloc((size_t)(C / 8) * 2 * part + ((size_t)6 * Hp * Wp + 40 * Wp + 64) * 16, &q));
+  unsigned char *planar = (unsigned char *)q;
+  FPL_TRY(tmp.alloc(64, &q));
+  unsigned *maxbits = (unsigned *)q;             // [0] activations, [1] weights
+  float *sc = (float *)q + 4;                    // [0..2] activations (s, 1/s, 1/(s s_w)), [4..5] weights
+  const int64_t wtotal = (int64_t)(C / 8) * u8::KP * 2 * 3 * 512;
+  FPL_TRY(tmp.alloc((size_t)wtotal * 2, &q));
+  unsigned short *wstream = (unsigned short *)q;
+  FPL_HIP(ctx, hipMemsetAsync(maxbits, 0, 8, st));
+  {
+    TimedLaunch tl(ctx, "train_split_prepare");
+    const int64_t nx = (int64_t)n * D * H * W_ * C;
+    ts_maxabs<<<(unsigned)std::min<int64_t>(ceil_div64(nx, 1024), (int64_t)ctx->n_cu * 8), 256, 0, st>>>(x, nx, maxbits);
+    ts_maxabs<<<8, 256, 0, st>>>(Wd, (int64_t)27 * C * C, maxbits + 1);
+    ts_scale<<<1, 1, 0, st>>>(maxbits + 1, 6, sc + 4, nullptr);
+    ts_scale<<<1, 1, 0, st>>>(maxbits, 11, sc, sc + 4);
+    ts_to_planar<<<(unsigned)std::min<int64_t>(ceil_div64(nv, 256), (int64_t)ctx->n_cu * 16), 256, 0, st>>>(
+        x, n, D, H, W_, pad, sc, planar, part);
+    ts_pack_w<<<(unsigned)ceil_div64(wtotal, 256), 256, 0, st>>>(Wd, C, C, dgrad, sc + 4, wstream, wtotal);
+  }
+  u8::U3Args a;
+  memset(&a, 0, sizeof(a));
+  for (int p = 0; p < C / 8; ++p) a.src[p] = planar + (int64_t)p * 2 * part;
+  a.npass = C / 8; a.nups = 0;
+  a.PD = Dp; a.PH = Hp; a.PW = Wp; a.Ppart = (unsigned)part;
+  a.UD = a.UH = a.UW = 1;
+  a.w = (const unsigned char *)wstream;
+  a.shift = bias;
+  a.relu = relu;
+  a.OD = Dp - 2; a.OH = Hp - 2; a.OW = Wp - 2;
+  a.keep_lo = 0; a.keep_hi = a.OD;
+  a.n_tiles = n;
+  a.out32 = y; a.opitch = C; a.unscale = sc + 2;
+  // rows per block: 10 where they divide the layer better (29 -> 30), else 8
+  const int w10 = (int)ceil_div64(a.OH, 10) * 10, w8 = (int)ceil_div64(a.OH, 8) * 8;
+  if (w10 < w8) return launch_u3<3, 5, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, dgrad ? "split_conv3_dgrad" : "split_conv3_fwd");
+  return launch_u3<3, 4, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, dgrad ? "split_conv3_dgrad" : "split_conv3_fwd");
+}
+#endif
+
 bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
   UnetDesc d;
   if (precision != FPL_THIS_PREC || !match_unet(prog, &d)) return false;

@@ -133,6 +133,12 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
                       const float *dy, int k, int cout, float *dw, const FplBnView *bn = nullptr,
                       const FplBnGrad *bg = nullptr, const FplPoolGrad *pg = nullptr);
 
+// Training: the 3x3x3 48 -> 48 convolutions (forward: dgrad = 0; input gradient: dgrad = 1, x = dy) on
+// split halves (conv_mfma.hip, split build): fp32-grade results at five times the fp32 matrix rate
+bool fpl_tm_conv3_split_supported(int k, int cin, int cout);
+int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, const float *Wd, const float *bias,
+                       int dgrad, int relu, float *y);
+
 // Split-operand IEEE-half path for vgg_like (vgg_split.hip, FPL_PREC_F16S): every
 // activation and folded weight is carried as hi + lo (two halves, ~22 significant bits)
 // and every product as three MFMAs - fp32-grade probabilities at a third of the 16-bit

@@ -135,12 +135,15 @@ struct U3Args {
   // EPI_HEAD
   FplTileIO io;
   const h16x8 *w8, *w9; const float *sh8; float bias9;
+  // EPI_F32 (training, conv_split_train): the output as fp32 channels-last (n, OD, OH, OW, opitch floats),
+  // every value times *unscale (the exact power of two the operands were scaled by, inverted)
+  float *out32; int opitch; const float *unscale;
   unsigned *flag;
   unsigned long long *dbgbuf;              // dbg & 32: per-workgroup cycle stamps [wg][16]
   int dbg;                                 // timing builds only (FPL_U3_DBG): 1 no tile DMA, 2 no weight DMA, 4 no stem fill
 };
 
-enum { EPI_STORE = 0, EPI_POOL = 1, EPI_HEAD = 2 };
+enum { EPI_STORE = 0, EPI_POOL = 1, EPI_HEAD = 2, EPI_F32 = 3 };
 
 // per-lane byte offsets of a wave's tile chunks (chunk j = wave + 8 i holds slots 64 j .. 64 j + 63
 // of [hi plane | lo plane]) from the block's origin voxel in the hi plane of the source
@@ -632,7 +635,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
     f32x4 acc[R][MB];
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
-      const f32x4 sh = *reinterpret_cast<const f32x4 *>(shiftL + 4 * MB * g + 4 * b);
+      // (EPI_F32: the operands are scaled, the bias is not: it is added behind the un-scaling)
+      const f32x4 sh = EPI == EPI_F32 ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(shiftL + 4 * MB * g + 4 * b);
 #pragma unroll
       for (int sub = 0; sub < R; ++sub) acc[sub][b] = sh;
     }
@@ -789,6 +793,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void FPLK(u3conv)(U3Args a) {
         if (g == 0 && in && oz < td.ext[0] - 2 * a.io.off && oy < td.ext[1] - 2 * a.io.off && ox < td.ext[2] - 2 * a.io.off)
           a.io.dst[((int64_t)(td.start[0] + a.io.off + oz - a.io.dst_z_base) * a.io.Y + td.start[1] + a.io.off + oy) * a.io.X +
                    td.start[2] + a.io.off + ox] = 1.f / (1.f + __expf(-logit));
+      }
+    } else if constexpr (EPI == EPI_F32) {
+      // interleaved rows: lane (c, g) holds the 4 MB contiguous channels [4 MB g, 4 MB (g + 1)) of voxel
+      // c - MB stores of 16 B, a wave's 16 voxels whole 64 MB-byte rows
+      const float us = *a.unscale;
+#pragma unroll
+      for (int sub = 0; sub < R; ++sub) {
+        const int oy = cur.y0 + row0 + GE::SUBROW * sub, ox = cur.x0 + c;
+        if (zin && oy < a.OH && ox < a.OW) {
+          float *d = a.out32 + ((((int64_t)cur.n * a.OD + oz) * a.OH + oy) * a.OW + ox) * a.opitch + 4 * MB * g;
+#pragma unroll
+          for (int b = 0; b < MB; ++b) {
+            f32x4 v = acc[sub][b];
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(shiftL + 4 * MB * g + 4 * b);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = v[r] * us + bias[r];
+              if (a.relu) v[r] = __builtin_fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<f32x4 *>(d + 4 * b) = v;
+          }
+        }
       }
     } else {
 #pragma unroll

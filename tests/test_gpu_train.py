@@ -115,6 +115,33 @@ def test_fused_and_separate_bn_relu_pool_agree(ctx, monkeypatch):
         assert _rel(a, b) < 2e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
 
 
+def test_split_half_conv3_agrees_with_the_fp32_kernels(ctx, monkeypatch):
+    """round 5: the 3x3x3 48 -> 48 convolutions of the step (forward and input gradient) run on split
+    IEEE halves - operands scaled by exact powers of two taken from their own maxima, three MFMAs per
+    product - instead of fp32 MFMAs (FPL_TRAIN_F32CONV=1 brings those back): same loss, the same
+    gradients to 2e-5 of each tensor's largest entry, also with gradients scaled down by 1e-6 (tiny
+    loss gradients stay as well resolved as large ones: the scale follows the tensor)"""
+    g = fplmodels.vgg_like()[0]
+    synth.synthetic_weights(g, 7)
+    rng = np.random.default_rng(4)
+    data = rng.standard_normal((4, 46, 46, 46, 1)).astype(np.float32)
+    labels = (rng.random((4, 8, 8, 8, 1)) > 0.7).astype(np.uint8)
+    tr = _capi.Trainer(ctx, g)
+    loss_s, acc_s = tr.step(data, labels, seed=9)
+    grads_s = [x.copy() for x in tr.get_grads()]
+    monkeypatch.setenv('FPL_TRAIN_F32CONV', '1')
+    tr2 = _capi.Trainer(ctx, g)
+    loss_f, acc_f = tr2.step(data, labels, seed=9)
+    grads_f = tr2.get_grads()
+    monkeypatch.delenv('FPL_TRAIN_F32CONV')
+    assert abs(loss_s - loss_f) < 1e-6 and acc_s == acc_f
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(grads_s, grads_f)):
+        worst = max(worst, _rel(a, b))
+        assert _rel(a, b) < 2e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
+    print('split vs fp32 convolutions: worst gradient tensor %.2e' % worst)
+
+
 def test_bn_in_the_conv_loader_and_sums_in_the_dgrad_epilogue(ctx, monkeypatch):
     """round 3's fusions around the first block's 1x1x1 convolution - BatchNorm + ReLU applied
     by its loader (forward and weight gradient), the BN backward sums made in its input-

@@ -1,11 +1,11 @@
 #!/bin/bash
 # End-of-round measurement set (run ON the GPU box): GPU test log, bench line, rocprofv3
 # kernel stats of the same command, HBM PMC traffic, voxel2obj bench / stats / PMC, the
-# other configs.   usage: bash tools/dev/round_profile.sh r02 [tests|bench|pmc|other ...]
+# other configs.   usage: bash tools/dev/round_profile.sh r02 [tests|bench|pmc|unet|other ...]
 set -o pipefail
 tag=${1:-rXX}
 shift
-what=${*:-tests bench pmc other}
+what=${*:-tests bench pmc unet other}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -14,9 +14,13 @@ case $w in
 tests)
   python -m pytest tests -m gpu -q > $out/${tag}_tests_gpu.log 2>&1; tail -2 $out/${tag}_tests_gpu.log ;;
 bench)
-  python bench.py > $out/${tag}_bench1024_f16s.json 2> $out/bench_f16s.err
-  cut -c1-200 $out/${tag}_bench1024_f16s.json
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --no-legs --no-cpu-baseline > $out/trace_bench.json 2> $out/trace.err
+  # the headline: BASELINE.json's 520^3 volume (bench.py's default), then configs[1]'s 1024^3
+  python bench.py > $out/${tag}_bench520_f16s.json 2> $out/bench_f16s.err
+  cut -c1-200 $out/${tag}_bench520_f16s.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --no-legs --no-cpu-baseline --steps 20 > $out/trace_bench.json 2> $out/trace.err
+  find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_bench520_f16s_kernel_stats.csv \;
+  rm -rf $out/trace
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --size 1024 --no-legs --no-cpu-baseline > $out/trace_bench1024.json 2> $out/trace.err
   find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_bench1024_f16s_kernel_stats.csv \;
   rm -rf $out/trace
   python tools/bench_v2o.py --reps 10 --out $out/${tag}_v2o582_bench.json > $out/v2o.log 2>&1; tail -1 $out/v2o.log
@@ -25,6 +29,9 @@ bench)
   rm -rf $out/trace
   echo bench done ;;
 pmc)
+  python tools/profile_pmc.py --size 520 --precision f16s --steps 4 --out $out/pmc520 > $out/pmc520.log 2>&1 && \
+    cp $out/pmc520/summary.json $out/${tag}_pmc_hbm_520_f16s.json && cp $out/pmc520/summary.md $out/${tag}_pmc_hbm_520_f16s.md
+  rm -rf $out/pmc520
   python tools/profile_pmc.py --size 1024 --precision f16s --out $out/pmc > $out/pmc.log 2>&1 && \
     cp $out/pmc/summary.json $out/${tag}_pmc_hbm_1024_f16s.json && cp $out/pmc/summary.md $out/${tag}_pmc_hbm_1024_f16s.md
   python tools/profile_pmc.py --size 1024 --precision f16 --out $out/pmc16 > $out/pmc16.log 2>&1 && \
@@ -34,6 +41,15 @@ pmc)
     cp $out/pmc_v2o/summary.json $out/${tag}_v2o582_pmc.json
   rm -rf $out/pmc $out/pmc_v2o
   echo pmc done ;;
+unet)
+  # unet_like2 (27 tiles of 100^3): counters and kernel stats of the four precisions
+  python tools/profile_pmc.py --target unet --size 264 --out $out/pmc_unet > $out/pmc_unet.log 2>&1 && \
+    cp $out/pmc_unet/summary.json $out/${tag}_pmc_unet264.json && cp $out/pmc_unet/summary.md $out/${tag}_pmc_unet264.md
+  rm -rf $out/pmc_unet
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o unet -- python3 tools/bench_configs.py --what unet > $out/trace_unet.json 2> $out/trace_unet.err
+  find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_unet264_kernel_stats.csv \;
+  rm -rf $out/trace
+  echo unet done ;;
 other)
   python tools/bench_configs.py --out $out/${tag}_other_configs.json > $out/other.log 2>&1; tail -2 $out/other.log
   python tools/bench_configs.py --what roi --out $out/${tag}_roi1536.json > $out/roi.log 2>&1; tail -1 $out/roi.log
