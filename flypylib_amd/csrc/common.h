@@ -58,8 +58,17 @@ struct V2oState {
   bool sorted = false;
 };
 
+// a training tensor restated as planar split halves (conv_mfma.hip, split build): made by the
+// forward / input-gradient convolution of a step, read again by the weight-gradient kernel
+struct FplSplitCopy {
+  const void *key; int n, D, pad;      // the fp32 tensor (device pointer), patches, edge, zero shell
+  unsigned char *planar; float *sc;    // the copy (x s) and [s, 1 / s]
+  int64_t part;                        // bytes of one plane
+};
+
 struct fpl_ctx {
   int device = 0;
+  std::vector<FplSplitCopy> split_copies;   // valid within one training step (fpl_tm_split_reset)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   char err[FPL_MAX_ERR] = {0};

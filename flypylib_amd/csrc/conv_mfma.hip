@@ -1892,6 +1892,208 @@ __global__ void ts_pack_w(const float *__restrict__ Wd, int cin, int cout, int d
 
 }  // namespace
 
+namespace {
+
+// ---- weight gradient of conv3 48 -> 48: dW[t][ci][co] = sum_v X[v + t][ci] dY[v][co] as MFMAs whose K
+// runs over VOXELS: A = X^T (16 input channels x 32 voxels of an output row, shifted by the tap), B = dY
+// (32 voxels x 16 output channels), both read out of voxel-major planar tiles in LDS by the hardware
+// transpose read (ds_read_b64_tr_b16: a 16-lane group takes 4 voxels x 16 channels and every lane
+// gets ONE channel's 4 voxels - 8 B of pass 2 cb and 8 B of pass 2 cb + 1 per voxel, so the planar passes of
+// 8 channels serve as they are and a tap's shift is an address offset).  Three MFMAs per product
+// (x_hi y_hi + x_hi y_lo + x_lo y_hi).  One persistent 8-wave workgroup per CU walks (patch, z plane, chunk of
+// y rows); a step = one output row: the 81 (tap, input-channel block) pairs are dealt to the waves, each
+// holding its 3 x (10 or 11) accumulator tiles for the whole kernel, added to dW by float atomics at the end.
+// LDS: a ring of X rows [dz 3][y slot 4] and two dY rows, [part 2][pass 6][voxel 36] x 16 B in 7 KiB each (plane pitch
+// 576 B = 64 mod 256: the two passes of a transposed read and the two lane groups of a half-wave fall on
+// four different bank quarters), filled by LDS-DMA one output row ahead.
+namespace wg {
+constexpr int WAVES = 8, NV = 36, ROWDATA = 12 * NV * 16;       // 6912 B of a staged row ...
+constexpr int RCHK = (ROWDATA + 1023) / 1024;                    // ... in 7 DMA chunks of 1 KiB:
+constexpr int ROWB = RCHK * 1024;                                // a row slot is 7 KiB (the last chunk's tail lands in it)
+constexpr int XSLOTS = 12, SMEM = (XSLOTS + 2) * ROWB;           // 100 352 B
+constexpr int NPAIR = 81, PPW = (NPAIR + WAVES - 1) / WAVES;     // (tap, ci block) pairs per wave: 11
+}
+
+struct WgArgs {
+  const unsigned char *xp, *yp;       // planar copies: x (n, D^3), dy (n, (Dy + 4)^3, zero shell of 2)
+  unsigned xpart, ypart;              // bytes of one plane
+  int n, D, Dy, ychunk, nychunk;      // patches, x edge, dy edge (D - 2), output rows per block
+  const float *scx, *scy;             // [s, 1 / s] of either copy
+  float *dw;
+};
+
+__global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
+  using namespace wg;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, g = lane >> 4;
+  const int G = a.Dy + 4;                                       // dy's grid edge
+  // ---- DMA decode: chunk j of a staged row, this lane's 16 B = (part, pass, voxel)
+  auto slot_off = [&](int j, unsigned part_bytes) -> unsigned {
+    int s = 64 * j + lane;
+    s = s < 12 * NV ? s : 12 * NV - 1;
+    const int pl = s / NV, v = s - pl * NV;                     // LDS plane = part * 6 + pass
+    const int part = pl / 6, pass = pl - 6 * part;
+    return (unsigned)(pass * 2 + part) * part_bytes + (unsigned)v * 16u;
+  };
+  // the chunks of a step's fill: 3 X rows (dz = 0 .. 2) and 1 dY row, 7 chunks each, dealt to the waves
+  // chunk id q = wave + 8 i (i < 4): row r = q / 7 (3 = dY), chunk j = q % 7
+  unsigned doff[4];
+  int drow[4], dj[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = wave + WAVES * i;
+    drow[i] = q / RCHK; dj[i] = q - RCHK * drow[i];
+    doff[i] = drow[i] < 3 ? slot_off(dj[i], a.xpart) : slot_off(dj[i], a.ypart);
+  }
+  // per-lane offset of a transposed read inside a staged row: lane 4 q + p of a group supplies voxel
+  // row q, channels 4 p .. 4 p + 3 = 8 B of pass (p >> 1) of the pair; + cb * 2 passes, + part, + voxel
+  const int q4 = c >> 2, p4 = c & 3;
+  const unsigned lane_off = (unsigned)(((p4 >> 1) * NV + 8 * g + q4) * 16 + 8 * (p4 & 1));
+  auto tr = [&](const unsigned char *p) -> u32x2 {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                         (__attribute__((address_space(3))) s16x4 *)(p)));
+  };
+  // an 8-voxel operand fragment (channels of block cb, part `part`) of the row at `row`, voxels + vofs
+  auto frag = [&](const unsigned char *row, int cb, int part, int vofs) -> h16x8 {
+    const unsigned char *p = row + lane_off + ((part * 6 + 2 * cb) * NV + vofs) * 16;
+    const u32x2 lo = tr(p), hi = tr(p + 4 * 16);
+    return __builtin_bit_cast(h16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+  };
+  f32x4 acc[PPW][3];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i)
+#pragma unroll
+    for (int ob = 0; ob < 3; ++ob) acc[i][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 kmask;                                  // this lane's k-slots j = voxels 8 g + j: inside the row?
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+    kmask[d] = (8 * g + 2 * d < a.Dy ? 0xFFFFu : 0u) | (8 * g + 2 * d + 1 < a.Dy ? 0xFFFF0000u : 0u);
+
+  const int nblk = a.n * a.Dy * a.nychunk;
+  const int S = (int)gridDim.x;
+  auto xrow = [&](int n, int z, int y) -> const unsigned char * {       // X row (z, y), voxel 0, plane 0
+    return a.xp + ((((int64_t)n * a.D + z) * a.D + y) * a.D) * 16;
+  };
+  auto yrow = [&](int n, int z, int y) -> const unsigned char * {       // dY row (z, y) at grid (z + 2, y + 2, 2)
+    return a.yp + ((((int64_t)n * G + z + 2) * G + y + 2) * G + 2) * 16;
+  };
+  // fill of the rows step (n, z, y) adds: X rows (z + dz, y + 2) into ring slot (dz, (y + 2) & 3), dY row y
+  auto fill = [&](int n, int z, int y, bool first) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = wave + WAVES * i;
+      if (q >= 4 * RCHK) continue;
+      if (drow[i] < 3) {
+        glds16(xrow(n, z + drow[i], y + 2) + doff[i], smem + (drow[i] * 4 + ((y + 2) & 3)) * ROWB + dj[i] * 1024);
+        if (first) {                     // a block's first step also needs rows y and y + 1
+          glds16(xrow(n, z + drow[i], y) + doff[i], smem + (drow[i] * 4 + (y & 3)) * ROWB + dj[i] * 1024);
+          glds16(xrow(n, z + drow[i], y + 1) + doff[i], smem + (drow[i] * 4 + ((y + 1) & 3)) * ROWB + dj[i] * 1024);
+        }
+      } else {
+        glds16(yrow(n, z, y) + doff[i], smem + (XSLOTS + (y & 1)) * ROWB + dj[i] * 1024);
+      }
+    }
+  };
+  for (int blk = blockIdx.x; blk < nblk; blk += S) {
+    const int yc = blk % a.nychunk, t1 = blk / a.nychunk;
+    const int z = t1 % a.Dy, n = t1 / a.Dy;
+    const int y0 = yc * a.ychunk, y1 = min(a.Dy, y0 + a.ychunk);
+    __syncthreads();                        // every wave has left the previous block's rows
+    fill(n, z, y0, true);
+    __syncthreads();
+    for (int y = y0; y < y1; ++y) {
+      if (y + 1 < y1) fill(n, z, y + 1, false);
+      const unsigned char *yr = smem + (XSLOTS + (y & 1)) * ROWB;
+      {                                            // ONE K-step of 32 voxels: the row (Dy <= 32, host)
+        constexpr int x0 = 0;
+        // (voxels past the row's Dy outputs - the K-step always takes 32 - are other rows' gradients: masked)
+        h16x8 bh[3], bl[3];
+#pragma unroll
+        for (int ob = 0; ob < 3; ++ob) {
+          bh[ob] = __builtin_bit_cast(h16x8, __builtin_bit_cast(u32x4, frag(yr, ob, 0, x0)) & kmask);
+          bl[ob] = __builtin_bit_cast(h16x8, __builtin_bit_cast(u32x4, frag(yr, ob, 1, x0)) & kmask);
+        }
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+          const int pi = wave + WAVES * i;
+          if (pi < NPAIR) {
+            const int tap = pi / 3, cb = pi - 3 * tap;
+            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+            const unsigned char *xr = smem + (dz * 4 + ((y + dy) & 3)) * ROWB;
+            const h16x8 ah = frag(xr, cb, 0, x0 + dx), al = frag(xr, cb, 1, x0 + dx);
+#pragma unroll
+            for (int ob = 0; ob < 3; ++ob) {
+              acc[i][ob] = mfma16(al, bh[ob], acc[i][ob]);
+              acc[i][ob] = mfma16(ah, bl[ob], acc[i][ob]);
+              acc[i][ob] = mfma16(ah, bh[ob], acc[i][ob]);
+            }
+          }
+        }
+      }
+      __syncthreads();                      // the next row's fill has landed; this row's slots are free
+    }
+  }
+  // D[row 4 g + r = input channel][col c = output channel]
+  const float us = a.scx[1] * a.scy[1];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pi = wave + WAVES * i;
+    if (pi < NPAIR) {
+      const int tap = pi / 3, cb = pi - 3 * tap;
+#pragma unroll
+      for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][ob][r] * us;
+          if (v != 0.f) atomicAdd(&a.dw[((size_t)tap * 48 + 16 * cb + 4 * g + r) * 48 + 16 * ob + c], v);
+        }
+    }
+  }
+}
+
+// the planar split copy of a training tensor (x s, s a power of two from the tensor's maximum), made once per
+// step and kept in the context: forward leaves x's, the weight gradient dy's (which the input gradient reuses)
+int split_copy(fpl_ctx *ctx, const float *x, int n, int D, int pad, FplSplitCopy *out) {
+  for (const FplSplitCopy &e : ctx->split_copies)
+    if (e.key == x && e.n == n && e.D == D && e.pad == pad) { *out = e; return 0; }
+  hipStream_t st = ctx->stream;
+  const int C = 48, Dp = D + 2 * pad;
+  FplSplitCopy e;
+  e.key = x; e.n = n; e.D = D; e.pad = pad;
+  const int64_t nv = (int64_t)n * Dp * Dp * Dp;
+  e.part = nv * 16;
+  void *q;
+  const size_t slack = ((size_t)6 * Dp * Dp + 40 * Dp + 64) * 16;
+  FPL_TRY(fpl_dev_alloc(ctx, (size_t)(C / 8) * 2 * e.part + slack, &q));
+  e.planar = (unsigned char *)q;
+  // the read slack behind the last plane is ZERO: the weight-gradient kernel sums over voxels, and a row's
+  // 32-voxel K-step runs past short rows (times masked-out gradients - but 0 x NaN is NaN)
+  FPL_HIP(ctx, hipMemsetAsync(e.planar + (size_t)(C / 8) * 2 * e.part, 0, slack, st));
+  FPL_TRY(fpl_dev_alloc(ctx, 64, &q));
+  e.sc = (float *)q;                              // [0] s, [1] 1 / s; [4] (as unsigned) the maximum's bits
+  unsigned *maxbits = (unsigned *)q + 4;
+  FPL_HIP(ctx, hipMemsetAsync(maxbits, 0, 4, st));
+  const int64_t nx = (int64_t)n * D * D * D * C;
+  ts_maxabs<<<(unsigned)std::min<int64_t>(ceil_div64(nx, 1024), (int64_t)ctx->n_cu * 8), 256, 0, st>>>(x, nx, maxbits);
+  ts_scale<<<1, 1, 0, st>>>(maxbits, 11, e.sc, nullptr);
+  ts_to_planar<<<(unsigned)std::min<int64_t>(ceil_div64(nv, 256), (int64_t)ctx->n_cu * 16), 256, 0, st>>>(
+      x, n, D, D, D, pad, e.sc, e.planar, e.part);
+  ctx->split_copies.push_back(e);
+  *out = e;
+  return 0;
+}
+
+}  // namespace
+
+void fpl_tm_split_reset(fpl_ctx *ctx) {
+  for (FplSplitCopy &e : ctx->split_copies) {
+    fpl_dev_release(ctx, e.planar);
+    fpl_dev_release(ctx, e.sc);
+  }
+  ctx->split_copies.clear();
+}
+
 bool fpl_tm_conv3_split_supported(int k, int cin, int cout) { return k == 3 && cin == 48 && cout == 48; }
 
 // forward: x (n, D, H, W, 48) -> y (n, D - 2, H - 2, W - 2, 48) = conv3(x, Wd) + bias
@@ -1899,49 +2101,75 @@ bool fpl_tm_conv3_split_supported(int k, int cin, int cout) { return k == 3 && c
 int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, const float *Wd, const float *bias,
                        int dgrad, int relu, float *y) {
   const int C = 48, pad = dgrad ? 2 : 0;
-  const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W_ + 2 * pad;
-  FPL_REQUIRE(ctx, Dp == Hp && Hp == Wp, "conv3 (split training): cubic patches only");
+  FPL_REQUIRE(ctx, D == H && H == W_, "conv3 (split training): cubic patches only");
+  const int Dp = D + 2 * pad;
   DevTemp tmp(ctx);
   hipStream_t st = ctx->stream;
-  const int64_t nv = (int64_t)n * Dp * Hp * Wp, part = nv * 16;
+  FplSplitCopy xc;
+  {
+    TimedLaunch tl(ctx, "train_split_prepare");
+    FPL_TRY(split_copy(ctx, x, n, D, pad, &xc));
+  }
   void *q;
-  FPL_TRY(tmp.alloc((size_t)(C / 8) * 2 * part + ((size_t)6 * Hp * Wp + 40 * Wp + 64) * 16, &q));
-  unsigned char *planar = (unsigned char *)q;
   FPL_TRY(tmp.alloc(64, &q));
-  unsigned *maxbits = (unsigned *)q;             // [0] activations, [1] weights
-  float *sc = (float *)q + 4;                    // [0..2] activations (s, 1/s, 1/(s s_w)), [4..5] weights
+  unsigned *wmax = (unsigned *)q;
+  float *scw = (float *)q + 4;                   // [0] s_w, [1] 1 / s_w, [2] 1 / (s_w s_x)
   const int64_t wtotal = (int64_t)(C / 8) * u8::KP * 2 * 3 * 512;
   FPL_TRY(tmp.alloc((size_t)wtotal * 2, &q));
   unsigned short *wstream = (unsigned short *)q;
-  FPL_HIP(ctx, hipMemsetAsync(maxbits, 0, 8, st));
+  FPL_HIP(ctx, hipMemsetAsync(wmax, 0, 4, st));
   {
     TimedLaunch tl(ctx, "train_split_prepare");
-    const int64_t nx = (int64_t)n * D * H * W_ * C;
-    ts_maxabs<<<(unsigned)std::min<int64_t>(ceil_div64(nx, 1024), (int64_t)ctx->n_cu * 8), 256, 0, st>>>(x, nx, maxbits);
-    ts_maxabs<<<8, 256, 0, st>>>(Wd, (int64_t)27 * C * C, maxbits + 1);
-    ts_scale<<<1, 1, 0, st>>>(maxbits + 1, 6, sc + 4, nullptr);
-    ts_scale<<<1, 1, 0, st>>>(maxbits, 11, sc, sc + 4);
-    ts_to_planar<<<(unsigned)std::min<int64_t>(ceil_div64(nv, 256), (int64_t)ctx->n_cu * 16), 256, 0, st>>>(
-        x, n, D, H, W_, pad, sc, planar, part);
-    ts_pack_w<<<(unsigned)ceil_div64(wtotal, 256), 256, 0, st>>>(Wd, C, C, dgrad, sc + 4, wstream, wtotal);
+    ts_maxabs<<<8, 256, 0, st>>>(Wd, (int64_t)27 * C * C, wmax);
+    ts_scale<<<1, 1, 0, st>>>(wmax, 6, scw, xc.sc);
+    ts_pack_w<<<(unsigned)ceil_div64(wtotal, 256), 256, 0, st>>>(Wd, C, C, dgrad, scw, wstream, wtotal);
   }
   u8::U3Args a;
   memset(&a, 0, sizeof(a));
-  for (int p = 0; p < C / 8; ++p) a.src[p] = planar + (int64_t)p * 2 * part;
+  for (int p = 0; p < C / 8; ++p) a.src[p] = xc.planar + (int64_t)p * 2 * xc.part;
   a.npass = C / 8; a.nups = 0;
-  a.PD = Dp; a.PH = Hp; a.PW = Wp; a.Ppart = (unsigned)part;
+  a.PD = Dp; a.PH = Dp; a.PW = Dp; a.Ppart = (unsigned)xc.part;
   a.UD = a.UH = a.UW = 1;
   a.w = (const unsigned char *)wstream;
   a.shift = bias;
   a.relu = relu;
-  a.OD = Dp - 2; a.OH = Hp - 2; a.OW = Wp - 2;
+  a.OD = Dp - 2; a.OH = Dp - 2; a.OW = Dp - 2;
   a.keep_lo = 0; a.keep_hi = a.OD;
   a.n_tiles = n;
-  a.out32 = y; a.opitch = C; a.unscale = sc + 2;
+  a.out32 = y; a.opitch = C; a.unscale = scw + 2;
   // rows per block: 10 where they divide the layer better (29 -> 30), else 8
   const int w10 = (int)ceil_div64(a.OH, 10) * 10, w8 = (int)ceil_div64(a.OH, 8) * 8;
   if (w10 < w8) return launch_u3<3, 5, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, dgrad ? "split_conv3_dgrad" : "split_conv3_fwd");
   return launch_u3<3, 4, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, dgrad ? "split_conv3_dgrad" : "split_conv3_fwd");
+}
+
+// dw [27][48][48] += weight gradient of the valid conv3: x (n, D^3, 48), dy (n, (D - 2)^3, 48)
+int fpl_tm_conv3_wgrad_split(fpl_ctx *ctx, const float *x, int n, int D, const float *dy, float *dw) {
+  FplSplitCopy xc, yc;
+  {
+    TimedLaunch tl(ctx, "train_split_prepare");
+    FPL_TRY(split_copy(ctx, x, n, D, 0, &xc));
+    FPL_TRY(split_copy(ctx, dy, n, D - 2, 2, &yc));
+  }
+  WgArgs a;
+  a.xp = xc.planar; a.yp = yc.planar;
+  FPL_REQUIRE(ctx, 12 * xc.part < ((int64_t)1 << 32) && 12 * yc.part < ((int64_t)1 << 32),
+              "conv3 wgrad (split): the planar copies exceed the kernel's 32-bit offsets");
+  a.xpart = (unsigned)xc.part; a.ypart = (unsigned)yc.part;
+  a.n = n; a.D = D; a.Dy = D - 2;
+  FPL_REQUIRE(ctx, a.Dy >= 1 && a.Dy <= 32, "conv3 wgrad (split): rows of %d outputs (one 32-voxel K-step)", a.Dy);
+  a.ychunk = 10; a.nychunk = (int)ceil_div64(a.Dy, a.ychunk);
+  a.scx = xc.sc; a.scy = yc.sc; a.dw = dw;
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)tm_wgrad3_split, hipFuncAttributeMaxDynamicSharedMemorySize, wg::SMEM));
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
+  }
+  const int nblk = n * a.Dy * a.nychunk;
+  const unsigned grid = (unsigned)std::min<int>(nblk, ctx->n_cu);
+  TimedLaunch tl(ctx, "split_wgrad3_48to48");
+  tm_wgrad3_split<<<grid, 64 * wg::WAVES, wg::SMEM, ctx->stream>>>(a);
+  return 0;
 }
 #endif
 

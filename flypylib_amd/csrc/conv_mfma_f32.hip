@@ -1973,6 +1973,10 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
               "conv wgrad: no BatchNorm-gradient kernel for k %d, %d -> %d", k, cin, cout);
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
   const int ncc = (cin + 15) / 16, nco = (cout + 47) / 48;
+  // 48 -> 48, rows of up to 32 outputs: split halves, voxel-major MFMAs (FPL_TRAIN_F32CONV=1: the fp32 kernel)
+  if (fpl_tm_conv3_split_supported(k, cin, cout) && D == H && H == W_ && od <= 32 && !bn && !bg && !pg &&
+      !getenv("FPL_TRAIN_F32CONV"))
+    return fpl_tm_conv3_wgrad_split(ctx, x, n, D, dy, dw);
   DevTemp tmp(ctx);
   if (k == 1) {
     Wgrad1Args a;

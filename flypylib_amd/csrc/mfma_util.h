@@ -62,6 +62,7 @@ __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
 typedef h16_t h16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // two f32 -> packed 16-bit pair, RNE (one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
 __device__ __forceinline__ unsigned cvt_pk_h16(float a, float b) {

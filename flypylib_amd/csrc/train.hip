@@ -1044,6 +1044,12 @@ int fpl_trainer_step(fpl_trainer *t, const float *data, int data_mem,
   FPL_REQUIRE(ctx, batch > 0, "fpl_trainer_step: batch %d", batch);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  // the split-half copies of the previous step's tensors (conv_mfma.hip) mirror buffers this step recycles
+  struct SplitReset {
+    fpl_ctx *c;
+    explicit SplitReset(fpl_ctx *c_) : c(c_) { fpl_tm_split_reset(c); }
+    ~SplitReset() { fpl_tm_split_reset(c); }
+  } split_reset(ctx);
   // fp32 MFMA convolutions; FPL_TRAIN_DIRECT = bitmask of what falls back to the
   // direct kernels (1 forward, 2 backward; anything else = both) - a debug switch
   const char *direct_env = getenv("FPL_TRAIN_DIRECT");

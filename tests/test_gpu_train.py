@@ -118,9 +118,10 @@ def test_fused_and_separate_bn_relu_pool_agree(ctx, monkeypatch):
 def test_split_half_conv3_agrees_with_the_fp32_kernels(ctx, monkeypatch):
     """round 5: the 3x3x3 48 -> 48 convolutions of the step (forward and input gradient) run on split
     IEEE halves - operands scaled by exact powers of two taken from their own maxima, three MFMAs per
-    product - instead of fp32 MFMAs (FPL_TRAIN_F32CONV=1 brings those back): same loss, the same
-    gradients to 2e-5 of each tensor's largest entry, also with gradients scaled down by 1e-6 (tiny
-    loss gradients stay as well resolved as large ones: the scale follows the tensor)"""
+    product - instead of fp32 MFMAs (FPL_TRAIN_F32CONV=1 brings those back), and so does their weight
+    gradient (voxel-major MFMAs through the LDS transpose read): same loss, the same gradients to 5e-5 of
+    each tensor's largest entry (two fp32 runs of the step differ by 1 - 3e-5 in the BatchNorm
+    parameters: float atomics; the oracle gate is 2e-4)"""
     g = fplmodels.vgg_like()[0]
     synth.synthetic_weights(g, 7)
     rng = np.random.default_rng(4)
@@ -138,7 +139,7 @@ def test_split_half_conv3_agrees_with_the_fp32_kernels(ctx, monkeypatch):
     worst = 0.0
     for i, (a, b) in enumerate(zip(grads_s, grads_f)):
         worst = max(worst, _rel(a, b))
-        assert _rel(a, b) < 2e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
+        assert _rel(a, b) < 5e-5, '%s: %g' % (g.weight_names[i], _rel(a, b))
     print('split vs fp32 convolutions: worst gradient tensor %.2e' % worst)
 
 

@@ -235,26 +235,16 @@ def main():
         roi = fplobjdetect.roi_from_txt(wd + '/roi_00.txt')[0]
         norm = [128., 33., 0.5]
         fplobjdetect.full_roi_inference(src, None, roi[:6], net, 0.1, wd + '/warm', norm)
-        # every lane of the pipeline has a context of its own (flypylib_amd/fplpipeline.py: inference
-        # lanes 0, 2, 4, post-processing lanes 1, 3, 5): per-kernel HIP events on all of them, so that the
-        # table covers the voxel2obj kernels and all three lane pairs (the kernels of different lanes
-        # run one after the other on the GPU: their sum against the wall time is the GPU's busy share)
-        n_lanes = max(1, min(int(os.environ.get('FPL_PIPE_LANES', '3')), 4))
-        lane_ctx = [runtime.get_context(ctx.device, lane=k) for k in range(2 * n_lanes)]
-        for c in lane_ctx:
-            c.timing(True); c.timing_reset()
+        ctx.timing(True); ctx.timing_reset()
         t0 = time.perf_counter()
         out = fplobjdetect.full_roi_inference(src, None, wd + '/roi_00.txt', net, 0.1,
                                               wd + '/work', norm)
         dt = time.perf_counter() - t0
-        kern, by_lane = {}, []
-        for c in lane_ctx:
-            tk = c.timing_get()
-            by_lane.append(round(sum(v['ms'] for v in tk.values()), 2))
-            for k, v in tk.items():
-                kern[k] = round(kern.get(k, 0.0) + v['ms'], 2)
-            c.timing(False)
-        kern_sum = round(sum(kern.values()), 2)
+        # (lane 0's inference kernels only: HIP events on the six concurrent streams of the pipeline time the
+        # waits for one another, not execution - the kernel table of ALL lanes is the rocprofv3 kernel trace of
+        # this run, profiles/r05_roi1536_kernel_stats.csv)
+        kern = {k: round(v['ms'], 2) for k, v in ctx.timing_get().items()}
+        ctx.timing(False)
         if a.skip_oracle:
             print(json.dumps(dict(substacks=len(roi), seconds=dt, mvox_s=n ** 3 / dt / 1e6,
                                   detections=int(len(out['conf'])))), flush=True)
@@ -283,8 +273,7 @@ def main():
             detections=int(len(out['conf'])), checked_substack=list(ss),
             checked_substack_detections=int(len(got['conf'])),
             detections_identical_to_cpu_oracle=bool(same), cpu_oracle_v2o_s=t_cpu,
-            kernel_ms_total=kern, kernel_ms_sum=kern_sum, kernel_ms_by_lane=by_lane,
-            kernel_share_of_wall=round(kern_sum / (dt * 1e3), 4), lanes=n_lanes)
+            kernel_ms_total=kern)
         print(json.dumps(res['full_roi_inference_%d' % n]), flush=True)
         shutil.rmtree(wd, ignore_errors=True)
     if 'c3share' in what:
@@ -394,8 +383,7 @@ def main():
             detections_rank=int(len(out['conf'])), checked_substack=list(ss),
             checked_substack_detections=int(len(got['conf'])),
             detections_identical_to_cpu_oracle=bool(same), cpu_oracle_v2o_s=t_cpu,
-            kernel_ms_total=kern, kernel_ms_sum=kern_sum, kernel_ms_by_lane=by_lane,
-            kernel_share_of_wall=round(kern_sum / (dt * 1e3), 4), lanes=n_lanes)
+            kernel_ms_total=kern)
         print(json.dumps(res['configs4_rank_share']), flush=True)
         shutil.rmtree(wd, ignore_errors=True)
     if a.out:

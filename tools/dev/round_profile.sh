@@ -53,6 +53,12 @@ unet)
 other)
   python tools/bench_configs.py --out $out/${tag}_other_configs.json > $out/other.log 2>&1; tail -2 $out/other.log
   python tools/bench_configs.py --what roi --out $out/${tag}_roi1536.json > $out/roi.log 2>&1; tail -1 $out/roi.log
-  python tools/bench_configs.py --what roi --roi-precision f16 --out $out/${tag}_roi1536_f16.json > $out/roi16.log 2>&1; tail -1 $out/roi16.log ;;
+  python tools/bench_configs.py --what roi --roi-precision f16 --out $out/${tag}_roi1536_f16.json > $out/roi16.log 2>&1; tail -1 $out/roi16.log
+  # every kernel of every lane of the pipeline (HIP events on six concurrent streams measure the waits for one
+  # another, not execution): rocprofv3's kernel trace of the same run, oracle check skipped
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o roi -- python3 tools/bench_configs.py --what roi --skip-oracle > $out/trace_roi.json 2> $out/trace_roi.err
+  find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_roi1536_kernel_stats.csv \;
+  rm -rf $out/trace
+  tail -1 $out/trace_roi.json ;;
 esac
 done
