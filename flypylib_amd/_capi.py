@@ -105,6 +105,7 @@ SIGNATURES = {
     'fpl_synth_volume_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _vp,
                                       C.c_int]),
     'fpl_synth_substack_u8': (C.c_int, [_vp, C.c_uint64, _pi64, _pi64, _pi64, _vp, C.c_int]),
+    'fpl_crop_substack_u8': (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _vp]),
     'fpl_histogram_u8': (C.c_int, [_vp, _vp, C.c_int, _i64, C.POINTER(C.c_uint64)]),
     'fpl_timing_enable': (C.c_int, [_vp, C.c_int]),
     'fpl_timing_reset': (C.c_int, [_vp]),
@@ -301,6 +302,16 @@ class Context:
         self.check(self.lib.fpl_synth_substack_u8(
             self.h, C.c_uint64(int(seed)), _arr(extent, C.c_int64), _arr(dims, C.c_int64),
             _arr(origin, C.c_int64), _ptr(out), _mem_of(out)))
+        return out
+
+    def crop_substack_u8(self, src, extent, dims, origin, out):
+        """`out` := the (dims) box at `origin` of the device-resident uint8 volume `src`
+        (extents `extent`), zeros outside it; stream-ordered"""
+        if _mem_of(src) != MEM_DEVICE or _mem_of(out) != MEM_DEVICE:
+            raise ValueError('crop_substack_u8: source and destination must be device memory')
+        self.check(self.lib.fpl_crop_substack_u8(
+            self.h, _ptr(src), _arr(extent, C.c_int64), _arr(dims, C.c_int64),
+            _arr(origin, C.c_int64), _ptr(out)))
         return out
 
     def histogram_u8(self, src, n=None):

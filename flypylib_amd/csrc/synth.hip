@@ -95,6 +95,52 @@ __global__ __launch_bounds__(256) void synth_u8(uint64_t seed, int E0, int E1, i
   }
 }
 
+// A substack + buffer cut out of a volume that is RESIDENT in HBM (a 4096^3 uint8 ROI is 64 GiB of
+// the 288): four consecutive voxels of the (D0, D1, D2) box per thread, one 32-bit store; voxels
+// outside [0, E) are 0, as fri_get_image pads at the faces (fplobjdetect.py:1044-1070).
+__global__ __launch_bounds__(256) void crop_u8(const uint8_t *__restrict__ src, int E0, int E1, int E2,
+                                               int D0, int D1, int D2, int o0, int o1, int o2,
+                                               int64_t n, int64_t n_chunks, uint8_t *__restrict__ dst) {
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t base = c * SYN_PER_WG;                 // uniform
+    const int64_t row0 = base / D2;
+    const uint32_t x0 = (uint32_t)(base - row0 * D2);
+    const uint32_t z0 = (uint32_t)(row0 / D1), y0 = (uint32_t)(row0 - (int64_t)z0 * D1);
+    const uint32_t off = x0 + 4u * threadIdx.x;
+    uint32_t dy = off / (uint32_t)D2;
+    int x = (int)(off - dy * (uint32_t)D2);
+    dy += y0;
+    const uint32_t dz = dy / (uint32_t)D1;
+    int y = (int)(dy - dz * (uint32_t)D1);
+    int z = (int)(z0 + dz);
+    const int64_t i = base + 4 * (int64_t)threadIdx.x;
+    if (i >= n) continue;
+    uint32_t word = 0;
+    const int gz0 = z + o0, gy0 = y + o1, gx0 = x + o2;
+    if (x + 4 <= D2 && gz0 >= 0 && gy0 >= 0 && gx0 >= 0 && gz0 < E0 && gy0 < E1 && gx0 + 4 <= E2 && i + 4 <= n) {
+      // the common case: four voxels of one source row (any alignment: a dword load on this target)
+      __builtin_memcpy(&word, src + ((int64_t)gz0 * E1 + gy0) * E2 + gx0, 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int gz = z + o0, gy = y + o1, gx = x + o2;
+        const bool in = gz >= 0 && gy >= 0 && gx >= 0 && gz < E0 && gy < E1 && gx < E2 && i + k < n;
+        const uint32_t v = in ? src[((int64_t)gz * E1 + gy) * E2 + gx] : 0u;
+        word |= v << (8 * k);
+        if (++x == D2) {
+          x = 0;
+          if (++y == D1) y = 0, ++z;
+        }
+      }
+    }
+    if (i + 4 <= n) {
+      *reinterpret_cast<uint32_t *>(dst + i) = word;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) dst[i + k] = (uint8_t)(word >> (8 * k));
+    }
+  }
+}
+
 // 256-bin histogram: per-wave private bins in LDS, one atomic per bin per block
 __global__ __launch_bounds__(256) void hist_u8(const uint8_t *__restrict__ src, int64_t n,
                                                unsigned long long *__restrict__ out) {
@@ -156,6 +202,30 @@ extern "C" int fpl_synth_substack_u8(fpl_ctx *ctx, uint64_t seed, const int64_t 
     FPL_HIP(ctx, hipMemcpyAsync(dst, d, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
   FPL_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+extern "C" int fpl_crop_substack_u8(fpl_ctx *ctx, const uint8_t *src, const int64_t extent[3],
+                                    const int64_t dims[3], const int64_t origin[3], uint8_t *dst) {
+  if (!ctx || !src || !extent || !dims || !origin || !dst)
+    return fpl_fail(ctx, "fpl_crop_substack_u8: NULL argument");
+  for (int a = 0; a < 3; ++a)
+    FPL_REQUIRE(ctx, dims[a] > 0 && dims[a] < ((int64_t)1 << 21) && extent[a] > 0 &&
+                         extent[a] < ((int64_t)1 << 21) && origin[a] > -((int64_t)1 << 21) &&
+                         origin[a] < ((int64_t)1 << 21),
+                "fpl_crop_substack_u8: axis %d out of the 2^21 coordinate range", a);
+  FPL_REQUIRE(ctx, ((uintptr_t)dst & 3) == 0, "fpl_crop_substack_u8: dst must be 4-byte aligned");
+  FPL_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n = dims[0] * dims[1] * dims[2];
+  const int64_t n_chunks = ceil_div64(n, SYN_PER_WG);
+  const unsigned grid = (unsigned)std::min<int64_t>(n_chunks, (int64_t)ctx->n_cu * 32);
+  {
+    TimedLaunch tl(ctx, "crop_u8");
+    crop_u8<<<grid, 256, 0, ctx->stream>>>(src, (int)extent[0], (int)extent[1], (int)extent[2], (int)dims[0],
+                                           (int)dims[1], (int)dims[2], (int)origin[0], (int)origin[1],
+                                           (int)origin[2], n, n_chunks, dst);
+  }
+  FPL_HIP(ctx, hipGetLastError());
+  return 0;                                     // stream-ordered: the consumers run on ctx->stream too
 }
 
 extern "C" int fpl_histogram_u8(fpl_ctx *ctx, const uint8_t *src, int src_mem, int64_t n,

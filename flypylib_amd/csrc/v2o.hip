@@ -1729,6 +1729,9 @@ static int v2o_nms(fpl_ctx *ctx, double thresh, double *out_zyxv, int64_t cap,
                 "fpl_v2o_nms: more than %lld detections; raise cap",
                 (long long)cap);
     const int done = (int)host_cnt[CNT_ROUNDS];
+    if (getenv("FPL_V2O_DBG"))
+      fprintf(stderr, "nms: rounds %d live %llu winners(last round) %llu dirty %llu total %llu of %lld cells\n", done,
+              host_cnt[CNT_LIVE], host_cnt[CNT_ROUND], host_cnt[CNT_DIRTY], host_cnt[CNT_TOTAL], (long long)n_cells);
     if (host_cnt[CNT_LIVE] == 0) { rounds = done; break; }
     FPL_REQUIRE(ctx, done == rounds + NMS_BATCH && host_cnt[CNT_ROUND] > 0,
                 "fpl_v2o_nms: round %d made no progress (internal error)", done);

@@ -22,6 +22,8 @@ results unchanged.
 Data sources.  DVID, DICED and n5 readers (`libdvid`, `diced`, `z5py`) are not
 available offline; `data_source` is instead
   * an array-like `(Z,Y,X)` uint8 with numpy slicing (ndarray, `np.memmap`, ...),
+  * a uint8 volume already RESIDENT on the GPU (a contiguous torch CUDA tensor or a
+    `_capi.DeviceBuffer`): substacks are cut device to device,
   * `'npy://<file>'` (opened with `np.load(mmap_mode='r')`), or
   * `'synth://<seed>,<Z>,<Y>,<X>'`, the counter-hash EM volume of `synth.py`,
     generated on the device substack by substack (nothing is stored);
@@ -129,9 +131,49 @@ class _SynthSource:
         return True
 
 
+class _DeviceSource:
+    """a uint8 (Z,Y,X) volume RESIDENT in the GPU's memory (a torch CUDA tensor or a
+    `_capi.DeviceBuffer`): substacks are cut device to device (`fpl_crop_substack_u8`), the
+    host never sees the grayscale.  One MI355X holds a 4096^3 ROI (64 GiB) whole."""
+
+    def __init__(self, vol):
+        assert len(vol.shape) == 3, 'volume must be (Z,Y,X)'
+        if hasattr(vol, 'is_contiguous'):
+            import torch
+            assert vol.dtype == torch.uint8 and vol.is_contiguous(), \
+                'a device volume must be contiguous uint8'
+            self.device = vol.device.index or 0
+        else:
+            assert np.dtype(vol.dtype) == np.uint8, 'a device volume must be uint8'
+            self.device = vol.ctx.device
+        self.vol = vol
+        self.extent = tuple(int(s) for s in vol.shape)
+
+    def cube_host(self, origin, size):
+        raise NotImplementedError('a device-resident volume is read on the device '
+                                  '(full_roi_inference); fri_get_image needs a host source')
+
+    def cube_device(self, ctx, origin, size, dst):
+        assert ctx.device == self.device, \
+            'the volume lives on GPU %d, the network on GPU %d' % (self.device, ctx.device)
+        lo = np.maximum(origin, 0)
+        hi = np.minimum(np.asarray(origin) + size, self.extent)
+        if np.any(lo > hi):
+            return False
+        ctx.crop_substack_u8(self.vol, self.extent, (size,) * 3, origin, dst)
+        return True
+
+
+def _is_device_volume(v):
+    from . import _capi
+    return isinstance(v, _capi.DeviceBuffer) or bool(getattr(v, 'is_cuda', False))
+
+
 def _open_source(data_source):
-    if isinstance(data_source, (_ArraySource, _SynthSource)):
+    if isinstance(data_source, (_ArraySource, _SynthSource, _DeviceSource)):
         return data_source
+    if _is_device_volume(data_source):
+        return _DeviceSource(data_source)
     if isinstance(data_source, str):
         if data_source.startswith('npy://'):
             return _ArraySource(np.load(data_source[6:], mmap_mode='r'))

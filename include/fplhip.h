@@ -355,6 +355,13 @@ int fpl_synth_substack_u8(fpl_ctx *ctx, uint64_t seed, const int64_t extent[3],
                           const int64_t dims[3], const int64_t origin[3],
                           uint8_t *dst, int dst_mem);
 
+/* a substack + buffer cut out of a uint8 volume RESIDENT in device memory (`src`, extents
+ * `extent`, e.g. a whole ROI: 4096^3 is 64 GiB of the 288): the crop + zero padding of
+ * fri_get_image (fplobjdetect.py:1044-1070), device to device on the context's stream
+ * (stream-ordered, returns without waiting) */
+int fpl_crop_substack_u8(fpl_ctx *ctx, const uint8_t *src, const int64_t extent[3],
+                         const int64_t dims[3], const int64_t origin[3], uint8_t *dst);
+
 /* ---- substack normalisation (fri_get_image, fplobjdetect.py:1088-1107) -------- */
 /* exact 256-bin histogram of a uint8 buffer; the raw / filtered (1 < v < 200) means
  * the reference takes with np.mean are exact functions of it */

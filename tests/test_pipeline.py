@@ -188,6 +188,40 @@ def test_full_roi_inference_resumes_and_bf16_synth_source(ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_device_resident_source_cuts_the_cubes_the_host_reader_cuts(ctx, tmp_path):
+    """fpl_crop_substack_u8 == fri_get_image's crop + zero padding (reference
+    fplobjdetect.py:1044-1070), and full_roi_inference over a volume resident in HBM
+    (torch tensor and DeviceBuffer) returns the host-array run's detections"""
+    import torch
+    net, vol, roi = _small_setup()
+    host = fplpipeline._ArraySource(vol)
+    dvol = torch.from_numpy(vol).cuda()
+    src = fplpipeline._open_source(dvol)
+    assert isinstance(src, fplpipeline._DeviceSource) and src.extent == vol.shape
+    for origin, size in [((-10, -10, -10), 52), ((0, 0, 0), 33), ((31, 47, 39), 41), ((5, -3, 60), 27),
+                         ((-200, 0, 0), 20), ((69, 89, 79), 9), ((3, 2, 1), 4)]:
+        ref = host.cube_host(list(origin), size)
+        out = ctx.malloc((size,) * 3, np.uint8)
+        have = src.cube_device(ctx, list(origin), size, out)
+        assert have == (ref is not None)
+        if have:
+            assert np.array_equal(out.to_host(), ref), (origin, size)
+        out.free()
+    kw = dict(obj_min_dist=5, smoothing_sigma=1.5, buffer_sz=10)
+    norm = [128., 33., 0.5]
+    want = fplobjdetect.full_roi_inference(vol, None, roi, net, 0.2, str(tmp_path / 'h'), norm, **kw)
+    got = fplobjdetect.full_roi_inference(dvol, None, roi, net, 0.2, str(tmp_path / 'd'), norm, **kw)
+    assert len(want['conf']) > 0
+    assert np.array_equal(got['locs'], want['locs']) and np.array_equal(got['conf'], want['conf'])
+    dbuf = ctx.malloc(vol.shape, np.uint8).from_host(vol)
+    got2 = fplobjdetect.full_roi_inference(dbuf, None, roi, net, 0.2, str(tmp_path / 'b'), norm, **kw)
+    assert np.array_equal(got2['locs'], want['locs']) and np.array_equal(got2['conf'], want['conf'])
+    dbuf.free()
+    with pytest.raises(NotImplementedError):
+        src.cube_host([0, 0, 0], 8)
+
+
+@pytest.mark.gpu
 def test_evaluate_substacks_usage_contract(ctx, tmp_path):
     """scripts/fpl_cx1_0_unet_4ss_all.py:60-66: evaluate_substacks(network, [[image,
     json], ...], thresholds, obj_min_dist, smoothing_sigma).  Ground truth = the

@@ -40,6 +40,10 @@ def main():
     ap.add_argument('--vgg2-size', type=int, default=1024)
     ap.add_argument('--sub', type=int, default=582)
     ap.add_argument('--roi-size', type=int, default=1536)
+    ap.add_argument('--roi-source', default='synth', choices=['synth', 'resident'],
+                    help="roi: 'synth' generates every substack + buffer on the device inside the timed "
+                         "region (the stand-in for the reference's DVID fetch); 'resident' keeps the whole "
+                         "volume in HBM (generated before the clock starts) and cuts the substacks out of it")
     ap.add_argument('--skip-oracle', action='store_true',
                     help='roi: do not re-derive one substack on the CPU oracle (for traces)')
     ap.add_argument('--out', default=None)
@@ -234,6 +238,12 @@ def main():
         fplobjdetect.gen_full_tab_roi(wd + '/roi', src, None, step_size=512)
         roi = fplobjdetect.roi_from_txt(wd + '/roi_00.txt')[0]
         norm = [128., 33., 0.5]
+        if a.roi_source == 'resident':
+            # the same voxels, made once and kept in HBM: inputs resident when the timed region starts
+            resident = torch.empty((n, n, n), dtype=torch.uint8, device='cuda')
+            ctx.synth_volume_u8(5, (n, n, n), out=resident)
+            torch.cuda.synchronize()
+            src = resident
         fplobjdetect.full_roi_inference(src, None, roi[:6], net, 0.1, wd + '/warm', norm)
         ctx.timing(True); ctx.timing_reset()
         t0 = time.perf_counter()
@@ -268,7 +278,7 @@ def main():
         got = pickle.load(open(fplobjdetect.fri_filename(wd + '/work', ss), 'rb'))
         same = np.array_equal(ref['locs'], got['locs']) and np.array_equal(ref['conf'], got['conf'])
         res['full_roi_inference_%d' % n] = dict(
-            precision=a.roi_precision, executor=ctx.last_path(),
+            precision=a.roi_precision, source=a.roi_source, executor=ctx.last_path(),
             substacks=len(roi), seconds=dt, mvox_s=n ** 3 / dt / 1e6,
             detections=int(len(out['conf'])), checked_substack=list(ss),
             checked_substack_detections=int(len(got['conf'])),
