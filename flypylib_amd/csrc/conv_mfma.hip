@@ -700,6 +700,7 @@ struct Conv1Args {
   float bias_tail;
   float *out_f32;                // TAIL: (M) sigmoid probabilities
   unsigned *flag;                // split build: half-range guard
+  int relu;                      // TAIL == 0: ReLU in front of the store (0: a convolution without activation)
 };
 
 template <int CIN, int MB, int TAIL>
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
       }
     }
     if (TAIL == 0) {
-      if (ok) store_il<MB, true>(a.out + m * CC, a.plane, g, acc, 1, ovf);
+      if (ok) store_il<MB, false>(a.out + m * CC, a.plane, g, acc, a.relu, ovf);
     } else {
       // chained 16*MB -> 1 conv (k-slots bound to the accumulator layout), sigmoid
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -1800,6 +1801,8 @@ int unet_forward_lds(fpl_ctx *ctx, fpl_program *prog, const UnetDesc &D, UnetSta
   return 0;
 }
 
+#include "gx_exec.h"         // the graph executor for the programs match_unet does not know
+
 }  // namespace
 
 #ifdef FPL_SPLIT
@@ -2175,9 +2178,9 @@ int fpl_tm_conv3_wgrad_split(fpl_ctx *ctx, const float *x, int n, int D, const f
 
 bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
   UnetDesc d;
-  if (precision != FPL_THIS_PREC || !match_unet(prog, &d)) return false;
-  (void)d;
-  return true;                  // every skeleton match_unet accepts, in every build
+  if (precision != FPL_THIS_PREC) return false;
+  // every skeleton match_unet accepts, in every build; the other layer programs op by op (gx_exec.h)
+  return match_unet(prog, &d) || (gx_match(prog) && !getenv("FPL_NO_GX"));
 }
 
 // in: (n, T,T,T) f32 normalised tiles on the device; out: (n, O,O,O) f32, O = T - 2 * rf_offset
@@ -2185,8 +2188,11 @@ bool FPLK(fpl_unet_fast_available)(const fpl_program *prog, int precision) {
 int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int n,
                           int T, float *out, const FplTileIO *io) {
   UnetDesc D;
-  FPL_REQUIRE(ctx, match_unet(prog, &D), "not a unet_like / unet_like2 / unet_like3 / unet_like4 program");
   FPL_REQUIRE(ctx, in && (io || out), "fpl_unet_forward: no input tiles / no output");
+  if (!match_unet(prog, &D)) {
+    FPL_REQUIRE(ctx, gx_match(prog), "no 16-bit / split-half executor for this layer program");
+    return gx_forward(ctx, prog, in, n, T, out, io);
+  }
   FPL_REQUIRE(ctx, !SPLIT || io, "fpl_unet_forward: the split-half build writes into a prediction volume");
   UnetState *st;
   FPL_TRY(unet_prepare(ctx, prog, D, &st));
@@ -2287,7 +2293,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
                    const char *name) {
     Conv1Args a;
     a.in = x; a.M = M; a.plane = M * CC; a.w = F + st->off_w[l]; a.shift = S + st->off_s[l];
-    a.out = y; a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr; a.flag = flag;
+    a.out = y; a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr; a.flag = flag; a.relu = 1;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, name);
     // (split: two fragment sets per K-step and twice the K-steps; up to 64 KiB of LDS)
@@ -2380,7 +2386,7 @@ int FPLK(fpl_unet_forward)(fpl_ctx *ctx, fpl_program *prog, const float *in, int
     Conv1Args a;
     a.in = c5a; a.M = (int64_t)n * cube(d5a); a.plane = a.M * CC; a.w = F + st->off_w[lu2 + 1]; a.shift = S + st->off_s[lu2 + 1];
     a.out = nullptr; a.w_tail = (const h16x8 *)(F + st->off_w[lu2 + 2]); a.bias_tail = st->bias_tail;
-    a.out_f32 = out; a.flag = nullptr;
+    a.out_f32 = out; a.flag = nullptr; a.relu = 1;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(a.M, 64), (int64_t)ctx->n_cu * 8);
     TimedLaunch tl(ctx, "unet_head_" FPL_PREC_STR);
     FPLK(conv1)<32, 2, 1><<<grid, 256, 2 * 1024, stm>>>(a);

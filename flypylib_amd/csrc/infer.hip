@@ -246,8 +246,9 @@ static int infer_volume_impl(fpl_ctx *ctx, fpl_program *prog, const void *src,
   const bool unet_split_ok = cubic && fpl_unet_fast_available_f16s(prog, FPL_PREC_F16S);
   const bool split = fpl_split_path_available(prog, precision, offset, out_sz);
   FPL_REQUIRE(ctx, precision != FPL_PREC_F16S || split || unet_split_ok,
-              "fpl_infer_volume: the split-half kernels exist for vgg_like / vgg_like2 (stride-4 lattice) and "
-              "unet_like / unet_like2 / unet_like3 / unet_like4 (cubic tiles) only; use precision f32 (or f16) "
+              "fpl_infer_volume: the split-half kernels exist for vgg_like / vgg_like2 (stride-4 lattice), the "
+              "U-Net skeletons and layer programs of 3x3x3 / 1x1x1 convolutions with up to 64 (or 128) outputs, "
+              "pools, upsamplings, crops, concatenations and adds on cubic tiles; use precision f32 (or 'auto') "
               "for this architecture");
   const bool fast = zb < ze && (split || fpl_fast_path_available_bf16(prog, precision, offset, out_sz) ||
                                 fpl_fast_path_available_f16(prog, precision, offset, out_sz));

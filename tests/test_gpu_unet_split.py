@@ -84,9 +84,9 @@ def test_unet_split_slabs_equal_whole(ctx):
     assert np.array_equal(out, whole)
 
 
-def test_unet_split_is_refused_for_graphs_outside_the_skeleton(ctx):
-    """unet_like4b (48-channel bottlenecks) is not the skeleton the fused kernels know:
-    'auto' gives it fp32, 'f16s' says no"""
+def test_graphs_outside_the_skeleton_go_to_the_graph_executor(ctx):
+    """unet_like4b (48-channel bottlenecks) is not the skeleton the fused kernels know: it runs op by op
+    on the same kernels (csrc/gx_exec.h; parity: tests/test_gpu_graph_split.py)"""
     from flypylib_amd import fplutils
     off = fplutils.to3d(fplmodels.unet_like4b()[1][1])[0]
     tile = fplmodels.unet_like4b()[2]
@@ -95,7 +95,7 @@ def test_unet_split_is_refused_for_graphs_outside_the_skeleton(ctx):
     synth.synthetic_weights(g, 3)
     prog = _capi.Program(ctx, g, (1, 1, 1))
     u8 = synth.em_volume_u8(1, (tile + 6, tile, tile + 9))
-    prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
-    assert ctx.last_path() == 'mfma_f32'
-    with pytest.raises(_capi.FplHipError, match='split-half kernels'):
-        prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_F16S)
+    a = prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
+    assert ctx.last_path() == 'graph_split_f16'
+    b = prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_F32)
+    assert ctx.last_path() == 'mfma_f32' and np.abs(a - b).max() < 1e-5

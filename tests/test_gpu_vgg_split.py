@@ -108,18 +108,20 @@ def test_split_slabs_chunks_and_tilings_are_bit_identical(ctx, monkeypatch, mean
 
 
 def test_split_is_refused_for_graphs_without_split_kernels(ctx):
-    """split kernels exist for vgg_like, vgg_like2 (tests/test_gpu_vgg2_fused.py) and
-    unet_like2 / 3 / 4 (tests/test_gpu_unet_split.py, test_gpu_unet_family.py); the baseline
-    model has none: 'f16s' says so, 'auto' runs it on fp32 MFMAs"""
-    from flypylib_amd import fplutils
-    g, rf, _, _ = fplmodels.baseline_model(22)
-    off = fplutils.to3d(rf[1])[0]
-    stride = fplutils.to3d(rf[2])
+    """split kernels exist for vgg_like, vgg_like2 (tests/test_gpu_vgg2_fused.py), the U-Net family
+    (tests/test_gpu_unet_split.py, test_gpu_unet_family.py) and, op by op, the other factories
+    (tests/test_gpu_graph_split.py); a 3x3x3 convolution with 96 outputs has none: 'f16s' says so, 'auto' runs it on
+    the fp32 executor"""
+    from flypylib_amd.program import LayerGraph
+    g = LayerGraph(22)
+    x = g.conv_bn_relu(g.input(), 32, 3)
+    x = g.conv_bn_relu(x, 96, 3)
+    g.finish(g.conv(x, 1, 1, use_bias=True, activation='sigmoid'))
     synth.synthetic_weights(g, 3)
-    prog = _capi.Program(ctx, g, stride)
+    prog = _capi.Program(ctx, g, (1, 1, 1))
     u8 = synth.em_volume_u8(1, (60, 41, 48))
     with pytest.raises(_capi.FplHipError, match='split-half kernels'):
-        prog.infer_volume(u8, (22,) * 3, (off,) * 3, mean=128.0, std=33.0,
+        prog.infer_volume(u8, (22,) * 3, (2,) * 3, mean=128.0, std=33.0,
                           precision=_capi.PREC_F16S)
-    prog.infer_volume(u8, (22,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
+    prog.infer_volume(u8, (22,) * 3, (2,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
     assert ctx.last_path() == 'mfma_f32'

@@ -7,6 +7,7 @@
             reduced volume (the fp32 per-op path; size via --unet-size)
   train     configs[3] vgg_like training step, batch 32 of 64^3 patches (1 GPU)
   v2o       voxel2obj on a 582^3 substack-sized probability volume (r=27, sigma=5)
+  graphs    baseline_model, resnet_like, unet_like4b, unet_like_vol: 'auto' (graph executor) vs fp32
   roi       configs[4] end to end: fplobjdetect.full_roi_inference over a synthetic
             --roi-size^3 volume (512-substacks + 35 buffer), one substack's points
             diffed against the CPU oracle
@@ -79,6 +80,40 @@ def main():
                 kernels={k: round(v['ms'], 2) for k, v in ctx.timing_get().items()})
             ctx.timing(False)
             print(json.dumps(res['unet_like2_' + pname]), flush=True)
+
+    if 'graphs' in what:
+        # the four factories of the graph executor (csrc/gx_exec.h) at their own infer_sz, a volume of
+        # 5 - 7 tiles per axis: 'auto' (split halves, op by op) against the fp32 MFMA executor
+        from flypylib_amd import fplutils
+        for name, tiles in (('baseline_model', 5), ('resnet_like', 5), ('unet_like4b', 7), ('unet_like_vol', 5)):
+            factory = getattr(fplmodels, name)
+            _, rf, infer_sz, _ = factory()
+            tile = fplutils.to3d(infer_sz)[0]
+            off = fplutils.to3d(rf[1])[0]
+            stride = fplutils.to3d(rf[2])
+            g = factory(tile)[0]
+            synth.synthetic_weights(g, 7)
+            prog = _capi.Program(ctx, g, stride)
+            n = tiles * (tile - 2 * off) + 2 * off
+            src = torch.empty((n, n, n), dtype=torch.uint8, device='cuda')
+            dst = torch.empty((n, n, n), dtype=torch.float32, device='cuda')
+            ctx.synth_volume_u8(3, (n, n, n), out=src)
+            for pname, prec in (('auto', _capi.PREC_AUTO), ('f16', _capi.PREC_F16), ('f32', _capi.PREC_F32)):
+                kw = dict(mean=128.0, std=33.0, precision=prec, dst=dst, dims=(n, n, n))
+                prog.infer_volume(src, (tile,) * 3, (off,) * 3, **kw)
+                ctx.synchronize()
+                ctx.timing(True); ctx.timing_reset()
+                t0 = time.perf_counter()
+                prog.infer_volume(src, (tile,) * 3, (off,) * 3, **kw)
+                ctx.synchronize()
+                dt = time.perf_counter() - t0
+                key = '%s_%s' % (name, pname)
+                res[key] = dict(volume=n, tile=tile, executor=ctx.last_path(), seconds=dt,
+                                mvox_s=(n - 2 * off) ** 3 / dt / 1e6,
+                                kernels={k: round(v['ms'], 2) for k, v in ctx.timing_get().items()})
+                ctx.timing(False)
+                print(key, json.dumps(res[key]), flush=True)
+            del src, dst
 
     if 'vgg2' in what:
         # vgg_like2 (scripts/fpl_cx1_0_vgg_4ss.py): 5 x conv3, 159 867 FLOP per output voxel
