@@ -137,7 +137,10 @@ def host_leg(ctx, prog, tile, off, n=520, reps=5):
     uint8 array in, a full-resolution float32 host array out - 4 B per voxel over PCIe, which,
     not the GPU, bounds it): wall time of `Program.infer_volume(host array)`
     at the default precision, the call FplNetwork.infer makes.  Pageable numpy buffers, as a
-    caller of the reference would hold."""
+    caller of the reference would hold; the returned array comes from the binding's recycling
+    pool (`_capi.host_empty`: memory fresh from the kernel costs 45 ms of first-touch page faults
+    per 520^3 result) and the copy out runs on a helper thread beside the next rows' kernels
+    (csrc/infer.hip) - the median of `reps` calls is the steady state of a loop over substacks."""
     from flypylib_amd import _capi, synth
     u8 = synth.em_volume_u8(5, (n, n, n))
     prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)

@@ -183,6 +183,66 @@ def comm_unique_id():
     return bytes(buf)
 
 
+class _HostPool:
+    """Recycled host memory for the arrays `infer_volume` returns (FplNetwork.infer: a full-resolution
+    float32 volume per call, flypylib/fplnetwork.py:136-189).  Memory fresh from the kernel is zeroed page
+    by page at its first touch - 45 of the 68 ms of a 520^3 call when that touch is the device-to-host
+    copy - so blocks are kept when their array (and every view of it) has died and handed out again:
+    22 ms from the third call of a loop on.  A block is owned by the ctypes buffer the array is built on
+    (`ndarray.base` of every view leads there), never by one ndarray object, so a caller that keeps a
+    slice keeps the block.  At most FPL_HOST_POOL_MB (default 4096) of dead blocks are kept; 0 disables."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.free = {}            # nbytes -> [address]
+        self.cached = 0
+        self.libc = C.CDLL(None)
+        self.libc.malloc.restype = C.c_void_p
+        self.libc.malloc.argtypes = [C.c_size_t]
+        self.libc.free.argtypes = [C.c_void_p]
+        self.cap = int(os.environ.get('FPL_HOST_POOL_MB', '4096')) << 20
+
+    def empty(self, shape, dtype):
+        import weakref
+        dtype = np.dtype(dtype)
+        shape = tuple(int(d) for d in shape)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if self.cap <= 0 or nbytes < (8 << 20):
+            return np.empty(shape, dtype)
+        with self.lock:
+            lst = self.free.get(nbytes)
+            addr = lst.pop() if lst else None
+            if addr is not None:
+                self.cached -= nbytes
+        if addr is None:
+            addr = self.libc.malloc(nbytes)
+            if not addr:
+                raise MemoryError('host pool: %d bytes' % nbytes)
+        buf = (C.c_char * nbytes).from_address(addr)
+        weakref.finalize(buf, self._release, addr, nbytes)
+        return np.ndarray(shape, dtype, buffer=buf)
+
+    def _release(self, addr, nbytes):
+        with self.lock:
+            if self.cached + nbytes <= self.cap:
+                self.free.setdefault(nbytes, []).append(addr)
+                self.cached += nbytes
+                return
+        self.libc.free(addr)
+
+
+_host_pool = None
+
+
+def host_empty(shape, dtype=np.float32):
+    """an uninitialised host array from the recycling pool (see _HostPool)"""
+    global _host_pool
+    if _host_pool is None:
+        _host_pool = _HostPool()
+    return _host_pool.empty(shape, dtype)
+
+
 class Context:
     """one GPU (fpl_ctx).  Create after fork(); use from one thread at a time."""
 
@@ -537,7 +597,7 @@ class Program:
             if dims is None:
                 dims = tuple(src.shape)
         if dst is None:
-            dst = np.empty(tuple(int(d) for d in dims), np.float32)
+            dst = host_empty(dims, np.float32)
         self.ctx.check(self.ctx.lib.fpl_infer_volume(
             self.ctx.h, self.h, _ptr(src), dt, _mem_of(src), float(mean),
             float(std), _arr(dims, C.c_int64), _arr(tile_in, C.c_int32),

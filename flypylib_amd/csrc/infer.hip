@@ -5,6 +5,11 @@
 // coordinates) off, off+out, ... while < dim - off; input window
 // [origin-off, min(origin+out+off, dim)), zero-padded (in the normalised domain)
 // up to tile_in; valid outputs [origin, window_end - off).
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
 #include "fast_paths.h"
 #include "program.h"
 
@@ -330,7 +335,10 @@ static int infer_volume_impl(fpl_ctx *ctx, fpl_program *prog, const void *src,
     // (vgg_like, m = 6).  m minimises the voxels computed under a per-tile memory cap.
     int32_t m = 1;
     std::vector<TensorShape> shp_s = shp;
-    if (f32_mfma && tiles_mergeable(prog, shp, out_sz) && !getenv("FPL_NO_TILE_MERGE")) {
+    // (the graph executor of conv_mfma.hip - the 16-bit / split forms of such networks - likewise: its
+    // per-voxel arithmetic does not depend on the voxel's place in a tile either; the U-Net skeletons
+    // upsample and are never mergeable)
+    if ((f32_mfma || unet_bf16) && tiles_mergeable(prog, shp, out_sz) && !getenv("FPL_NO_TILE_MERGE")) {
       const int64_t cnt[3] = {ze - zb, (int64_t)origins[1].size(), (int64_t)origins[2].size()};
       double best = -1;
       for (int32_t c = 1; c <= 8; ++c) {
@@ -386,7 +394,7 @@ static int infer_volume_impl(fpl_ctx *ctx, fpl_program *prog, const void *src,
     int64_t B = std::max<int64_t>(1, std::min<int64_t>(n_tiles, budget / std::max<int64_t>(per_tile, 1)));
     B = std::min<int64_t>(B, 64);
     if (m > 1) B = std::max<int64_t>(1, std::min<int64_t>(B, (((int64_t)1 << 31) - 1) / biggest));
-    if (unet_bf16) B = std::min<int64_t>(n_tiles, 48);
+    if (unet_bf16 && m == 1) B = std::min<int64_t>(n_tiles, 48);
     const int64_t tile_elems = (int64_t)tile_s[0] * tile_s[1] * tile_s[2];
     void *in_batch, *out_batch;
     FPL_TRY(tmp.alloc(B * tile_elems * sizeof(float), &in_batch));
@@ -416,7 +424,7 @@ static int infer_volume_impl(fpl_ctx *ctx, fpl_program *prog, const void *src,
         io.dst_z_base = dst_base; io.off = offset[0];
         FPL_TRY((precision == FPL_PREC_F16S ? fpl_unet_forward_f16s
                  : precision == FPL_PREC_F16 ? fpl_unet_forward_f16 : fpl_unet_forward_bf16)(
-            ctx, prog, (const float *)in_batch, (int)nb, tile_in[0], nullptr, &io));
+            ctx, prog, (const float *)in_batch, (int)nb, tile_s[0], nullptr, &io));
         continue;
       }
       if (f32_mfma)
@@ -469,9 +477,84 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
                        precision == FPL_PREC_AUTO,
               "fpl_infer_volume: unknown precision %d", precision);
   FPL_HIP(ctx, hipSetDevice(ctx->device));
-  auto run = [&](int prec, unsigned *bits) {
-    return infer_volume_impl(ctx, prog, src, src_dtype, src_mem, mean, sd, dims, tile_in, offset,
-                             prec, z_begin, z_end, dst, dst_mem, bits);
+  auto run = [&](int prec, unsigned *bits) -> int {
+    // A host destination (FplNetwork.infer: 4 B per voxel back over PCIe, more time than the kernels take):
+    // the tile rows go in up to four groups, and a helper thread copies a finished group out - a blocking
+    // copy into the caller's pageable array, on a stream of its own - while the GPU computes the next
+    // (520^3: 22 -> 15 ms host to host).  Groups of rows are independent (the N-GPU slabs: bit-identical).
+    const int64_t Z = dims[0], Y = dims[1], X = dims[2];
+    const int64_t out0 = (int64_t)tile_in[0] - 2 * offset[0];
+    std::vector<int64_t> org;
+    if (out0 > 0 && offset[0] >= 0)
+      for (int64_t o = offset[0]; o < Z - offset[0]; o += out0) org.push_back(o);
+    const int32_t nz = (int32_t)org.size();
+    const int32_t zb = z_begin < 0 ? 0 : z_begin, ze = (z_end < 0 || z_end > nz) ? nz : z_end;
+    const bool piped = dst_mem == FPL_MEM_HOST && ze - zb >= 2 && Y > 0 && X > 0 &&
+                       (int64_t)(ze - zb) * out0 * Y * X * 4 >= ((int64_t)64 << 20) && !getenv("FPL_NO_D2H_PIPE");
+    if (!piped)
+      return infer_volume_impl(ctx, prog, src, src_dtype, src_mem, mean, sd, dims, tile_in, offset,
+                               prec, z_begin, z_end, dst, dst_mem, bits);
+    auto rows = [&](int32_t b, int32_t e, int64_t *lo, int64_t *hi) {      // as infer_volume_impl writes them
+      *lo = b == 0 ? 0 : org[b];
+      *hi = e == nz ? Z : std::min<int64_t>(org[e - 1] + out0 + offset[0], Z) - offset[0];
+    };
+    int64_t lo_t, hi_t;
+    rows(zb, ze, &lo_t, &hi_t);
+    DevTemp tmp(ctx);
+    void *pd;
+    FPL_TRY(tmp.alloc((size_t)(hi_t - lo_t) * Y * X * sizeof(float), &pd));
+    float *vdst = (float *)pd - lo_t * Y * X;                                // "row 0" of the volume on the device
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<int64_t, int64_t>> todo;
+    bool closed = false;
+    hipError_t copy_err = hipSuccess;
+    const int device = ctx->device;
+    std::thread copier([&]() {
+      hipStream_t cs = nullptr;
+      hipError_t e = hipSetDevice(device);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+      for (;;) {
+        std::pair<int64_t, int64_t> r;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return closed || !todo.empty(); });
+          if (todo.empty()) break;
+          r = todo.front();
+          todo.pop_front();
+        }
+        if (e != hipSuccess) continue;
+        e = hipMemcpyAsync(dst + r.first * Y * X, vdst + r.first * Y * X,
+                           (size_t)(r.second - r.first) * Y * X * sizeof(float), hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);
+      }
+      if (cs) hipStreamDestroy(cs);
+      copy_err = e;
+    });
+    const int32_t G = std::min<int32_t>(4, ze - zb);
+    int rc = 0;
+    *bits = 0u;
+    for (int32_t g = 0; g < G && rc == 0 && !*bits; ++g) {
+      const int32_t b = zb + (int32_t)((int64_t)(ze - zb) * g / G), e = zb + (int32_t)((int64_t)(ze - zb) * (g + 1) / G);
+      rc = infer_volume_impl(ctx, prog, src, src_dtype, src_mem, mean, sd, dims, tile_in, offset, prec, b, e,
+                             vdst, FPL_MEM_DEVICE, bits);
+      if (rc == 0 && !*bits) {
+        int64_t lo, hi;
+        rows(b, e, &lo, &hi);
+        std::lock_guard<std::mutex> lk(mu);
+        todo.emplace_back(lo, hi);
+        cv.notify_one();
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      closed = true;
+      cv.notify_one();
+    }
+    copier.join();
+    if (rc == 0 && copy_err != hipSuccess)
+      return fpl_fail(ctx, "fpl_infer_volume: device-to-host copy: %s", hipGetErrorString(copy_err));
+    return rc;
   };
   auto where = [](unsigned bits) {
     return bits & FPL_RANGE_INPUT ? "a normalised input voxel (times the first layer's weights)"

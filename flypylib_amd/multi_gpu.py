@@ -58,7 +58,8 @@ class ParallelInfer:
         dims = image.shape
         parts = slab_partition(n_tile_rows(dims[0], tile_in[0], offset[0]),
                                self.n_gpu)
-        out = np.empty(dims, np.float32)
+        from . import _capi
+        out = _capi.host_empty(dims, np.float32)
         if not all(hi > lo for lo, hi in (slab_rows(p, dims[0], tile_in[0], offset[0])
                                           for p in parts)):
             out[...] = 0                 # more GPUs than tile rows: idle ranks write nothing

@@ -103,14 +103,28 @@ def test_infer_reports_the_executor(ctx):
     unet._set_infer()
     unet.infer(u8, normalize=(128., 33.), precision='f16')
     assert ctx.last_path() == 'unet_mfma_f16'
-    # a width the fused kernels do not know runs on the fp32 MFMA executor - and says so
+    # the other factories run op by op on the graph executor (csrc/gx_exec.h) - and say so
     other = FplNetwork(fplmodels.baseline_model)
     other.infer_sz = (30,) * 3
     other._set_infer()
     other.infer(u8, normalize=(128., 33.))
+    assert ctx.last_path() == 'graph_split_f16'
+    other.infer(u8, normalize=(128., 33.), precision='f16')
+    assert ctx.last_path() == 'graph_mfma_f16'
+    # a layer none of the 16-bit executors has runs on the fp32 MFMA executor - and says so
+    from flypylib_amd.program import LayerGraph
+
+    def wide(in_sz=None):
+        g = LayerGraph(in_sz)
+        x = g.conv_bn_relu(g.conv_bn_relu(g.input(), 32, 3), 96, 3)
+        return g.finish(g.conv(x, 1, 1, use_bias=True, activation='sigmoid')), (5, 2, 1), 30, None
+    odd = FplNetwork(wide)
+    odd.infer_sz = (30,) * 3
+    odd._set_infer()
+    odd.infer(u8, normalize=(128., 33.))
     assert ctx.last_path() == 'mfma_f32'
     with pytest.raises(_capi.FplHipError, match='no 16-bit MFMA kernels'):
-        other.infer(u8, normalize=(128., 33.), precision='f16')
+        odd.infer(u8, normalize=(128., 33.), precision='f16')
 
 
 # ---- RCCL in the C ABI ----------------------------------------------------------------

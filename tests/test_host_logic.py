@@ -331,3 +331,26 @@ def test_split_lo_halves_never_land_on_an_mfma_destination():
         assert len(re.findall(r'v_fma_mixlo_f16', text)) > 50, src
         bad = kr.fma_mix_mfma_overlaps(text)
         assert not bad, (src, bad[:3])
+
+
+def test_host_pool_recycles_blocks_only_when_every_view_is_dead():
+    """_capi.host_empty (the arrays FplNetwork.infer returns): a block goes back to the pool when the
+    LAST array built on it dies - a caller that keeps a slice keeps the block"""
+    import gc
+    from flypylib_amd import _capi
+    shape = (64, 256, 256)                       # 16 MiB of float32: above the pool's 8 MiB floor
+    a = _capi.host_empty(shape)
+    assert a.shape == shape and a.dtype == np.float32 and a.flags['C_CONTIGUOUS'] and a.flags['WRITEABLE']
+    addr = a.ctypes.data
+    a[...] = 3.0
+    keep = a[5:7, ::2]
+    del a
+    gc.collect()
+    b = _capi.host_empty(shape)
+    assert b.ctypes.data != addr and float(keep.mean()) == 3.0     # the slice still owns the first block
+    del keep
+    gc.collect()
+    c = _capi.host_empty(shape)
+    assert c.ctypes.data == addr                                  # ... and now it is handed out again
+    small = _capi.host_empty((4, 4, 4))                           # small arrays: plain numpy
+    assert small.base is None

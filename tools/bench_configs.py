@@ -85,7 +85,7 @@ def main():
         # the four factories of the graph executor (csrc/gx_exec.h) at their own infer_sz, a volume of
         # 5 - 7 tiles per axis: 'auto' (split halves, op by op) against the fp32 MFMA executor
         from flypylib_amd import fplutils
-        for name, tiles in (('baseline_model', 5), ('resnet_like', 5), ('unet_like4b', 7), ('unet_like_vol', 5)):
+        for name, tiles in (('baseline_model', 6), ('resnet_like', 6), ('unet_like4b', 7), ('unet_like_vol', 5)):
             factory = getattr(fplmodels, name)
             _, rf, infer_sz, _ = factory()
             tile = fplutils.to3d(infer_sz)[0]
