@@ -207,6 +207,23 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
             kernel_ms=kern)
     uprog.close()
 
+    # the other four factories (reference fplmodels.py:73, 174, 410, 470) at the default precision: the
+    # graph executor (csrc/gx_exec.h) on split halves, op by op; volumes of 6 / 6 / 5 / 4 tiles per axis
+    from flypylib_amd import fplutils
+    for name, tiles in (('baseline_model', 6), ('resnet_like', 6), ('unet_like4b', 5), ('unet_like_vol', 4)):
+        factory = getattr(fplmodels, name)
+        _, rf, infer_sz, _ = factory()
+        gt, go = fplutils.to3d(infer_sz)[0], fplutils.to3d(rf[1])[0]
+        gg = factory(gt)[0]
+        synth.synthetic_weights(gg, 7)
+        gprog = _capi.Program(ctx, gg, fplutils.to3d(rf[2]))
+        n = tiles * (gt - 2 * go) + 2 * go
+        dt, kern, path = _infer_pass(ctx, gprog, torch, n, gt, go, _capi.PREC_AUTO, 2, 1, seed=3)
+        legs['other_%s_%d_auto' % (name, n)] = dict(
+            workload='%s inference %d^3 uint8 (reference tiles %d^3), precision auto' % (name, n, gt),
+            executor=path, ms=round(dt * 1e3, 3), mvox_s=round((n - 2 * go) ** 3 / dt / 1e6, 1), kernel_ms=kern)
+        gprog.close()
+
     # configs[4] post-process: voxel2obj of one 512 + 2 x 35 substack (r 27, sigma 5)
     n = 582
     prob = torch.from_numpy(synth.blob_prob_volume(11, (n, n, n), period=64, radius=9.0)).cuda()
