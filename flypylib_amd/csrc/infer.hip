@@ -479,9 +479,9 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
   FPL_HIP(ctx, hipSetDevice(ctx->device));
   auto run = [&](int prec, unsigned *bits) -> int {
     // A host destination (FplNetwork.infer: 4 B per voxel back over PCIe, more time than the kernels take):
-    // the tile rows go in up to four groups, and a helper thread copies a finished group out - a blocking
+    // the tile rows go in up to six groups, and a helper thread copies a finished group out - a blocking
     // copy into the caller's pageable array, on a stream of its own - while the GPU computes the next
-    // (520^3: 22 -> 15 ms host to host).  Groups of rows are independent (the N-GPU slabs: bit-identical).
+    // (520^3: 22 -> 16 ms host to host).  Groups of rows are independent (the N-GPU slabs: bit-identical).
     const int64_t Z = dims[0], Y = dims[1], X = dims[2];
     const int64_t out0 = (int64_t)tile_in[0] - 2 * offset[0];
     std::vector<int64_t> org;
@@ -504,12 +504,54 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
     void *pd;
     FPL_TRY(tmp.alloc((size_t)(hi_t - lo_t) * Y * X * sizeof(float), &pd));
     float *vdst = (float *)pd - lo_t * Y * X;                                // "row 0" of the volume on the device
+    // ... and a host SOURCE is uploaded by a second helper, a group ahead of the kernels that read it
+    const size_t esz = src_dtype == FPL_U8 ? 1 : 4;
+    const int32_t G = std::min<int32_t>(6, ze - zb);
+    auto group = [&](int32_t g, int32_t *b, int32_t *e) {
+      *b = zb + (int32_t)((int64_t)(ze - zb) * g / G);
+      *e = zb + (int32_t)((int64_t)(ze - zb) * (g + 1) / G);
+    };
+    auto read_hi = [&](int32_t e) { return std::min<int64_t>(org[e - 1] + out0 + offset[0], Z); };
+    const void *vsrc = src;
+    int vsrc_mem = src_mem;
+    const int64_t rd_lo_t = org[zb] - offset[0];
+    if (src_mem == FPL_MEM_HOST) {
+      void *ps;
+      FPL_TRY(tmp.alloc((size_t)(read_hi(ze) - rd_lo_t) * Y * X * esz, &ps));
+      vsrc = (const uint8_t *)ps - rd_lo_t * Y * X * esz;                   // "row 0" of the source on the device
+      vsrc_mem = FPL_MEM_DEVICE;
+    }
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<int64_t, int64_t>> todo;
     bool closed = false;
-    hipError_t copy_err = hipSuccess;
+    int32_t uploaded = src_mem == FPL_MEM_HOST ? 0 : G;                     // groups whose source rows are resident
+    hipError_t copy_err = hipSuccess, up_err = hipSuccess;
     const int device = ctx->device;
+    std::thread uploader([&]() {
+      if (src_mem != FPL_MEM_HOST) return;
+      hipStream_t us = nullptr;
+      hipError_t e = hipSetDevice(device);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&us, hipStreamNonBlocking);
+      int64_t have = rd_lo_t;
+      for (int32_t g = 0; g < G; ++g) {
+        int32_t b, en;
+        group(g, &b, &en);
+        const int64_t need = read_hi(en);
+        if (e == hipSuccess && need > have) {
+          e = hipMemcpyAsync((uint8_t *)const_cast<void *>(vsrc) + have * Y * X * esz,
+                             (const uint8_t *)src + have * Y * X * esz, (size_t)(need - have) * Y * X * esz,
+                             hipMemcpyHostToDevice, us);
+          if (e == hipSuccess) e = hipStreamSynchronize(us);
+          have = need;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        if (e != hipSuccess) up_err = e;
+        uploaded = g + 1;                     // (on an error too: the main thread looks at up_err)
+        cv.notify_all();
+      }
+      if (us) hipStreamDestroy(us);
+    });
     std::thread copier([&]() {
       hipStream_t cs = nullptr;
       hipError_t e = hipSetDevice(device);
@@ -531,27 +573,35 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
       if (cs) hipStreamDestroy(cs);
       copy_err = e;
     });
-    const int32_t G = std::min<int32_t>(4, ze - zb);
     int rc = 0;
     *bits = 0u;
     for (int32_t g = 0; g < G && rc == 0 && !*bits; ++g) {
-      const int32_t b = zb + (int32_t)((int64_t)(ze - zb) * g / G), e = zb + (int32_t)((int64_t)(ze - zb) * (g + 1) / G);
-      rc = infer_volume_impl(ctx, prog, src, src_dtype, src_mem, mean, sd, dims, tile_in, offset, prec, b, e,
+      int32_t b, e;
+      group(g, &b, &e);
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return uploaded > g; });
+        if (up_err != hipSuccess) break;
+      }
+      rc = infer_volume_impl(ctx, prog, vsrc, src_dtype, vsrc_mem, mean, sd, dims, tile_in, offset, prec, b, e,
                              vdst, FPL_MEM_DEVICE, bits);
       if (rc == 0 && !*bits) {
         int64_t lo, hi;
         rows(b, e, &lo, &hi);
         std::lock_guard<std::mutex> lk(mu);
         todo.emplace_back(lo, hi);
-        cv.notify_one();
+        cv.notify_all();
       }
     }
     {
       std::lock_guard<std::mutex> lk(mu);
       closed = true;
-      cv.notify_one();
+      cv.notify_all();
     }
+    uploader.join();
     copier.join();
+    if (rc == 0 && up_err != hipSuccess)
+      return fpl_fail(ctx, "fpl_infer_volume: host-to-device copy: %s", hipGetErrorString(up_err));
     if (rc == 0 && copy_err != hipSuccess)
       return fpl_fail(ctx, "fpl_infer_volume: device-to-host copy: %s", hipGetErrorString(copy_err));
     return rc;
