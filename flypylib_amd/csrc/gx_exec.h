@@ -556,7 +556,7 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
   auto balloc = [&](int t) -> int {
     cp[t] = gx_pad32(pl.chan[t]);
     const int64_t elems = (int64_t)n * cube(dim[t]) * cp[t];
-    const size_t slack = ((size_t)5 * dim[t] * dim[t] + 9 * dim[t] + 18) * cp[t] * PM * 2;
+    const size_t slack = ((size_t)5 * dim[t] * dim[t] + 11 * dim[t] + 18) * cp[t] * PM * 2;      // (rows: up to R + 3, R = 8)
     void *q;
     FPL_TRY(tmp.alloc((size_t)elems * PM * 2 + slack + 64, &q));
     buf[t] = (h16_t *)q;
@@ -623,7 +623,11 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
             }
             const char *name = cw.cout_p <= 32 ? "gx_conv3_32" : cw.cout_p <= 64 ? "gx_conv3_64" : "gx_conv3_128";
             if (cw.cout_p <= 32) {
-              if (pu >= 0) FPL_TRY((launch_conv3<2, false, true>(ctx, a, n, name)));
+              // 32 outputs: 8 / 6 rows per wave where the layer is tall enough - a weight fragment then
+              // feeds 8 / 6 MFMAs instead of 4 (conv_mfma.hip, Geo<R>)
+              if (pu >= 0 && od >= 32) FPL_TRY((launch_conv3<2, false, true, false, 8>(ctx, a, n, name)));
+              else if (pu >= 0) FPL_TRY((launch_conv3<2, false, true>(ctx, a, n, name)));
+              else if (od >= 24) FPL_TRY((launch_conv3<2, false, false, false, 6>(ctx, a, n, name)));
               else FPL_TRY((launch_conv3<2>(ctx, a, n, name)));
             } else {
               if (pu >= 0) FPL_TRY((launch_conv3<4, false, true>(ctx, a, n, name)));
