@@ -99,6 +99,21 @@ bool gx_plain(const fpl_program *prog, const GxPlan &pl, int t, int *base) {
   return true;
 }
 
+// the first layer followed by a 1x1x1 convolution of the same (<= 32) width and a pool - unet_like_vol's first
+// stage, unet_like's - runs as ONE kernel (unet_stem_c1: the 1x1x1 chained in registers, c1 and the pooled
+// tensor stored): returns the 1x1x1 convolution's op index, or -1
+int gx_chain_c1(const fpl_program *prog, const GxPlan &pl, int i) {
+  const fpl_op &op = prog->ops[i];
+  if (op.kind != FPL_OP_CONV || op.k != 3 || op.cin != 1 || pl.users[op.dst].size() != 1) return -1;
+  const int j = pl.users[op.dst][0];
+  const fpl_op &c = prog->ops[j];
+  if (c.kind != FPL_OP_CONV || c.k != 1 || c.cin != op.cout || c.cout > 32 || c.cout == 1 || c.act != FPL_ACT_RELU ||
+      c.src0 != op.dst)
+    return -1;
+  for (int u : pl.users[c.dst]) if (prog->ops[u].kind == FPL_OP_POOL) return j;
+  return -1;
+}
+
 // the layer programs this executor takes (everything match_unet does not)
 bool gx_match(const fpl_program *prog) {
   if (prog->ops.empty() || prog->n_tensors < 2) return false;
@@ -474,7 +489,16 @@ int gx_prepare(fpl_ctx *ctx, fpl_program *prog, const GxPlan &pl, GxState **out)
       fpl_op opp;
       gx_padded_op(A, op, rows, cout_p, &Ap, &opp);
       cw.cin_p = opp.cin; cw.cout_p = cout_p;
-      if (op.k == 3 && cout_p > 64) {
+      const int pi = op.k == 1 ? pl.prod[op.src0] : -1;
+      if (pi >= 0 && gx_chain_c1(prog, pl, pi) == (int)i) {
+        // chained behind the first layer (unet_stem_c1): real channels as k-slots, [part][b]
+        std::vector<float> scale(Ap.begin() + opp.scale_off, Ap.begin() + opp.scale_off + cout_p);
+        for (int part = 0; part < PM; ++part) {
+          std::vector<uint16_t> fp;
+          fpl_pack_frags(Ap.data(), scale.data(), 1, 32, cout_p, 2, 1, SLOT_SPATIAL, &fp, true, part);
+          f.insert(f.end(), fp.begin(), fp.end());
+        }
+      } else if (op.k == 3 && cout_p > 64) {
         std::vector<uint16_t> h0, h1;
         pack_conv3(Ap.data(), opp, 0, 64, false, &h0);
         pack_conv3(Ap.data(), opp, 64, 64, false, &h1);
@@ -576,7 +600,26 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
       case FPL_OP_UP: case FPL_OP_CROP: case FPL_OP_CONCAT:
         break;                                             // views
       case FPL_OP_CONV: {
-        if (op.k == 3 && op.cin == 1) {
+        const int jc = gx_chain_c1(prog, pl, (int)i);
+        if (jc >= 0) {                                     // conv3 1 -> C, conv1 C -> C', pool: one kernel
+          const fpl_op &c1op = prog->ops[jc];
+          const int pu = pool_user(c1op.dst);
+          StemC1Args a;
+          a.raw = in; a.T = T;
+          a.wstem = (const h16x8 *)(F + cw.off_w); a.shstem = S + cw.off_s;
+          a.w1 = (const h16x8 *)(F + st->conv[jc].off_w); a.sh1 = S + st->conv[jc].off_s;
+          a.D = dim[op.dst];
+          FPL_REQUIRE(ctx, a.D == T - 2 && dim[c1op.dst] == a.D && dim[prog->ops[pu].dst] == a.D / 2, "gx: chained first stage shapes");
+          FPL_TRY(balloc(c1op.dst));
+          FPL_TRY(balloc(prog->ops[pu].dst));
+          a.c1 = buf[c1op.dst]; a.p1 = buf[prog->ops[pu].dst];
+          a.c1plane = plane(c1op.dst); a.p1plane = plane(prog->ops[pu].dst);
+          a.flag = flag;
+          a.zblocks = (int)ceil_div64(a.D, 4); a.nbx = (int)ceil_div64(a.D, 16); a.nby = (int)ceil_div64(a.D, 4);
+          done[jc] = 1; done[pu] = 1;
+          TimedLaunch tl(ctx, "gx_stem_conv3_conv1_pool");
+          FPLK(unet_stem_c1)<<<(unsigned)((int64_t)a.nbx * a.nby * n * a.zblocks), 256, 0, stm>>>(a);
+        } else if (op.k == 3 && op.cin == 1) {
           const int pu = pool_user(op.dst);
           const bool need_c1 = pl.users[op.dst].size() > (pu >= 0 ? 1u : 0u);
           GxStemArgs a;
