@@ -22,6 +22,11 @@ struct GxConvW {
   size_t off_s = 0;                       // shifts (floats), padded
   int cin_p = 0, cout_p = 0;
   float bias = 0.f;                       // the head's
+  float xlim = 0.f;                       // first layer computed in a tile loader: input limit of its half-range bound
+  // parity form (conv_mfma.hip) of a 3x3x3 convolution whose LEADING source chunks are an UpSampling3D(2):
+  // both weight streams, one after the other; 0 steps = none
+  size_t off_wp = 0, wp_stream = 0;
+  int wp_steps = 0;
 };
 
 struct GxState {
@@ -110,6 +115,19 @@ int gx_chain_c1(const fpl_program *prog, const GxPlan &pl, int i) {
   if (c.kind != FPL_OP_CONV || c.k != 1 || c.cin != op.cout || c.cout > 32 || c.cout == 1 || c.act != FPL_ACT_RELU ||
       c.src0 != op.dst)
     return -1;
+  for (int u : pl.users[c.dst]) if (prog->ops[u].kind == FPL_OP_POOL) return j;
+  return -1;
+}
+
+// the first layer (1 -> 32) in front of a 3x3x3 convolution 32 -> 32 + ReLU + pool - unet_like4b's first stage,
+// as unet_like2's - runs inside that convolution's tile loader (conv3<2, PF, STEM, POOL, ., 8>: the 32-channel
+// full-resolution tensor never exists in HBM): returns the convolution's op index, or -1
+int gx_chain_c3(const fpl_program *prog, const GxPlan &pl, int i) {
+  const fpl_op &op = prog->ops[i];
+  if (op.kind != FPL_OP_CONV || op.k != 3 || op.cin != 1 || op.cout != 32 || pl.users[op.dst].size() != 1) return -1;
+  const int j = pl.users[op.dst][0];
+  const fpl_op &c = prog->ops[j];
+  if (c.kind != FPL_OP_CONV || c.k != 3 || c.cin != 32 || c.cout != 32 || c.act != FPL_ACT_RELU || c.src0 != op.dst) return -1;
   for (int u : pl.users[c.dst]) if (prog->ops[u].kind == FPL_OP_POOL) return j;
   return -1;
 }
@@ -461,7 +479,36 @@ int gx_prepare(fpl_ctx *ctx, fpl_program *prog, const GxPlan &pl, GxState **out)
       cw.cin_p = op.cin; cw.cout_p = 1; cw.bias = A[op.shift_off];
       continue;
     }
-    if (op.k == 3 && op.cin == 1) {                        // first layer: [part][b], SLOT_STEM, interleaved rows
+    if (op.k == 3 && op.cin == 1 && gx_chain_c3(prog, pl, (int)i) >= 0) {
+      // first layer computed in the tile loader of the next convolution (conv3's STEM variant): split build
+      // per chunk of 16 output channels, plain rows, [chunk][part]; 16-bit builds two interleaved fragments
+      std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
+      if (SPLIT) {
+        for (int cc = 0; cc < 2; ++cc) {
+          std::vector<float> wc((size_t)27 * 16);
+          for (int t = 0; t < 27; ++t) memcpy(&wc[(size_t)t * 16], A + op.w_off + (size_t)t * op.cout + 16 * cc, 16 * sizeof(float));
+          for (int part = 0; part < 2; ++part) {
+            std::vector<uint16_t> fp;
+            fpl_pack_frags(wc.data(), scale.data() + 16 * cc, 27, 1, 16, 1, 1, SLOT_STEM, &fp, false, part);
+            f.insert(f.end(), fp.begin(), fp.end());
+          }
+        }
+        double xl = 65000.0;                               // (as unet_prepare: |conv| <= sum |w| |x| + |shift|)
+        for (int co = 0; co < op.cout; ++co) {
+          double sw = 0.0;
+          for (int tap = 0; tap < 27; ++tap) sw += std::fabs((double)A[op.w_off + (size_t)tap * op.cout + co]);
+          sw *= std::fabs((double)A[op.scale_off + co]);
+          const double sh = std::fabs((double)A[op.shift_off + co]);
+          if (!(sh < 65000.0)) return fpl_fail_range(ctx, "the first layer's shift exceeds the IEEE-half range");
+          if (sw > 0.0) xl = std::min(xl, (65000.0 - sh) / sw);
+        }
+        cw.xlim = (float)xl;
+      } else {
+        fpl_pack_frags(A + op.w_off, scale.data(), 27, 1, op.cout, 2, 1, SLOT_STEM, &f, true);
+      }
+      cw.cin_p = 1; cw.cout_p = 32;
+      for (int co = 0; co < 32; ++co) shifts.push_back(A[op.shift_off + co]);
+    } else if (op.k == 3 && op.cin == 1) {                 // first layer: [part][b], SLOT_STEM, interleaved rows
       std::vector<float> scale(A + op.scale_off, A + op.scale_off + op.cout);
       for (int part = 0; part < PM; ++part) {
         std::vector<uint16_t> fp;
@@ -507,6 +554,26 @@ int gx_prepare(fpl_ctx *ctx, fpl_program *prog, const GxPlan &pl, GxState **out)
         f.insert(f.end(), h1.begin(), h1.end());
       } else if (op.k == 3) {
         pack_conv3(Ap.data(), opp, 0, cout_p, false, &f);
+        // leading upsampled chunks, plain ones behind them: the z taps of the upsampled part pre-summed per
+        // output-plane parity (two thirds of its MFMAs and weight fragments)
+        std::vector<GxView> v;
+        gx_views(prog, pl, op.src0, &v);
+        int n_ups = 0, total = 0;
+        bool lead = true, ok = true;
+        for (auto &sv : v) {
+          const int nch = (pl.chan[sv.base] + RCH - 1) / RCH;
+          if (sv.ups) { if (!lead) ok = false; n_ups += nch; } else lead = false;
+          total += nch;
+        }
+        bool pooled = false;
+        for (int u : pl.users[op.dst]) pooled |= prog->ops[u].kind == FPL_OP_POOL;
+        if (ok && n_ups > 0 && n_ups < total && !pooled) {
+          std::vector<uint16_t> fp;
+          pack_conv3_parity(Ap.data(), opp, cout_p, n_ups, &fp, &cw.wp_steps);
+          cw.off_wp = all.size() * sizeof(uint16_t);
+          cw.wp_stream = fp.size() / 2 * sizeof(uint16_t);
+          all.insert(all.end(), fp.begin(), fp.end());
+        }
       } else if (SPLIT) {
         pack_conv1(Ap.data(), opp, true, &f);
       } else {
@@ -600,8 +667,27 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
       case FPL_OP_UP: case FPL_OP_CROP: case FPL_OP_CONCAT:
         break;                                             // views
       case FPL_OP_CONV: {
-        const int jc = gx_chain_c1(prog, pl, (int)i);
-        if (jc >= 0) {                                     // conv3 1 -> C, conv1 C -> C', pool: one kernel
+        const int jc = gx_chain_c1(prog, pl, (int)i), j3 = gx_chain_c3(prog, pl, (int)i);
+        if (j3 >= 0) {                                     // conv3 1 -> 32 inside the tile loader of conv3 32 -> 32 + pool
+          const fpl_op &c = prog->ops[j3];
+          const int pu = pool_user(c.dst);
+          const GxConvW &cj = st->conv[j3];
+          FPL_TRY(balloc(c.dst));
+          FPL_TRY(balloc(prog->ops[pu].dst));
+          Conv3Args a;
+          memset(&a, 0, sizeof(a));
+          a.w = F + cj.off_w; a.shift = S + cj.off_s; a.relu = 1;
+          a.out = buf[c.dst]; a.OD = a.OH = a.OW = dim[c.dst];
+          FPL_REQUIRE(ctx, dim[op.dst] == T - 2 && dim[c.dst] == T - 4, "gx: first pair shapes");
+          a.ncc = 32 / RCH;
+          for (int cc = 0; cc < a.ncc; ++cc) a.src[cc] = make_src(nullptr, T - 2, CC, 0, 1, 0);
+          a.raw = in; a.T = T;
+          a.wstem = (const h16x8 *)(F + cw.off_w); a.shstem = S + cw.off_s;
+          a.pool_out = buf[prog->ops[pu].dst];
+          a.flag = flag; a.xlim = cw.xlim;
+          done[j3] = 1; done[pu] = 1;
+          FPL_TRY((launch_conv3<2, true, true, false, 8>(ctx, a, n, "gx_stem_conv3_32_32_pool")));
+        } else if (jc >= 0) {                                     // conv3 1 -> C, conv1 C -> C', pool: one kernel
           const fpl_op &c1op = prog->ops[jc];
           const int pu = pool_user(c1op.dst);
           StemC1Args a;
@@ -665,7 +751,11 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
                 a.src[a.ncc++] = make_src(buf[b] + cc * plane(b), dim[b], CC, 0, s.ups ? 2 : 1, s.crop);
             }
             const char *name = cw.cout_p <= 32 ? "gx_conv3_32" : cw.cout_p <= 64 ? "gx_conv3_64" : "gx_conv3_128";
-            if (cw.cout_p <= 32) {
+            if (cw.wp_steps && pu < 0 && cw.cout_p <= 64) {
+              a.w = F + cw.off_wp; a.parity = 1; a.wstream = (int64_t)cw.wp_stream; a.total_steps = cw.wp_steps;
+              if (cw.cout_p <= 32) FPL_TRY((launch_conv3<2, false, false, false, 6, true>(ctx, a, n, name)));
+              else FPL_TRY((launch_conv3<4, false, false, false, 4, true>(ctx, a, n, name)));
+            } else if (cw.cout_p <= 32) {
               // 32 outputs: 8 / 6 rows per wave where the layer is tall enough - a weight fragment then
               // feeds 8 / 6 MFMAs instead of 4 (conv_mfma.hip, Geo<R>)
               if (pu >= 0 && od >= 32) FPL_TRY((launch_conv3<2, false, true, false, 8>(ctx, a, n, name)));
