@@ -27,6 +27,9 @@ struct GxConvW {
   // both weight streams, one after the other; 0 steps = none
   size_t off_wp = 0, wp_stream = 0;
   int wp_steps = 0;
+  // HEAD epilogue (gx_chain_head): the chained fragments of the 32 -> 32 and the 32 -> 1 convolution
+  size_t off_w8 = 0, off_w9 = 0;
+  bool head_chain = false;
 };
 
 struct GxState {
@@ -130,6 +133,26 @@ int gx_chain_c3(const fpl_program *prog, const GxPlan &pl, int i) {
   if (c.kind != FPL_OP_CONV || c.k != 3 || c.cin != 32 || c.cout != 32 || c.act != FPL_ACT_RELU || c.src0 != op.dst) return -1;
   for (int u : pl.users[c.dst]) if (prog->ops[u].kind == FPL_OP_POOL) return j;
   return -1;
+}
+
+// conv3 -> 32 (+ReLU), conv1 32 -> 32 (+ReLU), conv1 32 -> 1 (sigmoid) at the network's end - unet_like4b's and
+// unet_like_vol's, as unet_like2's - with rf_stride 1: the two 1x1x1 convolutions, the sigmoid and the store
+// into the prediction volume ride in the conv3's epilogue (HEAD).  Returns the 32 -> 32 op (the 32 -> 1 is its
+// only user), or -1
+int gx_chain_head(const fpl_program *prog, const GxPlan &pl, int i) {
+  const fpl_op &op = prog->ops[i];
+  if (op.kind != FPL_OP_CONV || op.k != 3 || op.cin == 1 || op.cout != 32 || op.act != FPL_ACT_RELU ||
+      pl.users[op.dst].size() != 1 || prog->stride[0] != 1)
+    return -1;
+  const int j = pl.users[op.dst][0];
+  const fpl_op &c = prog->ops[j];
+  if (c.kind != FPL_OP_CONV || c.k != 1 || c.cin != 32 || c.cout != 32 || c.act != FPL_ACT_RELU || c.src0 != op.dst ||
+      pl.users[c.dst].size() != 1)
+    return -1;
+  const fpl_op &h = prog->ops[pl.users[c.dst][0]];
+  if (h.kind != FPL_OP_CONV || h.k != 1 || h.cin != 32 || h.cout != 1 || h.act != FPL_ACT_SIGMOID || h.dst != prog->out_tensor)
+    return -1;
+  return j;
 }
 
 // the layer programs this executor takes (everything match_unet does not)
@@ -565,6 +588,24 @@ int gx_prepare(fpl_ctx *ctx, fpl_program *prog, const GxPlan &pl, GxState **out)
           if (sv.ups) { if (!lead) ok = false; n_ups += nch; } else lead = false;
           total += nch;
         }
+        const int jh = gx_chain_head(prog, pl, (int)i);
+        if (jh >= 0) {
+          const fpl_op &c8 = prog->ops[jh], &c9 = prog->ops[pl.users[c8.dst][0]];
+          std::vector<float> s8(A + c8.scale_off, A + c8.scale_off + 32), s9(A + c9.scale_off, A + c9.scale_off + 1);
+          cw.head_chain = true;
+          cw.off_w8 = all.size() * sizeof(uint16_t);
+          for (int part = 0; part < PM; ++part) {          // B fragments built in registers: REAL channels as k-slots
+            std::vector<uint16_t> fp;
+            fpl_pack_frags(A + c8.w_off, s8.data(), 1, 32, 32, 2, 1, SLOT_SPATIAL, &fp, false, part);
+            all.insert(all.end(), fp.begin(), fp.end());
+          }
+          cw.off_w9 = all.size() * sizeof(uint16_t);
+          for (int part = 0; part < PM; ++part) {
+            std::vector<uint16_t> fp;
+            fpl_pack_frags(A + c9.w_off, s9.data(), 1, 32, 1, 1, 1, SLOT_CHAIN, &fp, false, part);
+            all.insert(all.end(), fp.begin(), fp.end());
+          }
+        }
         bool pooled = false;
         for (int u : pl.users[op.dst]) pooled |= prog->ops[u].kind == FPL_OP_POOL;
         if (ok && n_ups > 0 && n_ups < total && !pooled) {
@@ -727,14 +768,15 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
         } else if (op.k == 3) {
           std::vector<GxView> v;
           FPL_REQUIRE(ctx, gx_views(prog, pl, op.src0, &v), "gx: unresolved convolution input");
-          FPL_TRY(balloc(op.dst));
+          const int jh = cw.head_chain && io ? gx_chain_head(prog, pl, (int)i) : -1;
+          if (jh < 0) FPL_TRY(balloc(op.dst));
           const int od = dim[op.dst];
           int pu = op.act == FPL_ACT_RELU && cw.cout_p <= 64 ? pool_user(op.dst) : -1;
           if (pu >= 0) { FPL_TRY(balloc(prog->ops[pu].dst)); done[pu] = 1; }
           for (int h = 0; h < (cw.cout_p > 64 ? 2 : 1); ++h) {
             Conv3Args a;
             a.w = F + cw.off_w + (h ? cw.half_bytes : 0); a.shift = S + cw.off_s + 64 * h; a.relu = op.act == FPL_ACT_RELU;
-            a.out = buf[op.dst] + (int64_t)(64 * PM / CC) * h * plane(op.dst);
+            a.out = jh >= 0 ? nullptr : buf[op.dst] + (int64_t)(64 * PM / CC) * h * plane(op.dst);
             a.oplane = a.pplane = 0; a.OD = a.OH = a.OW = od; a.ncc = 0; a.zblocks = 0;
             a.raw = nullptr; a.T = 0; a.wstem = nullptr; a.shstem = nullptr;
             a.pool_out = pu >= 0 ? buf[prog->ops[pu].dst] : nullptr;
@@ -751,7 +793,20 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
                 a.src[a.ncc++] = make_src(buf[b] + cc * plane(b), dim[b], CC, 0, s.ups ? 2 : 1, s.crop);
             }
             const char *name = cw.cout_p <= 32 ? "gx_conv3_32" : cw.cout_p <= 64 ? "gx_conv3_64" : "gx_conv3_128";
-            if (cw.wp_steps && pu < 0 && cw.cout_p <= 64) {
+            if (jh >= 0) {
+              // conv1 32 -> 32, conv1 32 -> 1, sigmoid and the store into the volume in the epilogue
+              const int j9 = pl.users[prog->ops[jh].dst][0];
+              a.io = *io;
+              a.w8 = (const h16x8 *)(F + cw.off_w8); a.sh8 = S + st->conv[jh].off_s;
+              a.w9 = (const h16x8 *)(F + cw.off_w9); a.bias9 = st->conv[j9].bias;
+              done[jh] = 1; done[j9] = 1;
+              if (cw.wp_steps) {
+                a.w = F + cw.off_wp; a.parity = 1; a.wstream = (int64_t)cw.wp_stream; a.total_steps = cw.wp_steps;
+                FPL_TRY((launch_conv3<2, false, false, true, 6, true>(ctx, a, n, "gx_conv3_32_head")));
+              } else {
+                FPL_TRY((launch_conv3<2, false, false, true, 6>(ctx, a, n, "gx_conv3_32_head")));
+              }
+            } else if (cw.wp_steps && pu < 0 && cw.cout_p <= 64) {
               a.w = F + cw.off_wp; a.parity = 1; a.wstream = (int64_t)cw.wp_stream; a.total_steps = cw.wp_steps;
               if (cw.cout_p <= 32) FPL_TRY((launch_conv3<2, false, false, false, 6, true>(ctx, a, n, name)));
               else FPL_TRY((launch_conv3<4, false, false, false, 4, true>(ctx, a, n, name)));

@@ -55,7 +55,7 @@ def _check(ctx, name, tile, shape, kind):
     names = set(ctx.timing_get())
     ctx.timing(False)
     want_path = 'graph_split_f16' if kind in ('f16s', 'auto') else 'graph_mfma_' + kind
-    assert ctx.last_path() == want_path and any(k.startswith('gx_stem_conv3') for k in names) and 'gx_head' in names, \
+    assert ctx.last_path() == want_path and any(k.startswith('gx_stem_conv3') for k in names) and ('gx_head' in names or 'gx_conv3_32_head' in names), \
         (ctx.last_path(), names)
     assert got.shape == shape and not got[:off].any() and not got[:, :, -off:].any()
     d = np.abs(got - ref)
