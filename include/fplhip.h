@@ -153,12 +153,13 @@ int fpl_infer_volume(fpl_ctx *ctx, fpl_program *prog, const void *src,
 
 /* name of the executor the last fpl_infer_volume / fpl_program_forward of this
  * context ran on: "vgg_fused_f16" | "vgg_fused_bf16" | "vgg_split_f16" | "unet_split_f16" | "unet_mfma_f16" |
- * "unet_mfma_bf16" | "mfma_f32" | "perop_f32" | "none" (empty slab); with the suffix
+ * "unet_mfma_bf16" | "graph_split_f16" | "graph_mfma_f16" | "graph_mfma_bf16" (the layer-by-layer
+ * executor of the other factories) | "mfma_f32" | "perop_f32" | "none" (empty slab); with the suffix
  * "(range)" - "mfma_f32(range)" - when FPL_PREC_AUTO fell back to fp32 because a weight,
- * an input voxel or an activation left the IEEE-half range of the split kernels.  The 16-bit
- * fused kernels are keyed on the architectures of flypylib/fplmodels.py; any other
- * graph runs on the fp32 executors - this says which, instead of leaving the caller
- * to infer it from the speed. */
+ * an input voxel or an activation left the IEEE-half range of the split kernels.  The fused
+ * 16-bit kernels are keyed on the architectures of flypylib/fplmodels.py, the graph executor on
+ * the layer kinds and widths it has kernels for; any other graph runs on the fp32 executors -
+ * this says which, instead of leaving the caller to infer it from the speed. */
 const char *fpl_last_path(fpl_ctx *ctx);
 
 /* ---- post-process ----------------------------------------------------------- */

@@ -58,7 +58,21 @@ other)
   # another, not execution): rocprofv3's kernel trace of the same run, oracle check skipped
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o roi -- python3 tools/bench_configs.py --what roi --skip-oracle > $out/trace_roi.json 2> $out/trace_roi.err
   find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_roi1536_kernel_stats.csv \;
+  python tools/dev/trace_union.py $out/trace --last-span-ms 430 > $out/${tag}_roi1536_trace_union.txt 2>&1
   rm -rf $out/trace
-  tail -1 $out/trace_roi.json ;;
+  tail -1 $out/trace_roi.json
+  # the same ROI kept RESIDENT in HBM (inputs in place when the clock starts), and its trace by kernel class
+  python tools/bench_configs.py --what roi --roi-source resident --out $out/${tag}_roi1536_resident.json > $out/roi_res.log 2>&1; tail -1 $out/roi_res.log
+  rocprofv3 --kernel-trace --output-format csv -d $out/trace -o roi -- python3 tools/bench_configs.py --what roi --roi-source resident --skip-oracle > $out/trace_roi_res.json 2> $out/trace_roi_res.err
+  python tools/dev/trace_union.py $out/trace --last-span-ms 430 > $out/${tag}_roi1536_resident_trace_union.txt 2>&1
+  rm -rf $out/trace
+  # the four factories of the graph executor: 'auto' / f16 / f32, and the kernel stats of that run
+  python tools/bench_configs.py --what graphs 2>&1 | grep -v "^#\|^[0-9]* \|total params\|amdgpu.ids" > $out/${tag}_graph_executor_four_factories.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o graphs -- python3 tools/bench_configs.py --what graphs > $out/trace_graphs.json 2> $out/trace_graphs.err
+  find $out/trace -name '*kernel_stats.csv' -exec cp {} $out/${tag}_graph_executor_kernel_stats.csv \;
+  rm -rf $out/trace
+  # the public API host to host (pool, pipelined copies): where its time goes
+  python tools/dev/host_api_rate.py 520 2>&1 | grep -v "^#\|^[0-9]* \|total params\|amdgpu.ids" > $out/${tag}_host_api_520.txt
+  tail -3 $out/${tag}_host_api_520.txt ;;
 esac
 done
