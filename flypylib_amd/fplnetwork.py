@@ -212,11 +212,18 @@ class FplNetwork:
 
         precision (default: the network's, 'auto'): 'auto' = fp32-grade results on the
         fastest executor that delivers them - split IEEE halves ('f16s': within ~4e-6 of
-        fp32, the same detected point set) for vgg_like, vgg_like2, unet_like and
-        unet_like2 / 3 / 4, rerun on the fp32 MFMA kernels when a weight, an input voxel or
-        an activation leaves the IEEE-half range (the kernels check), and the fp32 MFMA
-        kernels ('f32') for every other architecture; 'f16' / 'bf16' = plain 16-bit operands
-        (up to ~1e-3 / ~8e-3 off fp32 on trained weights, 3x faster than 'f16s')."""
+        fp32, the same detected point set) for all ten factories of fplmodels (the fused
+        kernels of vgg_like / vgg_like2 / the U-Net skeletons, the layer-by-layer graph
+        executor for the others), rerun on the fp32 MFMA kernels when a weight, an input
+        voxel or an activation leaves the IEEE-half range (the kernels check), and the fp32
+        MFMA kernels ('f32') for layer programs neither has kernels for; 'f16' / 'bf16' =
+        plain 16-bit operands (up to ~1e-3 / ~8e-3 off fp32 on trained weights, 2 - 3x faster
+        than 'f16s').
+
+        The returned array lives in memory recycled from earlier results that have died
+        (`_capi.host_empty`: a fresh 520^3 result would cost 45 ms of first-touch page faults,
+        three times the rest of the call); it is an ordinary writable ndarray, and a caller
+        that keeps it - or any slice of it - keeps its memory."""
         if isinstance(image, str):
             from . import keras_io
             image = np.load(image) if image.endswith('.npy') else keras_io.read_main(image)
