@@ -122,3 +122,41 @@ def test_graphs_outside_the_executors_are_refused(ctx):
         prog.infer_volume(u8, (22,) * 3, (2,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_F16S)
     prog.infer_volume(u8, (22,) * 3, (2,) * 3, mean=128.0, std=33.0, precision=_capi.PREC_AUTO)
     assert ctx.last_path() == 'mfma_f32'
+
+
+def _custom_graph(in_sz=None):
+    """not one of the reference's factories: 16- and 48-channel layers (padded to 32 / 64), a skip that is
+    cropped and concatenated behind an UpSampling3D (the parity form's leading chunks), a residual Add of two
+    uncropped tensors, a biased head behind the Add (the stand-alone fp32 head kernel)"""
+    g = LayerGraph(in_sz)
+    x = g.conv_bn_relu(g.input(), 16, 3)
+    x = g.conv_bn_relu(x, 48, 3)                 # T - 4
+    y = g.conv_bn_relu(g.pool(x), 64, 3)         # (T - 4) / 2 - 2
+    y = g.conv_bn_relu(y, 48, 1)
+    u = g.concat(g.up(y, 2), g.crop(x, 2))       # T - 8, 48 + 48 channels
+    z = g.conv_bn_relu(u, 32, 3)                 # T - 10
+    a = g.bn(g.conv(z, 32, 1))
+    r = g.relu(g.add(a, z))
+    return g.finish(g.conv(r, 1, 1, use_bias=True, activation='sigmoid')), (11, 5, 1), 44, None
+
+
+@pytest.mark.parametrize('kind', ['f16s', 'f16', 'auto'])
+def test_a_layer_program_of_the_callers_own(ctx, kind):
+    """the graph executor is keyed on layer kinds and widths, not on factory names"""
+    tile, off, shape = 44, 5, (60, 44, 77)
+    g = _custom_graph(tile)[0]
+    synth.synthetic_weights(g, 17)
+    prog = _capi.Program(ctx, g, (1, 1, 1))
+    u8 = synth.em_volume_u8(3, shape)
+    img = (u8.astype(np.float32) - np.float32(128)) / np.float32(33)
+    ref = _oracle(g, img, tile, off, (1, 1, 1))
+    ctx.timing(True)
+    ctx.timing_reset()
+    got = prog.infer_volume(u8, (tile,) * 3, (off,) * 3, mean=128.0, std=33.0, precision=PREC[kind])
+    names = set(ctx.timing_get())
+    ctx.timing(False)
+    assert ctx.last_path() == ('graph_mfma_f16' if kind == 'f16' else 'graph_split_f16')
+    assert {'gx_stem_conv3', 'gx_add', 'gx_head', 'gx_conv1', 'gx_conv3_32', 'gx_conv3_64'} <= names, names
+    d = np.abs(got - ref)
+    assert d.max() < TOL['f16' if kind == 'f16' else 'f16s'], d.max()
+    assert ref[off:-off, off:-off, off:-off].std() > 1e-4
