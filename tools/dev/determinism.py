@@ -6,10 +6,15 @@ sys.path.insert(0, '.')
 from flypylib_amd import _capi, fplmodels, synth, runtime
 ctx = runtime.get_context(0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-for name, fac, tile, off, n in (('vgg_like', fplmodels.vgg_like, 102, 7, 768), ('unet_like2', fplmodels.unet_like2, 100, 9, 346)):
+from flypylib_amd import fplutils
+CASES = [('vgg_like', fplmodels.vgg_like, 102, 7, 768), ('unet_like2', fplmodels.unet_like2, 100, 9, 346),
+         # the graph executor (csrc/gx_exec.h)
+         ('baseline_model', fplmodels.baseline_model, 102, 7, 454), ('resnet_like', fplmodels.resnet_like, 102, 7, 454),
+         ('unet_like4b', fplmodels.unet_like4b, 100, 17, 298), ('unet_like_vol', fplmodels.unet_like_vol, 102, 6, 282)]
+for name, fac, tile, off, n in CASES:
     g = fac(tile)[0]
     synth.synthetic_weights(g, 5)
-    prog = _capi.Program(ctx, g, (4, 4, 4) if name == 'vgg_like' else (1, 1, 1))
+    prog = _capi.Program(ctx, g, fplutils.to3d(fac()[1][2]))
     dims = (n,) * 3
     src = ctx.malloc(dims, np.uint8); ctx.synth_volume_u8(3, dims, out=src)
     dst = ctx.malloc(dims, np.float32)
