@@ -92,7 +92,7 @@ def main():
     ap.add_argument('--precision', default='bf16')
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--groups', default=','.join(GROUPS))
-    ap.add_argument('--target', default='bench', choices=['bench', 'unet', 'v2o'],
+    ap.add_argument('--target', default='bench', choices=['bench', 'unet', 'v2o', 'graphs'],
                     help="bench = bench.py (vgg_like); unet = tools/bench_configs.py "
                          "--what unet --unet-size SIZE; v2o = tools/bench_v2o.py --sub SIZE")
     a = ap.parse_args()
@@ -104,6 +104,9 @@ def main():
     if a.target == 'unet':
         script = os.path.join('tools', 'bench_configs.py')
         bench_args = ['--what', 'unet', '--unet-size', str(a.size)]
+    if a.target == 'graphs':           # the graph executor's four factories ('auto', f16, f32 in turn)
+        script = os.path.join('tools', 'bench_configs.py')
+        bench_args = ['--what', 'graphs']
     if a.target == 'v2o':
         script = os.path.join('tools', 'bench_v2o.py')
         bench_args = ['--sub', str(a.size), '--reps', str(a.steps)]
