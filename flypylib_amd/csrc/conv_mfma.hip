@@ -701,6 +701,13 @@ struct Conv1Args {
   float *out_f32;                // TAIL: (M) sigmoid probabilities
   unsigned *flag;                // split build: half-range guard
   int relu;                      // TAIL == 0: ReLU in front of the store (0: a convolution without activation)
+  // residual form (gx_exec.h; resnet_like's shortcuts): out = act(crop_ocrop(conv1(x)) + add[.. + acrop]) -
+  // the input voxels are n tiles of din^3, the output tensor n tiles of dout^3 = (din - 2 ocrop)^3 (chunk
+  // plane `oplane`), the operand n tiles of da^3 (chunk plane `aplane`) read at output coordinates + acrop.
+  // add == nullptr: the plain form (out at the input's voxel index, plane `plane`)
+  const h16_t *add = nullptr;
+  int64_t aplane = 0, oplane = 0;
+  int din = 0, dout = 0, da = 0, ocrop = 0, acrop = 0;
 };
 
 template <int CIN, int MB, int TAIL>
@@ -750,7 +757,31 @@ __global__ __launch_bounds__(256) void FPLK(conv1)(Conv1Args a) {
                           bf[s], acc[b]);
       }
     }
-    if (TAIL == 0) {
+    if (TAIL == 0 && a.add) {
+      // the voxel's place in its tile, the output's and the operand's
+      int64_t t = m;
+      const int x = (int)(t % a.din); t /= a.din;
+      const int y = (int)(t % a.din); t /= a.din;
+      const int z = (int)(t % a.din); t /= a.din;
+      const int ox = x - a.ocrop, oy = y - a.ocrop, oz = z - a.ocrop;
+      const bool in = ok && ox >= 0 && oy >= 0 && oz >= 0 && ox < a.dout && oy < a.dout && oz < a.dout;
+      if (in) {
+        const int64_t ov = ((t * a.dout + oz) * a.dout + oy) * (int64_t)a.dout + ox;
+        const int64_t av = ((t * a.da + oz + a.acrop) * a.da + oy + a.acrop) * (int64_t)a.da + ox + a.acrop;
+#pragma unroll
+        for (int h = 0; h < MB / 2; ++h) {               // the lane's channels [4 MB g + 8 h, + 8): one 16-B piece (and its lo)
+          const int ch = 4 * MB * g + 8 * h;
+          const h16_t *pa = a.add + (ch / RCH) * a.aplane + av * CC + ch % RCH;
+          const h16x8 hi = *reinterpret_cast<const h16x8 *>(pa);
+          h16x8 lo = hi;
+          if (SPLIT) lo = *reinterpret_cast<const h16x8 *>(pa + 16);
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            acc[2 * h + (q >> 2)][q & 3] += SPLIT ? (float)hi[q] + (float)lo[q] : (float)hi[q];
+        }
+        store_il<MB, false>(a.out + ov * CC, a.oplane, g, acc, a.relu, ovf);
+      }
+    } else if (TAIL == 0) {
       if (ok) store_il<MB, false>(a.out + m * CC, a.plane, g, acc, a.relu, ovf);
     } else {
       // chained 16*MB -> 1 conv (k-slots bound to the accumulator layout), sigmoid

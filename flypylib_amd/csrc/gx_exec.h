@@ -155,6 +155,29 @@ int gx_chain_head(const fpl_program *prog, const GxPlan &pl, int i) {
   return j;
 }
 
+// A 1x1x1 convolution without activation whose (possibly cropped) output is read by ONE Add and nothing else,
+// the Add's other operand computed earlier: the Add (and its ReLU) ride in the convolution's epilogue
+// (resnet_like's two shortcuts).  Returns the Add's op index, or -1; *self = 0 / 1: which operand the conv is
+int gx_fuse_add(const fpl_program *prog, const GxPlan &pl, int i, int *self) {
+  const fpl_op &op = prog->ops[i];
+  if (op.kind != FPL_OP_CONV || op.k != 1 || op.cout == 1 || op.act != FPL_ACT_NONE || pl.users[op.dst].size() != 1) return -1;
+  int u = pl.users[op.dst][0];
+  if (prog->ops[u].kind == FPL_OP_CROP) {                   // conv -> crop -> add
+    if (pl.users[prog->ops[u].dst].size() != 1) return -1;
+    u = pl.users[prog->ops[u].dst][0];
+  }
+  const fpl_op &ad = prog->ops[u];
+  if (ad.kind != FPL_OP_ADD) return -1;
+  std::vector<GxView> a, b;
+  if (!gx_views(prog, pl, ad.src0, &a) || !gx_views(prog, pl, ad.src1, &b) || a.size() != 1 || b.size() != 1) return -1;
+  const int me = a[0].base == op.dst ? 0 : b[0].base == op.dst ? 1 : -1;
+  if (me < 0 || a[0].base == b[0].base) return -1;
+  const GxView &other = me == 0 ? b[0] : a[0];
+  if (other.ups || other.base == 0 || pl.prod[other.base] >= i) return -1;      // must exist when this conv runs
+  *self = me;
+  return u;
+}
+
 // the layer programs this executor takes (everything match_unet does not)
 bool gx_match(const fpl_program *prog) {
   if (prog->ops.empty() || prog->n_tensors < 2) return false;
@@ -840,14 +863,34 @@ int gx_forward(fpl_ctx *ctx, fpl_program *prog, const float *in, int n, int T, f
         } else {                                           // 1x1x1 convolution
           int b;
           FPL_REQUIRE(ctx, gx_plain(prog, pl, op.src0, &b) && buf[b], "gx: conv1 input");
-          FPL_TRY(balloc(op.dst));
+          int me = 0;
+          const int fa = gx_fuse_add(prog, pl, (int)i, &me);
           Conv1Args a;
           a.in = buf[b]; a.M = (int64_t)n * cube(dim[b]); a.plane = a.M * CC;
-          a.w = F + cw.off_w; a.shift = S + cw.off_s; a.out = buf[op.dst];
+          a.w = F + cw.off_w; a.shift = S + cw.off_s;
           a.w_tail = nullptr; a.bias_tail = 0.f; a.out_f32 = nullptr; a.flag = flag;
           a.relu = op.act == FPL_ACT_RELU;
           FPL_REQUIRE(ctx, dim[b] == dim[op.dst] && cp[b] == cw.cin_p, "gx: conv1 shapes");
-          TimedLaunch tl(ctx, "gx_conv1");
+          if (fa >= 0) {                                    // out = act(crop(conv1(x)) + other): the Add in the epilogue
+            const fpl_op &ad = prog->ops[fa];
+            std::vector<GxView> va, vb;
+            gx_views(prog, pl, ad.src0, &va);
+            gx_views(prog, pl, ad.src1, &vb);
+            const GxView &mine = me == 0 ? va[0] : vb[0], &other = me == 0 ? vb[0] : va[0];
+            FPL_REQUIRE(ctx, buf[other.base], "gx: add operand not computed");
+            FPL_TRY(balloc(ad.dst));
+            FPL_REQUIRE(ctx, cp[ad.dst] == cw.cout_p && cp[other.base] == cw.cout_p, "gx: fused add widths");
+            a.out = buf[ad.dst]; a.oplane = plane(ad.dst);
+            a.add = buf[other.base]; a.aplane = plane(other.base);
+            a.din = dim[b]; a.dout = dim[ad.dst]; a.da = dim[other.base]; a.ocrop = mine.crop; a.acrop = other.crop;
+            FPL_REQUIRE(ctx, a.din - 2 * a.ocrop == a.dout && a.da - 2 * a.acrop == a.dout, "gx: fused add shapes");
+            a.relu = ad.act == FPL_ACT_RELU;
+            done[fa] = 1;
+          } else {
+            FPL_TRY(balloc(op.dst));
+            a.out = buf[op.dst];
+          }
+          TimedLaunch tl(ctx, fa >= 0 ? "gx_conv1_add" : "gx_conv1");
           const int key = cw.cin_p * 1000 + cw.cout_p;
           switch (key) {
             case 32032: gx_launch_conv1<32, 2>(ctx, a); break;

@@ -55,6 +55,8 @@ def _check(ctx, name, tile, shape, kind):
     names = set(ctx.timing_get())
     ctx.timing(False)
     want_path = 'graph_split_f16' if kind in ('f16s', 'auto') else 'graph_mfma_' + kind
+    if name == 'resnet_like':
+        assert 'gx_conv1_add' in names and 'gx_add' not in names, names      # both shortcuts in conv1 epilogues
     assert ctx.last_path() == want_path and any(k.startswith('gx_stem_conv3') for k in names) and ('gx_head' in names or 'gx_conv3_32_head' in names), \
         (ctx.last_path(), names)
     assert got.shape == shape and not got[:off].any() and not got[:, :, -off:].any()
@@ -135,8 +137,8 @@ def _custom_graph(in_sz=None):
     y = g.conv_bn_relu(y, 48, 1)
     u = g.concat(g.up(y, 2), g.crop(x, 2))       # T - 8, 48 + 48 channels
     z = g.conv_bn_relu(u, 32, 3)                 # T - 10
-    a = g.bn(g.conv(z, 32, 1))
-    r = g.relu(g.add(a, z))
+    a = g.conv_bn_relu(z, 32, 1)                 # (an activation in front of the Add: the stand-alone Add kernel;
+    r = g.relu(g.add(a, z))                      #  resnet_like's shortcuts take the fused conv1 + Add epilogue)
     return g.finish(g.conv(r, 1, 1, use_bias=True, activation='sigmoid')), (11, 5, 1), 44, None
 
 
