@@ -162,3 +162,49 @@ def test_a_layer_program_of_the_callers_own(ctx, kind):
     d = np.abs(got - ref)
     assert d.max() < TOL['f16' if kind == 'f16' else 'f16s'], d.max()
     assert ref[off:-off, off:-off, off:-off].std() > 1e-4
+
+
+@pytest.mark.parametrize('name,tiles', [('baseline_model', 6), ('unet_like_vol', 4)])
+def test_graph_executor_at_full_size_properties(ctx, name, tiles):
+    """the bench legs' volumes (542^3 / 372^3) on the default path: (a) two and three Z slabs of tile rows ==
+    the whole volume, bit for bit (super-tiles or not); (b) a zero rf_offset shell; (c) three reference tiles
+    (corner, interior, far corner) within 1e-5 of the fp32 oracle"""
+    from flypylib_amd import multi_gpu
+    factory = getattr(fplmodels, name)
+    _, rf, infer_sz, _ = factory()
+    tile, off, stride = fplutils.to3d(infer_sz)[0], fplutils.to3d(rf[1])[0], fplutils.to3d(rf[2])
+    pitch = tile - 2 * off
+    n = tiles * pitch + 2 * off
+    g = factory(tile)[0]
+    synth.synthetic_weights(g, 1234)
+    prog = _capi.Program(ctx, g, stride)
+    src = ctx.malloc((n, n, n), np.uint8)
+    ctx.synth_volume_u8(20250101, (n, n, n), out=src)
+    dst = ctx.malloc((n, n, n), np.float32)
+    kw = dict(mean=128.0, std=33.0, precision=_capi.PREC_AUTO, dims=(n, n, n))
+    prog.infer_volume(src, (tile,) * 3, (off,) * 3, dst=dst, **kw)
+    assert ctx.last_path() == 'graph_split_f16'
+    whole = dst.to_host()
+    for ax in range(3):
+        lo = [slice(None)] * 3
+        hi = [slice(None)] * 3
+        lo[ax], hi[ax] = slice(0, off), slice(n - off, n)
+        assert not whole[tuple(lo)].any() and not whole[tuple(hi)].any()
+    assert whole[off:-off, off:-off, off:-off].std() > 1e-4
+    rows = multi_gpu.n_tile_rows(n, tile, off)
+    dst2 = ctx.malloc((n, n, n), np.float32)
+    for parts in (2, 3):
+        for zr in multi_gpu.slab_partition(rows, parts):
+            prog.infer_volume(src, (tile,) * 3, (off,) * 3, dst=dst2, z_range=zr, **kw)
+        assert np.array_equal(dst2.to_host()[off:n - off], whole[off:n - off]), parts
+    u8 = src.to_host()
+    last = (tiles - 1) * pitch
+    for org in ((0, 0, 0), (2 * pitch, 3 * pitch, pitch), (last, last, last)):
+        sl = tuple(slice(o, o + tile) for o in org)
+        img = (u8[sl].astype(np.float32) - np.float32(128)) / np.float32(33)
+        ref = _oracle(g, img, tile, off, stride)
+        d = np.abs(whole[sl][off:-off, off:-off, off:-off] - ref[off:-off, off:-off, off:-off])
+        assert d.max() < 1e-5, (org, d.max())
+    for b in (src, dst, dst2):
+        b.free()
+    prog.close()
