@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/fplhip.h"
@@ -61,7 +62,7 @@ struct V2oState {
 // a training tensor restated as planar split halves (conv_mfma.hip, split build): made by the
 // forward / input-gradient convolution of a step, read again by the weight-gradient kernel
 struct FplSplitCopy {
-  const void *key; int n, D, pad;      // the fp32 tensor (device pointer), patches, edge, zero shell
+  const void *key; int n, D, pad, C;   // the fp32 tensor (device pointer), patches, edge, zero shell, channels
   unsigned char *planar; float *sc;    // the copy (x s) and [s, 1 / s]
   int64_t part;                        // bytes of one plane
 };
@@ -69,6 +70,7 @@ struct FplSplitCopy {
 struct fpl_ctx {
   int device = 0;
   std::vector<FplSplitCopy> split_copies;   // valid within one training step (fpl_tm_split_reset)
+  std::vector<std::pair<const void *, unsigned *>> split_wmax;   // ... and the maxima of the weight sets seen in it
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   char err[FPL_MAX_ERR] = {0};

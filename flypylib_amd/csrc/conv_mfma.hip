@@ -1857,8 +1857,11 @@ __global__ void ts_maxabs(const float *__restrict__ x, int64_t n, unsigned *out)
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
-// sc[0] = s (a power of two with max s in [2^(t-1), 2^t)), sc[1] = 1 / s; sc[2] (if `other`) = 1 / (s other_s)
-__global__ void ts_scale(const unsigned *maxbits, int t, float *sc, const float *other) {
+// s = the power of two with max s in [2^(t-1), 2^t).  Every thread of the consumer kernels derives it from the
+// maximum's bits itself (a one-thread kernel in between is a launch per tensor and per weight set, and the U-Net's
+// small layers are nothing but launches); thread 0 of block 0 publishes sc[0] = s, sc[1] = 1 / s, sc[2] (if
+// `other`) = 1 / (s other_s) for the kernels behind them
+__device__ __forceinline__ float ts_scale_of(const unsigned *maxbits, int t) {
   const float m = __builtin_bit_cast(float, *maxbits);
   int e = 0;
   float s = 1.f;
@@ -1868,19 +1871,25 @@ __global__ void ts_scale(const unsigned *maxbits, int t, float *sc, const float 
     e = e < -100 ? -100 : e > 100 ? 100 : e;
     s = ldexpf(1.f, e);
   }
-  sc[0] = s;
-  sc[1] = 1.f / s;
-  if (other) sc[2] = (1.f / s) * other[1];
+  return s;
 }
-// x (n, D, H, W, C = 48) fp32 -> planar split tensor of n tiles (D + 2 pad)^3..., 6 passes, values x s.
-// One thread per voxel: its 192 B read once (a thread per voxel AND pass fetched every line six times),
-// twelve 16-B stores, each a coalesced stream over the wave's consecutive voxels.
-__global__ void ts_to_planar(const float *__restrict__ x, int n, int D, int H, int W, int pad, const float *sc,
-                             unsigned char *out, int64_t part) {
-  constexpr int C = 48;
+__device__ __forceinline__ void ts_publish(float s, float *sc, const float *other) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sc[0] = s;
+    sc[1] = 1.f / s;
+    if (other) sc[2] = (1.f / s) * other[1];
+  }
+}
+// x (n, D, H, W, C) fp32, C a multiple of 16 -> planar split tensor of n tiles (D + 2 pad)^3, C / 8 passes, values
+// x s.  One thread per voxel walks its channels 16 at a time (64 B reads: the voxel's lines stay in L1 across
+// the steps; a thread per voxel AND pass fetched every line C / 8 times), four 16-B stores per step, each a
+// coalesced stream over the wave's consecutive voxels.
+__global__ void ts_to_planar(const float *__restrict__ x, int n, int D, int H, int W, int C, int pad,
+                             const unsigned *maxbits, float *sc, unsigned char *out, int64_t part) {
   const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int64_t nv = (int64_t)n * Dp * Hp * Wp;
-  const float s = sc[0];
+  const float s = ts_scale_of(maxbits, 11);
+  ts_publish(s, sc, nullptr);
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
     const int xx = (int)(v % Wp) - pad;
     int64_t t = v / Wp;
@@ -1889,37 +1898,43 @@ __global__ void ts_to_planar(const float *__restrict__ x, int n, int D, int H, i
     const int zz = (int)(t % Dp) - pad, b = (int)(t / Dp);
     const bool in = zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
     const float *q = x + ((((int64_t)b * D + zz) * H + yy) * W + xx) * C;
-    f32x4 a[C / 4];
+    for (int c0 = 0; c0 < C; c0 += 16) {
+      f32x4 a[4];
 #pragma unroll
-    for (int i = 0; i < C / 4; ++i) a[i] = in ? *reinterpret_cast<const f32x4 *>(q + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) a[i] = in ? *reinterpret_cast<const f32x4 *>(q + c0 + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < C / 8; ++p) {
-      unsigned dummy = 0u;
-      const f32x4 a0 = a[2 * p], a1 = a[2 * p + 1];
-      const Pair2 p0 = split_pk_signed(a0[0] * s, a0[1] * s, dummy), p1 = split_pk_signed(a0[2] * s, a0[3] * s, dummy);
-      const Pair2 p2 = split_pk_signed(a1[0] * s, a1[1] * s, dummy), p3 = split_pk_signed(a1[2] * s, a1[3] * s, dummy);
-      unsigned char *d = out + (int64_t)p * 2 * part + v * 16;
-      *reinterpret_cast<u32x4 *>(d) = u32x4{p0.hi, p1.hi, p2.hi, p3.hi};
-      *reinterpret_cast<u32x4 *>(d + part) = u32x4{p0.lo, p1.lo, p2.lo, p3.lo};
+      for (int pp = 0; pp < 2; ++pp) {
+        unsigned dummy = 0u;
+        const f32x4 a0 = a[2 * pp], a1 = a[2 * pp + 1];
+        const Pair2 p0 = split_pk_signed(a0[0] * s, a0[1] * s, dummy), p1 = split_pk_signed(a0[2] * s, a0[3] * s, dummy);
+        const Pair2 p2 = split_pk_signed(a1[0] * s, a1[1] * s, dummy), p3 = split_pk_signed(a1[2] * s, a1[3] * s, dummy);
+        unsigned char *d = out + (int64_t)(c0 / 8 + pp) * 2 * part + v * 16;
+        *reinterpret_cast<u32x4 *>(d) = u32x4{p0.hi, p1.hi, p2.hi, p3.hi};
+        *reinterpret_cast<u32x4 *>(d + part) = u32x4{p0.lo, p1.lo, p2.lo, p3.lo};
+      }
     }
   }
 }
-// W fp32 [27][cin][cout] (Keras order) -> the kernel's stream [pass][K-step][hi MB | lo MB][lane][8], MB = 3,
-// interleaved rows, values W s_w; dgrad: the transposed convolution's weights W'[tap][co][ci] = W[26 - tap][ci][co]
-__global__ void ts_pack_w(const float *__restrict__ Wd, int cin, int cout, int dgrad, const float *sc, unsigned short *out,
-                          int64_t total) {
+// W fp32 [27][cin][cout] (Keras order) -> the kernel's stream [pass][K-step][hi MB | lo MB][lane][8] for the MB
+// output blocks [co0, co0 + 16 MB) of THIS product (forward: outputs = cout, inputs = cin; input gradient: the
+// transposed convolution, outputs = cin, inputs = cout, weights W'[tap][co][ci] = W[26 - tap][ci][co]),
+// interleaved rows, values W s_w
+__global__ void ts_pack_w(const float *__restrict__ Wd, int cin, int cout, int dgrad, int co0, int MB,
+                          const unsigned *maxbits, float *sc, const float *xsc, unsigned short *out, int64_t total) {
+  const float sw = ts_scale_of(maxbits, 6);
+  ts_publish(sw, sc, xsc);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
   int64_t t = i >> 9;
-  const int b = (int)(t % 3); t /= 3;
+  const int b = (int)(t % MB); t /= MB;
   const int set = (int)(t & 1); t >>= 1;
   const int s = (int)(t % u8::KP), p = (int)(t / u8::KP);
   const int m = lane & 15, g = lane >> 4, tap = 4 * s + g;
-  const int ko = 12 * (m >> 2) + 4 * b + (m & 3), ki = 8 * p + j;       // output / input channel of THIS product
+  const int ko = co0 + 4 * MB * (m >> 2) + 4 * b + (m & 3), ki = 8 * p + j;   // output / input channel of THIS product
   float v = 0.f;
   if (tap < 27) v = dgrad ? Wd[((size_t)(26 - tap) * cin + ko) * cout + ki] : Wd[((size_t)tap * cin + ki) * cout + ko];
-  v *= sc[0];
+  v *= sw;
   const h16_t h = (h16_t)v;
   out[i] = set ? h16_bits(v - (float)h) : h16_bits(v);
 }
@@ -2088,31 +2103,30 @@ __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
 
 // the planar split copy of a training tensor (x s, s a power of two from the tensor's maximum), made once per
 // step and kept in the context: forward leaves x's, the weight gradient dy's (which the input gradient reuses)
-int split_copy(fpl_ctx *ctx, const float *x, int n, int D, int pad, FplSplitCopy *out) {
+int split_copy(fpl_ctx *ctx, const float *x, int n, int D, int pad, int C, FplSplitCopy *out) {
   for (const FplSplitCopy &e : ctx->split_copies)
-    if (e.key == x && e.n == n && e.D == D && e.pad == pad) { *out = e; return 0; }
+    if (e.key == x && e.n == n && e.D == D && e.pad == pad && e.C == C) { *out = e; return 0; }
   hipStream_t st = ctx->stream;
-  const int C = 48, Dp = D + 2 * pad;
+  const int Dp = D + 2 * pad;
   FplSplitCopy e;
-  e.key = x; e.n = n; e.D = D; e.pad = pad;
+  e.key = x; e.n = n; e.D = D; e.pad = pad; e.C = C;
   const int64_t nv = (int64_t)n * Dp * Dp * Dp;
   e.part = nv * 16;
   void *q;
   const size_t slack = ((size_t)6 * Dp * Dp + 40 * Dp + 64) * 16;
-  FPL_TRY(fpl_dev_alloc(ctx, (size_t)(C / 8) * 2 * e.part + slack, &q));
+  const size_t planes = ((size_t)(C / 8) * 2 * e.part + slack + 63) / 64 * 64;
+  FPL_TRY(fpl_dev_alloc(ctx, planes + 64, &q));
   e.planar = (unsigned char *)q;
   // the read slack behind the last plane is ZERO: the weight-gradient kernel sums over voxels, and a row's
-  // 32-voxel K-step runs past short rows (times masked-out gradients - but 0 x NaN is NaN)
-  FPL_HIP(ctx, hipMemsetAsync(e.planar + (size_t)(C / 8) * 2 * e.part, 0, slack, st));
-  FPL_TRY(fpl_dev_alloc(ctx, 64, &q));
-  e.sc = (float *)q;                              // [0] s, [1] 1 / s; [4] (as unsigned) the maximum's bits
-  unsigned *maxbits = (unsigned *)q + 4;
-  FPL_HIP(ctx, hipMemsetAsync(maxbits, 0, 4, st));
+  // 32-voxel K-step runs past short rows (times masked-out gradients - but 0 x NaN is NaN).  The scale record
+  // sits behind it (one memset for both): [0] s, [1] 1 / s; [4] (as unsigned) the maximum's bits
+  e.sc = (float *)(e.planar + planes);
+  unsigned *maxbits = (unsigned *)e.sc + 4;
+  FPL_HIP(ctx, hipMemsetAsync(e.planar + (size_t)(C / 8) * 2 * e.part, 0, planes + 64 - (size_t)(C / 8) * 2 * e.part, st));
   const int64_t nx = (int64_t)n * D * D * D * C;
   ts_maxabs<<<(unsigned)std::min<int64_t>(ceil_div64(nx, 1024), (int64_t)ctx->n_cu * 8), 256, 0, st>>>(x, nx, maxbits);
-  ts_scale<<<1, 1, 0, st>>>(maxbits, 11, e.sc, nullptr);
   ts_to_planar<<<(unsigned)std::min<int64_t>(ceil_div64(nv, 256), (int64_t)ctx->n_cu * 16), 256, 0, st>>>(
-      x, n, D, D, D, pad, e.sc, e.planar, e.part);
+      x, n, D, D, D, C, pad, maxbits, e.sc, e.planar, e.part);
   ctx->split_copies.push_back(e);
   *out = e;
   return 0;
@@ -2121,60 +2135,83 @@ int split_copy(fpl_ctx *ctx, const float *x, int n, int D, int pad, FplSplitCopy
 }  // namespace
 
 void fpl_tm_split_reset(fpl_ctx *ctx) {
-  for (FplSplitCopy &e : ctx->split_copies) {
-    fpl_dev_release(ctx, e.planar);
-    fpl_dev_release(ctx, e.sc);
-  }
+  for (FplSplitCopy &e : ctx->split_copies) fpl_dev_release(ctx, e.planar);      // (the scale record lives inside it)
   ctx->split_copies.clear();
+  for (auto &w : ctx->split_wmax) fpl_dev_release(ctx, w.second);
+  ctx->split_wmax.clear();
 }
 
-bool fpl_tm_conv3_split_supported(int k, int cin, int cout) { return k == 3 && cin == 48 && cout == 48; }
+// forward / input gradient on split halves: 3x3x3, both channel counts multiples of 16 from 32 up to 192 (inputs
+// are passes of 8 channels, at most u8::MAXPASS; outputs go 64 / 48 / 32 to a launch)
+bool fpl_tm_conv3_split_supported(int k, int cin, int cout) {
+  auto ok = [](int c) { return c >= 32 && c % 16 == 0 && c <= 8 * u8::MAXPASS; };
+  return k == 3 && ok(cin) && ok(cout);
+}
+// the weight gradient's kernel is written for 48 -> 48
+bool fpl_tm_conv3_wgrad_split_supported(int k, int cin, int cout) { return k == 3 && cin == 48 && cout == 48; }
 
-// forward: x (n, D, H, W, 48) -> y (n, D - 2, H - 2, W - 2, 48) = conv3(x, Wd) + bias
-// dgrad:   x = dy (n, D, H, W, 48) -> y = dx (n, D + 2, H + 2, W + 2, 48) (bias = zeros)
-int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, const float *Wd, const float *bias,
-                       int dgrad, int relu, float *y) {
-  const int C = 48, pad = dgrad ? 2 : 0;
+// forward: x (n, D, H, W, cin) -> y (n, D - 2, H - 2, W - 2, cout) = conv3(x, Wd) + bias
+// dgrad:   x = dy (n, D, H, W, cout) -> y = dx (n, D + 2, H + 2, W + 2, cin) (bias = zeros)
+int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int cout, const float *Wd,
+                       const float *bias, int dgrad, int relu, float *y) {
+  const int Ci = dgrad ? cout : cin, Co = dgrad ? cin : cout, pad = dgrad ? 2 : 0;
   FPL_REQUIRE(ctx, D == H && H == W_, "conv3 (split training): cubic patches only");
+  FPL_REQUIRE(ctx, fpl_tm_conv3_split_supported(3, cin, cout), "conv3 (split training): %d -> %d channels", cin, cout);
   const int Dp = D + 2 * pad;
   DevTemp tmp(ctx);
   hipStream_t st = ctx->stream;
   FplSplitCopy xc;
   {
     TimedLaunch tl(ctx, "train_split_prepare");
-    FPL_TRY(split_copy(ctx, x, n, D, pad, &xc));
+    FPL_TRY(split_copy(ctx, x, n, D, pad, Ci, &xc));
   }
   void *q;
   FPL_TRY(tmp.alloc(64, &q));
-  unsigned *wmax = (unsigned *)q;
-  float *scw = (float *)q + 4;                   // [0] s_w, [1] 1 / s_w, [2] 1 / (s_w s_x)
-  const int64_t wtotal = (int64_t)(C / 8) * u8::KP * 2 * 3 * 512;
-  FPL_TRY(tmp.alloc((size_t)wtotal * 2, &q));
-  unsigned short *wstream = (unsigned short *)q;
-  FPL_HIP(ctx, hipMemsetAsync(wmax, 0, 4, st));
-  {
+  float *scw = (float *)q;                       // [0] s_w, [1] 1 / s_w, [2] 1 / (s_w s_x): published by ts_pack_w
+  // the maximum of a weight tensor: once per step (the forward's and the input gradient's sets scale alike)
+  unsigned *wmax = nullptr;
+  for (auto &w : ctx->split_wmax) if (w.first == Wd) wmax = w.second;
+  if (!wmax) {
+    FPL_TRY(fpl_dev_alloc(ctx, 64, &q));
+    wmax = (unsigned *)q;
+    ctx->split_wmax.emplace_back((const void *)Wd, wmax);
+    FPL_HIP(ctx, hipMemsetAsync(wmax, 0, 4, st));
     TimedLaunch tl(ctx, "train_split_prepare");
-    ts_maxabs<<<8, 256, 0, st>>>(Wd, (int64_t)27 * C * C, wmax);
-    ts_scale<<<1, 1, 0, st>>>(wmax, 6, scw, xc.sc);
-    ts_pack_w<<<(unsigned)ceil_div64(wtotal, 256), 256, 0, st>>>(Wd, C, C, dgrad, scw, wstream, wtotal);
+    ts_maxabs<<<8, 256, 0, st>>>(Wd, (int64_t)27 * cin * cout, wmax);
   }
-  u8::U3Args a;
-  memset(&a, 0, sizeof(a));
-  for (int p = 0; p < C / 8; ++p) a.src[p] = xc.planar + (int64_t)p * 2 * xc.part;
-  a.npass = C / 8; a.nups = 0;
-  a.PD = Dp; a.PH = Dp; a.PW = Dp; a.Ppart = (unsigned)xc.part;
-  a.UD = a.UH = a.UW = 1;
-  a.w = (const unsigned char *)wstream;
-  a.shift = bias;
-  a.relu = relu;
-  a.OD = Dp - 2; a.OH = Dp - 2; a.OW = Dp - 2;
-  a.keep_lo = 0; a.keep_hi = a.OD;
-  a.n_tiles = n;
-  a.out32 = y; a.opitch = C; a.unscale = scw + 2;
-  // rows per block: 10 where they divide the layer better (29 -> 30), else 8
-  const int w10 = (int)ceil_div64(a.OH, 10) * 10, w8 = (int)ceil_div64(a.OH, 8) * 8;
-  if (w10 < w8) return launch_u3<3, 5, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, dgrad ? "split_conv3_dgrad" : "split_conv3_fwd");
-  return launch_u3<3, 4, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, dgrad ? "split_conv3_dgrad" : "split_conv3_fwd");
+  for (int co0 = 0; co0 < Co;) {                 // 64, 48 or 32 output channels per launch
+    const int rem = Co - co0, MB = rem >= 64 ? 4 : rem / 16;
+    FPL_REQUIRE(ctx, MB >= 2 && MB <= 4, "conv3 (split training): %d output channels left", rem);
+    const int64_t wtotal = (int64_t)(Ci / 8) * u8::KP * 2 * MB * 512;
+    FPL_TRY(tmp.alloc((size_t)wtotal * 2, &q));
+    unsigned short *wstream = (unsigned short *)q;
+    {
+      TimedLaunch tl(ctx, "train_split_prepare");
+      ts_pack_w<<<(unsigned)ceil_div64(wtotal, 256), 256, 0, st>>>(Wd, cin, cout, dgrad, co0, MB, wmax, scw, xc.sc, wstream, wtotal);
+    }
+    u8::U3Args a;
+    memset(&a, 0, sizeof(a));
+    for (int p = 0; p < Ci / 8; ++p) a.src[p] = xc.planar + (int64_t)p * 2 * xc.part;
+    a.npass = Ci / 8; a.nups = 0;
+    a.PD = Dp; a.PH = Dp; a.PW = Dp; a.Ppart = (unsigned)xc.part;
+    a.UD = a.UH = a.UW = 1;
+    a.w = (const unsigned char *)wstream;
+    a.shift = bias + co0;
+    a.relu = relu;
+    a.OD = Dp - 2; a.OH = Dp - 2; a.OW = Dp - 2;
+    a.keep_lo = 0; a.keep_hi = a.OD;
+    a.n_tiles = n;
+    a.out32 = y + co0; a.opitch = Co; a.unscale = scw + 2;
+    // rows per block: 10 where they divide the layer better (29 -> 30, 20 -> 20), else 8
+    const int w10 = (int)ceil_div64(a.OH, 10) * 10, w8 = (int)ceil_div64(a.OH, 8) * 8;
+    const char *name = dgrad ? "split_conv3_dgrad" : "split_conv3_fwd";
+    const bool r5 = w10 < w8;
+    if (MB == 2) FPL_TRY(r5 ? (launch_u3<2, 5, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, name)) : (launch_u3<2, 4, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, name)));
+    else if (MB == 3) FPL_TRY(r5 ? (launch_u3<3, 5, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, name)) : (launch_u3<3, 4, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, name)));
+    else FPL_TRY((launch_u3<4, 4, u8::UM_NONE, u8::EPI_F32>(ctx, a, 0, name)));
+    co0 += 16 * MB;
+  }
+  return 0;
 }
 
 // dw [27][48][48] += weight gradient of the valid conv3: x (n, D^3, 48), dy (n, (D - 2)^3, 48)
@@ -2182,8 +2219,8 @@ int fpl_tm_conv3_wgrad_split(fpl_ctx *ctx, const float *x, int n, int D, const f
   FplSplitCopy xc, yc;
   {
     TimedLaunch tl(ctx, "train_split_prepare");
-    FPL_TRY(split_copy(ctx, x, n, D, 0, &xc));
-    FPL_TRY(split_copy(ctx, dy, n, D - 2, 2, &yc));
+    FPL_TRY(split_copy(ctx, x, n, D, 0, 48, &xc));
+    FPL_TRY(split_copy(ctx, dy, n, D - 2, 2, 48, &yc));
   }
   WgArgs a;
   a.xp = xc.planar; a.yp = yc.planar;

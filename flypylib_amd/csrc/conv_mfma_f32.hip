@@ -1845,7 +1845,7 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
   // 48 -> 48: split halves (FPL_TRAIN_F32CONV=1: the fp32 MFMA kernel, A/B)
   if (fpl_tm_conv3_split_supported(k, cin, cout) && D == H && H == W_ && (act == FPL_ACT_NONE || act == FPL_ACT_RELU) &&
       !getenv("FPL_TRAIN_F32CONV"))
-    return fpl_tm_conv3_split(ctx, x, n, D, H, W_, Wd, bias, 0, act == FPL_ACT_RELU, y);
+    return fpl_tm_conv3_split(ctx, x, n, D, H, W_, cin, cout, Wd, bias, 0, act == FPL_ACT_RELU, y);
   const int ncc = (cin + 15) / 16, k3 = k * k * k;
   const int64_t tot = (int64_t)ncc * k3 * mb * 256;
   FPL_TRY(tmp.alloc(tot * 4, &fr));
@@ -1923,7 +1923,7 @@ int fpl_tm_conv_dgrad(fpl_ctx *ctx, const float *dy, int n, int od, int oh, int 
     return fpl_fail(ctx, "conv1 dgrad with %d channels", cin);
   }
   if (fpl_tm_conv3_split_supported(k, cin, cout) && od == oh && oh == ow && !getenv("FPL_TRAIN_F32CONV"))
-    return fpl_tm_conv3_split(ctx, dy, n, od, oh, ow, Wd, zeros, 1, 0, dx);
+    return fpl_tm_conv3_split(ctx, dy, n, od, oh, ow, cin, cout, Wd, zeros, 1, 0, dx);
   // 3x3x3: the kernel makes up to 64 channels per launch; a wider input gradient (unet's
   // 192- and 96-channel concats) is produced in 64-channel slices of the same tensor
   FPL_REQUIRE(ctx, ncc <= 12, "conv3 dgrad: %d > 192 output-gradient channels", cout);
@@ -1974,7 +1974,7 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
   const int ncc = (cin + 15) / 16, nco = (cout + 47) / 48;
   // 48 -> 48, rows of up to 32 outputs: split halves, voxel-major MFMAs (FPL_TRAIN_F32CONV=1: the fp32 kernel)
-  if (fpl_tm_conv3_split_supported(k, cin, cout) && D == H && H == W_ && od <= 32 && !bn && !bg && !pg &&
+  if (fpl_tm_conv3_wgrad_split_supported(k, cin, cout) && D == H && H == W_ && od <= 32 && !bn && !bg && !pg &&
       !getenv("FPL_TRAIN_F32CONV"))
     return fpl_tm_conv3_wgrad_split(ctx, x, n, D, dy, dw);
   DevTemp tmp(ctx);

@@ -133,11 +133,13 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
                       const float *dy, int k, int cout, float *dw, const FplBnView *bn = nullptr,
                       const FplBnGrad *bg = nullptr, const FplPoolGrad *pg = nullptr);
 
-// Training: the 3x3x3 48 -> 48 convolutions (forward: dgrad = 0; input gradient: dgrad = 1, x = dy) on
-// split halves (conv_mfma.hip, split build): fp32-grade results at five times the fp32 matrix rate
+// Training: 3x3x3 convolutions of 32 - 192 channels (multiples of 16) - forward: dgrad = 0; input gradient:
+// dgrad = 1, x = dy - on split halves (conv_mfma.hip, split build): fp32-grade results at five times the fp32
+// matrix rate
 bool fpl_tm_conv3_split_supported(int k, int cin, int cout);
-int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, const float *Wd, const float *bias,
-                       int dgrad, int relu, float *y);
+int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int cout, const float *Wd,
+                       const float *bias, int dgrad, int relu, float *y);
+bool fpl_tm_conv3_wgrad_split_supported(int k, int cin, int cout);
 // ... and the weight gradient dw [27][48][48] += x (n, D^3, 48) * dy (n, (D - 2)^3, 48) on the planar copies the
 // two calls above left in the context (made here when missing); fpl_tm_split_reset drops the copies
 // (start and end of a training step: the fp32 tensors they mirror are recycled between steps)
