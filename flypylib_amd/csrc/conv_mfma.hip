@@ -1956,44 +1956,57 @@ namespace {
 // 576 B = 64 mod 256: the two passes of a transposed read and the two lane groups of a half-wave fall on
 // four different bank quarters), filled by LDS-DMA one output row ahead.
 namespace wg {
-constexpr int WAVES = 8, NV = 36, ROWDATA = 12 * NV * 16;       // 6912 B of a staged row ...
-constexpr int RCHK = (ROWDATA + 1023) / 1024;                    // ... in 7 DMA chunks of 1 KiB:
-constexpr int ROWB = RCHK * 1024;                                // a row slot is 7 KiB (the last chunk's tail lands in it)
-constexpr int XSLOTS = 12, SMEM = (XSLOTS + 2) * ROWB;           // 100 352 B
-constexpr int NPAIR = 81, PPW = (NPAIR + WAVES - 1) / WAVES;     // (tap, ci block) pairs per wave: 11
+constexpr int WAVES = 8, NV = 36;
+constexpr int XSLOTS = 12;
+// one launch: CIB blocks of 16 input channels (X rows of 2 CIB passes) against COB blocks of 16 output channels
+// (dY rows of 2 COB passes); a staged row is [part 2][pass][voxel NV] x 16 B, in whole 1 KiB DMA chunks (the last
+// chunk's tail lands in the slot)
+template <int CIB, int COB> struct Cfg {
+  static constexpr int XP = 2 * CIB, YP = 2 * COB;
+  static constexpr int XCHK = (2 * XP * NV * 16 + 1023) / 1024, YCHK = (2 * YP * NV * 16 + 1023) / 1024;
+  static constexpr int XROWB = XCHK * 1024, YROWB = YCHK * 1024;
+  static constexpr int SMEM = XSLOTS * XROWB + 2 * YROWB;           // 48 -> 48: 14 x 7 KiB = 100 352 B
+  static constexpr int NPAIR = 27 * CIB, PPW = (NPAIR + WAVES - 1) / WAVES;   // (tap, ci block) pairs per wave
+  static constexpr int NCHK = 3 * XCHK + YCHK, NI = (NCHK + WAVES - 1) / WAVES;   // DMA chunks of a step, per wave
+  static_assert(SMEM <= 160 * 1024, "one workgroup's rows fit the LDS");
+};
 }
 
 struct WgArgs {
-  const unsigned char *xp, *yp;       // planar copies: x (n, D^3), dy (n, (Dy + 4)^3, zero shell of 2)
+  const unsigned char *xp, *yp;       // planar copies: x (n, D^3; the first pass of this launch's channels), dy (n, (Dy + 4)^3, zero shell of 2)
   unsigned xpart, ypart;              // bytes of one plane
   int n, D, Dy, ychunk, nychunk;      // patches, x edge, dy edge (D - 2), output rows per block
   const float *scx, *scy;             // [s, 1 / s] of either copy
   float *dw;
+  int cin, cout, ci0;                 // dw is [27][cin][cout]; this launch's input channels start at ci0
 };
 
+template <int CIB, int COB>
 __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
   using namespace wg;
+  typedef Cfg<CIB, COB> CF;
+  constexpr int XP = CF::XP, YP = CF::YP, PPW = CF::PPW, NPAIR = CF::NPAIR, NI = CF::NI;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
   const int G = a.Dy + 4;                                       // dy's grid edge
-  // ---- DMA decode: chunk j of a staged row, this lane's 16 B = (part, pass, voxel)
-  auto slot_off = [&](int j, unsigned part_bytes) -> unsigned {
+  // ---- DMA decode: chunk j of a staged row of NP passes, this lane's 16 B = (part, pass, voxel)
+  auto slot_off = [&](int j, unsigned part_bytes, int NP) -> unsigned {
     int s = 64 * j + lane;
-    s = s < 12 * NV ? s : 12 * NV - 1;
-    const int pl = s / NV, v = s - pl * NV;                     // LDS plane = part * 6 + pass
-    const int part = pl / 6, pass = pl - 6 * part;
+    s = s < 2 * NP * NV ? s : 2 * NP * NV - 1;
+    const int pl = s / NV, v = s - pl * NV;                     // LDS plane = part * NP + pass
+    const int part = pl / NP, pass = pl - NP * part;
     return (unsigned)(pass * 2 + part) * part_bytes + (unsigned)v * 16u;
   };
-  // the chunks of a step's fill: 3 X rows (dz = 0 .. 2) and 1 dY row, 7 chunks each, dealt to the waves
-  // chunk id q = wave + 8 i (i < 4): row r = q / 7 (3 = dY), chunk j = q % 7
-  unsigned doff[4];
-  int drow[4], dj[4];
+  // the chunks of a step's fill: 3 X rows (dz = 0 .. 2) of XCHK chunks and 1 dY row of YCHK, dealt to the waves:
+  // chunk id q = wave + 8 i: q < 3 XCHK: X row q / XCHK, chunk q % XCHK; else dY chunk q - 3 XCHK
+  unsigned doff[NI];
+  int drow[NI], dj[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int q = wave + WAVES * i;
-    drow[i] = q / RCHK; dj[i] = q - RCHK * drow[i];
-    doff[i] = drow[i] < 3 ? slot_off(dj[i], a.xpart) : slot_off(dj[i], a.ypart);
+    if (q < 3 * CF::XCHK) { drow[i] = q / CF::XCHK; dj[i] = q - CF::XCHK * drow[i]; doff[i] = slot_off(dj[i], a.xpart, XP); }
+    else { drow[i] = 3; dj[i] = q - 3 * CF::XCHK; doff[i] = slot_off(dj[i] < CF::YCHK ? dj[i] : 0, a.ypart, YP); }
   }
   // per-lane offset of a transposed read inside a staged row: lane 4 q + p of a group supplies voxel
   // row q, channels 4 p .. 4 p + 3 = 8 B of pass (p >> 1) of the pair; + cb * 2 passes, + part, + voxel
@@ -2003,17 +2016,17 @@ __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                          (__attribute__((address_space(3))) s16x4 *)(p)));
   };
-  // an 8-voxel operand fragment (channels of block cb, part `part`) of the row at `row`, voxels + vofs
-  auto frag = [&](const unsigned char *row, int cb, int part, int vofs) -> h16x8 {
-    const unsigned char *p = row + lane_off + ((part * 6 + 2 * cb) * NV + vofs) * 16;
+  // an 8-voxel operand fragment (channels of block cb, part `part`) of the row at `row` (NP passes), voxels + vofs
+  auto frag = [&](const unsigned char *row, int NP, int cb, int part, int vofs) -> h16x8 {
+    const unsigned char *p = row + lane_off + ((part * NP + 2 * cb) * NV + vofs) * 16;
     const u32x2 lo = tr(p), hi = tr(p + 4 * 16);
     return __builtin_bit_cast(h16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
   };
-  f32x4 acc[PPW][3];
+  f32x4 acc[PPW][COB];
 #pragma unroll
   for (int i = 0; i < PPW; ++i)
 #pragma unroll
-    for (int ob = 0; ob < 3; ++ob) acc[i][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ob = 0; ob < COB; ++ob) acc[i][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
   u32x4 kmask;                                  // this lane's k-slots j = voxels 8 g + j: inside the row?
 #pragma unroll
   for (int d = 0; d < 4; ++d)
@@ -2021,6 +2034,7 @@ __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
 
   const int nblk = a.n * a.Dy * a.nychunk;
   const int S = (int)gridDim.x;
+  unsigned char *ybuf = smem + XSLOTS * CF::XROWB;
   auto xrow = [&](int n, int z, int y) -> const unsigned char * {       // X row (z, y), voxel 0, plane 0
     return a.xp + ((((int64_t)n * a.D + z) * a.D + y) * a.D) * 16;
   };
@@ -2030,17 +2044,17 @@ __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
   // fill of the rows step (n, z, y) adds: X rows (z + dz, y + 2) into ring slot (dz, (y + 2) & 3), dY row y
   auto fill = [&](int n, int z, int y, bool first) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int q = wave + WAVES * i;
-      if (q >= 4 * RCHK) continue;
+      if (q >= CF::NCHK) continue;
       if (drow[i] < 3) {
-        glds16(xrow(n, z + drow[i], y + 2) + doff[i], smem + (drow[i] * 4 + ((y + 2) & 3)) * ROWB + dj[i] * 1024);
+        glds16(xrow(n, z + drow[i], y + 2) + doff[i], smem + (drow[i] * 4 + ((y + 2) & 3)) * CF::XROWB + dj[i] * 1024);
         if (first) {                     // a block's first step also needs rows y and y + 1
-          glds16(xrow(n, z + drow[i], y) + doff[i], smem + (drow[i] * 4 + (y & 3)) * ROWB + dj[i] * 1024);
-          glds16(xrow(n, z + drow[i], y + 1) + doff[i], smem + (drow[i] * 4 + ((y + 1) & 3)) * ROWB + dj[i] * 1024);
+          glds16(xrow(n, z + drow[i], y) + doff[i], smem + (drow[i] * 4 + (y & 3)) * CF::XROWB + dj[i] * 1024);
+          glds16(xrow(n, z + drow[i], y + 1) + doff[i], smem + (drow[i] * 4 + ((y + 1) & 3)) * CF::XROWB + dj[i] * 1024);
         }
       } else {
-        glds16(yrow(n, z, y) + doff[i], smem + (XSLOTS + (y & 1)) * ROWB + dj[i] * 1024);
+        glds16(yrow(n, z, y) + doff[i], ybuf + (y & 1) * CF::YROWB + dj[i] * 1024);
       }
     }
   };
@@ -2053,26 +2067,26 @@ __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
     __syncthreads();
     for (int y = y0; y < y1; ++y) {
       if (y + 1 < y1) fill(n, z, y + 1, false);
-      const unsigned char *yr = smem + (XSLOTS + (y & 1)) * ROWB;
+      const unsigned char *yr = ybuf + (y & 1) * CF::YROWB;
       {                                            // ONE K-step of 32 voxels: the row (Dy <= 32, host)
         constexpr int x0 = 0;
         // (voxels past the row's Dy outputs - the K-step always takes 32 - are other rows' gradients: masked)
-        h16x8 bh[3], bl[3];
+        h16x8 bh[COB], bl[COB];
 #pragma unroll
-        for (int ob = 0; ob < 3; ++ob) {
-          bh[ob] = __builtin_bit_cast(h16x8, __builtin_bit_cast(u32x4, frag(yr, ob, 0, x0)) & kmask);
-          bl[ob] = __builtin_bit_cast(h16x8, __builtin_bit_cast(u32x4, frag(yr, ob, 1, x0)) & kmask);
+        for (int ob = 0; ob < COB; ++ob) {
+          bh[ob] = __builtin_bit_cast(h16x8, __builtin_bit_cast(u32x4, frag(yr, YP, ob, 0, x0)) & kmask);
+          bl[ob] = __builtin_bit_cast(h16x8, __builtin_bit_cast(u32x4, frag(yr, YP, ob, 1, x0)) & kmask);
         }
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
           const int pi = wave + WAVES * i;
           if (pi < NPAIR) {
-            const int tap = pi / 3, cb = pi - 3 * tap;
+            const int tap = pi / CIB, cb = pi - CIB * tap;
             const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const unsigned char *xr = smem + (dz * 4 + ((y + dy) & 3)) * ROWB;
-            const h16x8 ah = frag(xr, cb, 0, x0 + dx), al = frag(xr, cb, 1, x0 + dx);
+            const unsigned char *xr = smem + (dz * 4 + ((y + dy) & 3)) * CF::XROWB;
+            const h16x8 ah = frag(xr, XP, cb, 0, x0 + dx), al = frag(xr, XP, cb, 1, x0 + dx);
 #pragma unroll
-            for (int ob = 0; ob < 3; ++ob) {
+            for (int ob = 0; ob < COB; ++ob) {
               acc[i][ob] = mfma16(al, bh[ob], acc[i][ob]);
               acc[i][ob] = mfma16(ah, bl[ob], acc[i][ob]);
               acc[i][ob] = mfma16(ah, bh[ob], acc[i][ob]);
@@ -2089,13 +2103,13 @@ __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
   for (int i = 0; i < PPW; ++i) {
     const int pi = wave + WAVES * i;
     if (pi < NPAIR) {
-      const int tap = pi / 3, cb = pi - 3 * tap;
+      const int tap = pi / CIB, cb = pi - CIB * tap;
 #pragma unroll
-      for (int ob = 0; ob < 3; ++ob)
+      for (int ob = 0; ob < COB; ++ob)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = acc[i][ob][r] * us;
-          if (v != 0.f) atomicAdd(&a.dw[((size_t)tap * 48 + 16 * cb + 4 * g + r) * 48 + 16 * ob + c], v);
+          if (v != 0.f) atomicAdd(&a.dw[((size_t)tap * a.cin + a.ci0 + 16 * cb + 4 * g + r) * a.cout + 16 * ob + c], v);
         }
     }
   }
@@ -2147,8 +2161,6 @@ bool fpl_tm_conv3_split_supported(int k, int cin, int cout) {
   auto ok = [](int c) { return c >= 32 && c % 16 == 0 && c <= 8 * u8::MAXPASS; };
   return k == 3 && ok(cin) && ok(cout);
 }
-// the weight gradient's kernel is written for 48 -> 48
-bool fpl_tm_conv3_wgrad_split_supported(int k, int cin, int cout) { return k == 3 && cin == 48 && cout == 48; }
 
 // forward: x (n, D, H, W, cin) -> y (n, D - 2, H - 2, W - 2, cout) = conv3(x, Wd) + bias
 // dgrad:   x = dy (n, D, H, W, cout) -> y = dx (n, D + 2, H + 2, W + 2, cin) (bias = zeros)
@@ -2214,32 +2226,60 @@ int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_
   return 0;
 }
 
-// dw [27][48][48] += weight gradient of the valid conv3: x (n, D^3, 48), dy (n, (D - 2)^3, 48)
-int fpl_tm_conv3_wgrad_split(fpl_ctx *ctx, const float *x, int n, int D, const float *dy, float *dw) {
+// the weight gradient on split halves: 48 -> 48 in one launch; input channels in multiples of 32 (two blocks of
+// 16 per launch) against 32 or 64 outputs
+bool fpl_tm_conv3_wgrad_split_supported(int k, int cin, int cout) {
+  return k == 3 && ((cin == 48 && cout == 48) || (cin % 32 == 0 && cin >= 32 && cin <= 8 * u8::MAXPASS && (cout == 32 || cout == 64)));
+}
+
+template <int CIB, int COB>
+int launch_wgrad_split(fpl_ctx *ctx, WgArgs &a, int n, const char *name) {
+  typedef wg::Cfg<CIB, COB> CF;
+  static bool attr_set[FPL_MAX_DEVICES] = {false};
+  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
+    FPL_HIP(ctx, hipFuncSetAttribute((const void *)tm_wgrad3_split<CIB, COB>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM));
+    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
+  }
+  // every workgroup ends with 27 x CIB x COB x 256 float atomics into dw: a small layer (the U-Net's 4 - 8-voxel
+  // ones) runs on as few workgroups as give each at least four blocks of rows
+  const int nblk = n * a.Dy * a.nychunk;
+  const unsigned grid = (unsigned)std::min<int>(std::max(8, nblk / 4), ctx->n_cu);
+  TimedLaunch tl(ctx, name);
+  tm_wgrad3_split<CIB, COB><<<grid, 64 * wg::WAVES, CF::SMEM, ctx->stream>>>(a);
+  return 0;
+}
+
+// dw [27][cin][cout] += weight gradient of the valid conv3: x (n, D^3, cin), dy (n, (D - 2)^3, cout)
+int fpl_tm_conv3_wgrad_split(fpl_ctx *ctx, const float *x, int n, int D, int cin, int cout, const float *dy, float *dw) {
+  FPL_REQUIRE(ctx, fpl_tm_conv3_wgrad_split_supported(3, cin, cout), "conv3 wgrad (split): %d -> %d channels", cin, cout);
   FplSplitCopy xc, yc;
   {
     TimedLaunch tl(ctx, "train_split_prepare");
-    FPL_TRY(split_copy(ctx, x, n, D, 0, 48, &xc));
-    FPL_TRY(split_copy(ctx, dy, n, D - 2, 2, 48, &yc));
+    FPL_TRY(split_copy(ctx, x, n, D, 0, cin, &xc));
+    FPL_TRY(split_copy(ctx, dy, n, D - 2, 2, cout, &yc));
   }
   WgArgs a;
-  a.xp = xc.planar; a.yp = yc.planar;
-  FPL_REQUIRE(ctx, 12 * xc.part < ((int64_t)1 << 32) && 12 * yc.part < ((int64_t)1 << 32),
+  a.yp = yc.planar;
+  FPL_REQUIRE(ctx, (cin / 4) * xc.part < ((int64_t)1 << 32) && (cout / 4) * yc.part < ((int64_t)1 << 32),
               "conv3 wgrad (split): the planar copies exceed the kernel's 32-bit offsets");
   a.xpart = (unsigned)xc.part; a.ypart = (unsigned)yc.part;
   a.n = n; a.D = D; a.Dy = D - 2;
   FPL_REQUIRE(ctx, a.Dy >= 1 && a.Dy <= 32, "conv3 wgrad (split): rows of %d outputs (one 32-voxel K-step)", a.Dy);
   a.ychunk = 10; a.nychunk = (int)ceil_div64(a.Dy, a.ychunk);
   a.scx = xc.sc; a.scy = yc.sc; a.dw = dw;
-  static bool attr_set[FPL_MAX_DEVICES] = {false};
-  if (!attr_set[ctx->device % FPL_MAX_DEVICES]) {
-    FPL_HIP(ctx, hipFuncSetAttribute((const void *)tm_wgrad3_split, hipFuncAttributeMaxDynamicSharedMemorySize, wg::SMEM));
-    attr_set[ctx->device % FPL_MAX_DEVICES] = true;
+  a.cin = cin; a.cout = cout;
+  if (cin == 48 && cout == 48) {
+    a.xp = xc.planar; a.ci0 = 0;
+    return launch_wgrad_split<3, 3>(ctx, a, n, "split_wgrad3_48to48");
   }
-  const int nblk = n * a.Dy * a.nychunk;
-  const unsigned grid = (unsigned)std::min<int>(nblk, ctx->n_cu);
-  TimedLaunch tl(ctx, "split_wgrad3_48to48");
-  tm_wgrad3_split<<<grid, 64 * wg::WAVES, wg::SMEM, ctx->stream>>>(a);
+  char name[48];
+  snprintf(name, sizeof(name), "split_wgrad3_%dto%d", cin, cout);
+  for (int ci0 = 0; ci0 < cin; ci0 += 32) {        // two blocks of 16 input channels per launch
+    a.xp = xc.planar + (int64_t)(ci0 / 8) * 2 * xc.part;
+    a.ci0 = ci0;
+    if (cout == 32) FPL_TRY((launch_wgrad_split<2, 2>(ctx, a, n, name)));
+    else FPL_TRY((launch_wgrad_split<2, 4>(ctx, a, n, name)));
+  }
   return 0;
 }
 #endif

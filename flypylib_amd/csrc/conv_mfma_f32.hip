@@ -1842,7 +1842,7 @@ int fpl_tm_conv_fwd(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, i
     }
     return fpl_fail(ctx, "stem with %d channels", cout);
   }
-  // 48 -> 48: split halves (FPL_TRAIN_F32CONV=1: the fp32 MFMA kernel, A/B)
+  // 32 - 192 channels: split halves (FPL_TRAIN_F32CONV=1: the fp32 MFMA kernel, A/B)
   if (fpl_tm_conv3_split_supported(k, cin, cout) && D == H && H == W_ && (act == FPL_ACT_NONE || act == FPL_ACT_RELU) &&
       !getenv("FPL_TRAIN_F32CONV"))
     return fpl_tm_conv3_split(ctx, x, n, D, H, W_, cin, cout, Wd, bias, 0, act == FPL_ACT_RELU, y);
@@ -1973,10 +1973,12 @@ int fpl_tm_conv_wgrad(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_,
               "conv wgrad: no BatchNorm-gradient kernel for k %d, %d -> %d", k, cin, cout);
   const int od = D - k + 1, oh = H - k + 1, ow = W_ - k + 1;
   const int ncc = (cin + 15) / 16, nco = (cout + 47) / 48;
-  // 48 -> 48, rows of up to 32 outputs: split halves, voxel-major MFMAs (FPL_TRAIN_F32CONV=1: the fp32 kernel)
-  if (fpl_tm_conv3_wgrad_split_supported(k, cin, cout) && D == H && H == W_ && od <= 32 && !bn && !bg && !pg &&
+  // rows of up to 32 outputs: split halves, voxel-major MFMAs (FPL_TRAIN_F32CONV=1: the fp32 kernel)
+  // (more than two launches of 32 input channels over rows shorter than 12 outputs lose to the fp32 kernel:
+  // unet_like2's 192 -> 64 at 4^3 0.36 against 0.19 ms, 96 -> 32 at 6^3 0.17 against 0.16)
+  if (fpl_tm_conv3_wgrad_split_supported(k, cin, cout) && D == H && H == W_ && od <= 32 && (cin <= 64 || od >= 12) && !bn && !bg && !pg &&
       !getenv("FPL_TRAIN_F32CONV"))
-    return fpl_tm_conv3_wgrad_split(ctx, x, n, D, dy, dw);
+    return fpl_tm_conv3_wgrad_split(ctx, x, n, D, cin, cout, dy, dw);
   DevTemp tmp(ctx);
   if (k == 1) {
     Wgrad1Args a;

@@ -140,10 +140,10 @@ bool fpl_tm_conv3_split_supported(int k, int cin, int cout);
 int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_, int cin, int cout, const float *Wd,
                        const float *bias, int dgrad, int relu, float *y);
 bool fpl_tm_conv3_wgrad_split_supported(int k, int cin, int cout);
-// ... and the weight gradient dw [27][48][48] += x (n, D^3, 48) * dy (n, (D - 2)^3, 48) on the planar copies the
+// ... and the weight gradient dw [27][cin][cout] += x (n, D^3, cin) * dy (n, (D - 2)^3, cout) on the planar copies the
 // two calls above left in the context (made here when missing); fpl_tm_split_reset drops the copies
 // (start and end of a training step: the fp32 tensors they mirror are recycled between steps)
-int fpl_tm_conv3_wgrad_split(fpl_ctx *ctx, const float *x, int n, int D, const float *dy, float *dw);
+int fpl_tm_conv3_wgrad_split(fpl_ctx *ctx, const float *x, int n, int D, int cin, int cout, const float *dy, float *dw);
 void fpl_tm_split_reset(fpl_ctx *ctx);
 
 // Split-operand IEEE-half path for vgg_like (vgg_split.hip, FPL_PREC_F16S): every
