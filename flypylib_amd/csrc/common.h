@@ -64,6 +64,7 @@ struct V2oState {
 struct FplSplitCopy {
   const void *key; int n, D, pad, C;   // the fp32 tensor (device pointer), patches, edge, zero shell, channels
   unsigned char *planar; float *sc;    // the copy (x s) and [s, 1 / s]
+  bool sc_owned;                       // sc is an allocation of its own (the zero-record pool was spent)
   int64_t part;                        // bytes of one plane
 };
 
@@ -71,6 +72,11 @@ struct fpl_ctx {
   int device = 0;
   std::vector<FplSplitCopy> split_copies;   // valid within one training step (fpl_tm_split_reset)
   std::vector<std::pair<const void *, unsigned *>> split_wmax;   // ... and the maxima of the weight sets seen in it
+  // 64-B records (scale [0..2], maximum's bits [4]) handed out ZEROED to those copies and weight sets: one memset
+  // of the used ones per step (fpl_tm_split_reset) instead of one per record - on the U-Net's small layers a
+  // training step is mostly launches
+  unsigned char *zero_pool = nullptr;
+  int zero_next = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   char err[FPL_MAX_ERR] = {0};

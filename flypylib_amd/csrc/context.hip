@@ -119,6 +119,7 @@ int fpl_ctx_destroy(fpl_ctx *ctx) {
   if (ctx->v2o.sort_idx) fpl_dev_release(ctx, ctx->v2o.sort_idx);
   fpl_dev_trim(ctx);
   for (auto &kv : ctx->live_blocks) hipFree(kv.first);
+  if (ctx->zero_pool) hipFree(ctx->zero_pool);
   if (ctx->range_flag_dev) hipFree(ctx->range_flag_dev);
   if (ctx->range_flag_host) hipHostFree(ctx->range_flag_host);
   hipStreamDestroy(ctx->own_stream);

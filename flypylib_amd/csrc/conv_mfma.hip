@@ -1885,11 +1885,14 @@ __device__ __forceinline__ void ts_publish(float s, float *sc, const float *othe
 // the steps; a thread per voxel AND pass fetched every line C / 8 times), four 16-B stores per step, each a
 // coalesced stream over the wave's consecutive voxels.
 __global__ void ts_to_planar(const float *__restrict__ x, int n, int D, int H, int W, int C, int pad,
-                             const unsigned *maxbits, float *sc, unsigned char *out, int64_t part) {
+                             const unsigned *maxbits, float *sc, unsigned char *out, int64_t part, int64_t slack16) {
   const int Dp = D + 2 * pad, Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int64_t nv = (int64_t)n * Dp * Hp * Wp;
   const float s = ts_scale_of(maxbits, 11);
   ts_publish(s, sc, nullptr);
+  // the read slack behind the last plane is ZERO (16-B pieces [0, slack16) behind the C / 8 x 2 planes)
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < slack16; v += (int64_t)gridDim.x * blockDim.x)
+    *reinterpret_cast<u32x4 *>(out + (int64_t)(C / 8) * 2 * part + v * 16) = u32x4{0u, 0u, 0u, 0u};
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
     const int xx = (int)(v % Wp) - pad;
     int64_t t = v / Wp;
@@ -2115,6 +2118,18 @@ __global__ __launch_bounds__(64 * wg::WAVES, 2) void tm_wgrad3_split(WgArgs a) {
   }
 }
 
+// a zeroed 64-B record of the context's pool (valid until fpl_tm_split_reset); nullptr when the pool is spent
+constexpr int ZERO_RECORDS = 1024;
+unsigned char *zero_record(fpl_ctx *ctx) {
+  if (!ctx->zero_pool) {
+    if (hipMalloc((void **)&ctx->zero_pool, ZERO_RECORDS * 64) != hipSuccess) { ctx->zero_pool = nullptr; return nullptr; }
+    if (hipMemsetAsync(ctx->zero_pool, 0, ZERO_RECORDS * 64, ctx->stream) != hipSuccess) return nullptr;
+    ctx->zero_next = 0;
+  }
+  if (ctx->zero_next >= ZERO_RECORDS) return nullptr;
+  return ctx->zero_pool + 64 * (size_t)ctx->zero_next++;
+}
+
 // the planar split copy of a training tensor (x s, s a power of two from the tensor's maximum), made once per
 // step and kept in the context: forward leaves x's, the weight gradient dy's (which the input gradient reuses)
 int split_copy(fpl_ctx *ctx, const float *x, int n, int D, int pad, int C, FplSplitCopy *out) {
@@ -2128,19 +2143,24 @@ int split_copy(fpl_ctx *ctx, const float *x, int n, int D, int pad, int C, FplSp
   e.part = nv * 16;
   void *q;
   const size_t slack = ((size_t)6 * Dp * Dp + 40 * Dp + 64) * 16;
-  const size_t planes = ((size_t)(C / 8) * 2 * e.part + slack + 63) / 64 * 64;
-  FPL_TRY(fpl_dev_alloc(ctx, planes + 64, &q));
+  // the read slack behind the last plane is ZERO (ts_to_planar writes it): the weight-gradient kernel sums over
+  // voxels, and a row's 32-voxel K-step runs past short rows (times masked-out gradients - but 0 x NaN is NaN).
+  // The scale record - [0] s, [1] 1 / s; [4] (as unsigned) the maximum's bits - comes zeroed from the pool
+  FPL_TRY(fpl_dev_alloc(ctx, (size_t)(C / 8) * 2 * e.part + slack, &q));
   e.planar = (unsigned char *)q;
-  // the read slack behind the last plane is ZERO: the weight-gradient kernel sums over voxels, and a row's
-  // 32-voxel K-step runs past short rows (times masked-out gradients - but 0 x NaN is NaN).  The scale record
-  // sits behind it (one memset for both): [0] s, [1] 1 / s; [4] (as unsigned) the maximum's bits
-  e.sc = (float *)(e.planar + planes);
-  unsigned *maxbits = (unsigned *)e.sc + 4;
-  FPL_HIP(ctx, hipMemsetAsync(e.planar + (size_t)(C / 8) * 2 * e.part, 0, planes + 64 - (size_t)(C / 8) * 2 * e.part, st));
+  unsigned char *rec = zero_record(ctx);
+  e.sc_owned = rec == nullptr;
+  if (!rec) {
+    FPL_TRY(fpl_dev_alloc(ctx, 64, &q));
+    rec = (unsigned char *)q;
+    FPL_HIP(ctx, hipMemsetAsync(rec, 0, 64, st));
+  }
+  e.sc = (float *)rec;
+  unsigned *maxbits = (unsigned *)rec + 4;
   const int64_t nx = (int64_t)n * D * D * D * C;
   ts_maxabs<<<(unsigned)std::min<int64_t>(ceil_div64(nx, 1024), (int64_t)ctx->n_cu * 8), 256, 0, st>>>(x, nx, maxbits);
   ts_to_planar<<<(unsigned)std::min<int64_t>(ceil_div64(nv, 256), (int64_t)ctx->n_cu * 16), 256, 0, st>>>(
-      x, n, D, D, D, C, pad, maxbits, e.sc, e.planar, e.part);
+      x, n, D, D, D, C, pad, maxbits, e.sc, e.planar, e.part, (int64_t)(slack / 16));
   ctx->split_copies.push_back(e);
   *out = e;
   return 0;
@@ -2149,10 +2169,19 @@ int split_copy(fpl_ctx *ctx, const float *x, int n, int D, int pad, int C, FplSp
 }  // namespace
 
 void fpl_tm_split_reset(fpl_ctx *ctx) {
-  for (FplSplitCopy &e : ctx->split_copies) fpl_dev_release(ctx, e.planar);      // (the scale record lives inside it)
+  for (FplSplitCopy &e : ctx->split_copies) {
+    fpl_dev_release(ctx, e.planar);
+    if (e.sc_owned) fpl_dev_release(ctx, e.sc);
+  }
   ctx->split_copies.clear();
-  for (auto &w : ctx->split_wmax) fpl_dev_release(ctx, w.second);
+  for (auto &w : ctx->split_wmax)
+    if (!ctx->zero_pool || (unsigned char *)w.second < ctx->zero_pool || (unsigned char *)w.second >= ctx->zero_pool + ZERO_RECORDS * 64)
+      fpl_dev_release(ctx, w.second);
   ctx->split_wmax.clear();
+  if (ctx->zero_pool && ctx->zero_next > 0) {        // the records go back zeroed, behind the kernels that used them
+    hipMemsetAsync(ctx->zero_pool, 0, (size_t)ctx->zero_next * 64, ctx->stream);
+    ctx->zero_next = 0;
+  }
 }
 
 // forward / input gradient on split halves: 3x3x3, both channel counts multiples of 16 from 32 up to 192 (inputs
@@ -2184,10 +2213,13 @@ int fpl_tm_conv3_split(fpl_ctx *ctx, const float *x, int n, int D, int H, int W_
   unsigned *wmax = nullptr;
   for (auto &w : ctx->split_wmax) if (w.first == Wd) wmax = w.second;
   if (!wmax) {
-    FPL_TRY(fpl_dev_alloc(ctx, 64, &q));
-    wmax = (unsigned *)q;
+    wmax = (unsigned *)zero_record(ctx);
+    if (!wmax) {
+      FPL_TRY(fpl_dev_alloc(ctx, 64, &q));
+      wmax = (unsigned *)q;
+      FPL_HIP(ctx, hipMemsetAsync(wmax, 0, 4, st));
+    }
     ctx->split_wmax.emplace_back((const void *)Wd, wmax);
-    FPL_HIP(ctx, hipMemsetAsync(wmax, 0, 4, st));
     TimedLaunch tl(ctx, "train_split_prepare");
     ts_maxabs<<<8, 256, 0, st>>>(Wd, (int64_t)27 * cin * cout, wmax);
   }
