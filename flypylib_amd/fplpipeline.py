@@ -308,6 +308,24 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
     prog0 = network.infer_network.program
     dev = prog0.ctx.device
     prec = fplobjdetect_precision(network, precision)
+    # A host volume (ndarray, np.memmap) that fits beside the work goes to the GPU ONCE - 3.6 GB for 1536^3, a few
+    # hundred ms - and the substacks are cut out of it there: cutting 582^3 cubes on the host (a strided 197 MB
+    # copy each) and uploading them one by one costs more than the inference.  FPL_PIPE_RESIDENT_GB (default 64;
+    # 0: never) bounds the size; larger volumes keep the host path (cut + upload per substack, prefetched).
+    uploaded = None
+    if isinstance(src, _ArraySource) and mine and np.dtype(src.arr.dtype) == np.uint8:
+        cap = float(os.environ.get('FPL_PIPE_RESIDENT_GB', '64')) * 2 ** 30
+        nbytes = int(np.prod(src.extent))
+        if 0 < nbytes <= cap:
+            uploaded = prog0.ctx.malloc(src.extent, np.uint8)
+            plane = int(src.extent[1]) * int(src.extent[2])
+            step = max(1, (256 << 20) // max(plane, 1))            # 256 MiB slabs: a memmap is read as it goes
+            for z0 in range(0, src.extent[0], step):
+                z1 = min(src.extent[0], z0 + step)
+                part = np.ascontiguousarray(src.arr[z0:z1])
+                prog0.ctx.memcpy(uploaded.ptr + z0 * plane, part, part.nbytes)
+            prog0.ctx.synchronize()
+            src = _DeviceSource(uploaded)
     # Lanes on the GPU.  An inference lane (a host thread + context + copy of the program)
     # prepares and infers its substacks; each has a post-processing lane of its own (a
     # second thread + context: own HIP stream and voxel2obj state) that works on substack
@@ -431,6 +449,8 @@ def full_roi_inference(data_source, dvid_uuid, dvid_roi,
     run_lane(0, mine[0::n_lanes])
     for t in lanes:
         t.join()
+    if uploaded is not None:
+        uploaded.free()
     if failure:
         raise failure[0]
     if timings is not None:
