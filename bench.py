@@ -314,6 +314,26 @@ def secondary_legs(ctx, torch, prog, tile, off, size, steps):
         achieved_tflops=round(tf, 2), peak_tflops=PEAK_TFLOPS['f32'],
         frac=round(tf / PEAK_TFLOPS['f32'], 4))
     tr.close()
+
+    # unet_like2 as scripts/fpl_cx1_0_unet_4ss_all.py trains it: rf-sized 24^3 patches, batch 64, masked focal loss
+    g = fplmodels.unet_like2()[0]
+    synth.synthetic_weights(g, 3)
+    tr = _capi.Trainer(ctx, g, loss='masked_focal_loss')
+    data = rng.standard_normal((64, 24, 24, 24, 1)).astype(np.float32)
+    labels = rng.integers(0, 3, (64, 6, 6, 6, 1)).astype(np.uint8)
+    tr.step(data, labels, 0)
+    tr.apply(1.0)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20):
+        tr.step(data, labels, i + 1)
+        tr.apply(1.0)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    legs['other_train_unet_like2_b64_24'] = dict(
+        workload='unet_like2 training step (fwd + bwd + Adam), 64 x 24^3 f32 patches (host arrays, H2D inside), '
+                 'masked focal loss, 1 GPU', ms=round(dt * 1e3, 3), steps_per_s=round(1 / dt, 2))
+    tr.close()
     return legs
 
 
