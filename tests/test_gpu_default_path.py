@@ -121,3 +121,33 @@ def test_cpu_oracle_in_the_loop_end_to_end_270_cubed(ctx):
     assert moved <= 2, moved
     hit = np.linalg.norm(np.asarray(a['locs'])[:, None, :] - locs[None, :, :].astype(float), axis=2).min(axis=1)
     assert np.mean(hit <= 4.0) > 0.9
+
+
+@pytest.mark.parametrize('dtype', ['uint8', 'float32'])
+def test_host_to_host_pipeline_equals_the_plain_copy_path(ctx, monkeypatch, dtype):
+    """fpl_infer_volume with host source and destination: groups of tile rows uploaded, computed and copied
+    out by helper threads beside each other (csrc/infer.hip) == upload everything, compute, copy everything
+    (FPL_NO_D2H_PIPE=1), for uint8 and float32 sources, whole volumes and a slab of rows; the result array
+    comes from the binding's recycling pool"""
+    n = 330                                            # 144 MB of float32 out: above the pipeline's 64 MB floor
+    g = fplmodels.vgg_like(102)[0]
+    synth.synthetic_weights(g, 77)
+    prog = _capi.Program(ctx, g, (4, 4, 4))
+    u8 = synth.em_volume_u8(9, (n, n, n))
+    if dtype == 'uint8':
+        src, kw = u8, dict(mean=128.0, std=33.0)
+    else:
+        src, kw = (u8.astype(np.float32) - np.float32(128)) / np.float32(33), dict()
+    kw['precision'] = _capi.PREC_AUTO
+    piped = prog.infer_volume(src, (102,) * 3, (7,) * 3, **kw)
+    assert piped.base is not None                      # pool memory
+    rows = multi_gpu.n_tile_rows(n, 102, 7)
+    part = np.zeros((n, n, n), np.float32)
+    prog.infer_volume(src, (102,) * 3, (7,) * 3, z_range=(1, rows), dst=part, **kw)
+    monkeypatch.setenv('FPL_NO_D2H_PIPE', '1')
+    plain = prog.infer_volume(src, (102,) * 3, (7,) * 3, **kw)
+    part2 = np.zeros((n, n, n), np.float32)
+    prog.infer_volume(src, (102,) * 3, (7,) * 3, z_range=(1, rows), dst=part2, **kw)
+    assert np.array_equal(piped, plain) and plain[7:-7, 7:-7, 7:-7].std() > 1e-3
+    assert np.array_equal(part, part2) and np.array_equal(part[100:], plain[100:]) and not part[:80].any()
+    prog.close()
