@@ -16,7 +16,7 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-template <int NB, int NWL, int NWG, int NM>
+template <int NB, int NWL, int NWG, int NM, int ND = 0>
 __global__ __launch_bounds__(512, 2) void k(const unsigned char *wglob, float *out, int iters, long long *cyc) {
   constexpr int NACC = NM / 3;                 // every accumulator tile takes three MFMAs a step (R x MB tiles, 3 taps)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -29,9 +29,34 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned char *wglob, float *o
   const unsigned char *tile = smem + (wave * 4096 + lane * 16) % (64 << 10);
   const unsigned char *wlds = smem + (96 << 10) + lane * 16;
   const unsigned char *wp = wglob + lane * 16;
+  // ND > 0: of the NB fragments only NB - ND are whole reads; per pair of derived ones (the dx = 1, 2 taps of a
+  // row) one PATCH read with two of every 16 lanes active, and the derived fragments are made from a whole one
+  // by two DPP moves per register (row_shl by the tap, the patched lanes by row_shr:15 / :14)
   auto loadB = [&](int s, int buf) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) b[buf][i] = *reinterpret_cast<const h8 *>(tile + ((s * 7 + i * 11) % 32) * 1024);
+    for (int i = 0; i < NB - ND; ++i) b[buf][i] = *reinterpret_cast<const h8 *>(tile + ((s * 7 + i * 11) % 32) * 1024);
+    if (ND > 0) {
+      h8 patch[ND / 2 > 0 ? ND / 2 : 1];
+#pragma unroll
+      for (int i = 0; i < ND / 2; ++i) {
+        patch[i] = b[buf][i % (NB - ND)];
+        if ((lane & 15) < 2) patch[i] = *reinterpret_cast<const h8 *>(tile + ((s * 3 + i * 5) % 32) * 1024 + 512);
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const u4 src = __builtin_bit_cast(u4, b[buf][(i / 2) % (NB - ND)]), pt = __builtin_bit_cast(u4, patch[i / 2]);
+        u4 d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int v = (i & 1) ? __builtin_amdgcn_update_dpp((int)src[r], (int)src[r], 0x102, 0xF, 0xF, false)
+                          : __builtin_amdgcn_update_dpp((int)src[r], (int)src[r], 0x101, 0xF, 0xF, false);
+          v = (i & 1) ? __builtin_amdgcn_update_dpp(v, (int)pt[r], 0x11E, 0xF, 0xF, false)
+                      : __builtin_amdgcn_update_dpp(v, (int)pt[r], 0x11F, 0xF, 0xF, false);
+          d[r] = (unsigned)v;
+        }
+        b[buf][NB - ND + i] = __builtin_bit_cast(h8, d);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NWL; ++i) wl[buf][i] = *reinterpret_cast<const h8 *>(wlds + ((s * 5 + i) % 32) * 1024);
   };
@@ -68,15 +93,15 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned char *wglob, float *o
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int NB, int NWL, int NWG, int NM>
+template <int NB, int NWL, int NWG, int NM, int ND = 0>
 void run(const unsigned char *w, float *out, long long *cyc, const char *what) {
   const int iters = 6000, blocks = 256;
-  hipFuncSetAttribute((const void *)k<NB, NWL, NWG, NM>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+  hipFuncSetAttribute((const void *)k<NB, NWL, NWG, NM, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k<NB, NWL, NWG, NM><<<blocks, 512, 128 << 10>>>(w, out, 600, cyc);
+  k<NB, NWL, NWG, NM, ND><<<blocks, 512, 128 << 10>>>(w, out, 600, cyc);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  k<NB, NWL, NWG, NM><<<blocks, 512, 128 << 10>>>(w, out, iters, cyc);
+  k<NB, NWL, NWG, NM, ND><<<blocks, 512, 128 << 10>>>(w, out, iters, cyc);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -88,7 +113,7 @@ void run(const unsigned char *w, float *out, long long *cyc, const char *what) {
   tick /= blocks;
   // s_memtime counts a 100 MHz constant clock: convert through the wall time of the launch
   const double sec = ms * 1e-3, flop = 2.0 * 16 * 16 * 32 * NM * (double)iters * 8 * blocks;
-  printf("%-44s B %2d  W lds %d  W L2 %d  MFMA %2d per step: %7.1f TFLOP/s = %4.1f %% of 2 500\n", what, NB, NWL, NWG, NM,
+  printf("%-44s B %2d (%d by DPP)  W lds %d  W L2 %d  MFMA %2d per step: %7.1f TFLOP/s = %4.1f %% of 2 500\n", what, NB, ND, NWL, NWG, NM,
          flop / sec / 1e12, 100.0 * flop / sec / 2.5e15);
   (void)tick;
 }
@@ -105,5 +130,8 @@ int main() {
   run<12, 3, 3, 36>(w, out, cyc, "3 of 6 in LDS");
   run<12, 2, 4, 36>(w, out, cyc, "2 of 6 in LDS");
   run<12, 0, 6, 36>(w, out, cyc, "weights per wave from L2 (shipped)");
+  run<12, 6, 0, 36, 8>(w, out, cyc, "weights in LDS, dx taps by DPP");
+  run<12, 0, 0, 36, 8>(w, out, cyc, "tile reads only, dx taps by DPP");
+  run<12, 3, 3, 36, 8>(w, out, cyc, "3 of 6 in LDS, dx taps by DPP");
   return 0;
 }
